@@ -1,0 +1,156 @@
+"""Pins the CPU oracle (oracle/mcpilco_oracle.py) against golden vectors produced by the
+reference itself (tests/golden/make_golden.py).  CPU only.
+
+Tolerances (fp64): per-op rel 1e-12; posterior rel 1e-10; short rollouts abs 1e-9;
+T=60 rollout abs 1e-6 / gradients rel 1e-6; indices exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROLLOUT_FIXTURES, T, hyper, oracle_cost_fn, oracle_model, oracle_policy
+from oracle import mcpilco_oracle as orc
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def kernel_hyper(fx):
+    pw = [fx[k] for k in ("poly_w1", "poly_w2") if k in fx]
+    return hyper(fx["lengthscales"], float(fx["sigma_n"]), float(fx["lam"]), pw or None)
+
+
+@pytest.mark.parametrize("name", ["kern_se", "kern_se_poly2", "kern_se_poly1_d24"])
+def test_gram_cholesky_posterior(golden, name):
+    fx = golden(name)
+    h = kernel_hyper(fx)
+    X, Y, Xs = T(fx["X"]), T(fx["Y"]), T(fx["Xs"])
+    assert relerr(orc.gp_cov(h, X, None, noise=True), fx["K_noise"]) < 1e-12
+    assert relerr(orc.gp_cov(h, Xs, X), fx["K_cross"]) < 1e-12
+    assert relerr(orc.gp_diag(h, Xs), fx["diag"]) < 1e-12
+    mX, K, Kinv, logdet = orc.gp_forward(h, X)
+    assert relerr(Kinv, fx["Kinv"]) < 1e-10
+    assert abs(float(logdet) - float(fx["logdet"])) < 1e-10 * abs(float(fx["logdet"]))
+    alpha, _, _ = orc.gp_alpha(h, X, Y)
+    assert relerr(alpha, fx["alpha"]) < 1e-10
+    mu, var = orc.gp_estimate_from_alpha(h, X, Xs, T(fx["alpha"]), T(fx["Kinv"]))
+    assert relerr(mu, fx["mu"]) < 1e-12
+    assert np.max(np.abs(var.numpy() - fx["var"])) < 1e-12 * max(1.0, np.max(np.abs(fx["diag"])))
+
+
+def test_sod_indices_exact(golden):
+    fx = golden("sod")
+    h = hyper(fx["lengthscales"], float(fx["sigma_n"]))
+    X, Y = T(fx["X"]), T(fx["Y"])
+    thr = float(fx["thr_rel_factor"]) * torch.sqrt(h.sigma_n_2())
+    assert abs(float(thr) - float(fx["thr_rel"])) < 1e-15
+    assert orc.gp_get_sod(h, X, Y, thr) == [int(i) for i in fx["idx_rel"]]
+    assert orc.gp_get_sod(h, X, Y, float(fx["thr_abs"])) == [int(i) for i in fx["idx_abs"]]
+    # decisions were not knife-edge: the oracle's own rounding cannot flip them
+    assert fx["min_margin"].min() > 1e-8
+
+
+def test_next_state_step(golden):
+    fx = golden("step_se")
+    for from_cache in (True, False):
+        m = oracle_model(fx, "se", from_cache=from_cache)
+        nxt, mu, var = orc.next_state(m, T(fx["x"]), T(fx["u"]), T(fx["eps"]))
+        tol = 1e-12 if from_cache else 1e-9
+        assert np.max(np.abs(mu.numpy() - fx["mu"])) < tol
+        assert np.max(np.abs(var.numpy() - fx["var"])) < tol
+        assert np.max(np.abs(nxt.numpy() - fx["next"])) < tol
+        nm, _, _ = orc.next_state(m, T(fx["x"]), T(fx["u"]), None, particle_pred=False)
+        assert np.max(np.abs(nm.numpy() - fx["next_mean"])) < tol
+
+
+def test_pretrain_matches_reference_cache(golden):
+    fx = golden("step_se")
+    m = oracle_model(fx, "se", from_cache=False)
+    for g in range(2):
+        assert relerr(m.cache[g].Kinv, fx["Kinv%d" % g]) < 1e-9
+        assert relerr(m.cache[g].alpha, fx["alpha%d" % g]) < 1e-9
+    fx = golden("rollout_se_sod")
+    m = oracle_model(fx, "se", from_cache=False, sod=True)
+    for g in range(2):
+        assert m.cache[g].sod == [int(i) for i in fx["sod%d" % g]]
+        assert relerr(m.cache[g].Kinv, fx["Kinv%d" % g]) < 1e-9
+
+
+@pytest.mark.parametrize("pre,kind", [("plain", "plain"), ("ang", "angles"), ("traj", "traj")])
+def test_policy_forward(golden, pre, kind):
+    fx = golden("policy")
+    um = fx[pre + "_umax"]
+    um = float(um) if um.ndim == 0 else [float(v) for v in um]
+    pp = orc.PolicyPar(torch.log(T(fx[pre + "_ls"])), T(fx[pre + "_centers"]), T(fx[pre + "_weight"]), um, kind,
+                       angle=[2], non_angle=[0, 1, 3], target_traj=T(fx["traj_target"]) if kind == "traj" else None)
+    t = int(fx["traj_t"]) if kind == "traj" else 0
+    x = T(fx[pre + "_x"])
+    assert relerr(orc.policy_forward(pp, x, t), fx[pre + "_u0"]) < 1e-12
+    assert relerr(orc.policy_forward(pp, x, t, T(fx[pre + "_mask"]), 0.25), fx[pre + "_u25"]) < 1e-12
+
+
+def test_costs(golden):
+    fx = golden("cost")
+    st = T(fx["cp_states"]).requires_grad_(True)
+    c, s = orc.expected_cost(orc.cart_pole_cost(st, T([np.pi, 0.0]), T([3.0, 1.0]), 2, 0))
+    c.backward()
+    assert abs(float(c) - float(fx["cp_cost"])) < 1e-12 * abs(float(fx["cp_cost"]))
+    assert abs(float(s) - float(fx["cp_std"])) < 1e-12 * abs(float(fx["cp_std"]))
+    assert relerr(st.grad, fx["cp_grad"]) < 1e-12
+    st = T(fx["tr_states"]).requires_grad_(True)
+    c, s = orc.expected_cost(orc.traj_cost(st, T(fx["tr_target"]), T(fx["tr_ls"])))
+    c.backward()
+    assert abs(float(c) - float(fx["tr_cost"])) < 1e-12 * abs(float(fx["tr_cost"]))
+    assert abs(float(s) - float(fx["tr_std"])) < 1e-12 * abs(float(fx["tr_std"]))
+    assert relerr(st.grad, fx["tr_grad"]) < 1e-12
+
+
+@pytest.mark.parametrize("name,kind", ROLLOUT_FIXTURES)
+def test_rollout_cost_gradient(golden, name, kind):
+    fx = golden(name)
+    m = oracle_model(fx, kind, from_cache=True)
+    pp = oracle_policy(fx, kind)
+    x0 = orc.sample_x0(T(fx["x0_mean"]), T(fx["x0_var"]), fx["eps0"].shape[0], T(fx["eps0"]))
+    assert np.array_equal(x0.numpy(), fx["states"][0])  # bit-exact x0
+    Tn = fx["states"].shape[0]
+    p = float(fx["p_drop"])
+    masks = T(fx["masks"]) if "masks" in fx else None
+    cost, std, g, st, inp = orc.policy_grad_step(m, pp, x0, Tn, oracle_cost_fn(fx, kind), p, T(fx["eps"]), masks)
+    long = Tn > 12
+    assert np.max(np.abs(st.numpy() - fx["states"])) < (1e-6 if long else 1e-9)
+    assert np.max(np.abs(inp.numpy() - fx["inputs"])) < (1e-6 if long else 1e-9)
+    assert abs(float(cost) - float(fx["cost"])) < (1e-8 if long else 1e-11) * abs(float(fx["cost"]))
+    assert abs(float(std) - float(fx["std"])) < (1e-7 if long else 1e-10) * max(abs(float(fx["std"])), 1e-3)
+    gt = 1e-6 if long else 1e-8
+    assert relerr(g["log_ls"], fx["g_log_ls"]) < gt
+    assert relerr(g["centers"], fx["g_centers"]) < gt
+    assert relerr(g["weight"], fx["g_weight"]) < gt
+
+
+def test_noise_draw_order_matches_reference(golden):
+    """oracle.draw_noise consumes the torch CPU generator exactly like MC_PILCO.apply_policy."""
+    fx = golden("rollout_se")
+    M, S = fx["eps0"].shape
+    Tn, _, B = fx["masks"].shape
+    torch.manual_seed(101)
+    e0, eps, masks = orc.draw_noise(M, S, 2, B, Tn, float(fx["p_drop"]))
+    assert np.array_equal(e0.numpy(), fx["eps0"])
+    assert np.array_equal(eps.numpy(), fx["eps"])
+    assert np.array_equal(masks.numpy().astype(np.uint8), fx["masks"])
+
+
+def test_initial_distributions(golden):
+    fx = golden("init_dists")
+    torch.manual_seed(int(fx["mg_seed"]))
+    idx = torch.randint(0, fx["means"].shape[0], [fx["mg_x0"].shape[0]])
+    assert np.array_equal(idx.numpy(), fx["mg_idx"])  # indices bit-exact
+    e0 = torch.empty(fx["mg_x0"].shape, dtype=torch.float64).normal_()
+    x0 = T(fx["means"])[idx] + torch.sqrt(T(fx["vars"])[idx]) * e0
+    assert np.array_equal(x0.numpy(), fx["mg_x0"])
+    torch.manual_seed(int(fx["un_seed"]))
+    r = torch.rand(fx["un_x0"].shape, dtype=torch.float64)
+    xu = T(fx["lb"]) + r * (T(fx["ub"]) - T(fx["lb"]))
+    assert np.array_equal(xu.numpy(), fx["un_x0"])
