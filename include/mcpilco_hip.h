@@ -1,0 +1,218 @@
+/*
+ * mcpilco_hip.h -- C ABI of libmcpilco_hip.so (gfx950 / MI355X).
+ *
+ * The reference (merlresearch/MC-PILCO) is pure Python on PyTorch and has no FFI of its own;
+ * its extension mechanism is constructor injection of Python classes.  This header is the
+ * boundary a maintainer would bind with ctypes underneath those classes:
+ * every entry point names the reference function(s) it replaces as file:line relative to
+ * the reference root.
+ *
+ * Conventions
+ *   - all matrices float64, row-major, contiguous; every pointer is a DEVICE pointer unless
+ *     the parameter is a `const mcp_*` descriptor struct (host memory, copied at launch);
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it; nothing here
+ *     allocates, frees or synchronises (graph-capture safe) -- scratch comes from the caller
+ *     through `workspace` (size from the matching *_workspace_bytes query);
+ *   - return value: MCP_OK (0) or a negative MCP_ERR_* for arguments the kernels cannot take;
+ *     never throws.  Numerical trouble is data, not an error: kernels OR bit flags into the
+ *     device word `status` (MCP_STATUS_*), which the host may read after synchronising
+ *     (reference behaviour: NaN cost -> retry, policy_learning/MC_PILCO.py:479-501,573-607);
+ *   - re-entrant per stream; the caller owns every buffer.
+ */
+#ifndef MCPILCO_HIP_H
+#define MCPILCO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCP_ABI_VERSION 1
+
+#define MCP_OK 0
+#define MCP_ERR_ARG (-1)       /* null pointer / non-positive size                       */
+#define MCP_ERR_LIMIT (-2)     /* a dimension exceeds a compiled limit (MCP_MAX_*)        */
+#define MCP_ERR_WORKSPACE (-3) /* workspace too small                                     */
+#define MCP_ERR_LAUNCH (-4)    /* hipLaunchKernel reported an error                       */
+
+#define MCP_STATUS_NAN 1u         /* a NaN was produced in a state / input / cost          */
+#define MCP_STATUS_NONPOS_VAR 2u  /* a GP posterior variance <= 0 (torch Normal would raise) */
+#define MCP_STATUS_NOT_SPD 4u     /* Cholesky met a non-positive pivot                     */
+
+#define MCP_MAX_GP 8
+#define MCP_MAX_STATE 16
+#define MCP_MAX_INPUT 8
+#define MCP_MAX_GPDIM 32   /* D  : GP input dimension                                   */
+#define MCP_MAX_PFEAT 32   /* P  : policy feature dimension                             */
+#define MCP_MAX_BASIS 1024 /* B  : policy basis functions                               */
+#define MCP_MAX_TRAIN 1024 /* N  : training points kept per GP (fused rollout kernels)  */
+
+/* Kernel hyper-parameters of one GP: squared-exponential (+ Volterra polynomial of degree
+ * 0, 1 or 2) -- gpr_lib/GP_prior/Stationary_GP.py:112-181 (RBF), gpr_lib/GP_prior/Sparse_GP.py:
+ * 559-737 (MPK_GP, get_Volterra_MPK_GP), gpr_lib/GP_prior/GP_prior.py:299-347 (Sum_Independent_GP).
+ * k(a,b) = lambda * exp(-sum_d ((a_d-b_d)/l_d)^2)                     (no factor 1/2)
+ *        + [deg>=1] sum_d w1_d a_d b_d + w1_D                         (MPK_1, offset feature)
+ *        + [deg==2] (sum_d w20_d a_d b_d) * (sum_d w21_d a_d b_d)     (MPK_2)
+ * where w = s^2 and s_d=(k-d)*exp(par) as the reference's get_Sigma builds it (host side). */
+typedef struct mcp_kernel {
+  int32_t D;
+  int32_t poly_deg;       /* 0, 1, 2                                                   */
+  double lambda;          /* exp(log_lambda_par)                                       */
+  double sigma_n2;        /* exp(sigma_n_log)^2 + sigma_n_num^2 (GP_prior.py:87-89)    */
+  double mean;            /* constant prior mean (RBF.mean_par)                        */
+  const double* inv_ls;   /* [D]      1/lengthscale                                    */
+  const double* w1;       /* [D+1]    MPK_1 weights s^2 (NULL when poly_deg==0)        */
+  const double* w20;      /* [D]      MPK_2 first-factor weights  (NULL unless deg==2) */
+  const double* w21;      /* [D]      MPK_2 second-factor weights                      */
+} mcp_kernel;
+
+/* One pretrained GP = what Model_learning.pretrain_gp caches (model_learning/Model_learning.py:
+ * 163-208: gp_inputs_tr_list, alpha_list, K_X_inv_list) in the kernels' layout.            */
+typedef struct mcp_gp {
+  mcp_kernel kern;
+  int32_t N;              /* training points kept (all, or the SOD subset)             */
+  int32_t Npad;           /* row pitch of X^T / Kinv, multiple of 16, >= N             */
+  const double* Xt;       /* [D][Npad]    training inputs, transposed, zero padded     */
+  const double* X;        /* [Npad][D]    same, row-major, zero padded                 */
+  const double* alpha;    /* [Npad]       K^-1 (Y - m), zero padded                    */
+  const double* Kinv;     /* [Npad][Npad] (K + sigma_n^2 I)^-1, symmetric, zero padded */
+  const double* aX;       /* [D]          sum_j alpha_j X_jd (used when poly_deg>=1)   */
+} mcp_gp;
+
+/* Speed-integration dynamics model -- Speed_Model_learning_RBF(_MPK)_angle_state,
+ * model_learning/Model_learning.py:619-760.  GP g predicts the change of state vel[g];
+ * not_vel[g] is the matching position.  GP input z=[x[not_angle], sin x[angle], cos x[angle], u]. */
+typedef struct mcp_model {
+  int32_t S, U, G, D;
+  int32_t n_angle, n_not_angle;
+  int32_t angle[MCP_MAX_STATE];
+  int32_t not_angle[MCP_MAX_STATE];
+  int32_t vel[MCP_MAX_GP];
+  int32_t not_vel[MCP_MAX_GP];
+  double Ts;
+  double var_scale[MCP_MAX_GP]; /* norm_list[g]^2 (Model_learning.py:220-221), 1 by default */
+  mcp_gp gp[MCP_MAX_GP];
+} mcp_model;
+
+#define MCP_POLICY_PLAIN 0  /* Sum_of_gaussians                        policy_learning/Policy.py:153-265 */
+#define MCP_POLICY_ANGLES 1 /* Sum_of_gaussians_with_angles            Policy.py:268-335  s=[x_na,cos,sin] */
+#define MCP_POLICY_TRAJ 2   /* Sum_of_gaussians_with_target_trajectory Policy.py:338-403  s=[x, x*_t-x]    */
+
+typedef struct mcp_policy {
+  int32_t kind;
+  int32_t S;              /* state dim of the system                                   */
+  int32_t P;              /* feature dim (state_dim of the RBF network)                */
+  int32_t B, U;
+  int32_t squash;         /* flg_squash                                                */
+  int32_t n_angle, n_non_angle;
+  int32_t angle[MCP_MAX_STATE];
+  int32_t non_angle[MCP_MAX_STATE];
+  int32_t traj_len;       /* rows of target_traj                                       */
+  double p_drop;          /* dropout probability (0 -> no mask, no draw)               */
+  const double* log_ls;   /* [P]     log_lengthscales                                  */
+  const double* centers;  /* [B][P]                                                    */
+  const double* weight;   /* [U][B]  f_linear.weight (no bias)                         */
+  const double* u_max;    /* [U]                                                       */
+  const double* target_traj; /* [traj_len][S] or NULL                                  */
+} mcp_policy;
+
+/* Where the rollout's random numbers come from.  Parity mode: the host draws them with the
+ * reference's own torch calls (SURVEY 8c order) and passes buffers.  Performance mode:
+ * eps==NULL / masks==NULL -> Philox4x32-10 keyed by (seed, call) and counted by GLOBAL particle
+ * id (m + particle_offset), so a sharded run draws the same numbers as a single-GPU run. */
+typedef struct mcp_noise {
+  const double* eps;      /* [T-1][M][G] standard normals, or NULL                     */
+  const uint8_t* masks;   /* [T][M][B]   dropout keep-masks {0,1}, or NULL             */
+  uint64_t seed;
+  uint64_t call;          /* increments once per rollout so draws never repeat         */
+  int64_t particle_offset;
+} mcp_noise;
+
+/* ---- library ------------------------------------------------------------------------ */
+int mcp_abi_version(void);
+const char* mcp_build_info(void);
+
+/* ---- pretrain: Gram / Cholesky / inverse / alpha -------------------------------------- */
+/* K[i][j] = k(X1_i, X2_j) (+ sigma_n2 on the diagonal when add_noise and X2==X1 semantics).
+ * Replaces RBF.get_covariance (Stationary_GP.py:162-170), MPK_GP/Linear_GP.get_covariance
+ * (Sparse_GP.py:426-441,625-646), Sum_Independent_GP.get_covariance (GP_prior.py:314-335). */
+int mcp_cov_build(const mcp_kernel* kern, int N1, const double* X1, int N2, const double* X2, int add_noise,
+                  double* K, int ldk, void* stream);
+/* diag k(x_i,x_i) -- get_diag_covariance (Stationary_GP.py:172-181, Sparse_GP.py:443-453,658-668,
+ * GP_prior.py:337-347). */
+int mcp_cov_diag(const mcp_kernel* kern, int N, const double* X, int add_noise, double* diag, void* stream);
+/* In place: A (symmetric, upper triangle read) -> U upper with A = U^T U; strictly-lower part
+ * zeroed; logdet = 2 sum log U_ii.  torch.cholesky(K, upper=True) + log_det, GP_prior.py:106-107. */
+int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32_t* status, void* stream);
+/* Uinv = U^-1 (upper) and Kinv = Uinv Uinv^T.  torch.inverse(U), GP_prior.py:109-110. */
+int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream);
+/* alpha = Kinv (Y - mean).  GP_prior.get_alpha, GP_prior.py:130-135. */
+int mcp_gp_alpha(int N, const double* Kinv, int ldk, const double* Y, double mean, double* alpha, void* stream);
+/* Greedy subset-of-data selection on the device, GP_prior.get_SOD (GP_prior.py:232-257):
+ * idx_out[0..*n_out) receives the kept sample indices (ascending, bit-exact contract).
+ * workspace: mcp_sod_workspace_bytes(N). */
+size_t mcp_sod_workspace_bytes(int N);
+int mcp_sod_select(const mcp_kernel* kern, int N, const double* X, double threshold, int32_t* idx_out, int32_t* n_out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* Packs pretrain outputs into the mcp_gp layout (padding, transposes, aX). */
+int mcp_gp_pack(int N, int D, const double* X, const double* alpha, const double* Kinv, int ldk, int Npad, double* Xt_out,
+                double* X_out, double* alpha_out, double* Kinv_out, double* aX_out, void* stream);
+
+/* ---- single-step GP posterior (GP_prior.get_estimate_from_alpha, GP_prior.py:137-155) -- */
+/* mu[M], var[M] at test inputs Z [M][D]; Jmu/Jvar [M][D] = d mu/dz, d var/dz (NULL to skip). */
+int mcp_posterior_fwd(const mcp_gp* gp, int M, const double* Z, double* mu, double* var, double* Jmu, double* Jvar,
+                      uint32_t* status, void* stream);
+/* gZ[m][d] = gmu[m]*Jmu[m][d] + gvar[m]*Jvar[m][d]  (adjoint of the above). */
+int mcp_posterior_bwd(int M, int D, const double* gmu, const double* gvar, const double* Jmu, const double* Jvar, double* gZ,
+                      void* stream);
+
+/* ---- fused particle rollout (MC_PILCO.apply_policy, policy_learning/MC_PILCO.py:615-674:
+ * T-loop of Model_learning.get_next_state (Model_learning.py:210-229,685-718) and the policy
+ * forward (Policy.py:242-265,323-335,389-403)) ----------------------------------------- */
+size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_policy* policy, int M, int T);
+/* x0 [M][S] -> states [T][M][S], inputs [T][M][U].  jac [T-1][M][G][D] (d delta_g/d z, sampling
+ * included) is written when non-NULL and is what mcp_rollout_bwd consumes.
+ * particle_pred==0 -> delta = posterior mean (Model_learning.py:707-708).  T==1 evaluates the
+ * policy only (Policy.forward). */
+int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
+                    const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
+                    size_t workspace_bytes, void* stream);
+/* Reverse-time adjoint of the rollout: given dJ/dstates, dJ/dinputs (either may be NULL) returns
+ * dJ/d{log_lengthscales [P], centers [B][P], f_linear.weight [U][B]} (overwritten, this rank's
+ * particles only) and optionally dJ/dx0 [M][S].  Replaces autograd's backward through
+ * MC_PILCO.py:522. */
+int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T,
+                    const double* states, const double* inputs, const double* jac, const double* g_states,
+                    const double* g_inputs, double* g_log_ls, double* g_centers, double* g_weight, double* g_x0,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- cost (policy_learning/Cost_function.py) ------------------------------------------ */
+#define MCP_COST_CARTPOLE 0 /* cart_pole_cost, Cost_function.py:170-182                          */
+#define MCP_COST_TRAJ 1     /* saturated_distance_from_trajectory, Cost_function.py:124-147      */
+typedef struct mcp_cost {
+  int32_t kind;
+  int32_t S;
+  int32_t angle_index, pos_index;       /* cart-pole                                    */
+  double target_angle, target_pos;      /* target_state = [theta*, x*]                  */
+  double ls_angle, ls_pos;              /* lengthscales = [l_theta, l_x]                */
+  int32_t n_used;                       /* trajectory cost: used_indeces                */
+  int32_t used[MCP_MAX_STATE];
+  const double* target_traj;            /* [T][S]                                       */
+  const double* lengthscales;           /* [n_used]                                     */
+} mcp_cost;
+/* costs[t][m] = c(x_{t,m});  moments[t] = {mean_m c, sum_m (c-mean)^2} over THIS rank's M
+ * particles (two-pass, as torch.mean/torch.std do; Cost_function.py:32-36). */
+int mcp_cost_fwd(const mcp_cost* cost, int T, int M, const double* states, double* costs, double* moments, uint32_t* status,
+                 void* stream);
+/* Pools R ranks' moments [R][T][2] with counts[R] (host array) and writes out[0]=sum_t mean,
+ * out[1]=sum_t unbiased std.  R==1 on a single GPU. */
+int mcp_cost_finalize(int T, int R, const double* moments, const int64_t* counts, double* out, void* stream);
+/* g_states[t][m][:] = gscale * d c/d x  (gscale = upstream grad / M_total). */
+int mcp_cost_bwd(const mcp_cost* cost, int T, int M, const double* states, double gscale, double* g_states, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCPILCO_HIP_H */

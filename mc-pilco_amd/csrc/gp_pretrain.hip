@@ -1,0 +1,349 @@
+// Gram / Cholesky / triangular inverse / alpha / packing / subset-of-data selection for gfx950.
+// Replaces GP_prior.forward, get_alpha and get_SOD of the reference (gpr_lib/GP_prior/GP_prior.py:
+// 91-135, 232-257) and the kernel classes' get_covariance (Stationary_GP.py:162-170,
+// Sparse_GP.py:426-441,625-646, GP_prior.py:314-335).  These run once per GP per trial
+// (Model_learning.pretrain_gp), so they are written for clarity and fp64 accuracy; the
+// per-step hot path is rollout.hip.
+#include "mcp_device.h"
+
+using namespace mcp;
+
+// ---------------------------------------------------------------------------------------
+// covariance matrices
+// ---------------------------------------------------------------------------------------
+__global__ void cov_build_kernel(mcp_kernel kn, int N1, const double* __restrict__ X1, int N2, const double* __restrict__ X2,
+                                 int add_noise, double* __restrict__ K, int ldk) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = blockIdx.y;
+  if (i >= N1 || j >= N2) return;
+  double k = kern_eval(kn, X1 + (size_t)i * kn.D, 1, X2 + (size_t)j * kn.D, 1);
+  if (add_noise && i == j) k += kn.sigma_n2;
+  K[(size_t)i * ldk + j] = k;
+}
+
+__global__ void cov_diag_kernel(mcp_kernel kn, int N, const double* __restrict__ X, int add_noise, double* __restrict__ diag) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double k = kern_diag(kn, X + (size_t)i * kn.D, 1);
+  diag[i] = add_noise ? k + kn.sigma_n2 : k;
+}
+
+// ---------------------------------------------------------------------------------------
+// Cholesky A = U^T U, upper, in place, one workgroup, blocked right-looking (NB = 16):
+//   per block row kb:  (1) 16x16 diagonal block factored in LDS by wave 0,
+//                      (2) row panel U[kb:kb+16, kb+16:N] = U_kk^-T A[...]  (thread per column),
+//                          kept in LDS for (3) the trailing update A[i][j] -= sum_m U[m][i] U[m][j].
+// ---------------------------------------------------------------------------------------
+#define CH_NB 16
+#define CH_NT 1024
+
+__global__ __launch_bounds__(CH_NT) void chol_factor_kernel(int N, double* __restrict__ A, int lda, double* __restrict__ logdet,
+                                                            uint32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* dg = smem;                     // [NB][NB+1] diagonal block
+  double* pn = smem + CH_NB * (CH_NB + 1);  // [NB][N] row panel
+  const int tid = threadIdx.x;
+  double ld_acc = 0.0;  // thread 0 only
+  uint32_t bad = 0;
+
+  for (int kb = 0; kb < N; kb += CH_NB) {
+    const int nb = min(CH_NB, N - kb);
+    // (1) diagonal block -> LDS, factor with the first nb lanes of wave 0
+    if (tid < CH_NB * CH_NB) {
+      int r = tid / CH_NB, c = tid % CH_NB;
+      dg[r * (CH_NB + 1) + c] = (r < nb && c < nb && c >= r) ? A[(size_t)(kb + r) * lda + kb + c] : 0.0;
+    }
+    __syncthreads();
+    if (tid < MCP_WAVE) {
+      volatile double* dgv = dg;  // single-wave section: LDS accesses must stay in program order
+      for (int k = 0; k < nb; ++k) {
+        double d = dgv[k * (CH_NB + 1) + k];
+        if (!(d > 0.0)) bad |= MCP_STATUS_NOT_SPD;
+        double sd = sqrt(d);
+        if (tid == 0) ld_acc += log(sd);
+        // scale row k, then rank-1 update of the rows below (lanes <-> columns)
+        double ukc = 0.0;
+        if (tid < nb && tid >= k) {
+          ukc = (tid == k) ? sd : dgv[k * (CH_NB + 1) + tid] / sd;
+          dgv[k * (CH_NB + 1) + tid] = ukc;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (tid < nb && tid > k) {
+          for (int r = k + 1; r <= tid; ++r) dgv[r * (CH_NB + 1) + tid] = dgv[r * (CH_NB + 1) + tid] - dgv[k * (CH_NB + 1) + r] * ukc;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    // write the factored diagonal block back (and zero below the diagonal)
+    if (tid < CH_NB * CH_NB) {
+      int r = tid / CH_NB, c = tid % CH_NB;
+      if (r < nb && c < nb) A[(size_t)(kb + r) * lda + kb + c] = (c >= r) ? dg[r * (CH_NB + 1) + c] : 0.0;
+    }
+    const int j0 = kb + nb;
+    const int nc = N - j0;
+    // (2) panel solve: column j of the panel solves U_kk^T x = a  (forward substitution)
+    for (int c = tid; c < nc; c += CH_NT) {
+      double x[CH_NB];
+#pragma unroll
+      for (int r = 0; r < CH_NB; ++r) {
+        if (r < nb) {
+          double s = A[(size_t)(kb + r) * lda + j0 + c];
+          for (int m = 0; m < r; ++m) s = fma(-dg[m * (CH_NB + 1) + r], x[m], s);
+          x[r] = s / dg[r * (CH_NB + 1) + r];
+          A[(size_t)(kb + r) * lda + j0 + c] = x[r];
+          pn[(size_t)r * nc + c] = x[r];
+        }
+      }
+    }
+    __syncthreads();
+    // (3) trailing update over the upper triangle (i <= j): flat index space so that every thread
+    //     has several independent read-modify-writes in flight
+    for (int idx = tid; idx < nc * nc; idx += CH_NT) {
+      int i = idx / nc, j = idx - i * nc;
+      if (j < i) continue;
+      double s = A[(size_t)(j0 + i) * lda + j0 + j];
+#pragma unroll
+      for (int m = 0; m < CH_NB; ++m)
+        if (m < nb) s = fma(-pn[(size_t)m * nc + i], pn[(size_t)m * nc + j], s);
+      A[(size_t)(j0 + i) * lda + j0 + j] = s;
+    }
+    __syncthreads();
+  }
+  // zero the strictly-lower part that lies outside the diagonal blocks
+  for (int idx = tid; idx < N * N; idx += CH_NT) {
+    int r = idx / N, c = idx % N;
+    if (c < r && (c / CH_NB) != (r / CH_NB)) A[(size_t)r * lda + c] = 0.0;
+  }
+  if (tid == 0) *logdet = 2.0 * ld_acc;
+  if (bad) atomicOr(status, bad);
+}
+
+// ---------------------------------------------------------------------------------------
+// Uinv = U^-1 : one thread per column, rows swept bottom-up with the row of U broadcast from LDS
+// ---------------------------------------------------------------------------------------
+#define TI_NT 64
+__global__ __launch_bounds__(TI_NT) void tri_inverse_kernel(int N, const double* __restrict__ U, int ldu, double* __restrict__ Ui,
+                                                            int ldi) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [N] one row of U
+  const int j = blockIdx.x * TI_NT + threadIdx.x;                // my column
+  const int jmax = min(N - 1, blockIdx.x * TI_NT + TI_NT - 1);   // last column of this block
+  for (int i = jmax; i >= 0; --i) {
+    __syncthreads();
+    for (int m = i + threadIdx.x; m <= jmax; m += TI_NT) smem[m] = U[(size_t)i * ldu + m];
+    __syncthreads();
+    if (j < N) {
+      double x;
+      if (j < i) {
+        x = 0.0;
+      } else {
+        double s0 = (j == i) ? 1.0 : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int m = i + 1;
+        for (; m + 3 <= j; m += 4) {
+          s0 = fma(-smem[m], Ui[(size_t)m * ldi + j], s0);
+          s1 = fma(-smem[m + 1], Ui[(size_t)(m + 1) * ldi + j], s1);
+          s2 = fma(-smem[m + 2], Ui[(size_t)(m + 2) * ldi + j], s2);
+          s3 = fma(-smem[m + 3], Ui[(size_t)(m + 3) * ldi + j], s3);
+        }
+        for (; m <= j; ++m) s0 = fma(-smem[m], Ui[(size_t)m * ldi + j], s0);
+        x = ((s0 + s1) + (s2 + s3)) / smem[i];
+      }
+      Ui[(size_t)i * ldi + j] = x;
+    }
+  }
+  // rows below the block's last column are zero for these columns
+  if (j < N)
+    for (int i = jmax + 1; i < N; ++i) Ui[(size_t)i * ldi + j] = 0.0;
+}
+
+// Kinv[i][j] = sum_{m >= max(i,j)} Ui[i][m] Ui[j][m]
+__global__ void kinv_from_uinv_kernel(int N, const double* __restrict__ Ui, int ldi, double* __restrict__ Kinv, int ldk) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = blockIdx.y;
+  if (i >= N || j >= N) return;
+  int m0 = max(i, j);
+  const double* a = Ui + (size_t)i * ldi;
+  const double* b = Ui + (size_t)j * ldi;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int m = m0;
+  for (; m + 3 < N; m += 4) {
+    s0 = fma(a[m], b[m], s0);
+    s1 = fma(a[m + 1], b[m + 1], s1);
+    s2 = fma(a[m + 2], b[m + 2], s2);
+    s3 = fma(a[m + 3], b[m + 3], s3);
+  }
+  for (; m < N; ++m) s0 = fma(a[m], b[m], s0);
+  Kinv[(size_t)i * ldk + j] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ void gp_alpha_kernel(int N, const double* __restrict__ Kinv, int ldk, const double* __restrict__ Y, double mean,
+                                double* __restrict__ alpha) {
+  // one wave per row: lanes stride the columns, DPP reduction
+  int row = blockIdx.x * (blockDim.x / MCP_WAVE) + (threadIdx.x / MCP_WAVE);
+  int lane = threadIdx.x % MCP_WAVE;
+  if (row >= N) return;
+  double s = 0.0;
+  for (int m = lane; m < N; m += MCP_WAVE) s = fma(Kinv[(size_t)row * ldk + m], Y[m] - mean, s);
+  s = wave_sum(s);
+  if (lane == 0) alpha[row] = s;
+}
+
+__global__ void gp_pack_kernel(int N, int D, const double* __restrict__ X, const double* __restrict__ alpha,
+                               const double* __restrict__ Kinv, int ldk, int Npad, double* __restrict__ Xt_out,
+                               double* __restrict__ X_out, double* __restrict__ alpha_out, double* __restrict__ Kinv_out,
+                               double* __restrict__ aX_out) {
+  size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t idx = gid; idx < (size_t)Npad * Npad; idx += stride) {
+    int i = (int)(idx / Npad), j = (int)(idx % Npad);
+    Kinv_out[idx] = (i < N && j < N) ? Kinv[(size_t)i * ldk + j] : 0.0;
+  }
+  for (size_t idx = gid; idx < (size_t)Npad * D; idx += stride) {
+    int j = (int)(idx / D), d = (int)(idx % D);
+    double v = j < N ? X[(size_t)j * D + d] : 0.0;
+    X_out[idx] = v;
+    Xt_out[(size_t)d * Npad + j] = v;
+  }
+  for (size_t idx = gid; idx < (size_t)Npad; idx += stride) alpha_out[idx] = idx < (size_t)N ? alpha[idx] : 0.0;
+  if (gid < (size_t)D) {
+    double s = 0.0;
+    for (int j = 0; j < N; ++j) s = fma(alpha[j], X[(size_t)j * D + gid], s);
+    aX_out[gid] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Greedy subset-of-data selection (GP_prior.get_SOD): one wave, incremental Cholesky.
+// Keeps U (upper, K_S + sigma_n^2 I = U^T U) of the current subset in the workspace; a candidate
+// x_i is tested with  var = k(x_i,x_i) - ||w||^2,  U^T w = k_S(x_i)  (== k_S^T (K_S+s I)^-1 k_S),
+// and appended (new column w, new pivot sqrt(k_ii + sigma_n^2 - ||w||^2)) when sqrt(var) > thr.
+// The reference refactors the subset from scratch for every candidate; the decisions are the
+// same comparisons in exact arithmetic and the fixtures record the smallest margin.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MCP_WAVE) void sod_select_kernel(mcp_kernel kn, int N, const double* __restrict__ X, double thr,
+                                                              int32_t* __restrict__ idx_out, int32_t* __restrict__ n_out,
+                                                              double* __restrict__ Uw) {
+  // Uw: [N][N] row-major upper factor of the subset Gram; kv (LDS): right-hand side, then w
+  extern __shared__ __attribute__((aligned(16))) double sod_smem[];
+  volatile double* kv = sod_smem;
+  const int lane = threadIdx.x;
+  int n = 1;
+  if (lane == 0) {
+    idx_out[0] = 0;
+    Uw[0] = sqrt(kern_diag(kn, X, 1) + kn.sigma_n2);
+  }
+  __threadfence_block();
+  for (int i = 1; i < N; ++i) {
+    const double* xi = X + (size_t)i * kn.D;
+    // right-hand side k_S(x_i)
+    for (int s = lane; s < n; s += MCP_WAVE) kv[s] = kern_eval(kn, xi, 1, X + (size_t)idx_out[s] * kn.D, 1);
+    __builtin_amdgcn_wave_barrier();
+    // forward substitution U^T w = kv, column-oriented: after w_s is final, eliminate it from the rest
+    double nrm = 0.0;
+    for (int s = 0; s < n; ++s) {
+      double ws = kv[s] / Uw[(size_t)s * N + s];
+      nrm = fma(ws, ws, nrm);
+      for (int r = s + 1 + lane; r < n; r += MCP_WAVE) kv[r] = fma(-Uw[(size_t)s * N + r], ws, kv[r]);
+      if (lane == 0) kv[s] = ws;
+      __builtin_amdgcn_wave_barrier();
+    }
+    double kii = kern_diag(kn, xi, 1);
+    double var = kii - nrm;
+    if (sqrt(var) > thr) {
+      for (int s = lane; s < n; s += MCP_WAVE) Uw[(size_t)s * N + n] = kv[s];
+      if (lane == 0) {
+        Uw[(size_t)n * N + n] = sqrt(kii + kn.sigma_n2 - nrm);
+        idx_out[n] = i;
+      }
+      n += 1;
+      __threadfence_block();
+    }
+  }
+  if (lane == 0) *n_out = n;
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+static inline bool kernel_ok(const mcp_kernel* k) {
+  return k && k->D > 0 && k->D <= MCP_MAX_GPDIM && k->poly_deg >= 0 && k->poly_deg <= 2 && k->inv_ls &&
+         (k->poly_deg < 1 || k->w1) && (k->poly_deg < 2 || (k->w20 && k->w21));
+}
+
+extern "C" int mcp_cov_build(const mcp_kernel* kern, int N1, const double* X1, int N2, const double* X2, int add_noise, double* K,
+                             int ldk, void* stream) {
+  if (!kernel_ok(kern) || !X1 || !X2 || !K || N1 <= 0 || N2 <= 0 || ldk < N2) return MCP_ERR_ARG;
+  dim3 grid((N2 + 255) / 256, N1);
+  hipLaunchKernelGGL(cov_build_kernel, grid, dim3(256), 0, (hipStream_t)stream, *kern, N1, X1, N2, X2, add_noise, K, ldk);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+extern "C" int mcp_cov_diag(const mcp_kernel* kern, int N, const double* X, int add_noise, double* diag, void* stream) {
+  if (!kernel_ok(kern) || !X || !diag || N <= 0) return MCP_ERR_ARG;
+  hipLaunchKernelGGL(cov_diag_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, *kern, N, X, add_noise, diag);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32_t* status, void* stream) {
+  if (!A || !logdet || !status || N <= 0 || lda < N) return MCP_ERR_ARG;
+  if (N > 1152) return MCP_ERR_LIMIT;  // row panel [16][N] must fit the 160 KiB LDS
+  size_t lds = sizeof(double) * ((size_t)CH_NB * (CH_NB + 1) + (size_t)CH_NB * N);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(CH_NT), lds, (hipStream_t)stream, N, A, lda, logdet, status);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+extern "C" int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream) {
+  if (!U || !Uinv || !Kinv || N <= 0 || ldu < N || ldi < N || ldk < N) return MCP_ERR_ARG;
+  if (N > 16384) return MCP_ERR_LIMIT;
+  hipLaunchKernelGGL(tri_inverse_kernel, dim3((N + TI_NT - 1) / TI_NT), dim3(TI_NT), sizeof(double) * N, (hipStream_t)stream, N, U,
+                     ldu, Uinv, ldi);
+  MCP_LAUNCH_CHECK();
+  dim3 grid((N + 255) / 256, N);
+  hipLaunchKernelGGL(kinv_from_uinv_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, Uinv, ldi, Kinv, ldk);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+extern "C" int mcp_gp_alpha(int N, const double* Kinv, int ldk, const double* Y, double mean, double* alpha, void* stream) {
+  if (!Kinv || !Y || !alpha || N <= 0 || ldk < N) return MCP_ERR_ARG;
+  hipLaunchKernelGGL(gp_alpha_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, Kinv, ldk, Y, mean, alpha);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+extern "C" int mcp_gp_pack(int N, int D, const double* X, const double* alpha, const double* Kinv, int ldk, int Npad, double* Xt_out,
+                           double* X_out, double* alpha_out, double* Kinv_out, double* aX_out, void* stream) {
+  if (!X || !alpha || !Kinv || !Xt_out || !X_out || !alpha_out || !Kinv_out || !aX_out) return MCP_ERR_ARG;
+  if (N <= 0 || D <= 0 || D > MCP_MAX_GPDIM || Npad < N || (Npad % 16) != 0 || ldk < N) return MCP_ERR_ARG;
+  hipLaunchKernelGGL(gp_pack_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, N, D, X, alpha, Kinv, ldk, Npad, Xt_out, X_out,
+                     alpha_out, Kinv_out, aX_out);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+extern "C" size_t mcp_sod_workspace_bytes(int N) { return N > 0 ? sizeof(double) * (size_t)N * N : 0; }
+
+extern "C" int mcp_sod_select(const mcp_kernel* kern, int N, const double* X, double threshold, int32_t* idx_out, int32_t* n_out,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (!kernel_ok(kern) || !X || !idx_out || !n_out || !workspace || N <= 0) return MCP_ERR_ARG;
+  if (workspace_bytes < mcp_sod_workspace_bytes(N)) return MCP_ERR_WORKSPACE;
+  if (N > 16384) return MCP_ERR_LIMIT;  // kv [N] lives in LDS
+  double* Uw = (double*)workspace;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(sod_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sod_select_kernel, dim3(1), dim3(MCP_WAVE), sizeof(double) * N, (hipStream_t)stream, *kern, N, X, threshold,
+                     idx_out, n_out, Uw);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}

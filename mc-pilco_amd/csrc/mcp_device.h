@@ -1,0 +1,150 @@
+// Device-side helpers shared by the gfx950 kernels: wave64 DPP reductions, Philox4x32-10,
+// and the covariance function of include/mcpilco_hip.h's mcp_kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mcpilco_hip.h"
+
+#define MCP_WAVE 64
+
+#define MCP_LAUNCH_CHECK()                                  \
+  do {                                                      \
+    if (hipGetLastError() != hipSuccess) return MCP_ERR_LAUNCH; \
+  } while (0)
+
+namespace mcp {
+
+// ---------------------------------------------------------------------------------------
+// wave64 sum of a double via DPP (gfx9 row_shr / row_bcast controls); result broadcast to
+// every lane through v_readlane of lane 63.  No LDS traffic.
+// ---------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_take<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_take<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_take<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_take<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of each row holds the row sum
+  v += dpp_take<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+  v += dpp_take<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the total
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011), counter-based: draws depend only on
+// (seed, call, global particle, time step, stream, index) -- never on launch geometry.
+// ---------------------------------------------------------------------------------------
+struct u32x4 {
+  uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    u32x4 n;
+    n.x = hi1 ^ c.y ^ k0;
+    n.y = lo1;
+    n.z = hi0 ^ c.w ^ k1;
+    n.w = lo0;
+    c = n;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+#define MCP_STREAM_EPS 0u
+#define MCP_STREAM_MASK 1u
+
+__device__ __forceinline__ u32x4 philox_draw(const mcp_noise& nz, int64_t particle, int t, uint32_t stream, uint32_t index) {
+  uint64_t gp = (uint64_t)(particle + nz.particle_offset);
+  u32x4 c;
+  c.x = (uint32_t)gp;
+  c.y = (uint32_t)(gp >> 32) ^ (stream << 30) ^ ((uint32_t)t << 8);
+  c.z = index;
+  c.w = (uint32_t)nz.call;
+  uint32_t k0 = (uint32_t)nz.seed ^ (uint32_t)(nz.call >> 32);
+  uint32_t k1 = (uint32_t)(nz.seed >> 32);
+  return philox4x32_10(c, k0, k1);
+}
+
+// standard normal for (particle, t, gp index g): Box-Muller on two 52-bit uniforms
+__device__ __forceinline__ double philox_normal(const mcp_noise& nz, int64_t particle, int t, int g) {
+  u32x4 r = philox_draw(nz, particle, t, MCP_STREAM_EPS, (uint32_t)g);
+  const double two_m52 = 2.220446049250313e-16;
+  double u1 = ((double)(((uint64_t)r.x << 20) | (r.y >> 12)) + 0.5) * two_m52;  // (0,1)
+  double u2 = ((double)(((uint64_t)r.z << 20) | (r.w >> 12)) + 0.5) * two_m52;
+  return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+
+// dropout keep decision for (particle, t, basis b): keep with probability 1-p
+__device__ __forceinline__ bool philox_keep(const mcp_noise& nz, int64_t particle, int t, int b, uint32_t drop_thresh) {
+  u32x4 r = philox_draw(nz, particle, t, MCP_STREAM_MASK, (uint32_t)(b >> 2));
+  uint32_t v = (b & 3) == 0 ? r.x : (b & 3) == 1 ? r.y : (b & 3) == 2 ? r.z : r.w;
+  return v >= drop_thresh;
+}
+
+__host__ __device__ inline uint32_t drop_threshold(double p) {
+  double t = p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+}
+
+// ---------------------------------------------------------------------------------------
+// covariance function  k(a, b)  with a, b given as strided vectors (element d at a[d*sa])
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double kern_eval(const mcp_kernel& kn, const double* a, int sa, const double* b, int sb) {
+  double dist = 0.0;
+  for (int d = 0; d < kn.D; ++d) {
+    double r = (a[d * sa] - b[d * sb]) * kn.inv_ls[d];
+    dist = fma(r, r, dist);
+  }
+  double k = kn.lambda * exp(-dist);
+  if (kn.poly_deg >= 1) {
+    double p1 = kn.w1[kn.D];
+    for (int d = 0; d < kn.D; ++d) p1 = fma(kn.w1[d] * a[d * sa], b[d * sb], p1);
+    k += p1;
+    if (kn.poly_deg >= 2) {
+      double pa = 0.0, pb = 0.0;
+      for (int d = 0; d < kn.D; ++d) {
+        double ab = a[d * sa] * b[d * sb];
+        pa = fma(kn.w20[d], ab, pa);
+        pb = fma(kn.w21[d], ab, pb);
+      }
+      k = fma(pa, pb, k);
+    }
+  }
+  return k;
+}
+
+__device__ __forceinline__ double kern_diag(const mcp_kernel& kn, const double* a, int sa) {
+  double k = kn.lambda;
+  if (kn.poly_deg >= 1) {
+    double p1 = kn.w1[kn.D];
+    for (int d = 0; d < kn.D; ++d) p1 = fma(kn.w1[d] * a[d * sa], a[d * sa], p1);
+    k += p1;
+    if (kn.poly_deg >= 2) {
+      double pa = 0.0, pb = 0.0;
+      for (int d = 0; d < kn.D; ++d) {
+        double aa = a[d * sa] * a[d * sa];
+        pa = fma(kn.w20[d], aa, pa);
+        pb = fma(kn.w21[d], aa, pb);
+      }
+      k = fma(pa, pb, k);
+    }
+  }
+  return k;
+}
+
+__device__ __forceinline__ bool is_bad(double v) { return !(fabs(v) <= 1.79769313486231570815e308); }
+
+}  // namespace mcp

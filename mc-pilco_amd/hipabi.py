@@ -1,0 +1,128 @@
+"""ctypes binding of libmcpilco_hip.so -- the C ABI declared in include/mcpilco_hip.h.
+
+The library is the product's only compute path: if it is missing or does not load, importing
+this module's ``lib()`` raises (there is no CPU fallback anywhere in the package).
+PyTorch is used for device memory and streams only: tensors are passed as ``data_ptr()``
+and launches go to ``torch.cuda.current_stream()``.
+"""
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmcpilco_hip.so")
+
+MAX_GP, MAX_STATE, MAX_INPUT, MAX_GPDIM, MAX_PFEAT, MAX_BASIS, MAX_TRAIN = 8, 16, 8, 32, 32, 1024, 1024
+OK = 0
+ERRORS = {-1: "MCP_ERR_ARG", -2: "MCP_ERR_LIMIT", -3: "MCP_ERR_WORKSPACE", -4: "MCP_ERR_LAUNCH"}
+STATUS_NAN, STATUS_NONPOS_VAR, STATUS_NOT_SPD = 1, 2, 4
+POLICY_PLAIN, POLICY_ANGLES, POLICY_TRAJ = 0, 1, 2
+COST_CARTPOLE, COST_TRAJ = 0, 1
+
+dptr = C.c_void_p
+
+
+class Kernel(C.Structure):
+    _fields_ = [("D", C.c_int32), ("poly_deg", C.c_int32), ("lam", C.c_double), ("sigma_n2", C.c_double), ("mean", C.c_double),
+                ("inv_ls", dptr), ("w1", dptr), ("w20", dptr), ("w21", dptr)]
+
+
+class GP(C.Structure):
+    _fields_ = [("kern", Kernel), ("N", C.c_int32), ("Npad", C.c_int32), ("Xt", dptr), ("X", dptr), ("alpha", dptr), ("Kinv", dptr),
+                ("aX", dptr)]
+
+
+class Model(C.Structure):
+    _fields_ = [("S", C.c_int32), ("U", C.c_int32), ("G", C.c_int32), ("D", C.c_int32), ("n_angle", C.c_int32),
+                ("n_not_angle", C.c_int32), ("angle", C.c_int32 * MAX_STATE), ("not_angle", C.c_int32 * MAX_STATE),
+                ("vel", C.c_int32 * MAX_GP), ("not_vel", C.c_int32 * MAX_GP), ("Ts", C.c_double), ("var_scale", C.c_double * MAX_GP),
+                ("gp", GP * MAX_GP)]
+
+
+class Policy(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("S", C.c_int32), ("P", C.c_int32), ("B", C.c_int32), ("U", C.c_int32), ("squash", C.c_int32),
+                ("n_angle", C.c_int32), ("n_non_angle", C.c_int32), ("angle", C.c_int32 * MAX_STATE),
+                ("non_angle", C.c_int32 * MAX_STATE), ("traj_len", C.c_int32), ("p_drop", C.c_double), ("log_ls", dptr),
+                ("centers", dptr), ("weight", dptr), ("u_max", dptr), ("target_traj", dptr)]
+
+
+class Noise(C.Structure):
+    _fields_ = [("eps", dptr), ("masks", dptr), ("seed", C.c_uint64), ("call", C.c_uint64), ("particle_offset", C.c_int64)]
+
+
+class Cost(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("S", C.c_int32), ("angle_index", C.c_int32), ("pos_index", C.c_int32),
+                ("target_angle", C.c_double), ("target_pos", C.c_double), ("ls_angle", C.c_double), ("ls_pos", C.c_double),
+                ("n_used", C.c_int32), ("used", C.c_int32 * MAX_STATE), ("target_traj", dptr), ("lengthscales", dptr)]
+
+
+_SIGS = {
+    "mcp_abi_version": (C.c_int, []),
+    "mcp_build_info": (C.c_char_p, []),
+    "mcp_cov_build": (C.c_int, [C.POINTER(Kernel), C.c_int, dptr, C.c_int, dptr, C.c_int, dptr, C.c_int, dptr]),
+    "mcp_cov_diag": (C.c_int, [C.POINTER(Kernel), C.c_int, dptr, C.c_int, dptr, dptr]),
+    "mcp_chol_factor": (C.c_int, [C.c_int, dptr, C.c_int, dptr, dptr, dptr]),
+    "mcp_chol_inverse": (C.c_int, [C.c_int, dptr, C.c_int, dptr, C.c_int, dptr, C.c_int, dptr]),
+    "mcp_gp_alpha": (C.c_int, [C.c_int, dptr, C.c_int, dptr, C.c_double, dptr, dptr]),
+    "mcp_sod_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "mcp_sod_select": (C.c_int, [C.POINTER(Kernel), C.c_int, dptr, C.c_double, dptr, dptr, dptr, C.c_size_t, dptr]),
+    "mcp_gp_pack": (C.c_int, [C.c_int, C.c_int, dptr, dptr, dptr, C.c_int, C.c_int, dptr, dptr, dptr, dptr, dptr, dptr]),
+    "mcp_posterior_fwd": (C.c_int, [C.POINTER(GP), C.c_int, dptr, dptr, dptr, dptr, dptr, dptr, dptr]),
+    "mcp_posterior_bwd": (C.c_int, [C.c_int, C.c_int, dptr, dptr, dptr, dptr, dptr, dptr]),
+    "mcp_rollout_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(Policy), C.c_int, C.c_int]),
+    "mcp_rollout_fwd": (C.c_int, [C.POINTER(Model), C.POINTER(Policy), C.POINTER(Noise), C.c_int, C.c_int, C.c_int, dptr, dptr, dptr,
+                                  dptr, dptr, dptr, C.c_size_t, dptr]),
+    "mcp_rollout_bwd": (C.c_int, [C.POINTER(Model), C.POINTER(Policy), C.POINTER(Noise), C.c_int, C.c_int, dptr, dptr, dptr, dptr, dptr,
+                                  dptr, dptr, dptr, dptr, dptr, C.c_size_t, dptr]),
+    "mcp_cost_fwd": (C.c_int, [C.POINTER(Cost), C.c_int, C.c_int, dptr, dptr, dptr, dptr, dptr]),
+    "mcp_cost_finalize": (C.c_int, [C.c_int, C.c_int, dptr, C.POINTER(C.c_int64), dptr, dptr]),
+    "mcp_cost_bwd": (C.c_int, [C.POINTER(Cost), C.c_int, C.c_int, dptr, C.c_double, dptr, dptr]),
+    "mcp_debug_set_particles_per_wg": (None, [C.c_int]),
+}
+EXPORTED = [k for k in _SIGS if not k.startswith("mcp_debug")]
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises RuntimeError when it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmcpilco_hip.so is missing (%s): build it with `python mc-pilco_amd/build.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if handle.mcp_abi_version() != 1:
+            raise RuntimeError("libmcpilco_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != OK:
+        raise RuntimeError("%s failed: %s" % (what, ERRORS.get(rc, rc)))
+
+
+def ptr(t):
+    """Device pointer of a contiguous CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("libmcpilco_hip operates on GPU memory only (got a %s tensor); there is no CPU path" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("non-contiguous tensor passed to the HIP ABI")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f64(t, device):
+    return torch.as_tensor(t, dtype=torch.float64).to(device).contiguous()

@@ -1,0 +1,499 @@
+"""Host-side operators over the C ABI (hipabi): descriptor packing, workspaces and the
+torch.autograd.Function wrappers that make the HIP kernels differentiable from Python.
+
+Everything here is plumbing around ``libmcpilco_hip.so``; no arithmetic of the hot path is
+done in PyTorch.  All tensors are float64 on the GPU.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import hipabi as abi
+
+DT = torch.float64
+
+
+def _dev(device=None):
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("mc_pilco_amd runs on the GPU only (device=%s requested); there is no CPU path" % device)
+    return device
+
+
+def _t(x, device):
+    if isinstance(x, torch.Tensor):
+        return x.detach().to(device=device, dtype=DT).contiguous()
+    return torch.as_tensor(np.asarray(x, dtype=np.float64)).to(device).contiguous()
+
+
+def pad16(n):
+    return (int(n) + 15) // 16 * 16
+
+
+# --------------------------------------------------------------------------------------
+# kernel hyper-parameters -> mcp_kernel
+# --------------------------------------------------------------------------------------
+@dataclass
+class KernelSpec:
+    """SE (+ Volterra polynomial) covariance in the library's parametrisation.
+
+    ``w1`` [D+1], ``w20``/``w21`` [D] are the squared diagonal weights the reference's
+    ``MPK_GP.get_Sigma`` builds (Sparse_GP.py:613-623): for MPK_k, factor d has
+    s_d = (k-d)*exp(par[d*n:(d+1)*n]) and weight s_d**2.
+    """
+
+    lengthscales: torch.Tensor  # [D]
+    lam: float
+    sigma_n2: float
+    mean: float = 0.0
+    w1: Optional[torch.Tensor] = None
+    w20: Optional[torch.Tensor] = None
+    w21: Optional[torch.Tensor] = None
+    _keep: list = field(default_factory=list)
+
+    @property
+    def D(self):
+        return int(self.lengthscales.numel())
+
+    @property
+    def poly_deg(self):
+        return 0 if self.w1 is None else (1 if self.w20 is None else 2)
+
+    def to_c(self, device):
+        device = _dev(device)
+        inv_ls = (1.0 / _t(self.lengthscales, device)).contiguous()
+        k = abi.Kernel()
+        k.D = self.D
+        k.poly_deg = self.poly_deg
+        k.lam = float(self.lam)
+        k.sigma_n2 = float(self.sigma_n2)
+        k.mean = float(self.mean)
+        keep = [inv_ls]
+        k.inv_ls = inv_ls.data_ptr()
+        for name in ("w1", "w20", "w21"):
+            v = getattr(self, name)
+            if v is not None:
+                tv = _t(v, device)
+                keep.append(tv)
+                setattr(k, name, tv.data_ptr())
+            else:
+                setattr(k, name, None)
+        self._keep = keep  # device copies must outlive the descriptor
+        return k
+
+
+def mpk_weights(log_par, k):
+    """Squared diagonal weights of MPK_k from its raw log parameters (list over the k factors)."""
+    par = torch.as_tensor(log_par, dtype=DT).reshape(-1)
+    n = par.numel() // k
+    return [((k - d) * torch.exp(par[d * n:(d + 1) * n])) ** 2 for d in range(k)]
+
+
+# --------------------------------------------------------------------------------------
+# pretrain primitives
+# --------------------------------------------------------------------------------------
+def cov_build(spec: KernelSpec, X1, X2=None, noise=False):
+    X1 = _t(X1, X1.device if isinstance(X1, torch.Tensor) else None)
+    dev = X1.device
+    X2t = X1 if X2 is None else _t(X2, dev)
+    K = torch.empty(X1.shape[0], X2t.shape[0], dtype=DT, device=dev)
+    kc = spec.to_c(dev)
+    abi.check(abi.lib().mcp_cov_build(C.byref(kc), X1.shape[0], abi.ptr(X1), X2t.shape[0], abi.ptr(X2t), int(bool(noise)), abi.ptr(K),
+                                      K.shape[1], abi.stream()), "mcp_cov_build")
+    return K
+
+
+def cov_diag(spec: KernelSpec, X, noise=False):
+    X = _t(X, X.device)
+    d = torch.empty(X.shape[0], dtype=DT, device=X.device)
+    kc = spec.to_c(X.device)
+    abi.check(abi.lib().mcp_cov_diag(C.byref(kc), X.shape[0], abi.ptr(X), int(bool(noise)), abi.ptr(d), abi.stream()), "mcp_cov_diag")
+    return d
+
+
+def chol_factor(K):
+    """Returns (U upper with K=U^T U, logdet, status word tensor).  K is not modified."""
+    U = K.detach().clone().contiguous()
+    N = U.shape[0]
+    logdet = torch.zeros(1, dtype=DT, device=U.device)
+    status = torch.zeros(1, dtype=torch.int32, device=U.device)
+    abi.check(abi.lib().mcp_chol_factor(N, abi.ptr(U), U.shape[1], abi.ptr(logdet), abi.ptr(status), abi.stream()), "mcp_chol_factor")
+    return U, logdet[0], status
+
+
+def chol_inverse(U):
+    N = U.shape[0]
+    Ui = torch.zeros(N, N, dtype=DT, device=U.device)
+    Kinv = torch.empty(N, N, dtype=DT, device=U.device)
+    abi.check(abi.lib().mcp_chol_inverse(N, abi.ptr(U), U.shape[1], abi.ptr(Ui), N, abi.ptr(Kinv), N, abi.stream()), "mcp_chol_inverse")
+    return Ui, Kinv
+
+
+def gp_alpha(Kinv, Y, mean=0.0):
+    N = Kinv.shape[0]
+    Y = _t(Y, Kinv.device).reshape(-1)
+    alpha = torch.empty(N, dtype=DT, device=Kinv.device)
+    abi.check(abi.lib().mcp_gp_alpha(N, abi.ptr(Kinv), Kinv.shape[1], abi.ptr(Y), float(mean), abi.ptr(alpha), abi.stream()), "mcp_gp_alpha")
+    return alpha.reshape(-1, 1)
+
+
+def sod_select(spec: KernelSpec, X, threshold) -> List[int]:
+    X = _t(X, X.device)
+    N = X.shape[0]
+    dev = X.device
+    nbytes = abi.lib().mcp_sod_workspace_bytes(N)
+    ws = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev)
+    idx = torch.zeros(N, dtype=torch.int32, device=dev)
+    n = torch.zeros(1, dtype=torch.int32, device=dev)
+    kc = spec.to_c(dev)
+    abi.check(abi.lib().mcp_sod_select(C.byref(kc), N, abi.ptr(X), float(threshold), abi.ptr(idx), abi.ptr(n), abi.ptr(ws), nbytes,
+                                       abi.stream()), "mcp_sod_select")
+    cnt = int(n.item())
+    return [int(i) for i in idx[:cnt].tolist()]
+
+
+# --------------------------------------------------------------------------------------
+# packed GP / model descriptors
+# --------------------------------------------------------------------------------------
+class PackedGP:
+    """Device-resident operands of one pretrained GP in the kernels' layout (mcp_gp)."""
+
+    def __init__(self, spec: KernelSpec, X, alpha, Kinv):
+        dev = _dev(Kinv.device)
+        X = _t(X, dev)
+        alpha = _t(alpha, dev).reshape(-1)
+        Kinv = _t(Kinv, dev)
+        N, D = X.shape
+        self.N, self.D, self.Npad = N, D, pad16(N)
+        self.spec = spec
+        self.Xt = torch.empty(D, self.Npad, dtype=DT, device=dev)
+        self.X = torch.empty(self.Npad, D, dtype=DT, device=dev)
+        self.alpha = torch.empty(self.Npad, dtype=DT, device=dev)
+        self.Kinv = torch.empty(self.Npad, self.Npad, dtype=DT, device=dev)
+        self.aX = torch.empty(D, dtype=DT, device=dev)
+        abi.check(abi.lib().mcp_gp_pack(N, D, abi.ptr(X), abi.ptr(alpha), abi.ptr(Kinv), Kinv.shape[1], self.Npad, abi.ptr(self.Xt),
+                                        abi.ptr(self.X), abi.ptr(self.alpha), abi.ptr(self.Kinv), abi.ptr(self.aX), abi.stream()),
+                  "mcp_gp_pack")
+        self.device = dev
+
+    def fill(self, g: abi.GP):
+        g.kern = self.spec.to_c(self.device)
+        g.N, g.Npad = self.N, self.Npad
+        g.Xt, g.X, g.alpha, g.Kinv, g.aX = (self.Xt.data_ptr(), self.X.data_ptr(), self.alpha.data_ptr(), self.Kinv.data_ptr(),
+                                            self.aX.data_ptr())
+
+    def to_c(self):
+        g = abi.GP()
+        self.fill(g)
+        return g
+
+
+class PackedModel:
+    """mcp_model: the speed-integration dynamics model with its G packed GPs."""
+
+    def __init__(self, gps: Sequence[PackedGP], S, U, Ts, angle, not_angle, vel, not_vel, var_scale=None):
+        self.gps = list(gps)
+        m = abi.Model()
+        m.S, m.U, m.G, m.D = int(S), int(U), len(self.gps), self.gps[0].D
+        m.n_angle, m.n_not_angle = len(angle), len(not_angle)
+        for i, v in enumerate(angle):
+            m.angle[i] = int(v)
+        for i, v in enumerate(not_angle):
+            m.not_angle[i] = int(v)
+        for i, v in enumerate(vel):
+            m.vel[i] = int(v)
+        for i, v in enumerate(not_vel):
+            m.not_vel[i] = int(v)
+        m.Ts = float(Ts)
+        for g in range(abi.MAX_GP):
+            m.var_scale[g] = 1.0 if var_scale is None or g >= len(var_scale) else float(var_scale[g])
+        for g, pg in enumerate(self.gps):
+            pg.fill(m.gp[g])
+        self.c = m
+        self.S, self.U, self.G, self.D = m.S, m.U, m.G, m.D
+        self.device = self.gps[0].device
+
+
+class PackedPolicy:
+    """mcp_policy over the live parameter tensors (no copies: the optimizer's updates are seen)."""
+
+    def __init__(self, kind, S, log_ls, centers, weight, u_max, squash=True, angle=(), non_angle=(), target_traj=None):
+        dev = _dev(centers.device)
+        self.log_ls, self.centers, self.weight = log_ls, centers, weight
+        B, P = centers.shape
+        U = weight.shape[0]
+        um = np.full(U, float(u_max)) if np.isscalar(u_max) else np.asarray(u_max, dtype=np.float64).reshape(-1)
+        self.u_max = _t(um, dev)
+        self.target_traj = None if target_traj is None else _t(target_traj, dev)
+        p = abi.Policy()
+        p.kind = {"plain": abi.POLICY_PLAIN, "angles": abi.POLICY_ANGLES, "traj": abi.POLICY_TRAJ}[kind]
+        p.S, p.P, p.B, p.U, p.squash = int(S), int(P), int(B), int(U), int(bool(squash))
+        p.n_angle, p.n_non_angle = len(angle), len(non_angle)
+        for i, v in enumerate(angle):
+            p.angle[i] = int(v)
+        for i, v in enumerate(non_angle):
+            p.non_angle[i] = int(v)
+        p.traj_len = 0 if self.target_traj is None else int(self.target_traj.shape[0])
+        p.u_max = self.u_max.data_ptr()
+        p.target_traj = None if self.target_traj is None else self.target_traj.data_ptr()
+        self.c = p
+        self.kind, self.S, self.P, self.B, self.U = kind, int(S), int(P), int(B), int(U)
+        self.device = dev
+
+    def bind(self, p_drop):
+        """Refreshes parameter pointers (they must be contiguous fp64 GPU tensors) and p_drop."""
+        for t in (self.log_ls, self.centers, self.weight):
+            if t.dtype != DT or not t.is_cuda or not t.is_contiguous():
+                raise RuntimeError("policy parameters must be contiguous float64 GPU tensors")
+        self.c.log_ls = self.log_ls.data_ptr()
+        self.c.centers = self.centers.data_ptr()
+        self.c.weight = self.weight.data_ptr()
+        self.c.p_drop = float(p_drop)
+        return self.c
+
+
+@dataclass
+class NoiseSpec:
+    """Parity mode: eps [T-1,M,G] float64 and masks [T,M,B] uint8 on the GPU.  Performance mode:
+    both None -> in-kernel Philox keyed by (seed, call) and the global particle id."""
+
+    eps: Optional[torch.Tensor] = None
+    masks: Optional[torch.Tensor] = None
+    seed: int = 0
+    call: int = 0
+    particle_offset: int = 0
+
+    def to_c(self):
+        n = abi.Noise()
+        n.eps = None if self.eps is None else self.eps.data_ptr()
+        n.masks = None if self.masks is None else self.masks.data_ptr()
+        n.seed, n.call, n.particle_offset = int(self.seed) & (2**64 - 1), int(self.call) & (2**64 - 1), int(self.particle_offset)
+        return n
+
+
+# --------------------------------------------------------------------------------------
+# fused rollout (autograd)
+# --------------------------------------------------------------------------------------
+def _check_noise(noise, T, M, G, B, p_drop, particle_pred):
+    if noise.eps is not None:
+        e = noise.eps
+        if e.dtype != DT or not e.is_cuda or not e.is_contiguous() or tuple(e.shape) != (max(T - 1, 0), M, G):
+            raise RuntimeError("eps must be a contiguous float64 GPU tensor of shape [T-1,M,G]")
+    if noise.masks is not None:
+        k = noise.masks
+        if k.dtype != torch.uint8 or not k.is_cuda or not k.is_contiguous() or tuple(k.shape) != (T, M, B):
+            raise RuntimeError("masks must be a contiguous uint8 GPU tensor of shape [T,M,B]")
+
+
+def rollout_forward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseSpec, x0, T, p_drop, particle_pred=True, need_jac=True):
+    dev = model.device
+    x0 = x0.detach().to(device=dev, dtype=DT).contiguous()
+    M = x0.shape[0]
+    _check_noise(noise, T, M, model.G, policy.B, p_drop, particle_pred)
+    states = torch.empty(T, M, model.S, dtype=DT, device=dev)
+    inputs = torch.empty(T, M, model.U, dtype=DT, device=dev)
+    jac = torch.empty(max(T - 1, 1), M, model.G, model.D, dtype=DT, device=dev) if need_jac else None
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    pc = policy.bind(p_drop)
+    nz = noise.to_c()
+    abi.check(abi.lib().mcp_rollout_fwd(C.byref(model.c), C.byref(pc), C.byref(nz), M, T, int(bool(particle_pred)), abi.ptr(x0),
+                                        abi.ptr(states), abi.ptr(inputs), abi.ptr(jac), abi.ptr(status), None, 0, abi.stream()),
+              "mcp_rollout_fwd")
+    return states, inputs, jac, status
+
+
+def rollout_backward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseSpec, states, inputs, jac, g_states, g_inputs, p_drop,
+                         want_gx0=False):
+    dev = model.device
+    T, M = states.shape[0], states.shape[1]
+    pc = policy.bind(p_drop)
+    nz = noise.to_c()
+    nbytes = abi.lib().mcp_rollout_workspace_bytes(C.byref(model.c), C.byref(pc), M, T)
+    ws = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev)
+    g_ls = torch.empty(1, policy.P, dtype=DT, device=dev)
+    g_c = torch.empty(policy.B, policy.P, dtype=DT, device=dev)
+    g_w = torch.empty(policy.U, policy.B, dtype=DT, device=dev)
+    g_x0 = torch.empty(M, model.S, dtype=DT, device=dev) if want_gx0 else None
+    gs = None if g_states is None else g_states.to(dtype=DT).contiguous()
+    gi = None if g_inputs is None else g_inputs.to(dtype=DT).contiguous()
+    abi.check(abi.lib().mcp_rollout_bwd(C.byref(model.c), C.byref(pc), C.byref(nz), M, T, abi.ptr(states), abi.ptr(inputs), abi.ptr(jac),
+                                        abi.ptr(gs), abi.ptr(gi), abi.ptr(g_ls), abi.ptr(g_c), abi.ptr(g_w), abi.ptr(g_x0), abi.ptr(ws),
+                                        nbytes, abi.stream()), "mcp_rollout_bwd")
+    return g_ls, g_c, g_w, g_x0
+
+
+class RolloutFunction(torch.autograd.Function):
+    """(x0, log_lengthscales, centers, weight) -> (states [T,M,S], inputs [T,M,U]) through the fused
+    HIP rollout; backward is the fused reverse-time adjoint.  Gradients flow to the three policy
+    parameters (and x0); the GP model is frozen, as after ``Model_learning.set_eval_mode``."""
+
+    @staticmethod
+    def forward(ctx, x0, log_ls, centers, weight, model, policy, noise, T, p_drop, particle_pred):
+        need = any(ctx.needs_input_grad[:4])
+        states, inputs, jac, status = rollout_forward_raw(model, policy, noise, x0, T, p_drop, particle_pred, need_jac=need)
+        ctx.model, ctx.policy, ctx.noise, ctx.p_drop = model, policy, noise, p_drop
+        ctx.save_for_backward(states, inputs, jac if jac is not None else torch.empty(0, device=states.device))
+        ctx.mark_non_differentiable(status)
+        return states, inputs, status
+
+    @staticmethod
+    def backward(ctx, g_states, g_inputs, _g_status):
+        states, inputs, jac = ctx.saved_tensors
+        g_ls, g_c, g_w, g_x0 = rollout_backward_raw(ctx.model, ctx.policy, ctx.noise, states, inputs, jac, g_states, g_inputs, ctx.p_drop,
+                                                    want_gx0=ctx.needs_input_grad[0])
+        return g_x0, g_ls.reshape(ctx.policy.log_ls.shape), g_c, g_w, None, None, None, None, None, None
+
+
+def rollout(model, policy, noise, x0, T, p_drop=0.0, particle_pred=True):
+    """Differentiable fused rollout.  Returns (states, inputs, status)."""
+    return RolloutFunction.apply(x0, policy.log_ls, policy.centers, policy.weight, model, policy, noise, int(T), float(p_drop),
+                                 bool(particle_pred))
+
+
+# --------------------------------------------------------------------------------------
+# cost (autograd)
+# --------------------------------------------------------------------------------------
+class PackedCost:
+    def __init__(self, kind, S, device, **kw):
+        dev = _dev(device)
+        c = abi.Cost()
+        c.S = int(S)
+        self._keep = []
+        if kind == "cartpole":
+            c.kind = abi.COST_CARTPOLE
+            c.angle_index, c.pos_index = int(kw["angle_index"]), int(kw["pos_index"])
+            ts = [float(v) for v in kw["target_state"]]
+            ls = [float(v) for v in kw["lengthscales"]]
+            c.target_angle, c.target_pos, c.ls_angle, c.ls_pos = ts[0], ts[1], ls[0], ls[1]
+        elif kind == "traj":
+            c.kind = abi.COST_TRAJ
+            used = list(range(S)) if kw.get("used") is None else [int(u) for u in kw["used"]]
+            c.n_used = len(used)
+            for i, u in enumerate(used):
+                c.used[i] = u
+            tt = _t(kw["target_traj"], dev)
+            ls = _t(kw["lengthscales"], dev).reshape(-1)
+            if ls.numel() != len(used):
+                raise ValueError("trajectory cost: one lengthscale per used state index is required")
+            self._keep = [tt, ls]
+            c.target_traj, c.lengthscales = tt.data_ptr(), ls.data_ptr()
+            self.traj_len = int(tt.shape[0])
+        else:
+            raise ValueError(kind)
+        self.kind, self.c, self.device = kind, c, dev
+
+
+def cost_moments(cost: PackedCost, states):
+    """Per-time-step (mean, centred sum of squares) over this rank's particles -> [T,2], plus costs [T,M]."""
+    T, M, _ = states.shape
+    if cost.kind == "traj" and cost.traj_len != T:
+        raise RuntimeError("target trajectory has %d rows but the rollout has %d steps" % (cost.traj_len, T))
+    st = states.detach().contiguous()
+    costs = torch.empty(T, M, dtype=DT, device=st.device)
+    mom = torch.empty(T, 2, dtype=DT, device=st.device)
+    status = torch.zeros(1, dtype=torch.int32, device=st.device)
+    abi.check(abi.lib().mcp_cost_fwd(C.byref(cost.c), T, M, abi.ptr(st), abi.ptr(costs), abi.ptr(mom), abi.ptr(status), abi.stream()),
+              "mcp_cost_fwd")
+    return mom, costs, status
+
+
+def cost_finalize(moments_all, counts):
+    """moments_all [R,T,2] (all ranks), counts: list of R ints -> tensor [2] = (cost, std)."""
+    R, T = moments_all.shape[0], moments_all.shape[1]
+    out = torch.empty(2, dtype=DT, device=moments_all.device)
+    cnt = (C.c_int64 * R)(*[int(c) for c in counts])
+    abi.check(abi.lib().mcp_cost_finalize(T, R, abi.ptr(moments_all.contiguous()), cnt, abi.ptr(out), abi.stream()), "mcp_cost_finalize")
+    return out
+
+
+class ExpectedCostFunction(torch.autograd.Function):
+    """states [T,M,S] -> (sum_t mean_m c, sum_t std_m c) with the HIP cost kernels; with
+    torch.distributed initialised and ``group`` given, mean/std pool all ranks' particles."""
+
+    @staticmethod
+    def forward(ctx, states, cost, group):
+        mom, _, _ = cost_moments(cost, states)
+        T, M = states.shape[0], states.shape[1]
+        if group is not None:
+            import torch.distributed as dist
+
+            R = dist.get_world_size(group)
+            allm = [torch.empty_like(mom) for _ in range(R)]
+            dist.all_gather(allm, mom, group=group)
+            cnt_t = torch.tensor([M], dtype=torch.int64, device=states.device)
+            cl = [torch.empty_like(cnt_t) for _ in range(R)]
+            dist.all_gather(cl, cnt_t, group=group)
+            counts = [int(c.item()) for c in cl]
+            mom_all = torch.stack(allm)
+        else:
+            counts = [M]
+            mom_all = mom.unsqueeze(0)
+        out = cost_finalize(mom_all, counts)
+        ctx.cost, ctx.m_total = cost, sum(counts)
+        ctx.save_for_backward(states.detach())
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_cost, _g_std):
+        (states,) = ctx.saved_tensors
+        T, M, _ = states.shape
+        g = torch.empty_like(states)
+        st = states.contiguous()
+        abi.check(abi.lib().mcp_cost_bwd(C.byref(ctx.cost.c), T, M, abi.ptr(st), float(g_cost) / float(ctx.m_total), abi.ptr(g), abi.stream()),
+                  "mcp_cost_bwd")
+        return g, None, None
+
+
+def expected_cost(cost: PackedCost, states, group=None):
+    return ExpectedCostFunction.apply(states, cost, group)
+
+
+# --------------------------------------------------------------------------------------
+# single-step posterior (autograd)
+# --------------------------------------------------------------------------------------
+class PosteriorFunction(torch.autograd.Function):
+    """Z [M,D] -> (mu [M,1], var [M]) = GP_prior.get_estimate_from_alpha on the packed GP."""
+
+    @staticmethod
+    def forward(ctx, Z, gp: PackedGP):
+        Zc = Z.detach().to(dtype=DT).contiguous()
+        M, D = Zc.shape
+        need = ctx.needs_input_grad[0]
+        mu = torch.empty(M, dtype=DT, device=Zc.device)
+        var = torch.empty(M, dtype=DT, device=Zc.device)
+        Jm = torch.empty(M, D, dtype=DT, device=Zc.device) if need else None
+        Jv = torch.empty(M, D, dtype=DT, device=Zc.device) if need else None
+        status = torch.zeros(1, dtype=torch.int32, device=Zc.device)
+        g = gp.to_c()
+        abi.check(abi.lib().mcp_posterior_fwd(C.byref(g), M, abi.ptr(Zc), abi.ptr(mu), abi.ptr(var), abi.ptr(Jm), abi.ptr(Jv), abi.ptr(status),
+                                              abi.stream()), "mcp_posterior_fwd")
+        if need:
+            ctx.save_for_backward(Jm, Jv)
+        return mu.reshape(-1, 1), var
+
+    @staticmethod
+    def backward(ctx, g_mu, g_var):
+        Jm, Jv = ctx.saved_tensors
+        M, D = Jm.shape
+        gz = torch.empty(M, D, dtype=DT, device=Jm.device)
+        gm = (torch.zeros(M, dtype=DT, device=Jm.device) if g_mu is None else g_mu.reshape(-1)).contiguous()
+        gv = (torch.zeros(M, dtype=DT, device=Jm.device) if g_var is None else g_var.reshape(-1)).contiguous()
+        abi.check(abi.lib().mcp_posterior_bwd(M, D, abi.ptr(gm), abi.ptr(gv), abi.ptr(Jm), abi.ptr(Jv), abi.ptr(gz), abi.stream()),
+                  "mcp_posterior_bwd")
+        return gz, None
+
+
+def posterior(gp: PackedGP, Z):
+    return PosteriorFunction.apply(Z, gp)
+
+
+def status_flags(status):
+    """Decodes a device status word (synchronises)."""
+    v = int(status.item())
+    return {"nan": bool(v & abi.STATUS_NAN), "nonpos_var": bool(v & abi.STATUS_NONPOS_VAR), "not_spd": bool(v & abi.STATUS_NOT_SPD)}

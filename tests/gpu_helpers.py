@@ -1,0 +1,60 @@
+"""Fixture arrays -> packed HIP descriptors (GPU tests only)."""
+import numpy as np
+import torch
+
+from helpers import fixture_poly, kind_cfg
+from mc_pilco_amd import ops
+
+DT = torch.float64
+
+
+def dev():
+    return torch.device("cuda", 0)
+
+
+def G(a):
+    return torch.as_tensor(np.asarray(a), dtype=DT).to(dev()).contiguous()
+
+
+def spec_from(ls, sigma_n, lam=1.0, poly_w=None):
+    """poly_w: list of raw (positive) weight vectors as given to the reference's
+    Sigma_pos_par_init_list (their log is the parameter)."""
+    w1 = w20 = w21 = None
+    if poly_w:
+        w1 = ops.mpk_weights(np.log(poly_w[0]), 1)[0]
+        if len(poly_w) > 1:
+            w20, w21 = ops.mpk_weights(np.log(poly_w[1]), 2)
+    return ops.KernelSpec(torch.as_tensor(np.asarray(ls), dtype=DT), float(lam), float(sigma_n) ** 2, 0.0, w1, w20, w21)
+
+
+def packed_model(fx, kind):
+    c = kind_cfg(kind)
+    gps = []
+    for g in range(c["G"]):
+        sp = spec_from(c["lengthscales"], float(fx["sigma_n"]), c["lam"], fixture_poly(fx, g))
+        gps.append(ops.PackedGP(sp, G(fx["Xtr%d" % g]), G(fx["alpha%d" % g]), G(fx["Kinv%d" % g])))
+    return ops.PackedModel(gps, c["S"], c["U"], c["Ts"], c["angle"], c["not_angle"], c["vel"], c["not_vel"])
+
+
+def packed_policy(fx, kind, requires_grad=True):
+    c = kind_cfg(kind)
+    log_ls = torch.log(G(fx["pol_ls"])).requires_grad_(requires_grad)
+    centers = G(fx["pol_centers"]).requires_grad_(requires_grad)
+    weight = G(fx["pol_weight"]).requires_grad_(requires_grad)
+    if kind == "ur5":
+        return ops.PackedPolicy("traj", c["S"], log_ls, centers, weight, c["u_max"], True, target_traj=fx["target_traj"])
+    return ops.PackedPolicy("angles", c["S"], log_ls, centers, weight, c["u_max"], True, angle=[2], non_angle=[0, 1, 3])
+
+
+def packed_cost(fx, kind):
+    c = kind_cfg(kind)
+    if kind == "ur5":
+        return ops.PackedCost("traj", c["S"], dev(), target_traj=fx["target_traj"], lengthscales=c["cost_ls"], used=None)
+    return ops.PackedCost("cartpole", c["S"], dev(), target_state=c["cost_target"], lengthscales=c["cost_ls"], angle_index=c["cost_angle_index"],
+                          pos_index=c["cost_pos_index"])
+
+
+def noise_from(fx):
+    eps = G(fx["eps"])
+    masks = torch.as_tensor(fx["masks"]).to(dev()).contiguous() if "masks" in fx else None
+    return ops.NoiseSpec(eps=eps, masks=masks)

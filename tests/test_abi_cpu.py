@@ -1,0 +1,90 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library is built, loads, exports every
+symbol include/mcpilco_hip.h declares, its structs have the layout the ctypes binding assumes,
+and the host-side argument validation rejects bad descriptors without touching a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mcpilco_hip.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mcp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mc_pilco_amd import hipabi
+
+    lib = hipabi.lib()
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "libmcpilco_hip.so does not export %s" % n
+    assert set(hipabi.EXPORTED) == set(names)
+    assert lib.mcp_abi_version() == 1
+    assert b"gfx950" in lib.mcp_build_info()
+
+
+def test_struct_layout_matches_header(tmp_path):
+    from mc_pilco_amd import hipabi
+
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "mcpilco_hip.h"\n'
+        "int main(){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(mcp_kernel), sizeof(mcp_gp), sizeof(mcp_model),"
+        " sizeof(mcp_policy), sizeof(mcp_noise), sizeof(mcp_cost), offsetof(mcp_model, gp), offsetof(mcp_policy, log_ls),"
+        " offsetof(mcp_cost, target_traj)); return 0;}\n"
+    )
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    want = [C.sizeof(hipabi.Kernel), C.sizeof(hipabi.GP), C.sizeof(hipabi.Model), C.sizeof(hipabi.Policy), C.sizeof(hipabi.Noise),
+            C.sizeof(hipabi.Cost), hipabi.Model.gp.offset, hipabi.Policy.log_ls.offset, hipabi.Cost.target_traj.offset]
+    assert got == want
+
+
+def test_argument_validation_without_gpu():
+    """Bad descriptors are rejected on the host (negative MCP_ERR_*), before any launch."""
+    from mc_pilco_amd import hipabi
+
+    lib = hipabi.lib()
+    assert lib.mcp_cov_build(None, 4, None, 4, None, 0, None, 4, None) == -1
+    assert lib.mcp_chol_factor(0, None, 0, None, None, None) == -1
+    m, p, n = hipabi.Model(), hipabi.Policy(), hipabi.Noise()
+    assert lib.mcp_rollout_fwd(C.byref(m), C.byref(p), C.byref(n), 4, 3, 1, None, None, None, None, None, None, 0, None) == -1
+    assert lib.mcp_rollout_workspace_bytes(C.byref(m), C.byref(p), 0, 0) == 0
+    p.P, p.B, p.U = 5, 200, 1
+    assert lib.mcp_rollout_workspace_bytes(C.byref(m), C.byref(p), 400, 150) == 8 * (5 + 200 * 5 + 200) * 400
+    assert lib.mcp_sod_workspace_bytes(300) == 8 * 300 * 300
+    c = hipabi.Cost()
+    c.kind, c.S = 7, 4
+    assert lib.mcp_cost_fwd(C.byref(c), 3, 4, None, None, None, None, None) == -1
+
+
+def test_product_refuses_cpu_tensors():
+    """No CPU fallback: handing the operators a CPU tensor raises instead of computing."""
+    import torch
+
+    from mc_pilco_amd import ops
+
+    sp = ops.KernelSpec(torch.ones(3, dtype=torch.float64), 1.0, 0.01)
+    with pytest.raises(RuntimeError):
+        ops.cov_build(sp, torch.zeros(4, 3, dtype=torch.float64))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = (
+        "import sys; sys.path.insert(0, %r); import mcp_boot\n"
+        "from mc_pilco_amd import hipabi\n"
+        "hipabi.LIB_PATH = %r\n"
+        "try:\n    hipabi.lib()\nexcept RuntimeError as e:\n    print('RAISED', 'no CPU fallback' in str(e).lower() or 'fallback' in str(e))\n"
+    ) % (ROOT, str(tmp_path / "nope.so"))
+    out = subprocess.check_output([sys.executable, "-c", code]).decode()
+    assert "RAISED True" in out
