@@ -209,8 +209,10 @@ int mcp_cost_fwd(const mcp_cost* cost, int T, int M, const double* states, doubl
 /* Pools R ranks' moments [R][T][2] with counts[R] (host array) and writes out[0]=sum_t mean,
  * out[1]=sum_t unbiased std.  R==1 on a single GPU. */
 int mcp_cost_finalize(int T, int R, const double* moments, const int64_t* counts, double* out, void* stream);
-/* g_states[t][m][:] = gscale * d c/d x  (gscale = upstream grad / M_total). */
-int mcp_cost_bwd(const mcp_cost* cost, int T, int M, const double* states, double gscale, double* g_states, void* stream);
+/* g_states[t][m][:] = (*g_cost) * gscale * d c/d x.  g_cost: DEVICE scalar with the upstream
+ * gradient of the cost (NULL = 1), so no host synchronisation is needed; gscale = 1/M_total. */
+int mcp_cost_bwd(const mcp_cost* cost, int T, int M, const double* states, const double* g_cost, double gscale, double* g_states,
+                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void cost_finalize_kernel(int T, int R, const 
   }
 }
 
-__global__ void cost_bwd_kernel(mcp_cost c, int T, int M, const double* __restrict__ states, double gscale,
-                                double* __restrict__ g_states) {
+__global__ void cost_bwd_kernel(mcp_cost c, int T, int M, const double* __restrict__ states, const double* __restrict__ g_cost,
+                                double gscale, double* __restrict__ g_states) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)T * M) return;
   int t = (int)(i / M);
@@ -107,7 +107,7 @@ __global__ void cost_bwd_kernel(mcp_cost c, int T, int M, const double* __restri
   double* g = g_states + i * c.S;
   double dist;
   cost_point(c, x, t, &dist);
-  double e = gscale * exp(-dist);  // d c / d dist = exp(-dist)
+  double e = (g_cost ? *g_cost : 1.0) * gscale * exp(-dist);  // d c / d dist = exp(-dist)
   for (int s = 0; s < c.S; ++s) g[s] = 0.0;
   if (c.kind == MCP_COST_CARTPOLE) {
     double th = x[c.angle_index];
@@ -157,11 +157,12 @@ extern "C" int mcp_cost_finalize(int T, int R, const double* moments, const int6
   return MCP_OK;
 }
 
-extern "C" int mcp_cost_bwd(const mcp_cost* cost, int T, int M, const double* states, double gscale, double* g_states, void* stream) {
+extern "C" int mcp_cost_bwd(const mcp_cost* cost, int T, int M, const double* states, const double* g_cost, double gscale,
+                            double* g_states, void* stream) {
   if (!cost_ok(cost) || !states || !g_states || T <= 0 || M <= 0) return MCP_ERR_ARG;
   size_t n = (size_t)T * M;
-  hipLaunchKernelGGL(cost_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *cost, T, M, states, gscale,
-                     g_states);
+  hipLaunchKernelGGL(cost_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *cost, T, M, states, g_cost,
+                     gscale, g_states);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }

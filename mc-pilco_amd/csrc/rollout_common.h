@@ -1,0 +1,64 @@
+// Shared by rollout_fwd.hip and rollout_bwd.hip: feature maps of the dynamics model and of the
+// policy, descriptor validation, small integer helpers.
+#pragma once
+#include "mcp_device.h"
+
+#define MCP_LDS_LIMIT (160 * 1024)
+
+__host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
+__host__ __device__ inline int imin(int a, int b) { return a < b ? a : b; }
+
+// GP input z = [x[not_angle], sin x[angle], cos x[angle], u]   (Model_learning.py:670-683)
+// policy feature s = [x_nonangle, COS, SIN] (Policy.py:326-333) or [x, x*_t - x] (:397-399)
+__device__ __forceinline__ double policy_feature(const mcp_policy& pl, const double* x, int q, int t) {
+  if (pl.kind == MCP_POLICY_ANGLES) {
+    int nna = pl.n_non_angle, na = pl.n_angle;
+    if (q < nna) return x[pl.non_angle[q]];
+    if (q < nna + na) return cos(x[pl.angle[q - nna]]);
+    return sin(x[pl.angle[q - nna - na]]);
+  }
+  if (pl.kind == MCP_POLICY_TRAJ) {
+    if (q < pl.S) return x[q];
+    return pl.target_traj[(size_t)t * pl.S + (q - pl.S)] - x[q - pl.S];
+  }
+  return x[q];
+}
+
+static inline bool model_ok(const mcp_model* m) {
+  if (!m) return false;
+  if (m->S <= 0 || m->S > MCP_MAX_STATE || m->U <= 0 || m->U > MCP_MAX_INPUT || m->G <= 0 || m->G > MCP_MAX_GP) return false;
+  if (m->D <= 0 || m->D > MCP_MAX_GPDIM) return false;
+  if (m->n_angle < 0 || m->n_not_angle < 0 || m->n_not_angle + 2 * m->n_angle + m->U != m->D) return false;
+  for (int i = 0; i < m->n_angle; ++i)
+    if (m->angle[i] < 0 || m->angle[i] >= m->S) return false;
+  for (int i = 0; i < m->n_not_angle; ++i)
+    if (m->not_angle[i] < 0 || m->not_angle[i] >= m->S) return false;
+  for (int g = 0; g < m->G; ++g) {
+    const mcp_gp& gp = m->gp[g];
+    if (gp.kern.D != m->D || gp.N <= 0 || gp.Npad < gp.N || (gp.Npad % 16) != 0 || gp.N > MCP_MAX_TRAIN) return false;
+    if (!gp.Xt || !gp.X || !gp.alpha || !gp.Kinv || !gp.kern.inv_ls) return false;
+    if (gp.kern.poly_deg < 0 || gp.kern.poly_deg > 2) return false;
+    if (gp.kern.poly_deg >= 1 && (!gp.kern.w1 || !gp.aX)) return false;
+    if (gp.kern.poly_deg >= 2 && (!gp.kern.w20 || !gp.kern.w21)) return false;
+    if (m->vel[g] < 0 || m->vel[g] >= m->S || m->not_vel[g] < 0 || m->not_vel[g] >= m->S) return false;
+  }
+  return true;
+}
+
+static inline bool policy_ok(const mcp_policy* p, int S, int U, int T) {
+  if (!p || p->S != S || p->U != U) return false;
+  if (p->B <= 0 || p->B > MCP_MAX_BASIS || p->P <= 0 || p->P > MCP_MAX_PFEAT) return false;
+  if (!p->log_ls || !p->centers || !p->weight || !p->u_max) return false;
+  if (!(p->p_drop >= 0.0 && p->p_drop < 1.0)) return false;
+  if (p->kind == MCP_POLICY_PLAIN) return p->P == S;
+  if (p->kind == MCP_POLICY_ANGLES) {
+    if (p->n_non_angle + 2 * p->n_angle != p->P) return false;
+    for (int i = 0; i < p->n_angle; ++i)
+      if (p->angle[i] < 0 || p->angle[i] >= S) return false;
+    for (int i = 0; i < p->n_non_angle; ++i)
+      if (p->non_angle[i] < 0 || p->non_angle[i] >= S) return false;
+    return true;
+  }
+  if (p->kind == MCP_POLICY_TRAJ) return p->P == 2 * S && p->target_traj && p->traj_len >= T;
+  return false;
+}

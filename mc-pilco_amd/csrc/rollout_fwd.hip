@@ -1,0 +1,868 @@
+// Fused Monte-Carlo particle rollout, forward pass, for gfx950 (MI355X).
+//
+// Replaces MC_PILCO.apply_policy (policy_learning/MC_PILCO.py:615-674), i.e. per time step
+//   Sum_of_gaussians*.forward                (policy_learning/Policy.py:242-265, 323-335, 389-403)
+//   Model_learning.get_next_state            (model_learning/Model_learning.py:210-242, 265-336)
+//     -> GP_prior.get_estimate_from_alpha    (gpr_lib/GP_prior/GP_prior.py:137-155), one per GP
+//     -> get_next_state_from_gp_output       (Model_learning.py:685-718)
+// and also produces what autograd's backward (MC_PILCO.py:522) needs from the GP.
+//
+// Parallel axis: particles.  They never interact inside the rollout, so a 512-thread workgroup
+// owns P particles for all T steps (no inter-workgroup synchronisation anywhere) and keeps their
+// state in LDS.  Per step and GP:  k = k(z,X) [N],  v = Kinv k [N]  (the N^2 term),  mu = m + k.a,
+// var = k(z,z) - k.v,  and d mu/dz, d var/dz -- formed HERE from v (d var/dz = dk(z,z)/dz -
+// 2 sum_j v_j dk_j/dz).  Only d delta_g/dz (G x D doubles per particle-step, sampling folded in)
+// is stored, so the backward sweep never touches the GP again (rollout_bwd.hip).
+//
+// Memory plan: Kinv (N x N fp64 = 720 KB per GP at N=300) cannot live in the 160 KiB
+// LDS; it stays L2-resident and is streamed once per step per workgroup -- symmetric, so
+// "column i" is read as 64-double row segments (coalesced 512-B wave loads), double-buffered in
+// registers, the stream cut into equal contiguous shares for the 8 waves (phase V).  Everything
+// small and re-read every step (X^T, alpha, policy centres/weights) is copied to LDS once per
+// launch when it fits (template XLDS).  Reductions over the training index use wave64 DPP sums,
+// partial results meet in LDS; 8 workgroup barriers per time step.
+#include "rollout_common.h"
+
+using namespace mcp;
+
+#define RF_NT 512
+#define RF_NW (RF_NT / 64)
+#define RF_MAX_NA 7  // accumulators per Jacobian item: 2 (SE), 3 (SE+P1), 7 (SE+P2)
+#define RF_MAX_CHUNKS (MCP_MAX_GP * (MCP_MAX_TRAIN / 128))
+#define RF_GS 8  // rows of Kinv per register buffer (two buffers in flight per wave)
+
+struct FwdLayout {
+  int invl, xs, us, z, sf, dl, kb, ks, pa, pb, vb, part, red, xt, al, cen, wgt, tab, total;  // offsets in doubles
+};
+
+// integer tables (in the `tab` region): cstart[NC+1], cg[NC], cbase[NC], cR[NC], gcb[GB], wc0[NW]
+#define TAB_CSTART 0
+#define TAB_CG (RF_MAX_CHUNKS + 1)
+#define TAB_CBASE (TAB_CG + RF_MAX_CHUNKS)
+#define TAB_CR (TAB_CBASE + RF_MAX_CHUNKS)
+#define TAB_GCB (TAB_CR + RF_MAX_CHUNKS)
+#define TAB_WC0 (TAB_GCB + MCP_MAX_GP)
+#define TAB_INTS (TAB_WC0 + RF_NW)
+#define RF_CW 128  // rows of v per column chunk: 64 lanes x 2 rows (one 16-byte load per lane)
+
+__host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int G, int PF, int B, int NpadMax, int maxdeg, int GB,
+                                                int NCmax, bool xlds) {
+  FwdLayout L;
+  int o = 0;
+  auto take = [&](int n) {
+    int r = o;
+    o += (n + 1) & ~1;  // keep 16-byte alignment
+    return r;
+  };
+  L.invl = take(PF);
+  L.xs = take(2 * P * S);
+  L.us = take(P * U);
+  L.z = take(P * D);
+  L.sf = take(P * PF);
+  L.dl = take(P * G);
+  L.kb = take(GB * NpadMax * P);
+  L.ks = maxdeg > 0 ? take(GB * NpadMax * P) : L.kb;
+  L.pa = maxdeg > 1 ? take(GB * NpadMax * P) : L.kb;
+  L.pb = maxdeg > 1 ? take(GB * NpadMax * P) : L.kb;
+  L.vb = take(GB * NpadMax * P);
+  L.part = take(imax((NCmax + RF_NW) * 128 * P, P * B));
+  L.red = take(GB * P * (D + 1) * RF_MAX_NA);
+  L.xt = xlds ? take(G * D * NpadMax) : 0;
+  L.al = xlds ? take(G * NpadMax) : 0;
+  L.cen = xlds ? take(B * PF) : 0;
+  L.wgt = xlds ? take(U * B) : 0;
+  L.tab = take((TAB_INTS + 1) / 2);
+  L.total = o;
+  return L;
+}
+
+struct FwdArgs {
+  mcp_model model;
+  mcp_policy pol;
+  mcp_noise nz;
+  int M, T, particle_pred;
+  int NpadMax, maxdeg, GB, NCmax;
+  const double* x0;
+  double* states;
+  double* inputs;
+  double* jac;
+  uint32_t* status;
+  unsigned long long* stamps;  // diagnostic only (mcp_debug_set_stamp_buffer): per-phase cycle totals of workgroup 0
+};
+
+#define RF_STAMP(k)                                 \
+  do {                                              \
+    if (a.stamps && tid == 0 && blockIdx.x == 0) {  \
+      unsigned long long now_ = clock64();          \
+      a.stamps[k] += now_ - last_stamp;             \
+      last_stamp = now_;                            \
+    }                                               \
+  } while (0)
+
+__device__ __forceinline__ int gp_num_acc(int deg) { return deg == 0 ? 2 : (deg == 1 ? 3 : RF_MAX_NA); }
+
+// ---------------------------------------------------------------------------------------
+// chunk table of one pass over GPs [g0, g0+gn): the Kinv stream is the list of 64-row-wide
+// column chunks (g, ic), each N_g row segments ("units") long
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int chunks_of(int Npad) { return (Npad + RF_CW - 1) / RF_CW; }
+
+__device__ __forceinline__ int build_chunk_table(const mcp_gp* gps, int g0, int gn, int* tab, int tid) {
+  int NC = 0;
+  for (int g = 0; g < gn; ++g) NC += chunks_of(gps[g0 + g].Npad);
+  if (tid == 0) {
+    int c = 0, acc = 0;
+    for (int g = 0; g < gn; ++g) {
+      tab[TAB_GCB + g] = c;
+      const int Npad = gps[g0 + g].Npad, N = gps[g0 + g].N;
+      const int nic = chunks_of(Npad);
+      for (int ic = 0; ic < nic; ++ic) {
+        const int width = imin(RF_CW, Npad - ic * RF_CW);
+        const int R = width <= 64 ? 2 : 1;  // a narrow (tail) chunk takes two rows j per wave-load
+        tab[TAB_CSTART + c] = acc;
+        tab[TAB_CG + c] = g;
+        tab[TAB_CBASE + c] = ic * RF_CW;
+        tab[TAB_CR + c] = R;
+        acc += (N + R - 1) / R;
+        ++c;
+      }
+    }
+    tab[TAB_CSTART + c] = acc;
+    const int L = (acc + RF_NW - 1) / RF_NW;
+    for (int w = 0; w < RF_NW; ++w) {
+      int u0 = w * L, cc = 0;
+      while (cc + 1 < c && tab[TAB_CSTART + cc + 1] <= u0) ++cc;
+      tab[TAB_WC0 + w] = cc;
+    }
+  }
+  return NC;
+}
+
+// ---------------------------------------------------------------------------------------
+// Phase K: covariance vectors of P test points against the training points of gn GPs
+// -> LDS [gl][j][p]   (rows j >= N are never read)
+// ---------------------------------------------------------------------------------------
+template <int P, bool XLDS>
+__device__ __forceinline__ void phase_k(const mcp_gp* gps, int g0, int gn, int D, int NpadMax, const double* z, const double* xt_l,
+                                        double* kb, double* ks, double* pa, double* pb, int tid) {
+  for (int it = tid; it < gn * P * NpadMax; it += RF_NT) {
+    int gl = it / (P * NpadMax);
+    int r = it - gl * P * NpadMax;
+    int p = r / NpadMax, j = r - p * NpadMax;
+    const mcp_gp& gp = gps[g0 + gl];
+    if (j >= gp.N) {
+      if (j < gp.Npad) kb[((size_t)gl * NpadMax + j) * P + p] = 0.0;  // phase V may touch one padded row
+      continue;
+    }
+    const mcp_kernel& kn = gp.kern;
+    const int deg = kn.poly_deg;
+    const double* zp = z + p * D;
+    const double* xc = XLDS ? xt_l + (size_t)(g0 + gl) * D * NpadMax + j : gp.Xt + j;
+    const int xs_ = XLDS ? NpadMax : gp.Npad;
+    double dist = 0.0;
+    for (int d = 0; d < D; ++d) {
+      double rr = (zp[d] - xc[(size_t)d * xs_]) * kn.inv_ls[d];
+      dist = fma(rr, rr, dist);
+    }
+    double kse = kn.lambda * exp(-dist);
+    double kt = kse;
+    const size_t o = ((size_t)gl * NpadMax + j) * P + p;
+    if (deg >= 1) {
+      double p1 = kn.w1[D];
+      for (int d = 0; d < D; ++d) p1 = fma(kn.w1[d] * zp[d], xc[(size_t)d * xs_], p1);
+      kt += p1;
+      if (deg >= 2) {
+        double A = 0.0, Bv = 0.0;
+        for (int d = 0; d < D; ++d) {
+          double zx = zp[d] * xc[(size_t)d * xs_];
+          A = fma(kn.w20[d], zx, A);
+          Bv = fma(kn.w21[d], zx, Bv);
+        }
+        kt = fma(A, Bv, kt);
+        pa[o] = A;
+        pb[o] = Bv;
+      }
+      ks[o] = kse;
+    }
+    kb[o] = kt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Phase V: v = Kinv k.  Measured on MI355X (tools/l2_stream_bench.hip): an L2-resident stream costs
+// ~16 cycles per wave-load per CU whatever its width -- 8 B/lane loads cap at 30 B/clk/CU, 16 B/lane
+// loads reach 60 B/clk/CU.  So: one 16-byte load per lane (global_load_dwordx4), a lane owns two
+// adjacent rows (2l, 2l+1) of a 128-row column chunk and walks the summation index j; Kinv is
+// symmetric, so element (i,j) is read from row j (contiguous).  A narrow tail chunk (<= 64 rows)
+// packs two rows j, j+1 into one wave-load (lanes 32..63 take j+1) and folds the two halves at the
+// end.  RF_GS loads per register buffer, two buffers in flight.  k_j[0..P) is an LDS broadcast read.
+// The stream (all chunks of all GPs of the pass) is cut into RF_NW equal contiguous shares.
+// ---------------------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ void consume_rows(const double2 (&A)[RF_GS], const double* __restrict__ kk, int kstride, double (&acc)[2][P]) {
+#pragma unroll
+  for (int u = 0; u < RF_GS; ++u) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      double kv = kk[u * kstride + p];
+      acc[0][p] = fma(A[u].x, kv, acc[0][p]);
+      acc[1][p] = fma(A[u].y, kv, acc[1][p]);
+    }
+  }
+}
+
+__device__ __forceinline__ void load_rows(double2 (&A)[RF_GS], const double* __restrict__ p, size_t rstride) {
+#pragma unroll
+  for (int u = 0; u < RF_GS; ++u) A[u] = *reinterpret_cast<const double2*>(p + (size_t)u * rstride);
+}
+
+// units [ua, ub) of one chunk; `base` already points at this lane's two columns of its first row,
+// `kk` at its k row; consecutive units are rstride / kstride apart
+template <int P>
+__device__ __forceinline__ void matvec_rows(const double* __restrict__ base, size_t rstride, const double* __restrict__ kk, int kstride,
+                                            int ua, int ub, double (&acc)[2][P]) {
+  const double* p = base + (size_t)ua * rstride;
+  const size_t gstep = (size_t)RF_GS * rstride;
+  int u0 = ua;
+  const int nfull = (ub - ua) / RF_GS;
+  double2 A[RF_GS], Bf[RF_GS];
+  if (nfull > 0) {
+    load_rows(A, p, rstride);
+    p += gstep;
+    for (int g = 0; g < nfull; g += 2) {
+      const bool hasB = g + 1 < nfull;
+      if (hasB) {
+        load_rows(Bf, p, rstride);
+        p += gstep;
+      }
+      consume_rows<P>(A, kk + (size_t)u0 * kstride, kstride, acc);
+      u0 += RF_GS;
+      if (hasB) {
+        if (g + 2 < nfull) {
+          load_rows(A, p, rstride);
+          p += gstep;
+        }
+        consume_rows<P>(Bf, kk + (size_t)u0 * kstride, kstride, acc);
+        u0 += RF_GS;
+      }
+    }
+  }
+  const int rem = ub - u0;  // 0 .. RF_GS-1, wave-uniform
+#pragma unroll
+  for (int u = 0; u < RF_GS - 1; ++u)
+    if (u < rem) A[u] = *reinterpret_cast<const double2*>(p + (size_t)u * rstride);
+#pragma unroll
+  for (int u = 0; u < RF_GS - 1; ++u) {
+    if (u < rem) {
+#pragma unroll
+      for (int q = 0; q < P; ++q) {
+        double kv = kk[(size_t)(u0 + u) * kstride + q];
+        acc[0][q] = fma(A[u].x, kv, acc[0][q]);
+        acc[1][q] = fma(A[u].y, kv, acc[1][q]);
+      }
+    }
+  }
+}
+
+template <int P>
+__device__ __forceinline__ void phase_v(const mcp_gp* gps, int g0, const int* tab, int NC, int NpadMax, const double* kb, double* part,
+                                        int wv, int lane) {
+  const int total = tab[TAB_CSTART + NC];
+  const int L = (total + RF_NW - 1) / RF_NW;
+  int u = wv * L;
+  const int u1 = imin(total, u + L);
+  if (u >= u1) return;
+  int c = tab[TAB_WC0 + wv];
+  while (u < u1) {
+    const int cs = tab[TAB_CSTART + c], ce = tab[TAB_CSTART + c + 1];
+    const int gl = tab[TAB_CG + c], rb = tab[TAB_CBASE + c], R = tab[TAB_CR + c];
+    const mcp_gp& gp = gps[g0 + gl];
+    const int Npad = gp.Npad;
+    const int ua = u - cs, ub = imin(ce, u1) - cs;
+    const int sub = (R == 2) ? (lane >> 5) : 0;   // which of the unit's R rows this lane reads
+    const int li = (R == 2) ? (lane & 31) : lane;  // lane's column pair inside the chunk
+    const int i = rb + 2 * li;
+    const bool ok = i < Npad;
+    double acc[2][P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) acc[0][p] = acc[1][p] = 0.0;
+    const double* base = gp.Kinv + (size_t)sub * Npad + (ok ? i : rb);
+    matvec_rows<P>(base, (size_t)R * Npad, kb + ((size_t)gl * NpadMax + sub) * P, R * P, ua, ub, acc);
+    if (R == 2) {
+      // fold rows j+1 (lanes 32..63) into rows j (lanes 0..31)
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        acc[0][p] += __shfl_xor(acc[0][p], 32);
+        acc[1][p] += __shfl_xor(acc[1][p], 32);
+      }
+    }
+    double* slot = part + (size_t)(c + wv) * 128 * P;  // slot id = chunk + wave: unique, contiguous per chunk
+    if (lane == li) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        slot[(2 * li) * P + p] = acc[0][p];
+        slot[(2 * li + 1) * P + p] = acc[1][p];
+      }
+    }
+    u += ub - ua;
+    ++c;
+  }
+}
+
+// v[gl][i][p] = sum of the chunk's partial slots, in a fixed order
+template <int P>
+__device__ __forceinline__ void phase_vsum(const mcp_gp* gps, int g0, int gn, const int* tab, int NC, int NpadMax, const double* part,
+                                           double* vb, int tid) {
+  const int total = tab[TAB_CSTART + NC];
+  const int L = (total + RF_NW - 1) / RF_NW;
+  for (int it = tid; it < gn * NpadMax * P; it += RF_NT) {
+    int gl = it / (NpadMax * P);
+    int r = it - gl * NpadMax * P;
+    int i = r / P, p = r - i * P;
+    if (i >= gps[g0 + gl].N) continue;
+    int c = tab[TAB_GCB + gl] + i / RF_CW;
+    int s_lo = c + tab[TAB_CSTART + c] / L, s_hi = c + (tab[TAB_CSTART + c + 1] - 1) / L;
+    double s = 0.0;
+    for (int sid = s_lo; sid <= s_hi; ++sid) s += part[((size_t)sid * 128 + (i % RF_CW)) * P + p];
+    vb[it] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// Phase J: moment / Jacobian sums, one wave per (gp, particle, column) item, lanes over j, DPP sum
+//   column c <  D : a0 = sum kse_j alpha_j (z_c - X_jc)      a1 = sum kse_j v_j (z_c - X_jc)
+//                   a2 = sum v_j X_jc            (deg>=1)
+//                   a3 = sum alpha_j B_j X_jc, a4 = sum alpha_j A_j X_jc, a5 = sum v_j B_j X_jc, a6 = sum v_j A_j X_jc (deg 2)
+//   column c == D : a0 = sum k_j alpha_j  (= mu - m)          a1 = sum k_j v_j  (= k^T Kinv k)
+// ---------------------------------------------------------------------------------------
+template <int P, bool XLDS>
+__device__ __forceinline__ void phase_j(const mcp_gp* gps, int g0, int gn, int D, int NpadMax, const double* z, const double* xt_l,
+                                        const double* al_l, const double* kb, const double* ks, const double* pa, const double* pb,
+                                        const double* vb, double* red, int wv, int lane) {
+  const int per = P * (D + 1);
+  for (int item = wv; item < gn * per; item += RF_NW) {
+    int gl = item / per;
+    int r = item - gl * per;
+    int p = r / (D + 1), c = r - p * (D + 1);
+    const mcp_gp& gp = gps[g0 + gl];
+    const int N = gp.N, deg = gp.kern.poly_deg, NA = gp_num_acc(deg);
+    const double* al = XLDS ? al_l + (size_t)(g0 + gl) * NpadMax : gp.alpha;
+    const size_t ob = (size_t)gl * NpadMax * P + p;
+    double acc[RF_MAX_NA];
+#pragma unroll
+    for (int q = 0; q < RF_MAX_NA; ++q) acc[q] = 0.0;
+    if (c < D) {
+      const double* xc = XLDS ? xt_l + ((size_t)(g0 + gl) * D + c) * NpadMax : gp.Xt + (size_t)c * gp.Npad;
+      const double zc = z[p * D + c];
+      for (int j = lane; j < N; j += 64) {
+        const size_t o = ob + (size_t)j * P;
+        double alj = al[j], v = vb[o], x = xc[j], kse = ks[o];
+        double dz = zc - x;
+        acc[0] = fma(kse * alj, dz, acc[0]);
+        acc[1] = fma(kse * v, dz, acc[1]);
+        if (deg >= 1) acc[2] = fma(v, x, acc[2]);
+        if (deg >= 2) {
+          double A = pa[o], Bv = pb[o];
+          acc[3] = fma(alj * Bv, x, acc[3]);
+          acc[4] = fma(alj * A, x, acc[4]);
+          acc[5] = fma(v * Bv, x, acc[5]);
+          acc[6] = fma(v * A, x, acc[6]);
+        }
+      }
+    } else {
+      for (int j = lane; j < N; j += 64) {
+        const size_t o = ob + (size_t)j * P;
+        double kt = kb[o];
+        acc[0] = fma(kt, al[j], acc[0]);
+        acc[1] = fma(kt, vb[o], acc[1]);
+      }
+    }
+    double* out = red + (size_t)item * RF_MAX_NA;
+#pragma unroll
+    for (int q = 0; q < RF_MAX_NA; ++q) {
+      if (q < NA) {
+        double s = wave_sum(acc[q]);
+        if (lane == 0) out[q] = s;
+      }
+    }
+  }
+}
+
+// posterior mean / variance and their z-Jacobians from the reduced sums R[(D+1)][RF_MAX_NA]
+__device__ __forceinline__ void gp_point(const mcp_gp& gp, const double* zp, const double* R, double& mu, double& var) {
+  const int D = gp.kern.D;
+  mu = gp.kern.mean + R[D * RF_MAX_NA + 0];
+  var = kern_diag(gp.kern, zp, 1) - R[D * RF_MAX_NA + 1];
+}
+__device__ __forceinline__ void gp_jac(const mcp_gp& gp, const double* zp, const double* R, int d, double& Jmu, double& Jvar) {
+  const mcp_kernel& kn = gp.kern;
+  const int D = kn.D, deg = kn.poly_deg;
+  const double* r = R + d * RF_MAX_NA;
+  double il2 = kn.inv_ls[d] * kn.inv_ls[d];
+  Jmu = -2.0 * il2 * r[0];
+  Jvar = 4.0 * il2 * r[1];
+  if (deg >= 1) {
+    Jmu = fma(kn.w1[d], gp.aX[d], Jmu);
+    Jvar += 2.0 * kn.w1[d] * (zp[d] - r[2]);
+    if (deg >= 2) {
+      double Sa = 0.0, Sb = 0.0;
+      for (int e = 0; e < D; ++e) {
+        double zz = zp[e] * zp[e];
+        Sa = fma(kn.w20[e], zz, Sa);
+        Sb = fma(kn.w21[e], zz, Sb);
+      }
+      Jmu += kn.w20[d] * r[3] + kn.w21[d] * r[4];
+      Jvar += 2.0 * zp[d] * (kn.w20[d] * Sb + kn.w21[d] * Sa) - 2.0 * (kn.w20[d] * r[5] + kn.w21[d] * r[6]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward rollout
+// ---------------------------------------------------------------------------------------
+template <int P, bool XLDS>
+__global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const mcp_model& md = a.model;
+  const mcp_policy& pl = a.pol;
+  const mcp_gp* gps = md.gp;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
+  const int NpadMax = a.NpadMax, GB = a.GB;
+  const FwdLayout L = fwd_layout(P, S, U, D, G, PF, B, NpadMax, a.maxdeg, GB, a.NCmax, XLDS);
+  double* invl = smem + L.invl;
+  double* xs = smem + L.xs;  // [2][P][S] double-buffered
+  double* us = smem + L.us;
+  double* z = smem + L.z;
+  double* sf = smem + L.sf;
+  double* dl = smem + L.dl;
+  double* kb = smem + L.kb;
+  double* ks = smem + L.ks;
+  double* pa = smem + L.pa;
+  double* pb = smem + L.pb;
+  double* vb = smem + L.vb;
+  double* part = smem + L.part;
+  double* red = smem + L.red;
+  double* xt_l = smem + L.xt;
+  double* al_l = smem + L.al;
+  double* cen_l = smem + L.cen;
+  double* wgt_l = smem + L.wgt;
+  int* tab = reinterpret_cast<int*>(smem + L.tab);
+  const int m0 = blockIdx.x * P;
+  uint32_t bad = 0;
+  const bool drop = pl.p_drop > 0.0;
+  const double keep_scale = 1.0 / (1.0 - pl.p_drop);
+  const uint32_t drop_thr = drop_threshold(pl.p_drop);
+  const int nna = md.n_not_angle, na = md.n_angle;
+
+  // ---- one-time staging ------------------------------------------------------------------
+  for (int it = tid; it < PF; it += RF_NT) invl[it] = exp(-pl.log_ls[it]);
+  if (XLDS) {
+    for (int g = 0; g < G; ++g) {
+      const mcp_gp& gp = gps[g];
+      for (int it = tid; it < D * gp.Npad; it += RF_NT) {
+        int d = it / gp.Npad, j = it - d * gp.Npad;
+        xt_l[((size_t)g * D + d) * NpadMax + j] = gp.Xt[it];
+      }
+      for (int it = tid; it < gp.Npad; it += RF_NT) al_l[(size_t)g * NpadMax + it] = gp.alpha[it];
+    }
+    for (int it = tid; it < B * PF; it += RF_NT) cen_l[it] = pl.centers[it];
+    for (int it = tid; it < U * B; it += RF_NT) wgt_l[it] = pl.weight[it];
+  }
+  const double* cen = XLDS ? cen_l : pl.centers;
+  const double* wgt = XLDS ? wgt_l : pl.weight;
+  int NC = 0;
+  if (GB >= G) NC = build_chunk_table(gps, 0, G, tab, tid);
+
+  // thread (p, s) owns state component s of particle p
+  const bool own = tid < P * S;
+  const int op = own ? tid / S : 0, os = own ? tid - op * S : 0;
+  const int om = imin(m0 + op, M - 1);
+  const bool ovalid = own && (m0 + op < M);
+  double xn = own ? a.x0[(size_t)om * S + os] : 0.0;
+  int cur = 0;
+  unsigned long long last_stamp = clock64();
+
+  for (int t = 0; t < T; ++t) {
+    // ---- phase S: publish x_t and everything derived from a single state component --------------
+    if (own) {
+      double* xc = xs + cur * P * S;
+      xc[op * S + os] = xn;
+      if (ovalid) {
+        a.states[((size_t)t * M + m0 + op) * S + os] = xn;
+        if (is_bad(xn)) bad |= MCP_STATUS_NAN;
+      }
+      bool is_ang = false;
+      for (int i = 0; i < na; ++i) is_ang |= (md.angle[i] == os);
+      if (pl.kind == MCP_POLICY_ANGLES)
+        for (int i = 0; i < pl.n_angle; ++i) is_ang |= (pl.angle[i] == os);
+      double sn = 0.0, cs = 0.0;
+      if (is_ang) sincos(xn, &sn, &cs);
+      // GP input z = [x[not_angle], sin x[angle], cos x[angle], u]   (Model_learning.py:670-683)
+      for (int i = 0; i < nna; ++i)
+        if (md.not_angle[i] == os) z[op * D + i] = xn;
+      for (int i = 0; i < na; ++i)
+        if (md.angle[i] == os) {
+          z[op * D + nna + i] = sn;
+          z[op * D + nna + na + i] = cs;
+        }
+      // policy features (Policy.py:326-333: [x_nonangle, COS, SIN];  :397-399: [x, x*_t - x])
+      if (pl.kind == MCP_POLICY_ANGLES) {
+        const int pn = pl.n_non_angle, pa_ = pl.n_angle;
+        for (int i = 0; i < pn; ++i)
+          if (pl.non_angle[i] == os) sf[op * PF + i] = xn;
+        for (int i = 0; i < pa_; ++i)
+          if (pl.angle[i] == os) {
+            sf[op * PF + pn + i] = cs;
+            sf[op * PF + pn + pa_ + i] = sn;
+          }
+      } else if (pl.kind == MCP_POLICY_TRAJ) {
+        sf[op * PF + os] = xn;
+        sf[op * PF + S + os] = pl.target_traj[(size_t)t * S + os] - xn;
+      } else {
+        sf[op * PF + os] = xn;
+      }
+    }
+    __syncthreads();
+    RF_STAMP(0);
+    // ---- phase PHI: phi_b = exp(-sum_q ((s_q - c_bq)/l_q)^2) * keep/(1-p) -------------------------
+    double* ph = part;
+    for (int it = tid; it < P * B; it += RF_NT) {
+      int p = it / B, b = it - p * B;
+      const double* cb = cen + (size_t)b * PF;
+      double dist = 0.0;
+      for (int q = 0; q < PF; ++q) {
+        double r = (sf[p * PF + q] - cb[q]) * invl[q];
+        dist = fma(r, r, dist);
+      }
+      double phi = exp(-dist);
+      if (drop) {
+        int mm = imin(m0 + p, M - 1);
+        bool keep = a.nz.masks ? (a.nz.masks[((size_t)t * M + mm) * B + b] != 0) : philox_keep(a.nz, mm, t, b, drop_thr);
+        phi = keep ? phi * keep_scale : 0.0;
+      }
+      ph[it] = phi;
+    }
+    __syncthreads();
+    RF_STAMP(1);
+    // ---- phase U: u = u_max tanh((W phi)/u_max), one wave per (particle, input) -------------------
+    for (int task = wv; task < P * U; task += RF_NW) {
+      int p = task / U, k = task - p * U;
+      const double* wk = wgt + (size_t)k * B;
+      double s = 0.0;
+      for (int b = lane; b < B; b += 64) s = fma(wk[b], ph[p * B + b], s);
+      s = wave_sum(s);
+      if (lane == 0) {
+        double um = pl.u_max[k];
+        double u = pl.squash ? um * tanh(s / um) : s;
+        us[p * U + k] = u;
+        z[p * D + nna + 2 * na + k] = u;
+        if (m0 + p < M) {
+          a.inputs[((size_t)t * M + m0 + p) * U + k] = u;
+          if (is_bad(u)) bad |= MCP_STATUS_NAN;
+        }
+      }
+    }
+    __syncthreads();
+    RF_STAMP(2);
+    if (t == T - 1) break;
+    // ---- GPs, GB at a time ---------------------------------------------------------------------
+    for (int g0 = 0; g0 < G; g0 += GB) {
+      const int gn = imin(GB, G - g0);
+      if (GB < G) {
+        __syncthreads();
+        NC = build_chunk_table(gps, g0, gn, tab, tid);
+        __syncthreads();
+      }
+      phase_k<P, XLDS>(gps, g0, gn, D, NpadMax, z, xt_l, kb, ks, pa, pb, tid);
+      __syncthreads();
+      RF_STAMP(3);
+      phase_v<P>(gps, g0, tab, NC, NpadMax, kb, part, wv, lane);
+      __syncthreads();
+      RF_STAMP(4);
+      phase_vsum<P>(gps, g0, gn, tab, NC, NpadMax, part, vb, tid);
+      __syncthreads();
+      RF_STAMP(5);
+      phase_j<P, XLDS>(gps, g0, gn, D, NpadMax, z, xt_l, al_l, kb, ks, pa, pb, vb, red, wv, lane);
+      __syncthreads();
+      RF_STAMP(6);
+      // ---- phase F: sample delta_g and fold the sampling into d delta/dz ------------------------
+      for (int it = tid; it < gn * P * (D + 1); it += RF_NT) {
+        int gl = it / (P * (D + 1));
+        int r = it - gl * P * (D + 1);
+        int p = r / (D + 1), c = r - p * (D + 1);
+        const int g = g0 + gl;
+        const mcp_gp& gp = gps[g];
+        const double* R = red + ((size_t)(gl * P + p) * (D + 1)) * RF_MAX_NA;
+        const double* zp = z + p * D;
+        int mm = imin(m0 + p, M - 1);
+        double mu, var;
+        gp_point(gp, zp, R, mu, var);
+        var *= md.var_scale[g];
+        double eps = 0.0, wj = 0.0, sd = 0.0;
+        if (a.particle_pred) {
+          eps = a.nz.eps ? a.nz.eps[((size_t)t * M + mm) * G + g] : philox_normal(a.nz, mm, t, g);
+          sd = sqrt(var);
+          wj = eps / (2.0 * sd);
+        }
+        if (c == D) {
+          dl[p * G + g] = a.particle_pred ? fma(sd, eps, mu) : mu;
+          if (m0 + p < M) {
+            if (a.particle_pred && !(var > 0.0)) bad |= MCP_STATUS_NONPOS_VAR;
+            if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
+          }
+        } else if (a.jac && m0 + p < M) {
+          double Jmu, Jvar;
+          gp_jac(gp, zp, R, c, Jmu, Jvar);
+          a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * md.var_scale[g], Jmu) : Jmu;
+        }
+      }
+    }
+    __syncthreads();
+    RF_STAMP(7);
+    // ---- integrate:  v' = v + delta ;  q' = q + Ts v + Ts/2 delta   (Model_learning.py:711-716) ----
+    if (own) {
+      const double* xc = xs + cur * P * S + op * S;
+      double nx = 0.0;
+      for (int g = 0; g < G; ++g) {
+        if (md.vel[g] == os) nx = xc[os] + dl[op * G + g];
+        if (md.not_vel[g] == os) nx = xc[os] + md.Ts * xc[md.vel[g]] + 0.5 * md.Ts * dl[op * G + g];
+      }
+      xn = nx;
+    }
+    cur ^= 1;  // x_{t+1} goes to the other buffer: no barrier between this read and the next write
+  }
+  if (bad) atomicOr(a.status, bad);
+}
+
+// ---------------------------------------------------------------------------------------
+// single-step posterior (GP_prior.get_estimate_from_alpha) through the same phases
+// ---------------------------------------------------------------------------------------
+struct PostArgs {
+  mcp_gp gp;
+  int M, NCmax;
+  const double* Z;
+  double* mu;
+  double* var;
+  double* Jmu;
+  double* Jvar;
+  uint32_t* status;
+};
+
+template <int P>
+__global__ __launch_bounds__(RF_NT) void posterior_fwd_kernel(PostArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const mcp_gp* gps = &a.gp;
+  const mcp_gp& gp = a.gp;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = gp.kern.D, deg = gp.kern.poly_deg, NpadMax = gp.Npad;
+  const FwdLayout L = fwd_layout(P, 1, 1, D, 1, 1, 1, NpadMax, deg, 1, a.NCmax, false);
+  double* z = smem + L.z;
+  double* kb = smem + L.kb;
+  double* ks = smem + L.ks;
+  double* pa = smem + L.pa;
+  double* pb = smem + L.pb;
+  double* vb = smem + L.vb;
+  double* part = smem + L.part;
+  double* red = smem + L.red;
+  int* tab = reinterpret_cast<int*>(smem + L.tab);
+  const int m0 = blockIdx.x * P;
+  uint32_t bad = 0;
+  for (int it = tid; it < P * D; it += RF_NT) {
+    int p = it / D, d = it - p * D;
+    z[it] = a.Z[(size_t)imin(m0 + p, a.M - 1) * D + d];
+  }
+  const int NC = build_chunk_table(gps, 0, 1, tab, tid);
+  __syncthreads();
+  phase_k<P, false>(gps, 0, 1, D, NpadMax, z, nullptr, kb, ks, pa, pb, tid);
+  __syncthreads();
+  phase_v<P>(gps, 0, tab, NC, NpadMax, kb, part, wv, lane);
+  __syncthreads();
+  phase_vsum<P>(gps, 0, 1, tab, NC, NpadMax, part, vb, tid);
+  __syncthreads();
+  phase_j<P, false>(gps, 0, 1, D, NpadMax, z, nullptr, nullptr, kb, ks, pa, pb, vb, red, wv, lane);
+  __syncthreads();
+  for (int it = tid; it < P * (D + 1); it += RF_NT) {
+    int p = it / (D + 1), c = it - p * (D + 1);
+    if (m0 + p >= a.M) continue;
+    const double* R = red + (size_t)p * (D + 1) * RF_MAX_NA;
+    const double* zp = z + p * D;
+    if (c == D) {
+      double mu, var;
+      gp_point(gp, zp, R, mu, var);
+      a.mu[m0 + p] = mu;
+      a.var[m0 + p] = var;
+      if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
+      if (!(var > 0.0)) bad |= MCP_STATUS_NONPOS_VAR;
+    } else if (a.Jmu) {
+      double Jm, Jv;
+      gp_jac(gp, zp, R, c, Jm, Jv);
+      a.Jmu[(size_t)(m0 + p) * D + c] = Jm;
+      a.Jvar[(size_t)(m0 + p) * D + c] = Jv;
+    }
+  }
+  if (bad && a.status) atomicOr(a.status, bad);
+}
+
+__global__ void posterior_bwd_kernel(int M, int D, const double* __restrict__ gmu, const double* __restrict__ gvar,
+                                     const double* __restrict__ Jmu, const double* __restrict__ Jvar, double* __restrict__ gZ) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * D) return;
+  size_t m = i / D;
+  gZ[i] = fma(gmu[m], Jmu[i], gvar[m] * Jvar[i]);
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+static int pick_particles_per_wg(int M) {
+  // small swarms: spread over as many CUs as possible (every workgroup re-streams Kinv, so the
+  // per-CU L2->L1 rate is the bound); large swarms: amortise the Kinv stream over more particles
+  if (M <= 256) return 1;
+  if (M <= 1024) return 2;
+  return 4;
+}
+
+static int g_force_ppw = 0;   // test hook: force particles per workgroup (0 = automatic)
+static int g_force_xlds = -1; // test hook: -1 automatic, 0 never stage small operands in LDS, 1 = automatic
+static int g_force_gb = 0;    // test hook: GPs per pass (0 = as many as fit)
+extern "C" void mcp_debug_set_particles_per_wg(int p) { g_force_ppw = p; }
+extern "C" void mcp_debug_set_fwd_mode(int xlds, int gb) {
+  g_force_xlds = xlds;
+  g_force_gb = gb;
+}
+static unsigned long long* g_stamps = nullptr;  // diagnostic hook: device buffer of 16 u64 phase-cycle totals
+extern "C" void mcp_debug_set_stamp_buffer(void* p) { g_stamps = (unsigned long long*)p; }
+
+static int chunks_in_pass(const mcp_model* m, int GB) {
+  int best = 0;
+  for (int g0 = 0; g0 < m->G; g0 += GB) {
+    int nc = 0;
+    for (int g = g0; g < m->G && g < g0 + GB; ++g) nc += (m->gp[g].Npad + RF_CW - 1) / RF_CW;
+    best = imax(best, nc);
+  }
+  return best;
+}
+
+template <int P, bool XLDS>
+static int launch_fwd(const FwdArgs& a, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_kernel<P, XLDS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              MCP_LDS_LIMIT);
+    attr_set = true;
+  }
+  int grid = (a.M + P - 1) / P;
+  hipLaunchKernelGGL((rollout_fwd_kernel<P, XLDS>), dim3(grid), dim3(RF_NT), lds, st, a);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
+                               const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  (void)workspace;
+  (void)workspace_bytes;
+  if (!noise || !x0 || !states || !inputs || !status || M <= 0 || T <= 0) return MCP_ERR_ARG;
+  if (!model_ok(model)) return MCP_ERR_ARG;
+  if (!policy_ok(policy, model->S, model->U, T)) return MCP_ERR_ARG;
+  FwdArgs a;
+  a.model = *model;
+  a.pol = *policy;
+  a.nz = *noise;
+  a.M = M;
+  a.T = T;
+  a.particle_pred = particle_pred;
+  a.NpadMax = 0;
+  a.maxdeg = 0;
+  for (int g = 0; g < model->G; ++g) {
+    a.NpadMax = imax(a.NpadMax, model->gp[g].Npad);
+    a.maxdeg = imax(a.maxdeg, model->gp[g].kern.poly_deg);
+  }
+  a.x0 = x0;
+  a.states = states;
+  a.inputs = inputs;
+  a.jac = jac;
+  a.status = status;
+  a.stamps = g_stamps;
+  hipStream_t st = (hipStream_t)stream;
+  // configuration search: most particles per workgroup first, operands in LDS if they fit, all GPs per pass if they fit
+  int P0 = g_force_ppw ? g_force_ppw : pick_particles_per_wg(M);
+  if (P0 != 1 && P0 != 2 && P0 != 4) return MCP_ERR_ARG;
+  for (int P = P0; P >= 1; P >>= 1) {
+    for (int xl = (g_force_xlds == 0 ? 0 : 1); xl >= 0; --xl) {
+      for (int GB = (g_force_gb > 0 ? imin(g_force_gb, model->G) : model->G); GB >= 1; --GB) {
+        int NCmax = chunks_in_pass(model, GB);
+        if (NCmax > RF_MAX_CHUNKS) continue;
+        FwdLayout L = fwd_layout(P, model->S, model->U, model->D, model->G, policy->P, policy->B, a.NpadMax, a.maxdeg, GB, NCmax, xl != 0);
+        size_t lds = sizeof(double) * (size_t)L.total;
+        if (lds > MCP_LDS_LIMIT) continue;
+        a.GB = GB;
+        a.NCmax = NCmax;
+        if (P == 4) return xl ? launch_fwd<4, true>(a, lds, st) : launch_fwd<4, false>(a, lds, st);
+        if (P == 2) return xl ? launch_fwd<2, true>(a, lds, st) : launch_fwd<2, false>(a, lds, st);
+        return xl ? launch_fwd<1, true>(a, lds, st) : launch_fwd<1, false>(a, lds, st);
+      }
+    }
+  }
+  return MCP_ERR_LIMIT;
+}
+
+template <int P>
+static int launch_post(const PostArgs& a, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(posterior_fwd_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              MCP_LDS_LIMIT);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(posterior_fwd_kernel<P>, dim3((a.M + P - 1) / P), dim3(RF_NT), lds, st, a);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+extern "C" int mcp_posterior_fwd(const mcp_gp* gp, int M, const double* Z, double* mu, double* var, double* Jmu, double* Jvar,
+                                 uint32_t* status, void* stream) {
+  if (!gp || !Z || !mu || !var || M <= 0) return MCP_ERR_ARG;
+  if ((Jmu == nullptr) != (Jvar == nullptr)) return MCP_ERR_ARG;
+  if (gp->kern.D <= 0 || gp->kern.D > MCP_MAX_GPDIM || gp->N <= 0 || gp->Npad < gp->N || (gp->Npad % 16) != 0) return MCP_ERR_ARG;
+  if (gp->N > MCP_MAX_TRAIN) return MCP_ERR_LIMIT;
+  if (!gp->Xt || !gp->X || !gp->alpha || !gp->Kinv || !gp->kern.inv_ls) return MCP_ERR_ARG;
+  if (gp->kern.poly_deg < 0 || gp->kern.poly_deg > 2) return MCP_ERR_ARG;
+  if (gp->kern.poly_deg >= 1 && (!gp->kern.w1 || !gp->aX)) return MCP_ERR_ARG;
+  if (gp->kern.poly_deg >= 2 && (!gp->kern.w20 || !gp->kern.w21)) return MCP_ERR_ARG;
+  PostArgs a;
+  a.gp = *gp;
+  a.M = M;
+  a.NCmax = (gp->Npad + RF_CW - 1) / RF_CW;
+  a.Z = Z;
+  a.mu = mu;
+  a.var = var;
+  a.Jmu = Jmu;
+  a.Jvar = Jvar;
+  a.status = status;
+  int P0 = g_force_ppw ? g_force_ppw : pick_particles_per_wg(M);
+  if (P0 != 1 && P0 != 2 && P0 != 4) return MCP_ERR_ARG;
+  for (int P = P0; P >= 1; P >>= 1) {
+    FwdLayout L = fwd_layout(P, 1, 1, gp->kern.D, 1, 1, 1, gp->Npad, gp->kern.poly_deg, 1, a.NCmax, false);
+    size_t lds = sizeof(double) * (size_t)L.total;
+    if (lds > MCP_LDS_LIMIT) continue;
+    hipStream_t st = (hipStream_t)stream;
+    if (P == 4) return launch_post<4>(a, lds, st);
+    if (P == 2) return launch_post<2>(a, lds, st);
+    return launch_post<1>(a, lds, st);
+  }
+  return MCP_ERR_LIMIT;
+}
+
+extern "C" int mcp_posterior_bwd(int M, int D, const double* gmu, const double* gvar, const double* Jmu, const double* Jvar, double* gZ,
+                                 void* stream) {
+  if (!gmu || !gvar || !Jmu || !Jvar || !gZ || M <= 0 || D <= 0) return MCP_ERR_ARG;
+  size_t n = (size_t)M * D;
+  hipLaunchKernelGGL(posterior_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, D, gmu, gvar, Jmu, Jvar,
+                     gZ);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}

@@ -413,23 +413,21 @@ def cost_finalize(moments_all, counts):
 
 
 class ExpectedCostFunction(torch.autograd.Function):
-    """states [T,M,S] -> (sum_t mean_m c, sum_t std_m c) with the HIP cost kernels; with
-    torch.distributed initialised and ``group`` given, mean/std pool all ranks' particles."""
+    """states [T,M,S] -> (sum_t mean_m c, sum_t std_m c) with the HIP cost kernels; with a
+    torch.distributed ``group`` the mean/std pool all ranks' particles (one all-gather of the
+    [T,2] moments).  ``counts``: particles per rank (default: every rank holds M)."""
 
     @staticmethod
-    def forward(ctx, states, cost, group):
+    def forward(ctx, states, cost, group, counts):
         mom, _, _ = cost_moments(cost, states)
-        T, M = states.shape[0], states.shape[1]
+        M = states.shape[1]
         if group is not None:
             import torch.distributed as dist
 
             R = dist.get_world_size(group)
             allm = [torch.empty_like(mom) for _ in range(R)]
             dist.all_gather(allm, mom, group=group)
-            cnt_t = torch.tensor([M], dtype=torch.int64, device=states.device)
-            cl = [torch.empty_like(cnt_t) for _ in range(R)]
-            dist.all_gather(cl, cnt_t, group=group)
-            counts = [int(c.item()) for c in cl]
+            counts = [M] * R if counts is None else [int(c) for c in counts]
             mom_all = torch.stack(allm)
         else:
             counts = [M]
@@ -445,13 +443,14 @@ class ExpectedCostFunction(torch.autograd.Function):
         T, M, _ = states.shape
         g = torch.empty_like(states)
         st = states.contiguous()
-        abi.check(abi.lib().mcp_cost_bwd(C.byref(ctx.cost.c), T, M, abi.ptr(st), float(g_cost) / float(ctx.m_total), abi.ptr(g), abi.stream()),
+        gc = g_cost.detach().to(dtype=DT).reshape(1).contiguous()  # stays on the device: no host sync
+        abi.check(abi.lib().mcp_cost_bwd(C.byref(ctx.cost.c), T, M, abi.ptr(st), abi.ptr(gc), 1.0 / float(ctx.m_total), abi.ptr(g), abi.stream()),
                   "mcp_cost_bwd")
-        return g, None, None
+        return g, None, None, None
 
 
-def expected_cost(cost: PackedCost, states, group=None):
-    return ExpectedCostFunction.apply(states, cost, group)
+def expected_cost(cost: PackedCost, states, group=None, counts=None):
+    return ExpectedCostFunction.apply(states, cost, group, counts)
 
 
 # --------------------------------------------------------------------------------------

@@ -1,0 +1,25 @@
+"""Diagnostic: per-phase cycle shares of rollout_fwd_kernel (workgroup 0), via the runtime-gated
+s_memtime stamps.  Read the SHARES, not the totals (the stamps serialise nothing but add a branch)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mcp_boot, torch
+from mc_pilco_amd import hipabi, ops, workloads
+name = sys.argv[1] if len(sys.argv) > 1 else "c1"
+ppw = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+dev = torch.device("cuda", 0)
+w = workloads.build(name, device=dev)
+buf = torch.zeros(16, dtype=torch.int64, device=dev)
+x0 = w.sample_x0()
+hipabi.lib().mcp_debug_set_particles_per_wg(ppw)
+for i in range(2):
+    ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=i), x0, w.T, w.p_drop)
+hipabi.lib().mcp_debug_set_stamp_buffer(buf.data_ptr())
+ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=9), x0, w.T, w.p_drop)
+torch.cuda.synchronize()
+hipabi.lib().mcp_debug_set_stamp_buffer(None)
+v = buf.cpu().tolist()
+names = ["S(state/feat)", "PHI", "U", "K", "V(matvec)", "vsum", "J", "F+integrate", "-"]
+tot = sum(v[:9])
+print("workload", name, "T", w.T, "M", w.M, "ppw", ppw, "total cycles", tot, "-> per step", tot / (w.T - 1))
+for n, c in zip(names, v):
+    print("%-14s %12d  %5.1f%%  %8.0f cyc/step" % (n, c, 100.0 * c / tot, c / (w.T - 1)))
