@@ -30,11 +30,22 @@ struct BwdArgs {
   const double* g_inputs;
   double* slab;  // [gridDim.x][nparam]
   double* g_x0;
+  unsigned long long* stamps;  // diagnostic only: per-stage cycle totals of workgroup 0 (slots 8..11)
 };
 
+#define BW_STAMP(k)                                 \
+  do {                                              \
+    if (a.stamps && tid == 0 && blockIdx.x == 0) {  \
+      unsigned long long now_ = clock64();          \
+      a.stamps[k] += now_ - last_stamp;             \
+      last_stamp = now_;                            \
+    }                                               \
+  } while (0)
+
 struct BwdLayout {
-  int invl, x, u, J, gs, xn, xb, zb, db, ub, ab, sf, sb, red, total;
+  int invl, rec, xn, xb, zb, db, ab, sf, sb, sn, cs, red, itab, total;
 };
+__host__ __device__ inline int bwd_rec_len(int S, int U, int D, int G) { return 2 * S + 2 * U + G * D; }
 __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int PF, int NW) {
   BwdLayout L;
   int o = 0;
@@ -44,53 +55,74 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
     return r;
   };
   L.invl = take(PF);
-  L.x = take(S);
-  L.u = take(U);
-  L.J = take(G * D);
-  L.gs = take(S + U);
+  L.rec = take(2 * bwd_rec_len(S, U, D, G));
   L.xn = take(S);
   L.xb = take(S);
   L.zb = take(D);
   L.db = take(G);
-  L.ub = take(U);
   L.ab = take(U);
   L.sf = take(PF);
   L.sb = take(PF);
+  L.sn = take(S);
+  L.cs = take(S);
   L.red = take(NW * PF);
+  L.itab = take((2 * MCP_MAX_GP + 2 * MCP_MAX_STATE + MCP_MAX_INPUT + 1) / 2 + 1);
   L.total = o;
   return L;
 }
 
+#define BW_RPT 5  // record elements a thread prefetches at most (record <= 304 doubles, >= 64 threads)
+
+// Per particle and time step the record is  [x_t (S) | u_t (U) | dJ/dx_t (S) | dJ/du_t (U) | d delta/dz (G*D)].
+// It is prefetched into registers one step ahead (global/L2 latency hidden behind the current step) and
+// parked in a double-buffered LDS copy.  The short dependent chain of tiny stages (integrator adjoint,
+// GP-Jacobian product, feature-map adjoints, squashing) runs in wave 0 alone with wave-level ordering;
+// only the RBF network stage uses the whole workgroup: two workgroup barriers per time step.
 template <int PFM, int UM, int MAXNT>
 __global__ __launch_bounds__(MAXNT) void rollout_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
-  const int tid = threadIdx.x, NT = blockDim.x, NW = NT >> 6, wv = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, NT = blockDim.x, NW = NT >> 6, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
   const BwdLayout L = bwd_layout(S, U, D, G, PF, NW);
+  const int NR = bwd_rec_len(S, U, D, G);
   double* invl = smem + L.invl;
-  double* xc = smem + L.x;
-  double* uc = smem + L.u;
-  double* Jr = smem + L.J;
-  double* gsu = smem + L.gs;  // [S] upstream dJ/dx_t, then [U] upstream dJ/du_t
-  double* xn = smem + L.xn;   // adjoint of x_{t+1}
-  double* xb = smem + L.xb;   // adjoint of x_t (being built)
-  double* zb = smem + L.zb;
-  double* db = smem + L.db;
-  double* ub = smem + L.ub;
-  double* ab = smem + L.ab;
-  double* sf = smem + L.sf;
-  double* sb = smem + L.sb;
-  double* red = smem + L.red;
+  volatile double* rec = smem + L.rec;  // [2][NR]
+  volatile double* xn = smem + L.xn;    // adjoint of x_{t+1}
+  volatile double* xb = smem + L.xb;    // adjoint of x_t without the policy path
+  volatile double* zb = smem + L.zb;
+  volatile double* db = smem + L.db;
+  volatile double* ab = smem + L.ab;
+  volatile double* sf = smem + L.sf;
+  volatile double* sb = smem + L.sb;
+  volatile double* sn = smem + L.sn;
+  volatile double* cs = smem + L.cs;
+  volatile double* red = smem + L.red;
+  // integer / per-input tables in LDS: indexing the by-value kernel argument with a per-lane index would
+  // make the compiler spill it to scratch
+  int* t_vel = reinterpret_cast<int*>(smem + L.itab);
+  int* t_pos = t_vel + MCP_MAX_GP;
+  int* t_pna = t_pos + MCP_MAX_GP;      // policy non_angle[]
+  int* t_pan = t_pna + MCP_MAX_STATE;   // policy angle[]
   const int b = tid;
   const bool act = b < B;
   const bool drop = pl.p_drop > 0.0;
   const double keep_scale = 1.0 / (1.0 - pl.p_drop);
   const uint32_t drop_thr = drop_threshold(pl.p_drop);
   const int nna_g = md.n_not_angle, na_g = md.n_angle;
+  const int oX = 0, oU = S, oGX = S + U, oGU = 2 * S + U, oJ = 2 * S + 2 * U;
 
   for (int it = tid; it < PF; it += NT) invl[it] = exp(-pl.log_ls[it]);
+  if (tid == 0) {
+    for (int g = 0; g < G; ++g) {
+      t_vel[g] = md.vel[g];
+      t_pos[g] = md.not_vel[g];
+    }
+    for (int i = 0; i < pl.n_non_angle; ++i) t_pna[i] = pl.non_angle[i];
+    for (int i = 0; i < pl.n_angle; ++i) t_pan[i] = pl.angle[i];
+  }
   double cen[PFM], gc[PFM], gl[PFM], wgt[UM], gw[UM];
 #pragma unroll
   for (int q = 0; q < PFM; ++q) {
@@ -103,87 +135,179 @@ __global__ __launch_bounds__(MAXNT) void rollout_bwd_kernel(BwdArgs a) {
     wgt[k] = (act && k < U) ? pl.weight[(size_t)k * B + b] : 0.0;
     gw[k] = 0.0;
   }
-  __syncthreads();
+  // lane-private index tables of the serial section (lane = state / feature index)
+  int zi_plain = -1, zi_ang = -1, pi_plain = -1, pi_ang = -1, g_vel = -1, g_pos = -1;
+  if (wv == 0 && lane < S) {
+    for (int i = 0; i < nna_g; ++i)
+      if (md.not_angle[i] == lane) zi_plain = i;
+    for (int i = 0; i < na_g; ++i)
+      if (md.angle[i] == lane) zi_ang = i;
+    if (pl.kind == MCP_POLICY_ANGLES) {
+      for (int i = 0; i < pl.n_non_angle; ++i)
+        if (pl.non_angle[i] == lane) pi_plain = i;
+      for (int i = 0; i < pl.n_angle; ++i)
+        if (pl.angle[i] == lane) pi_ang = i;
+    }
+    for (int g = 0; g < G; ++g) {
+      if (md.vel[g] == lane) g_vel = g;
+      if (md.not_vel[g] == lane) g_pos = g;
+    }
+  }
+  int pos_of_vel = 0;  // the position state integrated from this lane's velocity state
+  for (int g = 0; g < G; ++g)
+    if (md.vel[g] == lane) pos_of_vel = md.not_vel[g];
+  const double umax_lane = (wv == 0 && lane < U) ? pl.u_max[lane] : 1.0;
+  const bool need_trig = (zi_ang >= 0) || (pi_ang >= 0);
+  lds_barrier();
 
+  auto prefetch = [&](double (&pre)[BW_RPT], int t, int m) {
+    const size_t tm = (size_t)t * M + m;
+#pragma unroll
+    for (int k = 0; k < BW_RPT; ++k) {
+      int i = tid + k * NT;
+      double v = 0.0;
+      if (i < NR) {
+        if (i < oU)
+          v = a.states[tm * S + i];
+        else if (i < oGX)
+          v = a.inputs[tm * U + (i - oU)];
+        else if (i < oGU)
+          v = a.g_states ? a.g_states[tm * S + (i - oGX)] : 0.0;
+        else if (i < oJ)
+          v = a.g_inputs ? a.g_inputs[tm * U + (i - oGU)] : 0.0;
+        else if (t < T - 1)
+          v = a.jac[tm * G * D + (i - oJ)];
+      }
+      pre[k] = v;
+    }
+  };
+  auto park = [&](const double (&pre)[BW_RPT], int buf) {
+#pragma unroll
+    for (int k = 0; k < BW_RPT; ++k) {
+      int i = tid + k * NT;
+      if (i < NR) rec[buf * NR + i] = pre[k];
+    }
+  };
+
+  unsigned long long last_stamp = clock64();
   for (int m = blockIdx.x; m < M; m += gridDim.x) {
-    for (int it = tid; it < S; it += NT) xn[it] = 0.0;
+    double pre[BW_RPT];
+    int cur = 0;
+    prefetch(pre, T - 1, m);
+    park(pre, cur);
+    lds_barrier();
     for (int t = T - 1; t >= 0; --t) {
-      __syncthreads();
-      // ---- stage A: this step's record ------------------------------------------------------
-      const size_t tm = (size_t)t * M + m;
-      for (int it = tid; it < S; it += NT) {
-        xc[it] = a.states[tm * S + it];
-        gsu[it] = a.g_states ? a.g_states[tm * S + it] : 0.0;
-      }
-      for (int it = tid; it < U; it += NT) {
-        uc[it] = a.inputs[tm * U + it];
-        gsu[S + it] = a.g_inputs ? a.g_inputs[tm * U + it] : 0.0;
-      }
-      if (t < T - 1) {
-        for (int it = tid; it < G * D; it += NT) Jr[it] = a.jac[tm * G * D + it];
-        // adjoint of delta_g:  x_{t+1}[vel] = x[vel] + delta ; x_{t+1}[pos] = x[pos] + Ts x[vel] + Ts/2 delta
-        for (int it = tid; it < G; it += NT) db[it] = xn[md.vel[it]] + 0.5 * md.Ts * xn[md.not_vel[it]];
-      }
-      __syncthreads();
-      // ---- stage B: through the integrator and the GP Jacobian --------------------------------
-      for (int it = tid; it < D; it += NT) {
-        double s = 0.0;
-        if (t < T - 1)
-          for (int g = 0; g < G; ++g) s = fma(db[g], Jr[g * D + it], s);
-        zb[it] = s;
-      }
-      for (int it = tid; it < S; it += NT) {
-        double s = gsu[it];
-        if (t < T - 1) {
-          for (int g = 0; g < G; ++g) {
-            if (md.vel[g] == it) s += xn[it] + md.Ts * xn[md.not_vel[g]];
-            if (md.not_vel[g] == it) s += xn[it];
+      BW_STAMP(11);
+      if (t > 0) prefetch(pre, t - 1, m);
+      // ---- serial section: wave 0 ---------------------------------------------------------------
+      if (wv == 0) {
+        const volatile double* r = rec + cur * NR;
+        const bool last = (t == T - 1);
+        if (!last) {
+          // finish step t+1: adjoint of the policy features -> adjoint of x_{t+1}
+          if (lane < PF) {
+            double s = 0.0;
+            for (int w = 0; w < NW; ++w) s += red[w * PF + lane];
+            sb[lane] = s;
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (lane < S) {
+            double s;
+            if (pl.kind == MCP_POLICY_ANGLES) {
+              s = (pi_plain >= 0) ? sb[pi_plain] : 0.0;
+              if (pi_ang >= 0) s += -sb[pl.n_non_angle + pi_ang] * sn[lane] + sb[pl.n_non_angle + pl.n_angle + pi_ang] * cs[lane];
+            } else if (pl.kind == MCP_POLICY_TRAJ) {
+              s = sb[lane] - sb[S + lane];
+            } else {
+              s = sb[lane];
+            }
+            xn[lane] = xb[lane] + s;
+          }
+          __builtin_amdgcn_wave_barrier();
+          // through the integrator:  x_{t+1}[vel] = x[vel] + delta ; x_{t+1}[pos] = x[pos] + Ts x[vel] + Ts/2 delta
+          if (lane < G) db[lane] = xn[t_vel[lane]] + 0.5 * md.Ts * xn[t_pos[lane]];
+        }
+        // trig of this step's angles (used now by the GP feature map, next iteration by the policy's)
+        if (lane < S && need_trig) {
+          double sv, cv;
+          sincos(r[oX + lane], &sv, &cv);
+          sn[lane] = sv;
+          cs[lane] = cv;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // through the GP Jacobian and the integrator's direct paths
+        if (lane < D) {
+          double s = 0.0;
+          if (!last)
+            for (int g = 0; g < G; ++g) s = fma(db[g], r[oJ + g * D + lane], s);
+          zb[lane] = s;
+        }
+        double xbv = 0.0;
+        if (lane < S) {
+          xbv = r[oGX + lane];
+          if (!last) {
+            if (g_vel >= 0) xbv += xn[lane] + md.Ts * xn[pos_of_vel];
+            if (g_pos >= 0) xbv += xn[lane];
           }
         }
-        xb[it] = s;
+        // policy features of x_t  (Policy.py:326-333: [x_nonangle, COS, SIN];  :397-399: [x, x*_t - x])
+        if (lane < PF) {
+          double f;
+          if (pl.kind == MCP_POLICY_ANGLES) {
+            const int pn = pl.n_non_angle, pa_ = pl.n_angle;
+            if (lane < pn)
+              f = r[oX + t_pna[lane]];
+            else if (lane < pn + pa_)
+              f = cs[t_pan[lane - pn]];
+            else
+              f = sn[t_pan[lane - pn - pa_]];
+          } else if (pl.kind == MCP_POLICY_TRAJ) {
+            f = (lane < S) ? r[oX + lane] : pl.target_traj[(size_t)t * S + (lane - S)] - r[oX + lane - S];
+          } else {
+            f = r[oX + lane];
+          }
+          sf[lane] = f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // through the GP feature map z=[x_na, sin, cos, u]; adjoint of the pre-squash activation
+        if (lane < S) {
+          if (zi_plain >= 0) xbv += zb[zi_plain];
+          if (zi_ang >= 0) xbv += zb[nna_g + zi_ang] * cs[lane] - zb[nna_g + na_g + zi_ang] * sn[lane];
+          xb[lane] = xbv;
+        }
+        if (lane < U) {
+          double ubar = r[oGU + lane] + zb[nna_g + 2 * na_g + lane];
+          double th = r[oU + lane] / umax_lane;  // = tanh(a/u_max)
+          ab[lane] = pl.squash ? ubar * (1.0 - th * th) : ubar;
+        }
       }
-      for (int it = tid; it < PF; it += NT) sf[it] = policy_feature(pl, xc, it, t);
-      __syncthreads();
-      // ---- stage C: through the GP feature map; adjoint of the pre-squash activation ------------
-      for (int it = tid; it < S; it += NT) {
-        double s = 0.0;
-        for (int i = 0; i < nna_g; ++i)
-          if (md.not_angle[i] == it) s += zb[i];
-        for (int i = 0; i < na_g; ++i)
-          if (md.angle[i] == it) s += zb[nna_g + i] * cos(xc[it]) - zb[nna_g + na_g + i] * sin(xc[it]);
-        xb[it] += s;
-      }
-      for (int it = tid; it < U; it += NT) {
-        double ubar = gsu[S + it] + zb[nna_g + 2 * na_g + it];
-        ub[it] = ubar;
-        double um = pl.u_max[it];
-        double th = uc[it] / um;  // = tanh(a/u_max)
-        ab[it] = pl.squash ? ubar * (1.0 - th * th) : ubar;
-      }
-      __syncthreads();
-      // ---- stage D: RBF network, thread b owns basis b --------------------------------------------
+      BW_STAMP(8);
+      lds_barrier();
+      BW_STAMP(9);
+      // ---- RBF network, thread b owns basis b ---------------------------------------------------------
       double dd = 0.0;  // adjoint of dist_b (0 for idle threads, so they add nothing below)
       if (act) {
         double dist = 0.0;
 #pragma unroll
         for (int q = 0; q < PFM; ++q) {
           if (q < PF) {
-            double r = (sf[q] - cen[q]) * invl[q];
-            dist = fma(r, r, dist);
+            double rr = (sf[q] - cen[q]) * invl[q];
+            dist = fma(rr, rr, dist);
           }
         }
         double phi = exp(-dist);
         double mk = 1.0;
         if (drop) {
-          bool keep = a.nz.masks ? (a.nz.masks[tm * B + b] != 0) : philox_keep(a.nz, m, t, b, drop_thr);
+          bool keep = a.nz.masks ? (a.nz.masks[((size_t)t * M + m) * B + b] != 0) : philox_keep(a.nz, m, t, b, drop_thr);
           mk = keep ? keep_scale : 0.0;
         }
         double phibar = 0.0;
 #pragma unroll
         for (int k = 0; k < UM; ++k) {
           if (k < U) {
-            gw[k] = fma(ab[k], phi * mk, gw[k]);
-            phibar = fma(wgt[k], ab[k], phibar);
+            double abk = ab[k];
+            gw[k] = fma(abk, phi * mk, gw[k]);
+            phibar = fma(wgt[k], abk, phibar);
           }
         }
         dd = -phi * mk * phibar;
@@ -191,42 +315,41 @@ __global__ __launch_bounds__(MAXNT) void rollout_bwd_kernel(BwdArgs a) {
 #pragma unroll
       for (int q = 0; q < PFM; ++q) {
         if (q < PF) {
-          double r = (sf[q] - cen[q]) * invl[q];
-          double t2 = 2.0 * dd * r;
+          double rr = (sf[q] - cen[q]) * invl[q];
+          double t2 = 2.0 * dd * rr;
           gc[q] = fma(-t2, invl[q], gc[q]);
-          gl[q] = fma(-t2, r, gl[q]);
-          double s = wave_sum(t2 * invl[q]);
-          if (lane == 0) red[wv * PF + q] = s;
+          gl[q] = fma(-t2, rr, gl[q]);
+          double sm = wave_sum(t2 * invl[q]);
+          if (lane == 0) red[wv * PF + q] = sm;
         }
       }
-      __syncthreads();
-      for (int it = tid; it < PF; it += NT) {
+      BW_STAMP(10);
+      if (t > 0) park(pre, cur ^ 1);
+      cur ^= 1;
+      lds_barrier();
+    }
+    // finish step 0: adjoint of x_0
+    if (wv == 0) {
+      if (lane < PF) {
         double s = 0.0;
-        for (int w = 0; w < NW; ++w) s += red[w * PF + it];
-        sb[it] = s;
+        for (int w = 0; w < NW; ++w) s += red[w * PF + lane];
+        sb[lane] = s;
       }
-      __syncthreads();
-      // ---- stage E: through the policy feature map; x_bar complete -> becomes x_{t+1}'s adjoint ----
-      for (int it = tid; it < S; it += NT) {
-        double s = 0.0;
+      __builtin_amdgcn_wave_barrier();
+      if (lane < S) {
+        double s;
         if (pl.kind == MCP_POLICY_ANGLES) {
-          int nna = pl.n_non_angle, na = pl.n_angle;
-          for (int i = 0; i < nna; ++i)
-            if (pl.non_angle[i] == it) s += sb[i];
-          for (int i = 0; i < na; ++i)
-            if (pl.angle[i] == it) s += -sb[nna + i] * sin(xc[it]) + sb[nna + na + i] * cos(xc[it]);
+          s = (pi_plain >= 0) ? sb[pi_plain] : 0.0;
+          if (pi_ang >= 0) s += -sb[pl.n_non_angle + pi_ang] * sn[lane] + sb[pl.n_non_angle + pl.n_angle + pi_ang] * cs[lane];
         } else if (pl.kind == MCP_POLICY_TRAJ) {
-          s = sb[it] - sb[S + it];
+          s = sb[lane] - sb[S + lane];
         } else {
-          s = sb[it];
+          s = sb[lane];
         }
-        xn[it] = xb[it] + s;
+        if (a.g_x0) a.g_x0[(size_t)m * S + lane] = xb[lane] + s;
       }
     }
-    __syncthreads();
-    if (a.g_x0)
-      for (int it = tid; it < S; it += NT) a.g_x0[(size_t)m * S + it] = xn[it];
-    __syncthreads();
+    lds_barrier();
   }
 
   // ---- write this workgroup's partial parameter gradients ------------------------------------
@@ -240,19 +363,19 @@ __global__ __launch_bounds__(MAXNT) void rollout_bwd_kernel(BwdArgs a) {
     for (int k = 0; k < UM; ++k)
       if (k < U) out[PF + (size_t)B * PF + (size_t)k * B + b] = gw[k];
   }
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
   for (int q = 0; q < PFM; ++q) {
     if (q < PF) {
-      double s = wave_sum(gl[q]);
-      if (lane == 0) red[wv * PF + q] = s;
+      double sm = wave_sum(gl[q]);
+      if (lane == 0) red[wv * PF + q] = sm;
     }
   }
-  __syncthreads();
+  lds_barrier();
   for (int it = tid; it < PF; it += NT) {
-    double s = 0.0;
-    for (int w = 0; w < NW; ++w) s += red[w * PF + it];
-    out[it] = s;
+    double sm = 0.0;
+    for (int w = 0; w < NW; ++w) sm += red[w * PF + it];
+    out[it] = sm;
   }
 }
 
@@ -282,6 +405,8 @@ __global__ void grad_reduce_kernel(int nblk, int nparam, int PF, int BPF, const 
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
+static unsigned long long* g_bwd_stamps = nullptr;  // diagnostic hook
+extern "C" void mcp_debug_set_bwd_stamp_buffer(void* p) { g_bwd_stamps = (unsigned long long*)p; }
 static int bwd_threads(int B) { return imax(64, ((B + 63) / 64) * 64); }
 static int bwd_blocks(int M) { return imin(M, 1024); }
 
@@ -321,6 +446,7 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   a.g_inputs = g_inputs;
   a.slab = (double*)workspace;
   a.g_x0 = g_x0;
+  a.stamps = g_bwd_stamps;
   const int NT = bwd_threads(policy->B);
   const int grid = bwd_blocks(M);
   BwdLayout L = bwd_layout(model->S, model->U, model->D, model->G, policy->P, NT / 64);
@@ -328,14 +454,16 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   hipStream_t st = (hipStream_t)stream;
   int rc;
   const int PF = policy->P, U = policy->U;
-  // register budget: 3*PFM + 2*UM doubles of per-thread accumulators -> the widest variant runs
-  // with at most 512 threads (B <= 512) so that it keeps 256 VGPRs per lane
+  // register budget: 3*PFM + 2*UM doubles of per-thread accumulators plus the prefetched record; the
+  // launch bound is the tightest that fits the thread count so the allocator gets 256-512 VGPRs
+  // (at __launch_bounds__(1024) the kernel spilled ~600 B/lane to scratch)
   if (PF <= 8 && U <= 2)
-    rc = launch_bwd<8, 2, 1024>(a, grid, NT, lds, st);
+    rc = NT <= 256 ? launch_bwd<8, 2, 256>(a, grid, NT, lds, st) : launch_bwd<8, 2, 1024>(a, grid, NT, lds, st);
   else if (PF <= 16 && U <= 4)
-    rc = launch_bwd<16, 4, 1024>(a, grid, NT, lds, st);
+    rc = NT <= 256 ? launch_bwd<16, 4, 256>(a, grid, NT, lds, st) : launch_bwd<16, 4, 1024>(a, grid, NT, lds, st);
   else
-    rc = launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 512>(a, grid, NT, lds, st);
+    rc = NT <= 256 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 256>(a, grid, NT, lds, st)
+                   : launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 512>(a, grid, NT, lds, st);
   if (rc != MCP_OK) return rc;
   const int nparam = PF + policy->B * PF + U * policy->B;
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((nparam + 255) / 256), dim3(256), 0, st, grid, nparam, PF, policy->B * PF, a.slab, g_log_ls,

@@ -24,6 +24,10 @@ __device__ __forceinline__ double policy_feature(const mcp_policy& pl, const dou
   return x[q];
 }
 
+// workgroup barrier that orders LDS traffic only: global stores issued earlier are fire-and-forget in
+// the rollout kernels (nobody in the kernel reads them back), so they are not drained at every barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 static inline bool model_ok(const mcp_model* m) {
   if (!m) return false;
   if (m->S <= 0 || m->S > MCP_MAX_STATE || m->U <= 0 || m->U > MCP_MAX_INPUT || m->G <= 0 || m->G > MCP_MAX_GP) return false;

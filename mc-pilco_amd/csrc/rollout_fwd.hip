@@ -32,7 +32,7 @@ using namespace mcp;
 #define RF_GS 8  // rows of Kinv per register buffer (two buffers in flight per wave)
 
 struct FwdLayout {
-  int invl, xs, us, z, sf, dl, kb, ks, pa, pb, vb, part, red, xt, al, cen, wgt, tab, total;  // offsets in doubles
+  int invl, xs, us, z, sf, dl, kb, ks, pa, pb, vb, part, red, xt, al, cen, wgt, tab, gpl, kpar, total;  // offsets in doubles
 };
 
 // integer tables (in the `tab` region): cstart[NC+1], cg[NC], cbase[NC], cR[NC], gcb[GB], wc0[NW]
@@ -44,6 +44,25 @@ struct FwdLayout {
 #define TAB_WC0 (TAB_GCB + MCP_MAX_GP)
 #define TAB_INTS (TAB_WC0 + RF_NW)
 #define RF_CW 128  // rows of v per column chunk: 64 lanes x 2 rows (one 16-byte load per lane)
+
+// LDS-resident copy of what the kernels need from mcp_gp.  The descriptors arrive by value in the
+// kernel argument; indexing that copy with a per-lane GP index would make the compiler spill the
+// whole argument to scratch (global-latency loads in every phase), so it is staged here once.
+struct GpL {
+  const double* Kinv;
+  const double* Xt;
+  const double* alpha;
+  double lambda, mean, var_scale;
+  int N, Npad, deg, pad_;
+};
+#define GPL_DOUBLES ((int)(sizeof(GpL) / sizeof(double)))
+// kernel hyper-parameters per GP in LDS: inv_ls[D] | w1[D+1] | w20[D] | w21[D] | aX[D]
+#define KP_INVLS(D) 0
+#define KP_W1(D) (D)
+#define KP_W20(D) (2 * (D) + 1)
+#define KP_W21(D) (3 * (D) + 1)
+#define KP_AX(D) (4 * (D) + 1)
+#define KP_STRIDE(D) (5 * (D) + 1)
 
 __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int G, int PF, int B, int NpadMax, int maxdeg, int GB,
                                                 int NCmax, bool xlds) {
@@ -72,6 +91,8 @@ __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int 
   L.cen = xlds ? take(B * PF) : 0;
   L.wgt = xlds ? take(U * B) : 0;
   L.tab = take((TAB_INTS + 1) / 2);
+  L.gpl = take(G * GPL_DOUBLES);
+  L.kpar = take(G * (5 * D + 1));
   L.total = o;
   return L;
 }
@@ -107,14 +128,52 @@ __device__ __forceinline__ int gp_num_acc(int deg) { return deg == 0 ? 2 : (deg 
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int chunks_of(int Npad) { return (Npad + RF_CW - 1) / RF_CW; }
 
-__device__ __forceinline__ int build_chunk_table(const mcp_gp* gps, int g0, int gn, int* tab, int tid) {
+// one-time staging of the GP descriptors and kernel hyper-parameters into LDS (uniform indices only)
+__device__ __forceinline__ void stage_gp_tables(const mcp_gp* gps, const double* var_scale, int G, int D, GpL* gpl, double* kpar, int tid) {
+  for (int g = 0; g < G; ++g) {
+    const mcp_gp& gp = gps[g];
+    if (tid == 0) {
+      GpL e;
+      e.Kinv = gp.Kinv;
+      e.Xt = gp.Xt;
+      e.alpha = gp.alpha;
+      e.lambda = gp.kern.lambda;
+      e.mean = gp.kern.mean;
+      e.var_scale = var_scale ? var_scale[g] : 1.0;
+      e.N = gp.N;
+      e.Npad = gp.Npad;
+      e.deg = gp.kern.poly_deg;
+      e.pad_ = 0;
+      gpl[g] = e;
+    }
+    double* kp = kpar + (size_t)g * KP_STRIDE(D);
+    const int deg = gp.kern.poly_deg;
+    for (int it = tid; it < KP_STRIDE(D); it += RF_NT) {
+      double v = 0.0;
+      if (it < D)
+        v = gp.kern.inv_ls[it];
+      else if (it < 2 * D + 1)
+        v = deg >= 1 ? gp.kern.w1[it - D] : 0.0;
+      else if (it < 3 * D + 1)
+        v = deg >= 2 ? gp.kern.w20[it - KP_W20(D)] : 0.0;
+      else if (it < 4 * D + 1)
+        v = deg >= 2 ? gp.kern.w21[it - KP_W21(D)] : 0.0;
+      else
+        v = deg >= 1 ? gp.aX[it - KP_AX(D)] : 0.0;
+      kp[it] = v;
+    }
+  }
+}
+
+// the Kinv stream of one pass over GPs [g0, g0+gn): the list of column chunks, each N_g (or N_g/2) units long
+__device__ __forceinline__ int build_chunk_table(const GpL* gpl, int g0, int gn, int* tab, int tid) {
   int NC = 0;
-  for (int g = 0; g < gn; ++g) NC += chunks_of(gps[g0 + g].Npad);
+  for (int g = 0; g < gn; ++g) NC += chunks_of(gpl[g0 + g].Npad);
   if (tid == 0) {
     int c = 0, acc = 0;
     for (int g = 0; g < gn; ++g) {
       tab[TAB_GCB + g] = c;
-      const int Npad = gps[g0 + g].Npad, N = gps[g0 + g].N;
+      const int Npad = gpl[g0 + g].Npad, N = gpl[g0 + g].N;
       const int nic = chunks_of(Npad);
       for (int ic = 0; ic < nic; ++ic) {
         const int width = imin(RF_CW, Npad - ic * RF_CW);
@@ -143,40 +202,42 @@ __device__ __forceinline__ int build_chunk_table(const mcp_gp* gps, int g0, int 
 // -> LDS [gl][j][p]   (rows j >= N are never read)
 // ---------------------------------------------------------------------------------------
 template <int P, bool XLDS>
-__device__ __forceinline__ void phase_k(const mcp_gp* gps, int g0, int gn, int D, int NpadMax, const double* z, const double* xt_l,
-                                        double* kb, double* ks, double* pa, double* pb, int tid) {
+__device__ __forceinline__ void phase_k(const GpL* gpl, const double* kpar, int g0, int gn, int D, int NpadMax, const double* z,
+                                        const double* xt_l, double* kb, double* ks, double* pa, double* pb, int tid) {
   for (int it = tid; it < gn * P * NpadMax; it += RF_NT) {
     int gl = it / (P * NpadMax);
     int r = it - gl * P * NpadMax;
     int p = r / NpadMax, j = r - p * NpadMax;
-    const mcp_gp& gp = gps[g0 + gl];
-    if (j >= gp.N) {
-      if (j < gp.Npad) kb[((size_t)gl * NpadMax + j) * P + p] = 0.0;  // phase V may touch one padded row
+    const GpL& gp = gpl[g0 + gl];
+    const int N = gp.N, Npad = gp.Npad;
+    if (j >= N) {
+      if (j < Npad) kb[((size_t)gl * NpadMax + j) * P + p] = 0.0;  // phase V may touch one padded row
       continue;
     }
-    const mcp_kernel& kn = gp.kern;
-    const int deg = kn.poly_deg;
+    const double* kp = kpar + (size_t)(g0 + gl) * KP_STRIDE(D);
+    const int deg = gp.deg;
     const double* zp = z + p * D;
     const double* xc = XLDS ? xt_l + (size_t)(g0 + gl) * D * NpadMax + j : gp.Xt + j;
-    const int xs_ = XLDS ? NpadMax : gp.Npad;
+    const int xs_ = XLDS ? NpadMax : Npad;
     double dist = 0.0;
+#pragma unroll 6
     for (int d = 0; d < D; ++d) {
-      double rr = (zp[d] - xc[(size_t)d * xs_]) * kn.inv_ls[d];
+      double rr = (zp[d] - xc[(size_t)d * xs_]) * kp[KP_INVLS(D) + d];
       dist = fma(rr, rr, dist);
     }
-    double kse = kn.lambda * exp(-dist);
+    double kse = gp.lambda * exp(-dist);
     double kt = kse;
     const size_t o = ((size_t)gl * NpadMax + j) * P + p;
     if (deg >= 1) {
-      double p1 = kn.w1[D];
-      for (int d = 0; d < D; ++d) p1 = fma(kn.w1[d] * zp[d], xc[(size_t)d * xs_], p1);
+      double p1 = kp[KP_W1(D) + D];
+      for (int d = 0; d < D; ++d) p1 = fma(kp[KP_W1(D) + d] * zp[d], xc[(size_t)d * xs_], p1);
       kt += p1;
       if (deg >= 2) {
         double A = 0.0, Bv = 0.0;
         for (int d = 0; d < D; ++d) {
           double zx = zp[d] * xc[(size_t)d * xs_];
-          A = fma(kn.w20[d], zx, A);
-          Bv = fma(kn.w21[d], zx, Bv);
+          A = fma(kp[KP_W20(D) + d], zx, A);
+          Bv = fma(kp[KP_W21(D) + d], zx, Bv);
         }
         kt = fma(A, Bv, kt);
         pa[o] = A;
@@ -265,7 +326,7 @@ __device__ __forceinline__ void matvec_rows(const double* __restrict__ base, siz
 }
 
 template <int P>
-__device__ __forceinline__ void phase_v(const mcp_gp* gps, int g0, const int* tab, int NC, int NpadMax, const double* kb, double* part,
+__device__ __forceinline__ void phase_v(const GpL* gpl, int g0, const int* tab, int NC, int NpadMax, const double* kb, double* part,
                                         int wv, int lane) {
   const int total = tab[TAB_CSTART + NC];
   const int L = (total + RF_NW - 1) / RF_NW;
@@ -276,8 +337,8 @@ __device__ __forceinline__ void phase_v(const mcp_gp* gps, int g0, const int* ta
   while (u < u1) {
     const int cs = tab[TAB_CSTART + c], ce = tab[TAB_CSTART + c + 1];
     const int gl = tab[TAB_CG + c], rb = tab[TAB_CBASE + c], R = tab[TAB_CR + c];
-    const mcp_gp& gp = gps[g0 + gl];
-    const int Npad = gp.Npad;
+    const int Npad = __builtin_amdgcn_readfirstlane(gpl[g0 + gl].Npad);
+    const double* Kinv = gpl[g0 + gl].Kinv;
     const int ua = u - cs, ub = imin(ce, u1) - cs;
     const int sub = (R == 2) ? (lane >> 5) : 0;   // which of the unit's R rows this lane reads
     const int li = (R == 2) ? (lane & 31) : lane;  // lane's column pair inside the chunk
@@ -286,7 +347,7 @@ __device__ __forceinline__ void phase_v(const mcp_gp* gps, int g0, const int* ta
     double acc[2][P];
 #pragma unroll
     for (int p = 0; p < P; ++p) acc[0][p] = acc[1][p] = 0.0;
-    const double* base = gp.Kinv + (size_t)sub * Npad + (ok ? i : rb);
+    const double* base = Kinv + (size_t)sub * Npad + (ok ? i : rb);
     matvec_rows<P>(base, (size_t)R * Npad, kb + ((size_t)gl * NpadMax + sub) * P, R * P, ua, ub, acc);
     if (R == 2) {
       // fold rows j+1 (lanes 32..63) into rows j (lanes 0..31)
@@ -311,7 +372,7 @@ __device__ __forceinline__ void phase_v(const mcp_gp* gps, int g0, const int* ta
 
 // v[gl][i][p] = sum of the chunk's partial slots, in a fixed order
 template <int P>
-__device__ __forceinline__ void phase_vsum(const mcp_gp* gps, int g0, int gn, const int* tab, int NC, int NpadMax, const double* part,
+__device__ __forceinline__ void phase_vsum(const GpL* gpl, int g0, int gn, const int* tab, int NC, int NpadMax, const double* part,
                                            double* vb, int tid) {
   const int total = tab[TAB_CSTART + NC];
   const int L = (total + RF_NW - 1) / RF_NW;
@@ -319,7 +380,7 @@ __device__ __forceinline__ void phase_vsum(const mcp_gp* gps, int g0, int gn, co
     int gl = it / (NpadMax * P);
     int r = it - gl * NpadMax * P;
     int i = r / P, p = r - i * P;
-    if (i >= gps[g0 + gl].N) continue;
+    if (i >= gpl[g0 + gl].N) continue;
     int c = tab[TAB_GCB + gl] + i / RF_CW;
     int s_lo = c + tab[TAB_CSTART + c] / L, s_hi = c + (tab[TAB_CSTART + c + 1] - 1) / L;
     double s = 0.0;
@@ -336,7 +397,7 @@ __device__ __forceinline__ void phase_vsum(const mcp_gp* gps, int g0, int gn, co
 //   column c == D : a0 = sum k_j alpha_j  (= mu - m)          a1 = sum k_j v_j  (= k^T Kinv k)
 // ---------------------------------------------------------------------------------------
 template <int P, bool XLDS>
-__device__ __forceinline__ void phase_j(const mcp_gp* gps, int g0, int gn, int D, int NpadMax, const double* z, const double* xt_l,
+__device__ __forceinline__ void phase_j(const GpL* gpl, int g0, int gn, int D, int NpadMax, const double* z, const double* xt_l,
                                         const double* al_l, const double* kb, const double* ks, const double* pa, const double* pb,
                                         const double* vb, double* red, int wv, int lane) {
   const int per = P * (D + 1);
@@ -344,16 +405,17 @@ __device__ __forceinline__ void phase_j(const mcp_gp* gps, int g0, int gn, int D
     int gl = item / per;
     int r = item - gl * per;
     int p = r / (D + 1), c = r - p * (D + 1);
-    const mcp_gp& gp = gps[g0 + gl];
-    const int N = gp.N, deg = gp.kern.poly_deg, NA = gp_num_acc(deg);
+    const GpL& gp = gpl[g0 + gl];
+    const int N = __builtin_amdgcn_readfirstlane(gp.N), deg = __builtin_amdgcn_readfirstlane(gp.deg), NA = gp_num_acc(deg);
     const double* al = XLDS ? al_l + (size_t)(g0 + gl) * NpadMax : gp.alpha;
     const size_t ob = (size_t)gl * NpadMax * P + p;
     double acc[RF_MAX_NA];
 #pragma unroll
     for (int q = 0; q < RF_MAX_NA; ++q) acc[q] = 0.0;
     if (c < D) {
-      const double* xc = XLDS ? xt_l + ((size_t)(g0 + gl) * D + c) * NpadMax : gp.Xt + (size_t)c * gp.Npad;
+      const double* xc = XLDS ? xt_l + ((size_t)(g0 + gl) * D + c) * NpadMax : gp.Xt + (size_t)c * __builtin_amdgcn_readfirstlane(gp.Npad);
       const double zc = z[p * D + c];
+#pragma unroll 5
       for (int j = lane; j < N; j += 64) {
         const size_t o = ob + (size_t)j * P;
         double alj = al[j], v = vb[o], x = xc[j], kse = ks[o];
@@ -370,6 +432,7 @@ __device__ __forceinline__ void phase_j(const mcp_gp* gps, int g0, int gn, int D
         }
       }
     } else {
+#pragma unroll 5
       for (int j = lane; j < N; j += 64) {
         const size_t o = ob + (size_t)j * P;
         double kt = kb[o];
@@ -389,30 +452,47 @@ __device__ __forceinline__ void phase_j(const mcp_gp* gps, int g0, int gn, int D
 }
 
 // posterior mean / variance and their z-Jacobians from the reduced sums R[(D+1)][RF_MAX_NA]
-__device__ __forceinline__ void gp_point(const mcp_gp& gp, const double* zp, const double* R, double& mu, double& var) {
-  const int D = gp.kern.D;
-  mu = gp.kern.mean + R[D * RF_MAX_NA + 0];
-  var = kern_diag(gp.kern, zp, 1) - R[D * RF_MAX_NA + 1];
+__device__ __forceinline__ void gp_point(const GpL& gp, const double* kp, int D, const double* zp, const double* R, double& mu, double& var) {
+  mu = gp.mean + R[D * RF_MAX_NA + 0];
+  double kzz = gp.lambda;  // k(z,z): Stationary_GP.py:172-181, Sparse_GP.py:443-453,658-668
+  if (gp.deg >= 1) {
+    double p1 = kp[KP_W1(D) + D];
+    for (int d = 0; d < D; ++d) p1 = fma(kp[KP_W1(D) + d] * zp[d], zp[d], p1);
+    kzz += p1;
+    if (gp.deg >= 2) {
+      double sa = 0.0, sb = 0.0;
+      for (int d = 0; d < D; ++d) {
+        double zz = zp[d] * zp[d];
+        sa = fma(kp[KP_W20(D) + d], zz, sa);
+        sb = fma(kp[KP_W21(D) + d], zz, sb);
+      }
+      kzz = fma(sa, sb, kzz);
+    }
+  }
+  var = kzz - R[D * RF_MAX_NA + 1];
 }
-__device__ __forceinline__ void gp_jac(const mcp_gp& gp, const double* zp, const double* R, int d, double& Jmu, double& Jvar) {
-  const mcp_kernel& kn = gp.kern;
-  const int D = kn.D, deg = kn.poly_deg;
+__device__ __forceinline__ void gp_jac(const GpL& gp, const double* kp, int D, const double* zp, const double* R, int d, double& Jmu,
+                                       double& Jvar) {
+  const int deg = gp.deg;
   const double* r = R + d * RF_MAX_NA;
-  double il2 = kn.inv_ls[d] * kn.inv_ls[d];
+  double il = kp[KP_INVLS(D) + d];
+  double il2 = il * il;
   Jmu = -2.0 * il2 * r[0];
   Jvar = 4.0 * il2 * r[1];
   if (deg >= 1) {
-    Jmu = fma(kn.w1[d], gp.aX[d], Jmu);
-    Jvar += 2.0 * kn.w1[d] * (zp[d] - r[2]);
+    double w1d = kp[KP_W1(D) + d];
+    Jmu = fma(w1d, kp[KP_AX(D) + d], Jmu);
+    Jvar += 2.0 * w1d * (zp[d] - r[2]);
     if (deg >= 2) {
       double Sa = 0.0, Sb = 0.0;
       for (int e = 0; e < D; ++e) {
         double zz = zp[e] * zp[e];
-        Sa = fma(kn.w20[e], zz, Sa);
-        Sb = fma(kn.w21[e], zz, Sb);
+        Sa = fma(kp[KP_W20(D) + e], zz, Sa);
+        Sb = fma(kp[KP_W21(D) + e], zz, Sb);
       }
-      Jmu += kn.w20[d] * r[3] + kn.w21[d] * r[4];
-      Jvar += 2.0 * zp[d] * (kn.w20[d] * Sb + kn.w21[d] * Sa) - 2.0 * (kn.w20[d] * r[5] + kn.w21[d] * r[6]);
+      double a_ = kp[KP_W20(D) + d], b_ = kp[KP_W21(D) + d];
+      Jmu += a_ * r[3] + b_ * r[4];
+      Jvar += 2.0 * zp[d] * (a_ * Sb + b_ * Sa) - 2.0 * (a_ * r[5] + b_ * r[6]);
     }
   }
 }
@@ -449,6 +529,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   double* cen_l = smem + L.cen;
   double* wgt_l = smem + L.wgt;
   int* tab = reinterpret_cast<int*>(smem + L.tab);
+  GpL* gpl = reinterpret_cast<GpL*>(smem + L.gpl);
+  double* kpar = smem + L.kpar;
   const int m0 = blockIdx.x * P;
   uint32_t bad = 0;
   const bool drop = pl.p_drop > 0.0;
@@ -458,6 +540,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
 
   // ---- one-time staging ------------------------------------------------------------------
   for (int it = tid; it < PF; it += RF_NT) invl[it] = exp(-pl.log_ls[it]);
+  stage_gp_tables(gps, md.var_scale, G, D, gpl, kpar, tid);
   if (XLDS) {
     for (int g = 0; g < G; ++g) {
       const mcp_gp& gp = gps[g];
@@ -472,8 +555,9 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   }
   const double* cen = XLDS ? cen_l : pl.centers;
   const double* wgt = XLDS ? wgt_l : pl.weight;
+  lds_barrier();
   int NC = 0;
-  if (GB >= G) NC = build_chunk_table(gps, 0, G, tab, tid);
+  if (GB >= G) NC = build_chunk_table(gpl, 0, G, tab, tid);
 
   // thread (p, s) owns state component s of particle p
   const bool own = tid < P * S;
@@ -482,6 +566,29 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   const bool ovalid = own && (m0 + op < M);
   double xn = own ? a.x0[(size_t)om * S + os] : 0.0;
   int cur = 0;
+  // what this state component feeds (fixed for the whole rollout): GP-feature slots, policy-feature slots, integrator role
+  int zi_plain = -1, zi_ang = -1, pi_plain = -1, pi_ang = -1, g_vel = -1, g_pos = -1;
+  if (own) {
+    for (int i = 0; i < nna; ++i)
+      if (md.not_angle[i] == os) zi_plain = i;
+    for (int i = 0; i < na; ++i)
+      if (md.angle[i] == os) zi_ang = i;
+    if (pl.kind == MCP_POLICY_ANGLES) {
+      for (int i = 0; i < pl.n_non_angle; ++i)
+        if (pl.non_angle[i] == os) pi_plain = i;
+      for (int i = 0; i < pl.n_angle; ++i)
+        if (pl.angle[i] == os) pi_ang = i;
+    }
+    for (int g = 0; g < G; ++g) {
+      if (md.vel[g] == os) g_vel = g;
+      if (md.not_vel[g] == os) g_pos = g;
+    }
+  }
+  const int pol_nna = pl.n_non_angle, pol_na = pl.n_angle;
+  int vel_of_pos = 0;
+  for (int g = 0; g < G; ++g)
+    if (own && md.not_vel[g] == os) vel_of_pos = md.vel[g];
+  const double Ts = md.Ts;
   unsigned long long last_stamp = clock64();
 
   for (int t = 0; t < T; ++t) {
@@ -493,30 +600,21 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         a.states[((size_t)t * M + m0 + op) * S + os] = xn;
         if (is_bad(xn)) bad |= MCP_STATUS_NAN;
       }
-      bool is_ang = false;
-      for (int i = 0; i < na; ++i) is_ang |= (md.angle[i] == os);
-      if (pl.kind == MCP_POLICY_ANGLES)
-        for (int i = 0; i < pl.n_angle; ++i) is_ang |= (pl.angle[i] == os);
       double sn = 0.0, cs = 0.0;
-      if (is_ang) sincos(xn, &sn, &cs);
+      if (zi_ang >= 0 || pi_ang >= 0) sincos(xn, &sn, &cs);
       // GP input z = [x[not_angle], sin x[angle], cos x[angle], u]   (Model_learning.py:670-683)
-      for (int i = 0; i < nna; ++i)
-        if (md.not_angle[i] == os) z[op * D + i] = xn;
-      for (int i = 0; i < na; ++i)
-        if (md.angle[i] == os) {
-          z[op * D + nna + i] = sn;
-          z[op * D + nna + na + i] = cs;
-        }
+      if (zi_plain >= 0) z[op * D + zi_plain] = xn;
+      if (zi_ang >= 0) {
+        z[op * D + nna + zi_ang] = sn;
+        z[op * D + nna + na + zi_ang] = cs;
+      }
       // policy features (Policy.py:326-333: [x_nonangle, COS, SIN];  :397-399: [x, x*_t - x])
       if (pl.kind == MCP_POLICY_ANGLES) {
-        const int pn = pl.n_non_angle, pa_ = pl.n_angle;
-        for (int i = 0; i < pn; ++i)
-          if (pl.non_angle[i] == os) sf[op * PF + i] = xn;
-        for (int i = 0; i < pa_; ++i)
-          if (pl.angle[i] == os) {
-            sf[op * PF + pn + i] = cs;
-            sf[op * PF + pn + pa_ + i] = sn;
-          }
+        if (pi_plain >= 0) sf[op * PF + pi_plain] = xn;
+        if (pi_ang >= 0) {
+          sf[op * PF + pol_nna + pi_ang] = cs;
+          sf[op * PF + pol_nna + pol_na + pi_ang] = sn;
+        }
       } else if (pl.kind == MCP_POLICY_TRAJ) {
         sf[op * PF + os] = xn;
         sf[op * PF + S + os] = pl.target_traj[(size_t)t * S + os] - xn;
@@ -524,7 +622,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         sf[op * PF + os] = xn;
       }
     }
-    __syncthreads();
+    lds_barrier();
     RF_STAMP(0);
     // ---- phase PHI: phi_b = exp(-sum_q ((s_q - c_bq)/l_q)^2) * keep/(1-p) -------------------------
     double* ph = part;
@@ -532,6 +630,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       int p = it / B, b = it - p * B;
       const double* cb = cen + (size_t)b * PF;
       double dist = 0.0;
+#pragma unroll 5
       for (int q = 0; q < PF; ++q) {
         double r = (sf[p * PF + q] - cb[q]) * invl[q];
         dist = fma(r, r, dist);
@@ -544,13 +643,14 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       }
       ph[it] = phi;
     }
-    __syncthreads();
+    lds_barrier();
     RF_STAMP(1);
     // ---- phase U: u = u_max tanh((W phi)/u_max), one wave per (particle, input) -------------------
     for (int task = wv; task < P * U; task += RF_NW) {
       int p = task / U, k = task - p * U;
       const double* wk = wgt + (size_t)k * B;
       double s = 0.0;
+#pragma unroll 4
       for (int b = lane; b < B; b += 64) s = fma(wk[b], ph[p * B + b], s);
       s = wave_sum(s);
       if (lane == 0) {
@@ -564,28 +664,28 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     RF_STAMP(2);
     if (t == T - 1) break;
     // ---- GPs, GB at a time ---------------------------------------------------------------------
     for (int g0 = 0; g0 < G; g0 += GB) {
       const int gn = imin(GB, G - g0);
       if (GB < G) {
-        __syncthreads();
-        NC = build_chunk_table(gps, g0, gn, tab, tid);
-        __syncthreads();
+        lds_barrier();
+        NC = build_chunk_table(gpl, g0, gn, tab, tid);
+        lds_barrier();
       }
-      phase_k<P, XLDS>(gps, g0, gn, D, NpadMax, z, xt_l, kb, ks, pa, pb, tid);
-      __syncthreads();
+      phase_k<P, XLDS>(gpl, kpar, g0, gn, D, NpadMax, z, xt_l, kb, ks, pa, pb, tid);
+      lds_barrier();
       RF_STAMP(3);
-      phase_v<P>(gps, g0, tab, NC, NpadMax, kb, part, wv, lane);
-      __syncthreads();
+      phase_v<P>(gpl, g0, tab, NC, NpadMax, kb, part, wv, lane);
+      lds_barrier();
       RF_STAMP(4);
-      phase_vsum<P>(gps, g0, gn, tab, NC, NpadMax, part, vb, tid);
-      __syncthreads();
+      phase_vsum<P>(gpl, g0, gn, tab, NC, NpadMax, part, vb, tid);
+      lds_barrier();
       RF_STAMP(5);
-      phase_j<P, XLDS>(gps, g0, gn, D, NpadMax, z, xt_l, al_l, kb, ks, pa, pb, vb, red, wv, lane);
-      __syncthreads();
+      phase_j<P, XLDS>(gpl, g0, gn, D, NpadMax, z, xt_l, al_l, kb, ks, pa, pb, vb, red, wv, lane);
+      lds_barrier();
       RF_STAMP(6);
       // ---- phase F: sample delta_g and fold the sampling into d delta/dz ------------------------
       for (int it = tid; it < gn * P * (D + 1); it += RF_NT) {
@@ -593,13 +693,15 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         int r = it - gl * P * (D + 1);
         int p = r / (D + 1), c = r - p * (D + 1);
         const int g = g0 + gl;
-        const mcp_gp& gp = gps[g];
+        const GpL& gp = gpl[g];
+        const double* kp = kpar + (size_t)g * KP_STRIDE(D);
+        const double vscale = gp.var_scale;
         const double* R = red + ((size_t)(gl * P + p) * (D + 1)) * RF_MAX_NA;
         const double* zp = z + p * D;
         int mm = imin(m0 + p, M - 1);
         double mu, var;
-        gp_point(gp, zp, R, mu, var);
-        var *= md.var_scale[g];
+        gp_point(gp, kp, D, zp, R, mu, var);
+        var *= vscale;
         double eps = 0.0, wj = 0.0, sd = 0.0;
         if (a.particle_pred) {
           eps = a.nz.eps ? a.nz.eps[((size_t)t * M + mm) * G + g] : philox_normal(a.nz, mm, t, g);
@@ -614,21 +716,19 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
           }
         } else if (a.jac && m0 + p < M) {
           double Jmu, Jvar;
-          gp_jac(gp, zp, R, c, Jmu, Jvar);
-          a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * md.var_scale[g], Jmu) : Jmu;
+          gp_jac(gp, kp, D, zp, R, c, Jmu, Jvar);
+          a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     RF_STAMP(7);
     // ---- integrate:  v' = v + delta ;  q' = q + Ts v + Ts/2 delta   (Model_learning.py:711-716) ----
     if (own) {
       const double* xc = xs + cur * P * S + op * S;
       double nx = 0.0;
-      for (int g = 0; g < G; ++g) {
-        if (md.vel[g] == os) nx = xc[os] + dl[op * G + g];
-        if (md.not_vel[g] == os) nx = xc[os] + md.Ts * xc[md.vel[g]] + 0.5 * md.Ts * dl[op * G + g];
-      }
+      if (g_vel >= 0) nx = xc[os] + dl[op * G + g_vel];
+      if (g_pos >= 0) nx = xc[os] + Ts * xc[vel_of_pos] + 0.5 * Ts * dl[op * G + g_pos];
       xn = nx;
     }
     cur ^= 1;  // x_{t+1} goes to the other buffer: no barrier between this read and the next write
@@ -668,21 +768,25 @@ __global__ __launch_bounds__(RF_NT) void posterior_fwd_kernel(PostArgs a) {
   double* part = smem + L.part;
   double* red = smem + L.red;
   int* tab = reinterpret_cast<int*>(smem + L.tab);
+  GpL* gpl = reinterpret_cast<GpL*>(smem + L.gpl);
+  double* kpar = smem + L.kpar;
   const int m0 = blockIdx.x * P;
   uint32_t bad = 0;
   for (int it = tid; it < P * D; it += RF_NT) {
     int p = it / D, d = it - p * D;
     z[it] = a.Z[(size_t)imin(m0 + p, a.M - 1) * D + d];
   }
-  const int NC = build_chunk_table(gps, 0, 1, tab, tid);
+  stage_gp_tables(gps, nullptr, 1, D, gpl, kpar, tid);
   __syncthreads();
-  phase_k<P, false>(gps, 0, 1, D, NpadMax, z, nullptr, kb, ks, pa, pb, tid);
+  const int NC = build_chunk_table(gpl, 0, 1, tab, tid);
   __syncthreads();
-  phase_v<P>(gps, 0, tab, NC, NpadMax, kb, part, wv, lane);
+  phase_k<P, false>(gpl, kpar, 0, 1, D, NpadMax, z, nullptr, kb, ks, pa, pb, tid);
   __syncthreads();
-  phase_vsum<P>(gps, 0, 1, tab, NC, NpadMax, part, vb, tid);
+  phase_v<P>(gpl, 0, tab, NC, NpadMax, kb, part, wv, lane);
   __syncthreads();
-  phase_j<P, false>(gps, 0, 1, D, NpadMax, z, nullptr, nullptr, kb, ks, pa, pb, vb, red, wv, lane);
+  phase_vsum<P>(gpl, 0, 1, tab, NC, NpadMax, part, vb, tid);
+  __syncthreads();
+  phase_j<P, false>(gpl, 0, 1, D, NpadMax, z, nullptr, nullptr, kb, ks, pa, pb, vb, red, wv, lane);
   __syncthreads();
   for (int it = tid; it < P * (D + 1); it += RF_NT) {
     int p = it / (D + 1), c = it - p * (D + 1);
@@ -691,14 +795,14 @@ __global__ __launch_bounds__(RF_NT) void posterior_fwd_kernel(PostArgs a) {
     const double* zp = z + p * D;
     if (c == D) {
       double mu, var;
-      gp_point(gp, zp, R, mu, var);
+      gp_point(gpl[0], kpar, D, zp, R, mu, var);
       a.mu[m0 + p] = mu;
       a.var[m0 + p] = var;
       if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
       if (!(var > 0.0)) bad |= MCP_STATUS_NONPOS_VAR;
     } else if (a.Jmu) {
       double Jm, Jv;
-      gp_jac(gp, zp, R, c, Jm, Jv);
+      gp_jac(gpl[0], kpar, D, zp, R, c, Jm, Jv);
       a.Jmu[(size_t)(m0 + p) * D + c] = Jm;
       a.Jvar[(size_t)(m0 + p) * D + c] = Jv;
     }

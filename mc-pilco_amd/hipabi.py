@@ -81,6 +81,7 @@ _SIGS = {
     "mcp_debug_set_particles_per_wg": (None, [C.c_int]),
     "mcp_debug_set_stamp_buffer": (None, [dptr]),
     "mcp_debug_set_fwd_mode": (None, [C.c_int, C.c_int]),
+    "mcp_debug_set_bwd_stamp_buffer": (None, [dptr]),
 }
 EXPORTED = [k for k in _SIGS if not k.startswith("mcp_debug")]
 

@@ -20,6 +20,17 @@ hipabi.lib().mcp_debug_set_stamp_buffer(None)
 v = buf.cpu().tolist()
 names = ["S(state/feat)", "PHI", "U", "K", "V(matvec)", "vsum", "J", "F+integrate", "-"]
 tot = sum(v[:9])
+# backward stamps
+w.params[0].grad = None
+st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=10), x0, w.T, w.p_drop)
+c, sd = ops.expected_cost(w.cost, st)
+buf2 = torch.zeros(16, dtype=torch.int64, device=dev)
+hipabi.lib().mcp_debug_set_bwd_stamp_buffer(buf2.data_ptr())
+c.backward()
+torch.cuda.synchronize()
+hipabi.lib().mcp_debug_set_bwd_stamp_buffer(None)
+v2 = buf2.cpu().tolist()
+print("bwd per step cycles: serial(wave0) %.0f | barrier1 %.0f | RBF stage %.0f | park+barrier2 %.0f" % tuple(x / w.T for x in (v2[8], v2[9], v2[10], v2[11])))
 print("workload", name, "T", w.T, "M", w.M, "ppw", ppw, "total cycles", tot, "-> per step", tot / (w.T - 1))
 for n, c in zip(names, v):
     print("%-14s %12d  %5.1f%%  %8.0f cyc/step" % (n, c, 100.0 * c / tot, c / (w.T - 1)))
