@@ -411,7 +411,8 @@ static int bwd_threads(int B) { return imax(64, ((B + 63) / 64) * 64); }
 static int bwd_blocks(int M) { return imin(M, 1024); }
 
 extern "C" size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_policy* policy, int M, int T) {
-  if (!model || !policy || M <= 0 || T <= 0) return 0;
+  (void)model;
+  if (!policy || M <= 0 || T <= 0) return 0;
   size_t nparam = (size_t)policy->P + (size_t)policy->B * policy->P + (size_t)policy->U * policy->B;
   return sizeof(double) * nparam * (size_t)bwd_blocks(M);
 }
@@ -428,9 +429,16 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
                                const double* states, const double* inputs, const double* jac, const double* g_states,
                                const double* g_inputs, double* g_log_ls, double* g_centers, double* g_weight, double* g_x0,
                                void* workspace, size_t workspace_bytes, void* stream) {
-  if (!noise || !states || !inputs || !g_log_ls || !g_centers || !g_weight || !workspace || M <= 0 || T <= 0) return MCP_ERR_ARG;
+  if (!noise || !states || !inputs || !g_log_ls || !g_centers || !g_weight || !workspace || !policy || M <= 0 || T <= 0) return MCP_ERR_ARG;
   if (T > 1 && !jac) return MCP_ERR_ARG;
-  if (!model_ok(model)) return MCP_ERR_ARG;
+  mcp_model stub;
+  if (!model) {
+    if (T != 1) return MCP_ERR_ARG;
+    stub = policy_only_model(policy);
+    model = &stub;
+  } else if (!model_ok(model)) {
+    return MCP_ERR_ARG;
+  }
   if (!policy_ok(policy, model->S, model->U, T)) return MCP_ERR_ARG;
   if (workspace_bytes < mcp_rollout_workspace_bytes(model, policy, M, T)) return MCP_ERR_WORKSPACE;
   BwdArgs a;

@@ -1,6 +1,8 @@
 // Shared by rollout_fwd.hip and rollout_bwd.hip: feature maps of the dynamics model and of the
 // policy, descriptor validation, small integer helpers.
 #pragma once
+#include <string.h>
+
 #include "mcp_device.h"
 
 #define MCP_LDS_LIMIT (160 * 1024)
@@ -47,6 +49,18 @@ static inline bool model_ok(const mcp_model* m) {
     if (m->vel[g] < 0 || m->vel[g] >= m->S || m->not_vel[g] < 0 || m->not_vel[g] >= m->S) return false;
   }
   return true;
+}
+
+// policy-only evaluation (T == 1, no dynamics model): a stub model with no GPs
+static inline mcp_model policy_only_model(const mcp_policy* p) {
+  mcp_model m;
+  memset(&m, 0, sizeof(m));
+  m.S = p->S;
+  m.U = p->U;
+  m.G = 0;
+  m.D = p->U;  // z = [u]
+  m.Ts = 0.0;
+  return m;
 }
 
 static inline bool policy_ok(const mcp_policy* p, int S, int U, int T) {

@@ -869,8 +869,15 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
                                size_t workspace_bytes, void* stream) {
   (void)workspace;
   (void)workspace_bytes;
-  if (!noise || !x0 || !states || !inputs || !status || M <= 0 || T <= 0) return MCP_ERR_ARG;
-  if (!model_ok(model)) return MCP_ERR_ARG;
+  if (!noise || !x0 || !states || !inputs || !status || !policy || M <= 0 || T <= 0) return MCP_ERR_ARG;
+  mcp_model stub;
+  if (!model) {
+    if (T != 1) return MCP_ERR_ARG;  // without a dynamics model only the policy can be evaluated
+    stub = policy_only_model(policy);
+    model = &stub;
+  } else if (!model_ok(model)) {
+    return MCP_ERR_ARG;
+  }
   if (!policy_ok(policy, model->S, model->U, T)) return MCP_ERR_ARG;
   FwdArgs a;
   a.model = *model;
@@ -897,7 +904,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   if (P0 != 1 && P0 != 2 && P0 != 4) return MCP_ERR_ARG;
   for (int P = P0; P >= 1; P >>= 1) {
     for (int xl = (g_force_xlds == 0 ? 0 : 1); xl >= 0; --xl) {
-      for (int GB = (g_force_gb > 0 ? imin(g_force_gb, model->G) : model->G); GB >= 1; --GB) {
+      for (int GB = imax(1, (g_force_gb > 0 ? imin(g_force_gb, model->G) : model->G)); GB >= 1; --GB) {
         int NCmax = chunks_in_pass(model, GB);
         if (NCmax > RF_MAX_CHUNKS) continue;
         FwdLayout L = fwd_layout(P, model->S, model->U, model->D, model->G, policy->P, policy->B, a.NpadMax, a.maxdeg, GB, NCmax, xl != 0);

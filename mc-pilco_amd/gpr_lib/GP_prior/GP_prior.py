@@ -1,0 +1,265 @@
+"""GP base classes on the HIP path -- drop-in for the reference's ``gpr_lib/GP_prior/GP_prior.py``
+(class and method names, argument order and return arity follow it; numerics run in
+libmcpilco_hip.so through ``mc_pilco_amd.ops``).
+
+Reference lines replaced:
+  GP_prior.forward                GP_prior.py:91-115   Gram (+noise) -> Cholesky (upper) -> U^-1 -> K^-1, logdet
+  GP_prior.get_alpha              GP_prior.py:130-135
+  GP_prior.get_estimate_from_alpha  GP_prior.py:137-155  posterior mean / variance at test points
+  GP_prior.get_estimate           GP_prior.py:157-171
+  GP_prior.get_SOD                GP_prior.py:232-257  greedy subset-of-data (index-exact)
+  GP_prior.fit_model              GP_prior.py:179-230  hyper-parameter training (analytic NLL gradient, HIP)
+  Sum_Independent_GP              GP_prior.py:299-347  kernel sum; noise added once; mean of the first child
+Out of scope (unused by every launch script): Multiply_GP_prior, Scale_GP_prior.
+
+Every GP object describes its covariance to the kernels through ``kernel_spec()``: squared
+exponential (+ Volterra polynomial of degree <= 2) over the columns ``active_dims``.
+"""
+import time
+
+import numpy as np
+import torch
+
+from mc_pilco_amd import ops
+
+__all__ = ["GP_prior", "Combine_GP", "Sum_Independent_GP"]
+
+
+class GP_prior(torch.nn.Module):
+    """Base class: noise parameter, device/dtype bookkeeping and every operation that only needs
+    ``kernel_spec()``."""
+
+    def __init__(self, active_dims, sigma_n_init=None, flg_train_sigma_n=True, name="", dtype=torch.float64, sigma_n_num=None, device=None):
+        super().__init__()
+        self.name = name
+        self.dtype = dtype
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.active_dims = None if active_dims is None else torch.as_tensor(np.asarray(active_dims), dtype=torch.long, device=self.device)
+        self.GP_with_noise = sigma_n_init is not None
+        if self.GP_with_noise:
+            self.sigma_n_log = torch.nn.Parameter(torch.tensor(np.log(sigma_n_init), dtype=dtype, device=self.device),
+                                                  requires_grad=flg_train_sigma_n)
+        self.sigma_n_num = torch.tensor(0.0 if sigma_n_num is None else float(np.asarray(sigma_n_num)), dtype=dtype, device=self.device)
+        self._packed_cache = {}
+
+    # ---- bookkeeping ---------------------------------------------------------------------------
+    def to(self, dev):
+        super().to(dev)
+        self.device = torch.device(dev)
+        self.sigma_n_num = self.sigma_n_num.to(dev)
+        if self.active_dims is not None:
+            self.active_dims = self.active_dims.to(dev)
+
+    def set_eval_mode(self):
+        """Freezes every parameter (remembering which ones were trainable)."""
+        self.flg_trainable_list = [p.requires_grad for p in self.parameters()]
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def set_training_mode(self):
+        for flag, p in zip(self.flg_trainable_list, self.parameters()):
+            p.requires_grad = flag
+
+    def get_sigma_n_2(self):
+        """exp(sigma_n_log)^2 + sigma_n_num^2"""
+        return torch.exp(self.sigma_n_log) ** 2 + self.sigma_n_num ** 2
+
+    def print_model(self):
+        print(self.name + " parameters:")
+        for n, v in self.named_parameters():
+            print("-", n, ":", v.data)
+
+    # ---- what the HIP kernels need -----------------------------------------------------------------
+    def kernel_spec(self) -> ops.KernelSpec:
+        raise NotImplementedError()
+
+    def _cols(self, X):
+        """The active columns of X as a contiguous float64 GPU matrix."""
+        X = X.to(device=self.device, dtype=torch.float64)
+        ad = self._active()
+        if ad is not None and not (ad.numel() == X.shape[1] and bool((ad == torch.arange(X.shape[1], device=ad.device)).all())):
+            X = X[:, ad]
+        return X.contiguous()
+
+    def _active(self):
+        return self.active_dims
+
+    # ---- covariance / mean ----------------------------------------------------------------------------
+    def get_mean(self, X):
+        raise NotImplementedError()
+
+    def get_covariance(self, X1, X2=None, flg_noise=False):
+        noise = bool(flg_noise) and self.GP_with_noise
+        return ops.cov_build(self.kernel_spec(), self._cols(X1), None if X2 is None else self._cols(X2), noise=noise)
+
+    def get_diag_covariance(self, X, flg_noise=False):
+        noise = bool(flg_noise) and self.GP_with_noise
+        return ops.cov_diag(self.kernel_spec(), self._cols(X), noise=noise)
+
+    # ---- Gram / Cholesky / inverse ------------------------------------------------------------------------
+    def forward(self, X):
+        """(m_X, K_X, K_X_inv, log_det): K_X includes the noise, K_X_inv = U^-1 U^-T with U the upper
+        Cholesky factor, log_det = 2 sum log diag U."""
+        K = self.get_covariance(X, flg_noise=self.GP_with_noise)
+        U, log_det, status = ops.chol_factor(K)
+        if ops.status_flags(status)["not_spd"]:
+            raise RuntimeError("cholesky: the covariance matrix is not positive-definite")
+        _, K_inv = ops.chol_inverse(U)
+        return self.get_mean(X), K, K_inv, log_det
+
+    def get_alpha(self, X, Y):
+        m_X, _, K_X_inv, _ = self(X)
+        alpha = ops.gp_alpha(K_X_inv, (Y.to(self.device) - m_X).contiguous(), 0.0)
+        return alpha, m_X, K_X_inv
+
+    def _packed(self, X, alpha, K_X_inv):
+        key = (X.data_ptr(), alpha.data_ptr(), K_X_inv.data_ptr(), tuple(X.shape), getattr(X, "_version", 0))
+        hit = self._packed_cache.get("last")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        gp = ops.PackedGP(self.kernel_spec(), self._cols(X), alpha, K_X_inv)
+        self._packed_cache["last"] = (key, gp)
+        return gp
+
+    def get_estimate_from_alpha(self, X, X_test, alpha, m_X, K_X_inv=None, Y_test=None):
+        """Posterior at X_test from the cached alpha (and variance when K_X_inv is given).  Differentiable
+        with respect to X_test."""
+        N = X.shape[0]
+        Kinv = K_X_inv if K_X_inv is not None else torch.zeros(N, N, dtype=torch.float64, device=self.device)
+        gp = self._packed(X, alpha, Kinv)
+        Y_hat, var = ops.posterior(gp, self._cols(X_test))
+        if Y_test is not None:
+            print("MSE:", torch.sum((Y_test.to(self.device) - Y_hat) ** 2) / Y_test.shape[0])
+        if K_X_inv is None:
+            return Y_hat
+        return Y_hat, var
+
+    def get_estimate(self, X, Y, X_test, Y_test=None, flg_return_K_X_inv=False):
+        alpha, m_X, K_X_inv = self.get_alpha(X, Y)
+        self._packed_cache.clear()
+        Y_hat, var = self.get_estimate_from_alpha(X, X_test, alpha, m_X, K_X_inv=K_X_inv, Y_test=Y_test)
+        if flg_return_K_X_inv:
+            return Y_hat, var, alpha, m_X, K_X_inv
+        return Y_hat, var, alpha
+
+    # ---- subset of data ---------------------------------------------------------------------------------------
+    def get_SOD(self, X, Y, threshold, flg_permutation=False):
+        """Indices (python ints, in visiting order) of the greedy subset: sample i joins when the
+        posterior std given the current subset exceeds ``threshold``."""
+        print("\nSelection of the inducing inputs...")
+        Xc = self._cols(X)
+        n = Xc.shape[0]
+        thr = float(threshold)
+        if flg_permutation:
+            order = torch.cat([torch.zeros(1, dtype=torch.long), torch.arange(1, n)[torch.randperm(n - 1)]])
+            picked = ops.sod_select(self.kernel_spec(), Xc[order.to(self.device)].contiguous(), thr)
+            idx = [int(order[i]) for i in picked]
+        else:
+            idx = ops.sod_select(self.kernel_spec(), Xc, thr)
+        print("Shape inducing inputs selected:", torch.Size([len(idx), X.shape[1]]))
+        return idx
+
+    # ---- hyper-parameter training --------------------------------------------------------------------------------
+    def fit_model(self, trainloader=None, optimizer=None, criterion=None, N_epoch=1, N_epoch_print=1, f_saving_model=None, f_print=None):
+        """Full-batch optimisation of the marginal likelihood with the caller's optimizer.  ``criterion``
+        is called on ``self(inputs)`` like in the reference; gradients come from the analytic NLL
+        derivative evaluated by the HIP kernels (``criterion`` must be a Marginal_log_likelihood)."""
+        from mc_pilco_amd.gpr_lib.Likelihood.Gaussian_likelihood import Marginal_log_likelihood
+
+        if not isinstance(criterion, Marginal_log_likelihood):
+            raise NotImplementedError("fit_model on the HIP path supports the Marginal_log_likelihood criterion")
+        print("\nInitial parameters:")
+        self.print_model()
+        t0 = time.time()
+        for epoch in range(N_epoch):
+            running, nb = 0.0, 0
+            for inputs, labels in trainloader:
+                optimizer.zero_grad()
+                loss = criterion.loss_and_grad(self, inputs, labels)
+                optimizer.step()
+                running += float(loss)
+                nb += 1
+            if epoch % N_epoch_print == 0:
+                print("\nEPOCH:", epoch)
+                self.print_model()
+                print("Running loss:", running / max(nb, 1))
+                print("Time elapsed:", time.time() - t0)
+                t0 = time.time()
+                if f_saving_model is not None:
+                    f_saving_model(epoch)
+                if f_print is not None:
+                    f_print()
+        print("\nFinal parameters:")
+        self.print_model()
+
+
+class Combine_GP(GP_prior):
+    """Common part of kernels built from several GP objects."""
+
+    def __init__(self, *gp_priors_obj):
+        first = gp_priors_obj[0]
+        super().__init__(active_dims=None, sigma_n_num=float(first.sigma_n_num), dtype=first.dtype, device=first.device)
+        self.gp_list = torch.nn.ModuleList(gp_priors_obj)
+        self.GP_with_noise = any(gp.GP_with_noise for gp in self.gp_list)
+
+    def to(self, dev):
+        super().to(dev)
+        for gp in self.gp_list:
+            gp.to(dev)
+
+    def print_model(self):
+        for gp in self.gp_list:
+            gp.print_model()
+
+    def get_sigma_n_2(self):
+        s = torch.zeros(1, dtype=self.dtype, device=self.device)
+        for gp in self.gp_list:
+            if gp.GP_with_noise:
+                s = s + gp.get_sigma_n_2()
+        return s
+
+    def _leaves(self):
+        for gp in self.gp_list:
+            if isinstance(gp, Combine_GP):
+                yield from gp._leaves()
+            else:
+                yield gp
+
+    def _active(self):
+        ads = [gp._active() for gp in self._leaves()]
+        for a in ads[1:]:
+            if a is None or ads[0] is None or a.numel() != ads[0].numel() or not bool((a == ads[0]).all()):
+                raise NotImplementedError("summed kernels must share their active_dims on the HIP path")
+        return ads[0]
+
+
+class Sum_Independent_GP(Combine_GP):
+    """Sum of independent GPs: covariances add, the measurement noise (that of the noisy children) is
+    added once, and -- as in the reference -- the prior mean is the FIRST child's mean."""
+
+    def get_mean(self, X):
+        return self.gp_list[0].get_mean(X)
+
+    def kernel_spec(self) -> ops.KernelSpec:
+        se, w1, w20, w21 = None, None, None, None
+        for gp in self._leaves():
+            part = gp.kernel_spec()
+            if part.lam != 0.0:
+                if se is not None:
+                    raise NotImplementedError("at most one squared-exponential term per GP on the HIP path")
+                se = part
+            if part.w1 is not None:
+                w1 = part.w1 if w1 is None else w1 + part.w1
+            if part.w20 is not None:
+                if w20 is not None:
+                    raise NotImplementedError("at most one degree-2 polynomial term per GP on the HIP path")
+                w20, w21 = part.w20, part.w21
+        D = next(self._leaves()).kernel_spec().D
+        if w20 is not None and w1 is None:
+            w1 = torch.zeros(D + 1, dtype=torch.float64)
+        sig2 = float(self.get_sigma_n_2()) if self.GP_with_noise else 0.0
+        first = self.gp_list[0]
+        mean = float(first.mean_par.reshape(-1)[0]) if hasattr(first, "mean_par") else 0.0
+        if se is None:
+            return ops.KernelSpec(torch.ones(D, dtype=torch.float64), 0.0, sig2, mean, w1, w20, w21)
+        return ops.KernelSpec(se.lengthscales, se.lam, sig2, mean, w1, w20, w21)

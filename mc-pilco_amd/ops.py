@@ -291,18 +291,24 @@ def _check_noise(noise, T, M, G, B, p_drop, particle_pred):
             raise RuntimeError("masks must be a contiguous uint8 GPU tensor of shape [T,M,B]")
 
 
-def rollout_forward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseSpec, x0, T, p_drop, particle_pred=True, need_jac=True):
-    dev = model.device
+def _mc(model):
+    return None if model is None else C.byref(model.c)
+
+
+def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, noise: NoiseSpec, x0, T, p_drop, particle_pred=True, need_jac=True):
+    """model None (only with T == 1) evaluates the policy alone."""
+    dev = policy.device if model is None else model.device
     x0 = x0.detach().to(device=dev, dtype=DT).contiguous()
     M = x0.shape[0]
-    _check_noise(noise, T, M, model.G, policy.B, p_drop, particle_pred)
-    states = torch.empty(T, M, model.S, dtype=DT, device=dev)
-    inputs = torch.empty(T, M, model.U, dtype=DT, device=dev)
-    jac = torch.empty(max(T - 1, 1), M, model.G, model.D, dtype=DT, device=dev) if need_jac else None
+    G, D = (0, policy.U) if model is None else (model.G, model.D)
+    _check_noise(noise, T, M, G, policy.B, p_drop, particle_pred)
+    states = torch.empty(T, M, policy.S, dtype=DT, device=dev)
+    inputs = torch.empty(T, M, policy.U, dtype=DT, device=dev)
+    jac = torch.empty(max(T - 1, 1), M, max(G, 1), D, dtype=DT, device=dev) if (need_jac and T > 1) else None
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     pc = policy.bind(p_drop)
     nz = noise.to_c()
-    abi.check(abi.lib().mcp_rollout_fwd(C.byref(model.c), C.byref(pc), C.byref(nz), M, T, int(bool(particle_pred)), abi.ptr(x0),
+    abi.check(abi.lib().mcp_rollout_fwd(_mc(model), C.byref(pc), C.byref(nz), M, T, int(bool(particle_pred)), abi.ptr(x0),
                                         abi.ptr(states), abi.ptr(inputs), abi.ptr(jac), abi.ptr(status), None, 0, abi.stream()),
               "mcp_rollout_fwd")
     return states, inputs, jac, status
@@ -310,19 +316,19 @@ def rollout_forward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseSp
 
 def rollout_backward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseSpec, states, inputs, jac, g_states, g_inputs, p_drop,
                          want_gx0=False):
-    dev = model.device
+    dev = policy.device
     T, M = states.shape[0], states.shape[1]
     pc = policy.bind(p_drop)
     nz = noise.to_c()
-    nbytes = abi.lib().mcp_rollout_workspace_bytes(C.byref(model.c), C.byref(pc), M, T)
+    nbytes = abi.lib().mcp_rollout_workspace_bytes(_mc(model), C.byref(pc), M, T)
     ws = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev)
     g_ls = torch.empty(1, policy.P, dtype=DT, device=dev)
     g_c = torch.empty(policy.B, policy.P, dtype=DT, device=dev)
     g_w = torch.empty(policy.U, policy.B, dtype=DT, device=dev)
-    g_x0 = torch.empty(M, model.S, dtype=DT, device=dev) if want_gx0 else None
+    g_x0 = torch.empty(M, policy.S, dtype=DT, device=dev) if want_gx0 else None
     gs = None if g_states is None else g_states.to(dtype=DT).contiguous()
     gi = None if g_inputs is None else g_inputs.to(dtype=DT).contiguous()
-    abi.check(abi.lib().mcp_rollout_bwd(C.byref(model.c), C.byref(pc), C.byref(nz), M, T, abi.ptr(states), abi.ptr(inputs), abi.ptr(jac),
+    abi.check(abi.lib().mcp_rollout_bwd(_mc(model), C.byref(pc), C.byref(nz), M, T, abi.ptr(states), abi.ptr(inputs), abi.ptr(jac),
                                         abi.ptr(gs), abi.ptr(gi), abi.ptr(g_ls), abi.ptr(g_c), abi.ptr(g_w), abi.ptr(g_x0), abi.ptr(ws),
                                         nbytes, abi.stream()), "mcp_rollout_bwd")
     return g_ls, g_c, g_w, g_x0
@@ -338,6 +344,7 @@ class RolloutFunction(torch.autograd.Function):
         need = any(ctx.needs_input_grad[:4])
         states, inputs, jac, status = rollout_forward_raw(model, policy, noise, x0, T, p_drop, particle_pred, need_jac=need)
         ctx.model, ctx.policy, ctx.noise, ctx.p_drop = model, policy, noise, p_drop
+        ctx.has_jac = jac is not None
         ctx.save_for_backward(states, inputs, jac if jac is not None else torch.empty(0, device=states.device))
         ctx.mark_non_differentiable(status)
         return states, inputs, status
@@ -345,6 +352,8 @@ class RolloutFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_states, g_inputs, _g_status):
         states, inputs, jac = ctx.saved_tensors
+        if not ctx.has_jac:
+            jac = None
         g_ls, g_c, g_w, g_x0 = rollout_backward_raw(ctx.model, ctx.policy, ctx.noise, states, inputs, jac, g_states, g_inputs, ctx.p_drop,
                                                     want_gx0=ctx.needs_input_grad[0])
         return g_x0, g_ls.reshape(ctx.policy.log_ls.shape), g_c, g_w, None, None, None, None, None, None

@@ -1,0 +1,105 @@
+"""Expected costs on the HIP path -- drop-in for ``policy_learning/Cost_function.py``.
+
+  Expected_cost.forward                          Cost_function.py:25-36    sum_t mean_m c , sum_t std_m c (unbiased, detached)
+  Cart_pole_cost / cart_pole_cost                Cost_function.py:150-182
+  Expected_saturated_distance_from_trajectory    Cost_function.py:104-147
+
+The two costs the launch scripts use run in the HIP cost kernels (forward and state gradient).  A generic
+``Expected_cost(cost_function)`` with a user-supplied torch function keeps working (it is user code and runs
+as ordinary torch ops on the GPU), as do the simple distance variants built on it (:39-101).
+``forward(..., group=None)``: with a torch.distributed group the mean / std pool every rank's particles.
+"""
+import numpy as np
+import torch
+
+from mc_pilco_amd import ops
+
+
+def _np(a):
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+
+class Expected_cost(torch.nn.modules.loss._Loss):
+    """sum over time of the particle mean of ``cost_function(states, inputs, trial_index)`` [T,M]."""
+
+    def __init__(self, cost_function):
+        super().__init__()
+        self.cost_function = cost_function
+
+    def forward(self, states_sequence, inputs_sequence, trial_index=None, group=None):
+        costs = self.cost_function(states_sequence, inputs_sequence, trial_index)
+        if group is not None:
+            import torch.distributed as dist
+
+            R = dist.get_world_size(group)
+            n = costs.shape[1] * R
+            s1 = costs.sum(1)
+            s1_all = s1.detach().clone()
+            dist.all_reduce(s1_all, group=group)
+            mean = s1_all / n
+            m2 = ((costs.detach() - mean[:, None]) ** 2).sum(1)
+            dist.all_reduce(m2, group=group)
+            return torch.sum(s1) / n + (torch.sum(mean) - torch.sum(s1.detach()) / n), torch.sum(torch.sqrt(m2 / (n - 1)))
+        return torch.sum(torch.mean(costs, 1)), torch.sum(torch.std(costs.detach(), 1))
+
+
+class _HipExpectedCost(Expected_cost):
+    def __init__(self):
+        super().__init__(None)
+        self._packed = None
+
+    def _pack(self, states):
+        raise NotImplementedError()
+
+    def forward(self, states_sequence, inputs_sequence=None, trial_index=None, group=None, counts=None):
+        if self._packed is None or self._packed.device != states_sequence.device:
+            self._packed = self._pack(states_sequence)
+        return ops.expected_cost(self._packed, states_sequence, group, counts)
+
+
+class Cart_pole_cost(_HipExpectedCost):
+    """1 - exp(-((|theta|-theta*)/l_theta)^2 - ((x-x*)/l_x)^2);  target_state=[theta*, x*], lengthscales=[l_theta, l_x]."""
+
+    def __init__(self, target_state, lengthscales, angle_index, pos_index):
+        super().__init__()
+        self.target_state, self.lengthscales = _np(target_state).reshape(-1), _np(lengthscales).reshape(-1)
+        self.angle_index, self.pos_index = int(angle_index), int(pos_index)
+
+    def _pack(self, states):
+        return ops.PackedCost("cartpole", states.shape[2], states.device, target_state=self.target_state, lengthscales=self.lengthscales,
+                              angle_index=self.angle_index, pos_index=self.pos_index)
+
+
+class Expected_saturated_distance_from_trajectory(_HipExpectedCost):
+    """1 - exp(-sum_i ((x_i - x*_{t,i}) / l_i)^2) over ``used_indeces``; target_traj must have one row per time step."""
+
+    def __init__(self, target_traj, lengthscales, flg_var_lengthscales=False, used_indeces=None):
+        super().__init__()
+        if flg_var_lengthscales:
+            raise NotImplementedError("flg_var_lengthscales=True is not implemented on the HIP path (unused by the launch scripts)")
+        self.target_traj, self.lengthscales = _np(target_traj), _np(lengthscales).reshape(-1)
+        self.used_indeces = None if used_indeces is None else [int(i) for i in used_indeces]
+
+    def _pack(self, states):
+        return ops.PackedCost("traj", states.shape[2], states.device, target_traj=self.target_traj, lengthscales=self.lengthscales,
+                              used=self.used_indeces)
+
+
+# ---- simple torch-level variants (Cost_function.py:39-101) -------------------------------------------------------------
+def distance_from_target(states_sequence, inputs_sequence, trial_index, target_state, lengthscales, active_dims):
+    d = (states_sequence[:, :, active_dims] - target_state) / lengthscales
+    return (d * d).sum(2)
+
+
+def saturated_distance_from_target(states_sequence, inputs_sequence, trial_index, target_state, lengthscales, active_dims):
+    return 1 - torch.exp(-distance_from_target(states_sequence, inputs_sequence, trial_index, target_state, lengthscales, active_dims))
+
+
+class Expected_distance(Expected_cost):
+    def __init__(self, target_state, lengthscales, active_dims):
+        super().__init__(lambda x, u, k: distance_from_target(x, u, k, target_state, lengthscales, active_dims))
+
+
+class Expected_saturated_distance(Expected_cost):
+    def __init__(self, target_state, lengthscales, active_dims):
+        super().__init__(lambda x, u, k: saturated_distance_from_target(x, u, k, target_state, lengthscales, active_dims))

@@ -1,0 +1,400 @@
+"""MC-PILCO driver on the HIP path -- drop-in for ``policy_learning/MC_PILCO.py`` (class ``MC_PILCO``).
+
+  apply_policy       MC_PILCO.py:615-674   particle rollout  -> ONE fused HIP launch (mcp_rollout_fwd)
+  reinforce_policy   MC_PILCO.py:375-613   optimizer loop: rollout, expected cost, backward (fused reverse-time adjoint,
+                                           mcp_rollout_bwd), optimizer step, cost monitors, lr / dropout annealing, NaN retries
+  reinforce          MC_PILCO.py:89-258    trial loop and ``log.pkl`` bookkeeping (same keys)
+  rollout            MC_PILCO.py:347-373   mean-only single-trajectory prediction
+
+Constructor injection is the plug-in mechanism, as in the reference: model / policy / cost classes and their kwargs.
+Additions (all optional): ``noise_mode`` -- "philox" (in-kernel generator, default) or "reference" (noise drawn on the
+CPU with the reference's torch calls in its order, for seed-for-seed parity); ``shard_particles(group)`` -- split the
+particles over the ranks of a torch.distributed group (one all-gather of cost moments and one all-reduce of the
+policy gradient per optimizer step; every rank then applies the identical update).
+Out of scope: MC_PILCO4PMS, MC_PILCO_Experiment, MuJoCo environments.
+"""
+import copy
+import pickle as pkl
+import time
+
+import numpy as np
+import torch
+from torch.distributions.multivariate_normal import MultivariateNormal
+from torch.distributions.uniform import Uniform
+
+from mc_pilco_amd import ops
+from mc_pilco_amd.policy_learning import Policy as _Policy
+from mc_pilco_amd.simulation_class import model as _sim
+
+
+class MC_PILCO(torch.nn.Module):
+    def __init__(self, T_sampling, state_dim, input_dim, f_sim, f_model_learning, model_learning_par, f_rand_exploration_policy,
+                 rand_exploration_policy_par, f_control_policy, control_policy_par, f_cost_function, cost_function_par, std_meas_noise=None,
+                 log_path=None, dtype=torch.float64, device=torch.device("cuda")):
+        super().__init__()
+        self.T_sampling = T_sampling
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self.state_dim = state_dim
+        self.input_dim = input_dim
+        print("\n\nGet the system...")
+        self.system = _sim.Model(f_sim)
+        self.std_meas_noise = np.zeros(state_dim) if std_meas_noise is None else std_meas_noise
+        print("\n\nGet the learning object...")
+        self.model_learning = f_model_learning(**model_learning_par)
+        print("\n\nGet the exploration policy...")
+        self.rand_exploration_policy = f_rand_exploration_policy(**rand_exploration_policy_par)
+        print("\n\nGet the control policy...")
+        self.control_policy = f_control_policy(**control_policy_par)
+        print("\n\nGet the cost function...")
+        self.cost_function = f_cost_function(**cost_function_par)
+        self.state_samples_history = []
+        self.input_samples_history = []
+        self.noiseless_states_history = []
+        self.num_data_collection = 0
+        self.log_path = log_path
+        if self.log_path is not None:
+            self.log_dict = {}
+        # HIP-path options
+        self.noise_mode = "philox"
+        self.seed = 0
+        self._rollout_calls = 0
+        self.dist_group = None
+        self.last_status = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    # particle sharding
+    # ------------------------------------------------------------------------------------------------------------
+    def shard_particles(self, group=None):
+        """Split ``num_particles`` over the ranks of ``group`` (default: the WORLD group)."""
+        import torch.distributed as dist
+
+        self.dist_group = dist.group.WORLD if group is None else group
+
+    def _world(self):
+        if self.dist_group is None:
+            return 1, 0
+        import torch.distributed as dist
+
+        return dist.get_world_size(self.dist_group), dist.get_rank(self.dist_group)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # forward simulation of the particles
+    # ------------------------------------------------------------------------------------------------------------
+    def sample_initial_particles(self, mean, var, flg_uniform, up_bound, low_bound, flg_multi_gauss, num_particles):
+        """x_0 ~ uniform / mixture of Gaussians / Gaussian.  In "reference" noise mode the draw is made on the CPU with
+        the reference's own distribution calls (bit-exact for a given torch seed)."""
+        on = torch.device("cpu") if self.noise_mode == "reference" else self.device
+        mean, var = mean.to(on), var.to(on)
+        if flg_uniform:
+            dist_ = Uniform(low_bound.to(on).repeat(num_particles, 1), up_bound.to(on).repeat(num_particles, 1))
+        elif flg_multi_gauss:
+            idx = torch.randint(0, mean.shape[0], [num_particles], device=on)
+            dist_ = MultivariateNormal(loc=mean[idx, :], covariance_matrix=torch.diag_embed(var[idx, :]))
+        else:
+            dist_ = MultivariateNormal(loc=mean.repeat(num_particles, 1), covariance_matrix=torch.diag_embed(var.repeat(num_particles, 1)))
+        return dist_.rsample().to(self.device)
+
+    def _rollout_noise(self, M, T, p_dropout):
+        pol = self.control_policy
+        p = float(p_dropout) if getattr(pol, "flg_drop", True) else 0.0
+        G, B = self.model_learning.num_gp, pol.num_basis
+        world, rank = self._world()
+        self._rollout_calls += 1
+        if self.noise_mode == "reference":
+            # the reference's draw order: mask_0, then for t = 1..T-1: eps_t, mask_t   
+            masks = [torch.empty(M, 1, B, dtype=self.dtype).bernoulli_(1 - p).reshape(M, B)] if p > 0 else None
+            eps = []
+            for _ in range(1, T):
+                eps.append(torch.empty(M, G, dtype=self.dtype).normal_())
+                if p > 0:
+                    masks.append(torch.empty(M, 1, B, dtype=self.dtype).bernoulli_(1 - p).reshape(M, B))
+            eps = (torch.stack(eps) if eps else torch.zeros(0, M, G, dtype=self.dtype)).to(self.device).contiguous()
+            mk = None if masks is None else torch.stack(masks).to(torch.uint8).to(self.device).contiguous()
+            return ops.NoiseSpec(eps=eps, masks=mk), p
+        return ops.NoiseSpec(seed=self.seed, call=self._rollout_calls, particle_offset=rank * M), p
+
+    def apply_policy(self, particles_initial_state_mean, particles_initial_state_var, flg_particles_init_uniform, particles_init_up_bound,
+                     particles_init_low_bound, flg_particles_init_multi_gauss, num_particles, T_control, p_dropout=0.0):
+        """Simulates ``num_particles`` particles for ``T_control`` steps under the control policy.
+        Returns states [T,M,S] and inputs [T,M,U] (differentiable w.r.t. the policy parameters)."""
+        world, _ = self._world()
+        M = int(num_particles) // world
+        T = int(T_control)
+        x0 = self.sample_initial_particles(particles_initial_state_mean, particles_initial_state_var, flg_particles_init_uniform,
+                                           particles_init_up_bound, particles_init_low_bound, flg_particles_init_multi_gauss, M)
+        pol, ml = self.control_policy, self.model_learning
+        if isinstance(pol, _Policy.Sum_of_gaussians) and hasattr(ml, "vel_indeces"):
+            noise, p = self._rollout_noise(M, T, p_dropout)
+            states, inputs, status = ops.rollout(ml.packed(), pol.packed(), noise, x0, T, p)
+            self.last_status = status
+            return states, inputs
+        # generic (unfused) path: any model / policy object with the reference's step interface
+        xs = [x0]
+        us = [pol(x0, t=0, p_dropout=p_dropout)]
+        for t in range(1, T):
+            x, _, _ = ml.get_next_state(current_state=xs[-1], current_input=us[-1])
+            xs.append(x)
+            us.append(pol(x, t=t, p_dropout=p_dropout))
+        return torch.stack(xs), torch.stack(us)
+
+    def _cost(self, states, inputs, trial_index):
+        if self.dist_group is not None:
+            return self.cost_function(states, inputs, trial_index, group=self.dist_group)
+        return self.cost_function(states, inputs, trial_index)
+
+    def _allreduce_grads(self):
+        if self.dist_group is None:
+            return
+        import torch.distributed as dist
+
+        ps = [p for p in self.control_policy.parameters() if p.grad is not None]
+        flat = torch.cat([p.grad.reshape(-1) for p in ps])
+        dist.all_reduce(flat, group=self.dist_group)
+        o = 0
+        for p in ps:
+            n = p.numel()
+            p.grad.copy_(flat[o:o + n].reshape(p.shape))
+            o += n
+
+    # ------------------------------------------------------------------------------------------------------------
+    # policy optimisation
+    # ------------------------------------------------------------------------------------------------------------
+    def reinforce_policy(self, T_control, num_particles, trial_index, particles_initial_state_mean, particles_initial_state_var,
+                         flg_particles_init_uniform, particles_init_up_bound, particles_init_low_bound, flg_particles_init_multi_gauss,
+                         opt_steps_list, lr_list, f_optimizer, num_step_print=10, policy_reinit_dict=None, p_dropout_list=None,
+                         std_cost_filt_order=None, std_cost_filt_cutoff=None, max_std_cost=None, alpha_cost=0.99, alpha_input=0.99,
+                         alpha_diff_cost=0.99, lr_reduction_ratio=0.5, lr_min=0.001, p_drop_reduction=0.0, min_diff_cost=0.1,
+                         num_min_diff_cost=200, min_step=np.inf):
+        """Monte-Carlo policy gradient: at most ``opt_steps_list[trial_index]`` optimizer steps."""
+        dev, dt = self.device, self.dtype
+        horizon = int(T_control / self.T_sampling)
+        n_steps = opt_steps_list[trial_index]
+        sim = dict(particles_initial_state_mean=particles_initial_state_mean, particles_initial_state_var=particles_initial_state_var,
+                   flg_particles_init_uniform=flg_particles_init_uniform, flg_particles_init_multi_gauss=flg_particles_init_multi_gauss,
+                   particles_init_up_bound=particles_init_up_bound, particles_init_low_bound=particles_init_low_bound,
+                   num_particles=num_particles, T_control=horizon)
+        p_drop0 = 0.0 if p_dropout_list is None else p_dropout_list[trial_index]
+        if p_dropout_list is not None:
+            print("\nDROPOUT ACTIVE:")
+            print("p_dropout:", p_drop0)
+        make_opt = eval(f_optimizer)  # the reference passes optimizers as strings, e.g. "lambda p, lr : torch.optim.Adam(p, lr)"
+
+        def fresh_state():
+            return dict(cost=torch.zeros(n_steps, device=dev, dtype=dt), std=torch.zeros(n_steps, device=dev, dtype=dt),
+                        es1=torch.zeros(n_steps + 1, device=dev, dtype=dt), ratio=torch.zeros(n_steps + 1, device=dev, dtype=dt),
+                        lr=lr_list[trial_index], p_drop=p_drop0, min_diff=min_diff_cost, min_step=min_step, prev_cost=0.0)
+
+        # reference value for the cost-difference monitor (policy re-initialised while the cost is NaN)
+        with torch.no_grad():
+            for _ in range(10):
+                st0, in0 = self.apply_policy(p_dropout=p_drop0, **sim)
+                cost0, _ = self._cost(st0, in0, trial_index)
+                if not bool(torch.isnan(cost0)):
+                    break
+                print("\nSE filter initialization: Cost is NaN - reinit the policy")
+                self.control_policy.reinit(**policy_reinit_dict)
+        s = fresh_state()
+        es2 = 0.0
+        cost_prev = cost0
+        opt = make_opt(p=self.control_policy.parameters(), lr=s["lr"])
+        step = done = reinits = 0
+        t_mark = time.time()
+        states = inputs = None
+        while step < n_steps:
+            opt.zero_grad()
+            nan = True
+            for _ in range(10):
+                states, inputs = self.apply_policy(p_dropout=s["p_drop"], **sim)
+                cost, std = self._cost(states, inputs, trial_index)
+                if bool(torch.isnan(cost)):
+                    print("\nCost is NaN: try sampling again")
+                else:
+                    nan = False
+                    break
+            s["cost"][step] = cost.detach()
+            s["std"][step] = std.detach()
+            with torch.no_grad():  # exponential moving statistics of the cost change
+                diff = cost - cost_prev
+                s["es1"][step + 1] = alpha_diff_cost * s["es1"][step] + (1 - alpha_diff_cost) * diff
+                es2 = alpha_diff_cost * (es2 + (1 - alpha_diff_cost) * (diff - s["es1"][step]) ** 2)
+                cost_prev = s["cost"][step]
+                s["ratio"][step + 1] = alpha_diff_cost * s["ratio"][step] + (1 - alpha_diff_cost) * (s["es1"][step + 1] / es2.sqrt())
+            cost.backward(retain_graph=False)
+            self._allreduce_grads()
+            opt.step()
+            if step % num_step_print == 0:
+                now = float(cost.detach())
+                print("\nOptimization step: ", step)
+                print("cost: ", now)
+                print("cost improvement: ", s["prev_cost"] - now)
+                print("p_dropout_applied: ", s["p_drop"])
+                print("current_min_diff_cost; ", s["min_diff"])
+                print("current_min_step: ", s["min_step"])
+                print("diff_cost_ratio: ", float(torch.abs(s["ratio"][step + 1])))
+                print("time elapsed: ", time.time() - t_mark)
+                s["prev_cost"] = now
+                t_mark = time.time()
+            if step > s["min_step"]:
+                window = torch.abs(s["ratio"][step + 1 - num_min_diff_cost:step + 1])
+                if int(torch.sum(window < s["min_diff"])) >= num_min_diff_cost:
+                    if s["lr"] > lr_min:
+                        print("Optimization_step:", step)
+                        print("\nREDUCING THE LEARNING RATE:")
+                        s["lr"] = max(s["lr"] * lr_reduction_ratio, lr_min)
+                        print("lr: ", s["lr"])
+                        s["min_diff"] = max(s["min_diff"] / 2, 0.01)
+                        s["min_step"] = step + num_min_diff_cost
+                        opt = make_opt(p=self.control_policy.parameters(), lr=s["lr"])
+                        print("\nREDUCING THE DROPOUT:")
+                        s["p_drop"] = max(s["p_drop"] - p_drop_reduction, 0.0)
+                        print("p_dropout_applied: ", s["p_drop"])
+                    else:
+                        print("\nEXIT FROM OPTIMIZATION: diff_cost_ratio < min_diff_cost for num_min_diff_cost steps")
+                        step = n_steps
+            step += 1
+            done += 1
+            if nan:  # ten NaN rollouts in a row: restart from a re-initialised policy
+                reinits += 1
+                print("\nCost is NaN: re-initialize control policy [attempt #" + str(reinits) + "]")
+                self.control_policy.reinit(**policy_reinit_dict)
+                step = done = 0
+                s = fresh_state()
+                opt = make_opt(p=self.control_policy.parameters(), lr=s["lr"])
+        return (s["cost"][0:done].detach().cpu().numpy(), s["std"][0:done].detach().cpu().numpy(), states.detach().cpu().numpy(),
+                inputs.detach().cpu().numpy())
+
+    # ------------------------------------------------------------------------------------------------------------
+    # trial loop
+    # ------------------------------------------------------------------------------------------------------------
+    def _draw_x0(self, initial_state, initial_state_var, random_initial_state, flg_uniform, low, up, flg_multi):
+        if not random_initial_state:
+            return initial_state
+        if flg_uniform:
+            return np.random.uniform(low, up)
+        if flg_multi:
+            k = np.random.randint(initial_state.shape[0])
+            return np.random.normal(initial_state[k, :], np.sqrt(initial_state_var[k, :]))
+        return np.random.normal(initial_state, np.sqrt(initial_state_var))
+
+    def _save_log(self):
+        if self.log_path is not None:
+            print("Save log file...")
+            pkl.dump(self.log_dict, open(self.log_path + "/log.pkl", "wb"))
+
+    def reinforce(self, initial_state, initial_state_var, T_exploration, T_control, num_trials, model_optimization_opt_list,
+                  policy_optimization_dict, num_explorations=1, flg_init_uniform=False, init_up_bound=None, init_low_bound=None,
+                  flg_init_multi_gauss=False, random_initial_state=True, loaded_model=False):
+        """Alternates model learning, policy optimisation on the learned model, and interaction with the system."""
+        x0_args = (initial_state, initial_state_var, random_initial_state, flg_init_uniform, init_low_bound, init_up_bound, flg_init_multi_gauss)
+        if not loaded_model:
+            print("\n\n\n\n----------------- INITIAL EXPLORATIONS -----------------")
+            for k in range(num_explorations):
+                print("\nEXPLORATION # " + str(k))
+                self.get_data_from_system(initial_state=self._draw_x0(*x0_args), T_exploration=T_exploration, flg_exploration=True, trial_index=k)
+            costs, stds, params, pstates, pinputs = [], [], [], [], []
+            first = num_explorations - 1
+        else:
+            costs, stds = self.log_dict["cost_trial_list"], self.log_dict["std_cost_trial_list"]
+            params, pstates, pinputs = (self.log_dict["parameters_trial_list"], self.log_dict["particles_states_list"],
+                                        self.log_dict["particles_inputs_list"])
+            first = len(self.state_samples_history) - 1
+        t_dev = lambda a: torch.tensor(a, dtype=self.dtype, device=self.device)
+        for trial in range(first, first + num_trials):
+            print("\n\n\n\n----------------- TRIAL " + str(trial) + " -----------------")
+            print("\n\n----- REINFORCE THE MODEL -----")
+            self.model_learning.reinforce_model(optimization_opt_list=model_optimization_opt_list)
+            with torch.no_grad():
+                if self.log_path is not None:
+                    ml = self.model_learning
+                    self.log_dict["parameters_gp_" + str(trial)] = [copy.deepcopy(ml.gp_list[k].state_dict()) for k in range(ml.num_gp)]
+                    self.log_dict["gp_inputs_" + str(trial)] = ml.gp_inputs
+                    self.log_dict["gp_output_list_" + str(trial)] = ml.gp_output_list
+                    self.log_dict["state_samples_history"] = self.state_samples_history
+                    self.log_dict["input_samples_history"] = self.input_samples_history
+                    self.log_dict["noiseless_states_history"] = self.noiseless_states_history
+                    self._save_log()
+                print("\n\n----- CHECK THE ROLLOUT PERFORMANCE (after model update) -----")
+                self.get_rollout_prediction_performance(data_collection_index=trial)
+            print("\n\n----- REINFORCE THE POLICY -----")
+            self.model_learning.set_eval_mode()
+            cost_list, std_list, p_states, p_inputs = self.reinforce_policy(
+                T_control=T_control, particles_initial_state_mean=t_dev(initial_state), particles_initial_state_var=t_dev(initial_state_var),
+                flg_particles_init_uniform=flg_init_uniform, particles_init_up_bound=t_dev(init_up_bound) if flg_init_uniform else None,
+                particles_init_low_bound=t_dev(init_low_bound) if flg_init_uniform else None,
+                flg_particles_init_multi_gauss=flg_init_multi_gauss, trial_index=trial, **policy_optimization_dict)
+            costs.append(cost_list)
+            stds.append(std_list)
+            pstates.append(p_states)
+            pinputs.append(p_inputs)
+            params.append(copy.deepcopy(self.control_policy.state_dict()))
+            if self.log_path is not None:
+                self.log_dict.update(cost_trial_list=costs, std_cost_trial_list=stds, parameters_trial_list=params, particles_states_list=pstates,
+                                     particles_inputs_list=pinputs)
+                self._save_log()
+            self.model_learning.set_training_mode()
+            print("\n\n----- APPLY THE CONTROL POLICY -----")
+            self.get_data_from_system(initial_state=self._draw_x0(*x0_args), T_exploration=T_control, flg_exploration=False, trial_index=trial + 1)
+            if self.log_path is not None:
+                self.log_dict["state_samples_history"] = self.state_samples_history
+                self.log_dict["input_samples_history"] = self.input_samples_history
+                self.log_dict["noiseless_states_history"] = self.noiseless_states_history
+                self._save_log()
+        return costs, pstates, pinputs
+
+    # ------------------------------------------------------------------------------------------------------------
+    # interaction with the system, mean rollouts, logs
+    # ------------------------------------------------------------------------------------------------------------
+    def get_data_from_system(self, initial_state, T_exploration, trial_index, flg_exploration=False):
+        policy = self.rand_exploration_policy if flg_exploration else self.control_policy
+        noisy, inputs, clean = self.system.rollout(s0=initial_state, policy=policy.get_np_policy(), T=T_exploration, dt=self.T_sampling,
+                                                   noise=self.std_meas_noise)
+        self.state_samples_history.append(noisy)
+        self.input_samples_history.append(inputs)
+        self.noiseless_states_history.append(clean)
+        self.num_data_collection += 1
+        self.model_learning.add_data(new_state_samples=noisy, new_input_samples=inputs)
+
+    def rollout(self, data_collection_index, T_rollout=None, particle_pred=False):
+        """Open-loop prediction of one recorded trajectory with the learned model (mean prediction by default)."""
+        xs = self.state_samples_history[data_collection_index]
+        us = torch.tensor(self.input_samples_history[data_collection_index], dtype=self.dtype, device=self.device)
+        n = xs.shape[0] if T_rollout is None else T_rollout
+        traj = torch.zeros([n, self.state_dim], dtype=self.dtype, device=self.device)
+        traj[0:1, :] = torch.tensor(xs[0:1, :], dtype=self.dtype, device=self.device)
+        for t in range(1, n):
+            traj[t:t + 1, :], _, _ = self.model_learning.get_next_state(current_state=traj[t - 1:t, :], current_input=us[t - 1:t, :],
+                                                                         particle_pred=particle_pred)
+        return traj.detach().cpu().numpy()
+
+    def get_rollout_prediction_performance(self, data_collection_index, T_rollout=None, add_name=""):
+        pred = self.rollout(data_collection_index, T_rollout=T_rollout)
+        obs = self.state_samples_history[data_collection_index][: pred.shape[0]]
+        print("Rollout prediction MSE per state:", np.mean((pred - obs) ** 2, 0))
+        return pred, obs, self.input_samples_history[data_collection_index]
+
+    def load_policy_from_log(self, num_trial, folder="results_tmp/1/"):
+        log = pkl.load(open(folder + "log.pkl", "rb"))
+        self.control_policy.load_state_dict(log["parameters_trial_list"][num_trial - 1])
+
+    def load_model_from_log(self, num_trial, folder="results_tmp/1/"):
+        """Replays the logged data into the model, restores the GP hyper-parameters of trial ``num_trial-1`` and pretrains."""
+        log = pkl.load(open(folder + "log.pkl", "rb"))
+        self.log_dict = log
+        for k in ("cost_trial_list", "parameters_trial_list", "particles_states_list", "particles_inputs_list"):
+            self.log_dict[k] = self.log_dict[k][0:num_trial]
+        for j in range(num_trial + 1):
+            self.state_samples_history.append(log["state_samples_history"][j])
+            self.input_samples_history.append(log["input_samples_history"][j])
+            self.noiseless_states_history.append(log["noiseless_states_history"][j])
+            self.num_data_collection += 1
+            self.model_learning.add_data(new_state_samples=log["state_samples_history"][j], new_input_samples=log["input_samples_history"][j])
+        t = num_trial - 1
+        ml = self.model_learning
+        ml.gp_inputs = log["gp_inputs_" + str(t)].to(self.device)
+        ml.gp_output_list = [y.to(self.device) for y in log["gp_output_list_" + str(t)]]
+        for k in range(ml.num_gp):
+            ml.gp_list[k].load_state_dict(log["parameters_gp_" + str(t)][k])
+        with torch.no_grad():
+            for k in range(ml.num_gp):
+                ml.pretrain_gp(k)
