@@ -103,7 +103,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         group = dist.group.WORLD
 
-    from mc_pilco_amd import ops, workloads
+    from mc_pilco_amd import ops, sharding, workloads
 
     w = workloads.build(args.workload, device=dev, M=args.particles or None, T=args.horizon or None)
     M, T = w.M, w.T
@@ -133,15 +133,7 @@ def main():
         cost, std = ops.expected_cost(w.cost, states, group)
         cost.backward()
         if world > 1:
-            import torch.distributed as dist
-
-            flat = torch.cat([p.grad.reshape(-1) for p in w.params])
-            dist.all_reduce(flat, group=group)
-            o = 0
-            for p in w.params:
-                n = p.numel()
-                p.grad.copy_(flat[o:o + n].reshape(p.shape))
-                o += n
+            sharding.allreduce_gradients(w.params, group)
         opt.step()
         return cost, status
 

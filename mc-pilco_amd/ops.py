@@ -431,13 +431,10 @@ class ExpectedCostFunction(torch.autograd.Function):
         mom, _, _ = cost_moments(cost, states)
         M = states.shape[1]
         if group is not None:
-            import torch.distributed as dist
+            from . import sharding
 
-            R = dist.get_world_size(group)
-            allm = [torch.empty_like(mom) for _ in range(R)]
-            dist.all_gather(allm, mom, group=group)
-            counts = [M] * R if counts is None else [int(c) for c in counts]
-            mom_all = torch.stack(allm)
+            mom_all = sharding.gather_moments(mom, group)
+            counts = [M] * mom_all.shape[0] if counts is None else [int(c) for c in counts]
         else:
             counts = [M]
             mom_all = mom.unsqueeze(0)

@@ -1,0 +1,80 @@
+"""GPU, two ranks (both on cuda:0, gloo rendezvous): the sharded HIP path -- per-rank fused rollout with global
+particle ids, pooled expected cost (mcp_cost_finalize over all-gathered moments), all-reduced gradient --
+reproduces the single-process HIP result on the same particles, in both noise modes."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import conftest  # noqa: F401  (registers the package, also in spawned workers)
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, out_q):
+    import torch.distributed as dist
+
+    import mcp_boot  # noqa: F401
+    from mc_pilco_amd import ops, sharding, workloads
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    group = dist.group.WORLD if world > 1 else None
+    m_total, Tn = 48, 10
+    w = workloads.build("tiny", device=dev, M=m_total, T=Tn)
+    off, cnt = sharding.shard_range(m_total, world, rank)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(11)
+    x0_all = (w.x0_mean.cpu() + w.x0_std.cpu() * torch.randn(m_total, 4, dtype=torch.float64, generator=g)).to(dev)
+    nz = ops.NoiseSpec(seed=5, call=3, particle_offset=off)
+    for p in w.params:
+        p.grad = None
+    st, inp, status = ops.rollout(w.model, w.policy, nz, x0_all[off:off + cnt], Tn, w.p_drop)
+    cost, std = ops.expected_cost(w.cost, st, group, sharding.shard_counts(m_total, world) if world > 1 else None)
+    cost.backward()
+    if world > 1:
+        sharding.allreduce_gradients(w.params, group)
+    torch.cuda.synchronize()
+    res = (float(cost), float(std), [p.grad.cpu().numpy().copy() for p in w.params], st.detach().cpu().numpy(), off, cnt)
+    if rank == 0 or world == 1:
+        out_q.put(res)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_hip_sharding_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p1 = ctx.Process(target=_run, args=(0, 1, 0, q))
+    p1.start()
+    c1, s1, g1, st1, _, _ = q.get(timeout=300)
+    p1.join(timeout=60)
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    c2, s2, g2, st2, off, cnt = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(st2, st1[:, off:off + cnt])  # same noise per GLOBAL particle: bit-identical trajectories
+    assert abs(c2 - c1) < 1e-13 * abs(c1)
+    assert abs(s2 - s1) < 1e-11 * abs(s1)
+    for a, b in zip(g2, g1):
+        assert np.max(np.abs(a - b)) < 1e-12 * max(1.0, np.max(np.abs(b)))

@@ -1,0 +1,96 @@
+"""N>1 path on CPU: two gloo ranks shard the particles, exchange cost moments and policy gradients through
+mc_pilco_amd.sharding, and must reproduce the single-process result (cost, std, gradient) of the same particles.
+The per-rank rollouts are computed by the CPU oracle here (the HIP path needs a GPU; its own 2-rank test is
+tests/test_gpu_sharding.py); what is under test is the sharding arithmetic and the collectives."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import load_golden  # noqa: I001  (first: registers the package, also in spawned workers)
+from helpers import T, oracle_cost_fn, oracle_model, oracle_policy
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, m_total, out_q):
+    import torch.distributed as dist
+
+    import mcp_boot  # noqa: F401
+    from mc_pilco_amd import sharding
+    from oracle import mcpilco_oracle as orc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fx = load_golden("rollout_se")
+    m = oracle_model(fx, "se")
+    pp = oracle_policy(fx, "se")
+    cost_fn = oracle_cost_fn(fx, "se")
+    off, cnt = sharding.shard_range(m_total, world, rank)
+    sl = slice(off, off + cnt)
+    x0 = T(fx["states"][0][sl])
+    eps, masks = T(fx["eps"][:, sl]), T(fx["masks"][:, sl])
+    prm = [pp.log_ls, pp.centers, pp.weight]
+    for p in prm:
+        p.requires_grad_(True)
+    st, _ = orc.apply_policy(m, pp, x0, fx["states"].shape[0], float(fx["p_drop"]), eps, masks)
+    c = cost_fn(st)  # [T, cnt]
+    mean = c.mean(1)
+    mom = torch.stack([mean.detach(), ((c.detach() - mean.detach()[:, None]) ** 2).sum(1)], 1)
+    mom_all = sharding.gather_moments(mom, dist.group.WORLD)
+    cost, std = sharding.pooled_cost_reference(mom_all, sharding.shard_counts(m_total, world))
+    (c.sum() / m_total).backward()  # this rank's share of d(sum_t mean_m c)/dtheta
+    sharding.allreduce_gradients(prm, dist.group.WORLD)
+    if rank == 0:
+        out_q.put((float(cost), float(std), [p.grad.numpy().copy() for p in prm]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("m_total", [24, 23])
+def test_two_rank_sharding_reproduces_single_process(m_total):
+    from oracle import mcpilco_oracle as orc
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, m_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    cost, std, grads = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process on the same particles
+    fx = load_golden("rollout_se")
+    m, pp, cost_fn = oracle_model(fx, "se"), oracle_policy(fx, "se"), oracle_cost_fn(fx, "se")
+    sl = slice(0, m_total)
+    c1, s1, g1, _, _ = orc.policy_grad_step(m, pp, T(fx["states"][0][sl]), fx["states"].shape[0], cost_fn, float(fx["p_drop"]), T(fx["eps"][:, sl]),
+                                            T(fx["masks"][:, sl]))
+    assert abs(cost - float(c1)) < 1e-12 * abs(float(c1))
+    assert abs(std - float(s1)) < 1e-10 * abs(float(s1))
+    for g, k in zip(grads, ["log_ls", "centers", "weight"]):
+        assert np.max(np.abs(g - g1[k].numpy())) < 1e-12 * max(1.0, float(g1[k].abs().max()))
+
+
+def test_shard_ranges_partition_the_particles():
+    from mc_pilco_amd import sharding
+
+    for m_total in (1, 7, 8, 400, 401, 32000):
+        for world in (1, 2, 3, 8):
+            rs = [sharding.shard_range(m_total, world, r) for r in range(world)]
+            assert rs[0][0] == 0 and sum(c for _, c in rs) == m_total
+            for (o0, c0), (o1, _) in zip(rs, rs[1:]):
+                assert o0 + c0 == o1
+            assert max(c for _, c in rs) - min(c for _, c in rs) <= 1
