@@ -48,6 +48,9 @@ struct FwdLayout {
 // LDS-resident copy of what the kernels need from mcp_gp.  The descriptors arrive by value in the
 // kernel argument; indexing that copy with a per-lane GP index would make the compiler spill the
 // whole argument to scratch (global-latency loads in every phase), so it is staged here once.
+typedef const double __attribute__((address_space(1))) * gptr_t;  // explicit global pointer: loads become global_load, not flat_load
+typedef double v2d __attribute__((ext_vector_type(2)));            // native vector: loadable through an address-space pointer
+typedef const v2d __attribute__((address_space(1))) * gptr2_t;
 struct GpL {
   const double* Kinv;
   const double* Xt;
@@ -85,7 +88,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int 
   L.pb = maxdeg > 1 ? take(GB * NpadMax * P) : L.kb;
   L.vb = take(GB * NpadMax * P);
   L.part = take(imax((NCmax + RF_NW) * 128 * P, P * B));
-  L.red = take(GB * P * (D + 1) * RF_MAX_NA);
+  L.red = take(GB * RF_NW * (D + 1) * P * (maxdeg == 0 ? 2 : 9));
   L.xt = xlds ? take(G * D * NpadMax) : 0;
   L.al = xlds ? take(G * NpadMax) : 0;
   L.cen = xlds ? take(B * PF) : 0;
@@ -201,7 +204,7 @@ __device__ __forceinline__ int build_chunk_table(const GpL* gpl, int g0, int gn,
 // Phase K: covariance vectors of P test points against the training points of gn GPs
 // -> LDS [gl][j][p]   (rows j >= N are never read)
 // ---------------------------------------------------------------------------------------
-template <int P, bool XLDS>
+template <int P, bool XLDS, int MAXDEG>
 __device__ __forceinline__ void phase_k(const GpL* gpl, const double* kpar, int g0, int gn, int D, int NpadMax, const double* z,
                                         const double* xt_l, double* kb, double* ks, double* pa, double* pb, int tid) {
   for (int it = tid; it < gn * P * NpadMax; it += RF_NT) {
@@ -211,31 +214,31 @@ __device__ __forceinline__ void phase_k(const GpL* gpl, const double* kpar, int 
     const GpL& gp = gpl[g0 + gl];
     const int N = gp.N, Npad = gp.Npad;
     if (j >= N) {
-      if (j < Npad) kb[((size_t)gl * NpadMax + j) * P + p] = 0.0;  // phase V may touch one padded row
+      if (j < Npad) kb[(gl * NpadMax + j) * P + p] = 0.0;  // phase V may touch one padded row
       continue;
     }
-    const double* kp = kpar + (size_t)(g0 + gl) * KP_STRIDE(D);
-    const int deg = gp.deg;
+    const double* kp = kpar + (g0 + gl) * KP_STRIDE(D);
+    const int deg = MAXDEG == 0 ? 0 : gp.deg;  // MAXDEG == 0: the polynomial code is compiled out
     const double* zp = z + p * D;
-    const double* xc = XLDS ? xt_l + (size_t)(g0 + gl) * D * NpadMax + j : gp.Xt + j;
+    const double* xc = XLDS ? xt_l + (g0 + gl) * D * NpadMax + j : gp.Xt + j;
     const int xs_ = XLDS ? NpadMax : Npad;
     double dist = 0.0;
 #pragma unroll 6
     for (int d = 0; d < D; ++d) {
-      double rr = (zp[d] - xc[(size_t)d * xs_]) * kp[KP_INVLS(D) + d];
+      double rr = (zp[d] - xc[d * xs_]) * kp[KP_INVLS(D) + d];
       dist = fma(rr, rr, dist);
     }
     double kse = gp.lambda * exp(-dist);
     double kt = kse;
-    const size_t o = ((size_t)gl * NpadMax + j) * P + p;
+    const int o = (gl * NpadMax + j) * P + p;
     if (deg >= 1) {
       double p1 = kp[KP_W1(D) + D];
-      for (int d = 0; d < D; ++d) p1 = fma(kp[KP_W1(D) + d] * zp[d], xc[(size_t)d * xs_], p1);
+      for (int d = 0; d < D; ++d) p1 = fma(kp[KP_W1(D) + d] * zp[d], xc[d * xs_], p1);
       kt += p1;
       if (deg >= 2) {
         double A = 0.0, Bv = 0.0;
         for (int d = 0; d < D; ++d) {
-          double zx = zp[d] * xc[(size_t)d * xs_];
+          double zx = zp[d] * xc[d * xs_];
           A = fma(kp[KP_W20(D) + d], zx, A);
           Bv = fma(kp[KP_W21(D) + d], zx, Bv);
         }
@@ -243,8 +246,8 @@ __device__ __forceinline__ void phase_k(const GpL* gpl, const double* kpar, int 
         pa[o] = A;
         pb[o] = Bv;
       }
-      ks[o] = kse;
     }
+    if (MAXDEG >= 1) ks[o] = kse;  // (with MAXDEG == 0 the layout aliases ks to kb)
     kb[o] = kt;
   }
 }
@@ -260,7 +263,7 @@ __device__ __forceinline__ void phase_k(const GpL* gpl, const double* kpar, int 
 // The stream (all chunks of all GPs of the pass) is cut into RF_NW equal contiguous shares.
 // ---------------------------------------------------------------------------------------
 template <int P>
-__device__ __forceinline__ void consume_rows(const double2 (&A)[RF_GS], const double* __restrict__ kk, int kstride, double (&acc)[2][P]) {
+__device__ __forceinline__ void consume_rows(const v2d (&A)[RF_GS], const double* __restrict__ kk, int kstride, double (&acc)[2][P]) {
 #pragma unroll
   for (int u = 0; u < RF_GS; ++u) {
 #pragma unroll
@@ -272,21 +275,21 @@ __device__ __forceinline__ void consume_rows(const double2 (&A)[RF_GS], const do
   }
 }
 
-__device__ __forceinline__ void load_rows(double2 (&A)[RF_GS], const double* __restrict__ p, size_t rstride) {
+__device__ __forceinline__ void load_rows(v2d (&A)[RF_GS], gptr_t p, size_t rstride) {
 #pragma unroll
-  for (int u = 0; u < RF_GS; ++u) A[u] = *reinterpret_cast<const double2*>(p + (size_t)u * rstride);
+  for (int u = 0; u < RF_GS; ++u) A[u] = *(gptr2_t)(p + (size_t)u * rstride);
 }
 
 // units [ua, ub) of one chunk; `base` already points at this lane's two columns of its first row,
 // `kk` at its k row; consecutive units are rstride / kstride apart
 template <int P>
-__device__ __forceinline__ void matvec_rows(const double* __restrict__ base, size_t rstride, const double* __restrict__ kk, int kstride,
+__device__ __forceinline__ void matvec_rows(gptr_t base, size_t rstride, const double* __restrict__ kk, int kstride,
                                             int ua, int ub, double (&acc)[2][P]) {
-  const double* p = base + (size_t)ua * rstride;
+  gptr_t p = base + (size_t)ua * rstride;
   const size_t gstep = (size_t)RF_GS * rstride;
   int u0 = ua;
   const int nfull = (ub - ua) / RF_GS;
-  double2 A[RF_GS], Bf[RF_GS];
+  v2d A[RF_GS], Bf[RF_GS];
   if (nfull > 0) {
     load_rows(A, p, rstride);
     p += gstep;
@@ -296,14 +299,14 @@ __device__ __forceinline__ void matvec_rows(const double* __restrict__ base, siz
         load_rows(Bf, p, rstride);
         p += gstep;
       }
-      consume_rows<P>(A, kk + (size_t)u0 * kstride, kstride, acc);
+      consume_rows<P>(A, kk + u0 * kstride, kstride, acc);
       u0 += RF_GS;
       if (hasB) {
         if (g + 2 < nfull) {
           load_rows(A, p, rstride);
           p += gstep;
         }
-        consume_rows<P>(Bf, kk + (size_t)u0 * kstride, kstride, acc);
+        consume_rows<P>(Bf, kk + u0 * kstride, kstride, acc);
         u0 += RF_GS;
       }
     }
@@ -311,13 +314,13 @@ __device__ __forceinline__ void matvec_rows(const double* __restrict__ base, siz
   const int rem = ub - u0;  // 0 .. RF_GS-1, wave-uniform
 #pragma unroll
   for (int u = 0; u < RF_GS - 1; ++u)
-    if (u < rem) A[u] = *reinterpret_cast<const double2*>(p + (size_t)u * rstride);
+    if (u < rem) A[u] = *(gptr2_t)(p + (size_t)u * rstride);
 #pragma unroll
   for (int u = 0; u < RF_GS - 1; ++u) {
     if (u < rem) {
 #pragma unroll
       for (int q = 0; q < P; ++q) {
-        double kv = kk[(size_t)(u0 + u) * kstride + q];
+        double kv = kk[(u0 + u) * kstride + q];
         acc[0][q] = fma(A[u].x, kv, acc[0][q]);
         acc[1][q] = fma(A[u].y, kv, acc[1][q]);
       }
@@ -347,8 +350,8 @@ __device__ __forceinline__ void phase_v(const GpL* gpl, int g0, const int* tab, 
     double acc[2][P];
 #pragma unroll
     for (int p = 0; p < P; ++p) acc[0][p] = acc[1][p] = 0.0;
-    const double* base = Kinv + (size_t)sub * Npad + (ok ? i : rb);
-    matvec_rows<P>(base, (size_t)R * Npad, kb + ((size_t)gl * NpadMax + sub) * P, R * P, ua, ub, acc);
+    gptr_t base = (gptr_t)Kinv + (size_t)sub * Npad + (ok ? i : rb);
+    matvec_rows<P>(base, (size_t)R * Npad, kb + (gl * NpadMax + sub) * P, R * P, ua, ub, acc);
     if (R == 2) {
       // fold rows j+1 (lanes 32..63) into rows j (lanes 0..31)
 #pragma unroll
@@ -357,7 +360,7 @@ __device__ __forceinline__ void phase_v(const GpL* gpl, int g0, const int* tab, 
         acc[1][p] += __shfl_xor(acc[1][p], 32);
       }
     }
-    double* slot = part + (size_t)(c + wv) * 128 * P;  // slot id = chunk + wave: unique, contiguous per chunk
+    double* slot = part + (c + wv) * 128 * P;  // slot id = chunk + wave: unique, contiguous per chunk
     if (lane == li) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -384,7 +387,7 @@ __device__ __forceinline__ void phase_vsum(const GpL* gpl, int g0, int gn, const
     int c = tab[TAB_GCB + gl] + i / RF_CW;
     int s_lo = c + tab[TAB_CSTART + c] / L, s_hi = c + (tab[TAB_CSTART + c + 1] - 1) / L;
     double s = 0.0;
-    for (int sid = s_lo; sid <= s_hi; ++sid) s += part[((size_t)sid * 128 + (i % RF_CW)) * P + p];
+    for (int sid = s_lo; sid <= s_hi; ++sid) s += part[(sid * 128 + (i % RF_CW)) * P + p];
     vb[it] = s;
   }
 }
@@ -396,70 +399,131 @@ __device__ __forceinline__ void phase_vsum(const GpL* gpl, int g0, int gn, const
 //                   a3 = sum alpha_j B_j X_jc, a4 = sum alpha_j A_j X_jc, a5 = sum v_j B_j X_jc, a6 = sum v_j A_j X_jc (deg 2)
 //   column c == D : a0 = sum k_j alpha_j  (= mu - m)          a1 = sum k_j v_j  (= k^T Kinv k)
 // ---------------------------------------------------------------------------------------
-template <int P, bool XLDS>
-__device__ __forceinline__ void phase_j(const GpL* gpl, int g0, int gn, int D, int NpadMax, const double* z, const double* xt_l,
-                                        const double* al_l, const double* kb, const double* ks, const double* pa, const double* pb,
-                                        const double* vb, double* red, int wv, int lane) {
-  const int per = P * (D + 1);
-  for (int item = wv; item < gn * per; item += RF_NW) {
-    int gl = item / per;
-    int r = item - gl * per;
-    int p = r / (D + 1), c = r - p * (D + 1);
-    const GpL& gp = gpl[g0 + gl];
-    const int N = __builtin_amdgcn_readfirstlane(gp.N), deg = __builtin_amdgcn_readfirstlane(gp.deg), NA = gp_num_acc(deg);
-    const double* al = XLDS ? al_l + (size_t)(g0 + gl) * NpadMax : gp.alpha;
-    const size_t ob = (size_t)gl * NpadMax * P + p;
-    double acc[RF_MAX_NA];
+// Phase J on the matrix cores.  Per GP the moment / Jacobian sums are one skinny contraction over the training index
+//     R[c][n] = sum_j Xe[c][j] * W[j][n],      Xe = [X^T ; 1]  ((D+1) x N),   W (N x P*NAX) = per-particle weight vectors
+// with, per particle, the columns  0: kse*alpha   1: kse*v   [deg>=1] 2: v   [deg 2] 3: alpha*B  4: alpha*A  5: v*B  6: v*A
+// and, when deg>=1, the two totals columns  NAX-2: k*alpha   NAX-1: k*v   (for deg 0  k == kse, so columns 0/1 serve).
+// v_mfma_f64_16x16x4_f64 sums 4 values of j per instruction inside the matrix core, so no cross-lane reduction is needed:
+// A operand  lane l -> Xe[c = l&15][j = jb + (l>>4)]   (an LDS read),  B operand  lane l -> W[j = jb + (l>>4)][n = l&15]
+// (three LDS reads and a multiply), accumulator  D[row = (l>>4) + 4r][col = l&15].  The 8 waves split N; their partial tiles
+// meet in LDS (redw) and the finalize phase adds the 8 partials.  The centred sums the Jacobians need follow from
+//     sum_j w_j (z_c - X_jc) = z_c * R[D][n] - R[c][n].
+typedef double v4d __attribute__((ext_vector_type(4)));
+#define RF_NAX(deg) ((deg) == 0 ? 2 : ((deg) == 1 ? 5 : 9))
+
+template <int P, bool XLDS, int DEG>
+__device__ __forceinline__ void phase_j_gp(const GpL& gp, int ggl, int gl, int D, int NpadMax, int ncolmax, const double* xt_l,
+                                           const double* al_l, const double* kb, const double* ks, const double* pa, const double* pb,
+                                           const double* vb, double* redw, int wv, int lane) {
+  constexpr int NAX = RF_NAX(DEG);
+  constexpr int NCOLS = P * NAX;
+  constexpr int CT = (NCOLS + 15) / 16;
+  const int RT = (D + 1 + 15) >> 4;  // <= 3
+  const int N = __builtin_amdgcn_readfirstlane(gp.N);
+  const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
+  const int per = ((N + RF_NW * 4 - 1) / (RF_NW * 4)) * 4;  // this wave's share of j, a multiple of 4
+  const int j0 = wv * per, j1 = imin(N, j0 + per);
+  const int kq = lane >> 4, li = lane & 15;
+  v4d acc[3][CT];
 #pragma unroll
-    for (int q = 0; q < RF_MAX_NA; ++q) acc[q] = 0.0;
-    if (c < D) {
-      const double* xc = XLDS ? xt_l + ((size_t)(g0 + gl) * D + c) * NpadMax : gp.Xt + (size_t)c * __builtin_amdgcn_readfirstlane(gp.Npad);
-      const double zc = z[p * D + c];
-#pragma unroll 5
-      for (int j = lane; j < N; j += 64) {
-        const size_t o = ob + (size_t)j * P;
-        double alj = al[j], v = vb[o], x = xc[j], kse = ks[o];
-        double dz = zc - x;
-        acc[0] = fma(kse * alj, dz, acc[0]);
-        acc[1] = fma(kse * v, dz, acc[1]);
-        if (deg >= 1) acc[2] = fma(v, x, acc[2]);
-        if (deg >= 2) {
-          double A = pa[o], Bv = pb[o];
-          acc[3] = fma(alj * Bv, x, acc[3]);
-          acc[4] = fma(alj * A, x, acc[4]);
-          acc[5] = fma(v * Bv, x, acc[5]);
-          acc[6] = fma(v * A, x, acc[6]);
+  for (int rt = 0; rt < 3; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+  for (int jb = j0; jb < j1; jb += 4) {
+    const int j = jb + kq;
+    const bool jok = j < j1;
+    const int jc = jok ? j : j0;  // clamp: out-of-range lanes read a valid address and contribute zero
+    const double alj = XLDS ? al_l[ggl * NpadMax + jc] : ((gptr_t)gp.alpha)[jc];
+    double bv[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      const int n = ct * 16 + li;
+      const int p = imin(n / NAX, P - 1), aidx = n % NAX;
+      const int o = (gl * NpadMax + jc) * P + p;
+      const double kse = ks[o], v = vb[o];
+      double w = (aidx == 0) ? kse * alj : kse * v;
+      if (DEG >= 1) {
+        const double kt = kb[o];
+        if (aidx == 2) w = v;
+        if (aidx == NAX - 2) w = kt * alj;
+        if (aidx == NAX - 1) w = kt * v;
+        if (DEG >= 2) {
+          const double A = pa[o], Bv = pb[o];
+          if (aidx == 3) w = alj * Bv;
+          if (aidx == 4) w = alj * A;
+          if (aidx == 5) w = v * Bv;
+          if (aidx == 6) w = v * A;
         }
       }
-    } else {
-#pragma unroll 5
-      for (int j = lane; j < N; j += 64) {
-        const size_t o = ob + (size_t)j * P;
-        double kt = kb[o];
-        acc[0] = fma(kt, al[j], acc[0]);
-        acc[1] = fma(kt, vb[o], acc[1]);
+      bv[ct] = (jok && n < NCOLS) ? w : 0.0;
+    }
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+      if (rt < RT) {
+        const int c = rt * 16 + li;
+        const int cc = imin(c, D - 1);
+        const double x = XLDS ? xt_l[(ggl * D + cc) * NpadMax + jc] : ((gptr_t)gp.Xt)[(size_t)cc * Npad + jc];
+        const double av = !jok ? 0.0 : (c < D ? x : (c == D ? 1.0 : 0.0));
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[ct], acc[rt][ct], 0, 0, 0);
       }
     }
-    double* out = red + (size_t)item * RF_MAX_NA;
+  }
+  double* out = redw + (gl * RF_NW + wv) * (D + 1) * ncolmax;
 #pragma unroll
-    for (int q = 0; q < RF_MAX_NA; ++q) {
-      if (q < NA) {
-        double s = wave_sum(acc[q]);
-        if (lane == 0) out[q] = s;
+  for (int rt = 0; rt < 3; ++rt) {
+    if (rt < RT) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = rt * 16 + kq + 4 * r, n = ct * 16 + li;
+          if (c <= D && n < NCOLS) out[c * ncolmax + n] = acc[rt][ct][r];
+        }
       }
     }
   }
 }
 
-// posterior mean / variance and their z-Jacobians from the reduced sums R[(D+1)][RF_MAX_NA]
-__device__ __forceinline__ void gp_point(const GpL& gp, const double* kp, int D, const double* zp, const double* R, double& mu, double& var) {
-  mu = gp.mean + R[D * RF_MAX_NA + 0];
+template <int P, bool XLDS, int MAXDEG>
+__device__ __forceinline__ void phase_j(const GpL* gpl, int g0, int gn, int D, int NpadMax, const double* xt_l, const double* al_l,
+                                        const double* kb, const double* ks, const double* pa, const double* pb, const double* vb,
+                                        double* redw, int wv, int lane) {
+  constexpr int NCOLMAX = P * RF_NAX(MAXDEG);
+  for (int gl = 0; gl < gn; ++gl) {
+    const GpL& gp = gpl[g0 + gl];
+    const int deg = MAXDEG == 0 ? 0 : __builtin_amdgcn_readfirstlane(gp.deg);
+    if (MAXDEG == 0 || deg == 0)
+      phase_j_gp<P, XLDS, 0>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane);
+    else if (deg == 1)
+      phase_j_gp<P, XLDS, 1>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane);
+    else
+      phase_j_gp<P, XLDS, 2>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane);
+  }
+}
+
+// R[c][col] summed over the 8 waves' partial tiles (fixed order); Rg = redw + gl*RF_NW*(D+1)*ncolmax
+__device__ __forceinline__ double j_sum(const double* Rg, int D, int ncolmax, int c, int col) {
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < RF_NW; ++w) s += Rg[(w * (D + 1) + c) * ncolmax + col];
+  return s;
+}
+
+// posterior mean / variance and their z-Jacobians from the contraction results of this (gp, particle); col0 = p * NAX
+template <int MAXDEG>
+__device__ __forceinline__ void gp_point(const GpL& gp, const double* kp, int D, const double* zp, const double* Rg, int ncolmax, int p,
+                                         double& mu, double& var) {
+  const int deg = MAXDEG == 0 ? 0 : gp.deg;
+  const int nax = RF_NAX(deg), col0 = p * nax;
+  mu = gp.mean + j_sum(Rg, D, ncolmax, D, col0 + (deg == 0 ? 0 : nax - 2));
   double kzz = gp.lambda;  // k(z,z): Stationary_GP.py:172-181, Sparse_GP.py:443-453,658-668
-  if (gp.deg >= 1) {
+  if (MAXDEG >= 1 && deg >= 1) {
     double p1 = kp[KP_W1(D) + D];
     for (int d = 0; d < D; ++d) p1 = fma(kp[KP_W1(D) + d] * zp[d], zp[d], p1);
     kzz += p1;
-    if (gp.deg >= 2) {
+    if (deg >= 2) {
       double sa = 0.0, sb = 0.0;
       for (int d = 0; d < D; ++d) {
         double zz = zp[d] * zp[d];
@@ -469,20 +533,24 @@ __device__ __forceinline__ void gp_point(const GpL& gp, const double* kp, int D,
       kzz = fma(sa, sb, kzz);
     }
   }
-  var = kzz - R[D * RF_MAX_NA + 1];
+  var = kzz - j_sum(Rg, D, ncolmax, D, col0 + (deg == 0 ? 1 : nax - 1));
 }
-__device__ __forceinline__ void gp_jac(const GpL& gp, const double* kp, int D, const double* zp, const double* R, int d, double& Jmu,
-                                       double& Jvar) {
-  const int deg = gp.deg;
-  const double* r = R + d * RF_MAX_NA;
+template <int MAXDEG>
+__device__ __forceinline__ void gp_jac(const GpL& gp, const double* kp, int D, const double* zp, const double* Rg, int ncolmax, int p, int d,
+                                       double& Jmu, double& Jvar) {
+  const int deg = MAXDEG == 0 ? 0 : gp.deg;
+  const int col0 = p * RF_NAX(deg);
   double il = kp[KP_INVLS(D) + d];
   double il2 = il * il;
-  Jmu = -2.0 * il2 * r[0];
-  Jvar = 4.0 * il2 * r[1];
-  if (deg >= 1) {
+  // centred sums  sum_j w_j (z_d - X_jd) = z_d * R[D][.] - R[d][.]
+  double r0 = fma(zp[d], j_sum(Rg, D, ncolmax, D, col0 + 0), -j_sum(Rg, D, ncolmax, d, col0 + 0));
+  double r1 = fma(zp[d], j_sum(Rg, D, ncolmax, D, col0 + 1), -j_sum(Rg, D, ncolmax, d, col0 + 1));
+  Jmu = -2.0 * il2 * r0;
+  Jvar = 4.0 * il2 * r1;
+  if (MAXDEG >= 1 && deg >= 1) {
     double w1d = kp[KP_W1(D) + d];
     Jmu = fma(w1d, kp[KP_AX(D) + d], Jmu);
-    Jvar += 2.0 * w1d * (zp[d] - r[2]);
+    Jvar += 2.0 * w1d * (zp[d] - j_sum(Rg, D, ncolmax, d, col0 + 2));
     if (deg >= 2) {
       double Sa = 0.0, Sb = 0.0;
       for (int e = 0; e < D; ++e) {
@@ -491,8 +559,8 @@ __device__ __forceinline__ void gp_jac(const GpL& gp, const double* kp, int D, c
         Sb = fma(kp[KP_W21(D) + e], zz, Sb);
       }
       double a_ = kp[KP_W20(D) + d], b_ = kp[KP_W21(D) + d];
-      Jmu += a_ * r[3] + b_ * r[4];
-      Jvar += 2.0 * zp[d] * (a_ * Sb + b_ * Sa) - 2.0 * (a_ * r[5] + b_ * r[6]);
+      Jmu += a_ * j_sum(Rg, D, ncolmax, d, col0 + 3) + b_ * j_sum(Rg, D, ncolmax, d, col0 + 4);
+      Jvar += 2.0 * zp[d] * (a_ * Sb + b_ * Sa) - 2.0 * (a_ * j_sum(Rg, D, ncolmax, d, col0 + 5) + b_ * j_sum(Rg, D, ncolmax, d, col0 + 6));
     }
   }
 }
@@ -500,7 +568,7 @@ __device__ __forceinline__ void gp_jac(const GpL& gp, const double* kp, int D, c
 // ---------------------------------------------------------------------------------------
 // forward rollout
 // ---------------------------------------------------------------------------------------
-template <int P, bool XLDS>
+template <int P, bool XLDS, int MAXDEG>
 __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
@@ -546,9 +614,9 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       const mcp_gp& gp = gps[g];
       for (int it = tid; it < D * gp.Npad; it += RF_NT) {
         int d = it / gp.Npad, j = it - d * gp.Npad;
-        xt_l[((size_t)g * D + d) * NpadMax + j] = gp.Xt[it];
+        xt_l[(g * D + d) * NpadMax + j] = gp.Xt[it];
       }
-      for (int it = tid; it < gp.Npad; it += RF_NT) al_l[(size_t)g * NpadMax + it] = gp.alpha[it];
+      for (int it = tid; it < gp.Npad; it += RF_NT) al_l[g * NpadMax + it] = gp.alpha[it];
     }
     for (int it = tid; it < B * PF; it += RF_NT) cen_l[it] = pl.centers[it];
     for (int it = tid; it < U * B; it += RF_NT) wgt_l[it] = pl.weight[it];
@@ -628,7 +696,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
     double* ph = part;
     for (int it = tid; it < P * B; it += RF_NT) {
       int p = it / B, b = it - p * B;
-      const double* cb = cen + (size_t)b * PF;
+      const double* cb = cen + b * PF;
       double dist = 0.0;
 #pragma unroll 5
       for (int q = 0; q < PF; ++q) {
@@ -648,7 +716,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
     // ---- phase U: u = u_max tanh((W phi)/u_max), one wave per (particle, input) -------------------
     for (int task = wv; task < P * U; task += RF_NW) {
       int p = task / U, k = task - p * U;
-      const double* wk = wgt + (size_t)k * B;
+      const double* wk = wgt + k * B;
       double s = 0.0;
 #pragma unroll 4
       for (int b = lane; b < B; b += 64) s = fma(wk[b], ph[p * B + b], s);
@@ -675,7 +743,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         NC = build_chunk_table(gpl, g0, gn, tab, tid);
         lds_barrier();
       }
-      phase_k<P, XLDS>(gpl, kpar, g0, gn, D, NpadMax, z, xt_l, kb, ks, pa, pb, tid);
+      phase_k<P, XLDS, MAXDEG>(gpl, kpar, g0, gn, D, NpadMax, z, xt_l, kb, ks, pa, pb, tid);
       lds_barrier();
       RF_STAMP(3);
       phase_v<P>(gpl, g0, tab, NC, NpadMax, kb, part, wv, lane);
@@ -684,7 +752,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       phase_vsum<P>(gpl, g0, gn, tab, NC, NpadMax, part, vb, tid);
       lds_barrier();
       RF_STAMP(5);
-      phase_j<P, XLDS>(gpl, g0, gn, D, NpadMax, z, xt_l, al_l, kb, ks, pa, pb, vb, red, wv, lane);
+      phase_j<P, XLDS, MAXDEG>(gpl, g0, gn, D, NpadMax, xt_l, al_l, kb, ks, pa, pb, vb, red, wv, lane);
       lds_barrier();
       RF_STAMP(6);
       // ---- phase F: sample delta_g and fold the sampling into d delta/dz ------------------------
@@ -694,13 +762,14 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         int p = r / (D + 1), c = r - p * (D + 1);
         const int g = g0 + gl;
         const GpL& gp = gpl[g];
-        const double* kp = kpar + (size_t)g * KP_STRIDE(D);
+        const double* kp = kpar + g * KP_STRIDE(D);
         const double vscale = gp.var_scale;
-        const double* R = red + ((size_t)(gl * P + p) * (D + 1)) * RF_MAX_NA;
+        constexpr int NCOLMAX = P * RF_NAX(MAXDEG);
+        const double* Rg = red + gl * RF_NW * (D + 1) * NCOLMAX;
         const double* zp = z + p * D;
         int mm = imin(m0 + p, M - 1);
         double mu, var;
-        gp_point(gp, kp, D, zp, R, mu, var);
+        gp_point<MAXDEG>(gp, kp, D, zp, Rg, NCOLMAX, p, mu, var);
         var *= vscale;
         double eps = 0.0, wj = 0.0, sd = 0.0;
         if (a.particle_pred) {
@@ -716,7 +785,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
           }
         } else if (a.jac && m0 + p < M) {
           double Jmu, Jvar;
-          gp_jac(gp, kp, D, zp, R, c, Jmu, Jvar);
+          gp_jac<MAXDEG>(gp, kp, D, zp, Rg, NCOLMAX, p, c, Jmu, Jvar);
           a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
         }
       }
@@ -758,7 +827,7 @@ __global__ __launch_bounds__(RF_NT) void posterior_fwd_kernel(PostArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = gp.kern.D, deg = gp.kern.poly_deg, NpadMax = gp.Npad;
-  const FwdLayout L = fwd_layout(P, 1, 1, D, 1, 1, 1, NpadMax, deg, 1, a.NCmax, false);
+  const FwdLayout L = fwd_layout(P, 1, 1, D, 1, 1, 1, NpadMax, 2, 1, a.NCmax, false);
   double* z = smem + L.z;
   double* kb = smem + L.kb;
   double* ks = smem + L.ks;
@@ -780,29 +849,29 @@ __global__ __launch_bounds__(RF_NT) void posterior_fwd_kernel(PostArgs a) {
   __syncthreads();
   const int NC = build_chunk_table(gpl, 0, 1, tab, tid);
   __syncthreads();
-  phase_k<P, false>(gpl, kpar, 0, 1, D, NpadMax, z, nullptr, kb, ks, pa, pb, tid);
+  phase_k<P, false, 2>(gpl, kpar, 0, 1, D, NpadMax, z, nullptr, kb, ks, pa, pb, tid);
   __syncthreads();
   phase_v<P>(gpl, 0, tab, NC, NpadMax, kb, part, wv, lane);
   __syncthreads();
   phase_vsum<P>(gpl, 0, 1, tab, NC, NpadMax, part, vb, tid);
   __syncthreads();
-  phase_j<P, false>(gpl, 0, 1, D, NpadMax, z, nullptr, nullptr, kb, ks, pa, pb, vb, red, wv, lane);
+  phase_j<P, false, 2>(gpl, 0, 1, D, NpadMax, nullptr, nullptr, kb, ks, pa, pb, vb, red, wv, lane);
   __syncthreads();
   for (int it = tid; it < P * (D + 1); it += RF_NT) {
     int p = it / (D + 1), c = it - p * (D + 1);
     if (m0 + p >= a.M) continue;
-    const double* R = red + (size_t)p * (D + 1) * RF_MAX_NA;
+    constexpr int NCOLMAX = P * RF_NAX(2);
     const double* zp = z + p * D;
     if (c == D) {
       double mu, var;
-      gp_point(gpl[0], kpar, D, zp, R, mu, var);
+      gp_point<2>(gpl[0], kpar, D, zp, red, NCOLMAX, p, mu, var);
       a.mu[m0 + p] = mu;
       a.var[m0 + p] = var;
       if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
       if (!(var > 0.0)) bad |= MCP_STATUS_NONPOS_VAR;
     } else if (a.Jmu) {
       double Jm, Jv;
-      gp_jac(gpl[0], kpar, D, zp, R, c, Jm, Jv);
+      gp_jac<2>(gpl[0], kpar, D, zp, red, NCOLMAX, p, c, Jm, Jv);
       a.Jmu[(size_t)(m0 + p) * D + c] = Jm;
       a.Jvar[(size_t)(m0 + p) * D + c] = Jv;
     }
@@ -812,8 +881,8 @@ __global__ __launch_bounds__(RF_NT) void posterior_fwd_kernel(PostArgs a) {
 
 __global__ void posterior_bwd_kernel(int M, int D, const double* __restrict__ gmu, const double* __restrict__ gvar,
                                      const double* __restrict__ Jmu, const double* __restrict__ Jvar, double* __restrict__ gZ) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)M * D) return;
+  size_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * D) return;
   size_t m = i / D;
   gZ[i] = fma(gmu[m], Jmu[i], gvar[m] * Jvar[i]);
 }
@@ -850,18 +919,23 @@ static int chunks_in_pass(const mcp_model* m, int GB) {
   return best;
 }
 
-template <int P, bool XLDS>
-static int launch_fwd(const FwdArgs& a, size_t lds, hipStream_t st) {
+template <int P, bool XLDS, int MAXDEG>
+static int launch_fwd_deg(const FwdArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_kernel<P, XLDS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_kernel<P, XLDS, MAXDEG>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               MCP_LDS_LIMIT);
     attr_set = true;
   }
   int grid = (a.M + P - 1) / P;
-  hipLaunchKernelGGL((rollout_fwd_kernel<P, XLDS>), dim3(grid), dim3(RF_NT), lds, st, a);
+  hipLaunchKernelGGL((rollout_fwd_kernel<P, XLDS, MAXDEG>), dim3(grid), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
+}
+// the SE-only instantiation carries no polynomial code: a markedly smaller kernel (instruction-cache footprint)
+template <int P, bool XLDS>
+static int launch_fwd(const FwdArgs& a, size_t lds, hipStream_t st) {
+  return a.maxdeg == 0 ? launch_fwd_deg<P, XLDS, 0>(a, lds, st) : launch_fwd_deg<P, XLDS, 2>(a, lds, st);
 }
 
 extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
@@ -957,7 +1031,7 @@ extern "C" int mcp_posterior_fwd(const mcp_gp* gp, int M, const double* Z, doubl
   int P0 = g_force_ppw ? g_force_ppw : pick_particles_per_wg(M);
   if (P0 != 1 && P0 != 2 && P0 != 4) return MCP_ERR_ARG;
   for (int P = P0; P >= 1; P >>= 1) {
-    FwdLayout L = fwd_layout(P, 1, 1, gp->kern.D, 1, 1, 1, gp->Npad, gp->kern.poly_deg, 1, a.NCmax, false);
+    FwdLayout L = fwd_layout(P, 1, 1, gp->kern.D, 1, 1, 1, gp->Npad, 2, 1, a.NCmax, false);
     size_t lds = sizeof(double) * (size_t)L.total;
     if (lds > MCP_LDS_LIMIT) continue;
     hipStream_t st = (hipStream_t)stream;
