@@ -156,6 +156,15 @@ int mcp_gp_alpha(int N, const double* Kinv, int ldk, const double* Y, double mea
 size_t mcp_sod_workspace_bytes(int N);
 int mcp_sod_select(const mcp_kernel* kern, int N, const double* X, double threshold, int32_t* idx_out, int32_t* n_out,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* Gradient of the marginal likelihood  L = 1/2 ((Y-m)^T Kinv (Y-m) + logdet K)  w.r.t. the kernel's log-parameters --
+ * what autograd computes through GP_prior.forward + Marginal_log_likelihood in GP_prior.fit_model (GP_prior.py:179-230,
+ * gpr_lib/Likelihood/Gaussian_likelihood.py:15-24):  dL/dtheta = 1/2 tr((Kinv - alpha alpha^T) dK/dtheta).
+ * grad [4D+3]: [0,D) d/d log lengthscale | D d/d log lambda | D+1  1/2 tr(Kinv - alpha alpha^T) (multiply by
+ * d sigma_n^2/d sigma_n_log = 2 exp(2 sigma_n_log)) | [D+2,2D+3) MPK_1 Sigma_pos_par | [2D+3,3D+3), [3D+3,4D+3) the two
+ * factors of MPK_2's Sigma_pos_par.  workspace: mcp_nll_workspace_bytes(N, D). */
+size_t mcp_nll_workspace_bytes(int N, int D);
+int mcp_nll_grad(const mcp_kernel* kern, int N, const double* X, const double* Kinv, int ldk, const double* alpha, double* grad,
+                 void* workspace, size_t workspace_bytes, void* stream);
 /* Packs pretrain outputs into the mcp_gp layout (padding, transposes, aX). */
 int mcp_gp_pack(int N, int D, const double* X, const double* alpha, const double* Kinv, int ldk, int Npad, double* Xt_out,
                 double* X_out, double* alpha_out, double* Kinv_out, double* aX_out, void* stream);

@@ -263,6 +263,95 @@ __global__ __launch_bounds__(MCP_WAVE) void sod_select_kernel(mcp_kernel kn, int
 }
 
 // ---------------------------------------------------------------------------------------
+// Marginal-likelihood gradient (GP_prior.fit_model's objective, Gaussian_likelihood.py:15-24):
+//   L = 1/2 (r^T Kinv r + logdet K),   dL/dtheta = 1/2 sum_ij Wm_ij dK_ij/dtheta,   Wm = Kinv - alpha alpha^T.
+// One workgroup per row i: (1) threads over j stage Wm_ij, Wm_ij*kse_ij and the two MPK_2 factor values in LDS,
+// (2) one thread per hyper-parameter sums over j.  slab[i][p]; nll_colsum_kernel adds the rows in a fixed order.
+// Parameter layout (NP = 4D+3): [0,D) log lengthscales | D log lambda | D+1 noise (1/2 tr Wm) | [D+2,2D+3) MPK_1 (D+1)
+//                               | [2D+3,3D+3) MPK_2 factor 0 | [3D+3,4D+3) MPK_2 factor 1
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nll_grad_kernel(mcp_kernel kn, int N, const double* __restrict__ X, const double* __restrict__ Kinv,
+                                                       int ldk, const double* __restrict__ alpha, double* __restrict__ slab) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* wm = sm;          // [N] Wm_ij
+  double* wk = sm + N;      // [N] Wm_ij * kse_ij
+  double* fa = sm + 2 * N;  // [N] MPK_2 factor A_ij
+  double* fb = sm + 3 * N;  // [N] MPK_2 factor B_ij
+  const int i = blockIdx.x, tid = threadIdx.x, D = kn.D;
+  const double* xi = X + (size_t)i * D;
+  const double ai = alpha[i];
+  for (int j = tid; j < N; j += 256) {
+    const double* xj = X + (size_t)j * D;
+    double dist = 0.0, A = 0.0, Bv = 0.0;
+    for (int d = 0; d < D; ++d) {
+      double r = (xi[d] - xj[d]) * kn.inv_ls[d];
+      dist = fma(r, r, dist);
+      if (kn.poly_deg >= 2) {
+        double xx = xi[d] * xj[d];
+        A = fma(kn.w20[d], xx, A);
+        Bv = fma(kn.w21[d], xx, Bv);
+      }
+    }
+    double w = Kinv[(size_t)i * ldk + j] - ai * alpha[j];
+    wm[j] = w;
+    wk[j] = w * kn.lambda * exp(-dist);
+    fa[j] = A;
+    fb[j] = Bv;
+  }
+  __syncthreads();
+  const int NP = 4 * D + 3;
+  for (int p = tid; p < NP; p += 256) {
+    double s = 0.0;
+    if (p < D) {  // d/d log l_p :  kse * 2 (dx/l)^2
+      const double il2 = kn.inv_ls[p] * kn.inv_ls[p];
+      for (int j = 0; j < N; ++j) {
+        double dx = xi[p] - X[(size_t)j * D + p];
+        s = fma(wk[j], 2.0 * dx * dx * il2, s);
+      }
+    } else if (p == D) {  // d/d log lambda
+      for (int j = 0; j < N; ++j) s += wk[j];
+    } else if (p == D + 1) {  // 1/2 tr Wm (the caller multiplies by d sigma_n^2 / d sigma_n_log)
+      s = wm[i];
+    } else if (p < 2 * D + 3) {  // MPK_1, feature e (e == D: the offset feature)
+      const int e = p - (D + 2);
+      if (kn.poly_deg >= 1) {
+        const double we = 2.0 * kn.w1[e];
+        const double pie = e < D ? xi[e] : 1.0;
+        for (int j = 0; j < N; ++j) s = fma(wm[j], we * pie * (e < D ? X[(size_t)j * D + e] : 1.0), s);
+      }
+    } else if (p < 3 * D + 3) {  // MPK_2 factor 0 parameter e: 2 w20_e x_ie x_je * B_ij
+      const int e = p - (2 * D + 3);
+      if (kn.poly_deg >= 2) {
+        const double we = 2.0 * kn.w20[e] * xi[e];
+        for (int j = 0; j < N; ++j) s = fma(wm[j] * fb[j], we * X[(size_t)j * D + e], s);
+      }
+    } else {  // MPK_2 factor 1 parameter e: 2 w21_e x_ie x_je * A_ij
+      const int e = p - (3 * D + 3);
+      if (kn.poly_deg >= 2) {
+        const double we = 2.0 * kn.w21[e] * xi[e];
+        for (int j = 0; j < N; ++j) s = fma(wm[j] * fa[j], we * X[(size_t)j * D + e], s);
+      }
+    }
+    slab[(size_t)i * NP + p] = 0.5 * s;
+  }
+}
+
+__global__ void nll_colsum_kernel(int rows, int cols, const double* __restrict__ slab, double* __restrict__ out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int r = 0;
+  for (; r + 3 < rows; r += 4) {
+    s0 += slab[(size_t)r * cols + c];
+    s1 += slab[(size_t)(r + 1) * cols + c];
+    s2 += slab[(size_t)(r + 2) * cols + c];
+    s3 += slab[(size_t)(r + 3) * cols + c];
+  }
+  for (; r < rows; ++r) s0 += slab[(size_t)r * cols + c];
+  out[c] = (s0 + s1) + (s2 + s3);
+}
+
+// ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
 static inline bool kernel_ok(const mcp_kernel* k) {
@@ -344,6 +433,28 @@ extern "C" int mcp_sod_select(const mcp_kernel* kern, int N, const double* X, do
   }
   hipLaunchKernelGGL(sod_select_kernel, dim3(1), dim3(MCP_WAVE), sizeof(double) * N, (hipStream_t)stream, *kern, N, X, threshold,
                      idx_out, n_out, Uw);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+extern "C" size_t mcp_nll_workspace_bytes(int N, int D) { return (N > 0 && D > 0) ? sizeof(double) * (size_t)N * (4 * D + 3) : 0; }
+
+extern "C" int mcp_nll_grad(const mcp_kernel* kern, int N, const double* X, const double* Kinv, int ldk, const double* alpha, double* grad,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (!kernel_ok(kern) || !X || !Kinv || !alpha || !grad || !workspace || N <= 0 || ldk < N) return MCP_ERR_ARG;
+  if (N > 4096) return MCP_ERR_LIMIT;  // four [N] row buffers live in LDS
+  if (workspace_bytes < mcp_nll_workspace_bytes(N, kern->D)) return MCP_ERR_WORKSPACE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nll_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int NP = 4 * kern->D + 3;
+  double* slab = (double*)workspace;
+  hipLaunchKernelGGL(nll_grad_kernel, dim3(N), dim3(256), sizeof(double) * 4 * (size_t)N, (hipStream_t)stream, *kern, N, X, Kinv, ldk, alpha,
+                     slab);
+  MCP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nll_colsum_kernel, dim3((NP + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, NP, slab, grad);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }

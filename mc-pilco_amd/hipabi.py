@@ -67,6 +67,8 @@ _SIGS = {
     "mcp_gp_alpha": (C.c_int, [C.c_int, dptr, C.c_int, dptr, C.c_double, dptr, dptr]),
     "mcp_sod_workspace_bytes": (C.c_size_t, [C.c_int]),
     "mcp_sod_select": (C.c_int, [C.POINTER(Kernel), C.c_int, dptr, C.c_double, dptr, dptr, dptr, C.c_size_t, dptr]),
+    "mcp_nll_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "mcp_nll_grad": (C.c_int, [C.POINTER(Kernel), C.c_int, dptr, dptr, C.c_int, dptr, dptr, dptr, C.c_size_t, dptr]),
     "mcp_gp_pack": (C.c_int, [C.c_int, C.c_int, dptr, dptr, dptr, C.c_int, C.c_int, dptr, dptr, dptr, dptr, dptr, dptr]),
     "mcp_posterior_fwd": (C.c_int, [C.POINTER(GP), C.c_int, dptr, dptr, dptr, dptr, dptr, dptr, dptr]),
     "mcp_posterior_bwd": (C.c_int, [C.c_int, C.c_int, dptr, dptr, dptr, dptr, dptr, dptr]),

@@ -109,6 +109,15 @@ def kernel_fixture(name, D, deg, Z, Y, ztest, ls, sigma_n, pw):
     save(name, **out)
 
 
+ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+if ONLY is not None:
+    _real_save = save
+
+    def save(name, **kw):  # noqa: F811  regenerate a single fixture without touching the others
+        if name.startswith(ONLY):
+            _real_save(name, **kw)
+
+
 rng = np.random.RandomState(7)
 cp = sy.cartpole_rollouts()
 Zc, Yc = sy.gp_io(cp, sy.CARTPOLE["angle"], sy.CARTPOLE["not_angle"], sy.CARTPOLE["vel"])
@@ -446,4 +455,33 @@ def init_fixture():
 
 
 init_fixture()
+
+
+# ---------------------------------------------------------------------------------------
+# (10) marginal likelihood and its gradient w.r.t. every hyper-parameter (GP_prior.fit_model's objective)
+# ---------------------------------------------------------------------------------------
+def nll_fixture(name, D, deg, Z, Y, ls, sigma_n, pw):
+    with quiet:
+        if deg == 0:
+            gp = RSGP.RBF(**dict(rbf_dict(D, ls, sigma_n), flg_train_lambda=True))
+        else:
+            gp = RGP.Sum_Independent_GP(RSGP.RBF(**dict(rbf_dict(D, ls, sigma_n), flg_train_lambda=True)),
+                                        RSP.get_Volterra_MPK_GP(**mpk_dict(D, deg, pw)))
+    crit = gpr_lib.Likelihood.Gaussian_likelihood.Marginal_log_likelihood()
+    with quiet:
+        loss = crit(gp(T(Z)), T(Y))
+    loss.backward()
+    out = dict(X=Z, Y=Y, lengthscales=ls, sigma_n=sigma_n, deg=deg, loss=N(loss))
+    for n_, p_ in gp.named_parameters():
+        if p_.grad is not None:
+            out["grad__" + n_] = N(p_.grad)
+    for k, w in enumerate(pw or []):
+        out["poly_w%d" % (k + 1)] = w
+    save(name, **out)
+
+
+rs_n = np.random.RandomState(21)
+nll_fixture("nll_se", 6, 0, Zc[:80], Yc[0][:80], sy.CARTPOLE["lengthscales"], 0.05, None)
+nll_fixture("nll_se_poly2", 6, 2, Zc[:80], Yc[1][:80], sy.CARTPOLE["lengthscales"], 0.05, poly_weights(6, 2, rs_n, 0.05))
+nll_fixture("nll_se_poly1_d24", 24, 1, Zu[:64], Yu[1][:64], sy.UR5["lengthscales"], 0.01, poly_weights(24, 1, rs_n, 0.05))
 print("done")

@@ -184,3 +184,79 @@ def test_reinforce_policy_runs_and_improves(golden):
     assert costs.shape == (40,) and np.all(np.isfinite(costs)) and np.all(np.isfinite(stds))
     assert st.shape == (12, 64, 4) and inp.shape == (12, 64, 1)
     assert costs[-10:].mean() < costs[:10].mean()
+
+
+@pytest.mark.parametrize("name,D,deg", [("nll_se", 6, 0), ("nll_se_poly2", 6, 2), ("nll_se_poly1_d24", 24, 1)])
+def test_marginal_likelihood_and_gradient_match_reference_autograd(golden, name, D, deg):
+    """fit_model's objective: loss and d loss / d every hyper-parameter against the reference's autograd."""
+    from mc_pilco_amd.gpr_lib.GP_prior import GP_prior as GP
+    from mc_pilco_amd.gpr_lib.GP_prior import Sparse_GP, Stationary_GP
+    from mc_pilco_amd.gpr_lib.Likelihood import Gaussian_likelihood as Likelihood
+
+    fx = golden(name)
+    rbf = dict(rbf_dict(D, fx["lengthscales"], float(fx["sigma_n"])), flg_train_lambda=True)
+    with quiet():
+        if deg == 0:
+            gp = Stationary_GP.RBF(**rbf)
+        else:
+            pw = [fx["poly_w%d" % k] for k in range(1, deg + 1)]
+            gp = GP.Sum_Independent_GP(Stationary_GP.RBF(**rbf), Sparse_GP.get_Volterra_MPK_GP(**mpk_dict(D, deg, pw)))
+    loss = Likelihood.Marginal_log_likelihood().loss_and_grad(gp, T(fx["X"]), T(fx["Y"]))
+    assert abs(float(loss) - float(fx["loss"])) < 1e-9 * abs(float(fx["loss"]))
+    checked = 0
+    for n, p in gp.named_parameters():
+        key = "grad__" + n
+        if key in fx:
+            ref = fx[key]
+            assert float((p.grad.cpu() - torch.as_tensor(ref)).abs().max()) < 1e-8 * max(1.0, float(np.abs(ref).max())), n
+            checked += 1
+    assert checked == (3 if deg == 0 else 3 + deg)
+
+
+def test_reinforce_runs_end_to_end():
+    """The whole algorithm on the drop-in: exploration on the simulated cart-pole, GP training (fit_model on the device),
+    SOD pretrain, policy optimisation with the fused kernels, policy applied to the system -- two short trials."""
+    import tempfile
+
+    from mc_pilco_amd.gpr_lib.Likelihood import Gaussian_likelihood as Likelihood
+    from mc_pilco_amd.model_learning import Model_learning as ML
+    from mc_pilco_amd.policy_learning import MC_PILCO, Cost_function, Policy
+    from mc_pilco_amd.simulation_class import ode_systems as f_ode
+
+    np.random.seed(1)
+    torch.manual_seed(1)
+    c = sy.CARTPOLE
+    init = dict(rbf_dict(6, np.ones(6), 1.0))
+    mlp = dict(num_gp=2, angle_indeces=[2], not_angle_indeces=[0, 1, 3], T_sampling=0.05, vel_indeces=[1, 3], not_vel_indeces=[0, 2], device=dev(),
+               dtype=dtype, approximation_mode="SOD",
+               approximation_dict={"SOD_threshold_mode": "relative", "SOD_threshold": 0.5, "flg_SOD_permutation": False},
+               init_dict_list=[init] * 2)
+    B = 50
+    pi = sy.cartpole_policy_init(B=B, seed=2)
+    ppar = dict(state_dim=4, input_dim=1, angle_indices=np.array([2]), non_angle_indices=np.array([0, 1, 3]), u_max=10.0, num_basis=B,
+                dtype=dtype, device=dev(), centers_init=pi["centers"], lengthscales_init=pi["lengthscales"], weight_init=pi["weight"],
+                flg_squash=True, flg_drop=True)
+    with tempfile.TemporaryDirectory() as tmp, quiet():
+        obj = MC_PILCO.MC_PILCO(T_sampling=0.05, state_dim=4, input_dim=1, f_sim=f_ode.cartpole, std_meas_noise=1e-2 * np.ones(4),
+                                f_model_learning=ML.Speed_Model_learning_RBF_angle_state, model_learning_par=mlp,
+                                f_rand_exploration_policy=Policy.Random_exploration,
+                                rand_exploration_policy_par=dict(state_dim=4, input_dim=1, u_max=10.0, dtype=dtype),
+                                f_control_policy=Policy.Sum_of_gaussians_with_angles, control_policy_par=ppar,
+                                f_cost_function=Cost_function.Cart_pole_cost,
+                                cost_function_par=dict(pos_index=0, angle_index=2, target_state=T([np.pi, 0.0]), lengthscales=T([3.0, 1.0])),
+                                log_path=tmp, dtype=dtype, device=dev())
+        mopt = dict(f_optimizer="lambda p : torch.optim.Adam(p, lr=0.01)", criterion=Likelihood.Marginal_log_likelihood, N_epoch=40, N_epoch_print=20)
+        popt = dict(num_particles=32, opt_steps_list=[8, 8], lr_list=[0.01, 0.01], f_optimizer="lambda p, lr : torch.optim.Adam(p, lr)",
+                    num_step_print=4, p_dropout_list=[0.25, 0.25], p_drop_reduction=0.125, alpha_diff_cost=0.99, min_diff_cost=0.08,
+                    num_min_diff_cost=200, min_step=200, lr_min=0.0025,
+                    policy_reinit_dict=dict(lenghtscales_par=np.ones(5), centers_par=np.array([np.pi, np.pi, np.pi, 1.0, 1.0]), weight_par=10.0))
+        costs, pstates, pinputs = obj.reinforce(initial_state=np.zeros(4), initial_state_var=1e-4 * np.ones(4), T_exploration=1.5, T_control=1.0,
+                                                num_trials=2, model_optimization_opt_list=[mopt] * 2, policy_optimization_dict=popt)
+        import pickle
+
+        log = pickle.load(open(tmp + "/log.pkl", "rb"))
+    assert len(costs) == 2 and all(np.all(np.isfinite(cl)) for cl in costs)
+    assert pstates[0].shape == (20, 32, 4) and pinputs[0].shape == (20, 32, 1)
+    for k in ("parameters_gp_0", "gp_inputs_0", "cost_trial_list", "parameters_trial_list", "state_samples_history"):
+        assert k in log
+    assert len(obj.state_samples_history) == 3  # one exploration + the policy applied after each of the two trials
