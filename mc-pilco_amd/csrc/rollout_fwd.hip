@@ -86,7 +86,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int 
   L.ks = maxdeg > 0 ? take(GB * NpadMax * P) : L.kb;
   L.pa = maxdeg > 1 ? take(GB * NpadMax * P) : L.kb;
   L.pb = maxdeg > 1 ? take(GB * NpadMax * P) : L.kb;
-  L.vb = take(GB * NpadMax * P);
+  L.vb = take(GB * NpadMax * P * (maxdeg == 0 ? 2 : 1));  // SE-only models store the phase-J weight matrix W[j][2p+a] instead of v
   L.part = take(imax((NCmax + RF_NW) * 128 * P, P * B));
   L.red = take(GB * RF_NW * (D + 1) * P * (maxdeg == 0 ? 2 : 9));
   L.xt = xlds ? take(G * D * NpadMax) : 0;
@@ -373,22 +373,32 @@ __device__ __forceinline__ void phase_v(const GpL* gpl, int g0, const int* tab, 
   }
 }
 
-// v[gl][i][p] = sum of the chunk's partial slots, in a fixed order
-template <int P>
+// v[gl][i][p] = sum of the chunk's partial slots, in a fixed order.  For SE-only models (MAXDEG == 0) the thread goes one
+// step further and stores the two phase-J weights of its (j, p):  W[j][2p] = kse_j alpha_j,  W[j][2p+1] = kse_j v_j,
+// so that phase J needs a single LDS read per MFMA operand.
+template <int P, bool XLDS, int MAXDEG>
 __device__ __forceinline__ void phase_vsum(const GpL* gpl, int g0, int gn, const int* tab, int NC, int NpadMax, const double* part,
-                                           double* vb, int tid) {
+                                           const double* kb, const double* al_l, double* vb, int tid) {
   const int total = tab[TAB_CSTART + NC];
   const int L = (total + RF_NW - 1) / RF_NW;
   for (int it = tid; it < gn * NpadMax * P; it += RF_NT) {
     int gl = it / (NpadMax * P);
     int r = it - gl * NpadMax * P;
     int i = r / P, p = r - i * P;
-    if (i >= gpl[g0 + gl].N) continue;
+    const GpL& gp = gpl[g0 + gl];
+    if (i >= gp.N) continue;
     int c = tab[TAB_GCB + gl] + i / RF_CW;
     int s_lo = c + tab[TAB_CSTART + c] / L, s_hi = c + (tab[TAB_CSTART + c + 1] - 1) / L;
     double s = 0.0;
     for (int sid = s_lo; sid <= s_hi; ++sid) s += part[(sid * 128 + (i % RF_CW)) * P + p];
-    vb[it] = s;
+    if (MAXDEG == 0) {
+      const double kse = kb[it];
+      const double alj = XLDS ? al_l[(g0 + gl) * NpadMax + i] : ((gptr_t)gp.alpha)[i];
+      vb[2 * it] = kse * alj;
+      vb[2 * it + 1] = kse * s;
+    } else {
+      vb[it] = s;
+    }
   }
 }
 
@@ -411,10 +421,11 @@ __device__ __forceinline__ void phase_vsum(const GpL* gpl, int g0, int gn, const
 typedef double v4d __attribute__((ext_vector_type(4)));
 #define RF_NAX(deg) ((deg) == 0 ? 2 : ((deg) == 1 ? 5 : 9))
 
-template <int P, bool XLDS, int DEG>
+template <int P, bool XLDS, int DEG, bool WPRE>
 __device__ __forceinline__ void phase_j_gp(const GpL& gp, int ggl, int gl, int D, int NpadMax, int ncolmax, const double* xt_l,
                                            const double* al_l, const double* kb, const double* ks, const double* pa, const double* pb,
-                                           const double* vb, double* redw, int wv, int lane) {
+                                           const double* vb, double* redw, int wv, int lane, unsigned long long* jst = nullptr) {
+  unsigned long long t0_ = jst ? clock64() : 0;
   constexpr int NAX = RF_NAX(DEG);
   constexpr int NCOLS = P * NAX;
   constexpr int CT = (NCOLS + 15) / 16;
@@ -429,16 +440,46 @@ __device__ __forceinline__ void phase_j_gp(const GpL& gp, int ggl, int gl, int D
   for (int rt = 0; rt < 3; ++rt)
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
+  if (WPRE && CT == 1 && RT == 1) {
+    // fast path (SE-only model, one 16x16 tile): batch the operand reads of RF_JU steps, then issue the MFMAs back to back
+    constexpr int RF_JU = 5;
+    const int c = li, cc = imin(c, D - 1);
+    const double* xrow = XLDS ? xt_l + (ggl * D + cc) * NpadMax : nullptr;
+    const double* wrow = vb + gl * NpadMax * NCOLS + imin(li, NCOLS - 1);
+    const bool nok = li < NCOLS;
+    v4d a0 = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int jb = j0; jb < j1; jb += 4 * RF_JU) {
+      double av[RF_JU], bw[RF_JU];
+#pragma unroll
+      for (int u = 0; u < RF_JU; ++u) {
+        const int j = jb + 4 * u + kq;
+        const bool jok = j < j1;
+        const int jc = jok ? j : j0;
+        const double x = XLDS ? xrow[jc] : ((gptr_t)gp.Xt)[(size_t)cc * Npad + jc];
+        const double w = wrow[jc * NCOLS];
+        av[u] = !jok ? 0.0 : (c < D ? x : (c == D ? 1.0 : 0.0));
+        bw[u] = (jok && nok) ? w : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < RF_JU; ++u) a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bw[u], a0, 0, 0, 0);
+    }
+    acc[0][0] = a0;
+  } else
   for (int jb = j0; jb < j1; jb += 4) {
     const int j = jb + kq;
     const bool jok = j < j1;
     const int jc = jok ? j : j0;  // clamp: out-of-range lanes read a valid address and contribute zero
-    const double alj = XLDS ? al_l[ggl * NpadMax + jc] : ((gptr_t)gp.alpha)[jc];
+    double alj = 0.0;
+    if (!WPRE) alj = XLDS ? al_l[ggl * NpadMax + jc] : ((gptr_t)gp.alpha)[jc];
     double bv[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       const int n = ct * 16 + li;
+      if (WPRE) {  // SE-only: the weights were stored by phase vsum, W[j][n], n < 2P
+        const double w = vb[(gl * NpadMax + jc) * NCOLS + imin(n, NCOLS - 1)];
+        bv[ct] = (jok && n < NCOLS) ? w : 0.0;
+        continue;
+      }
       const int p = imin(n / NAX, P - 1), aidx = n % NAX;
       const int o = (gl * NpadMax + jc) * P + p;
       const double kse = ks[o], v = vb[o];
@@ -470,6 +511,8 @@ __device__ __forceinline__ void phase_j_gp(const GpL& gp, int ggl, int gl, int D
       }
     }
   }
+  unsigned long long t1_ = jst ? clock64() : 0;
+  if (jst && lane == 0) jst[12] += t1_ - t0_;
   double* out = redw + (gl * RF_NW + wv) * (D + 1) * ncolmax;
 #pragma unroll
   for (int rt = 0; rt < 3; ++rt) {
@@ -484,22 +527,25 @@ __device__ __forceinline__ void phase_j_gp(const GpL& gp, int ggl, int gl, int D
       }
     }
   }
+  if (jst && lane == 0) jst[13] += clock64() - t1_;
 }
 
 template <int P, bool XLDS, int MAXDEG>
 __device__ __forceinline__ void phase_j(const GpL* gpl, int g0, int gn, int D, int NpadMax, const double* xt_l, const double* al_l,
                                         const double* kb, const double* ks, const double* pa, const double* pb, const double* vb,
-                                        double* redw, int wv, int lane) {
+                                        double* redw, int wv, int lane, unsigned long long* jst = nullptr) {
   constexpr int NCOLMAX = P * RF_NAX(MAXDEG);
   for (int gl = 0; gl < gn; ++gl) {
     const GpL& gp = gpl[g0 + gl];
     const int deg = MAXDEG == 0 ? 0 : __builtin_amdgcn_readfirstlane(gp.deg);
-    if (MAXDEG == 0 || deg == 0)
-      phase_j_gp<P, XLDS, 0>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane);
+    if (MAXDEG == 0)
+      phase_j_gp<P, XLDS, 0, true>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane, jst);
+    else if (deg == 0)
+      phase_j_gp<P, XLDS, 0, false>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane);
     else if (deg == 1)
-      phase_j_gp<P, XLDS, 1>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane);
+      phase_j_gp<P, XLDS, 1, false>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane);
     else
-      phase_j_gp<P, XLDS, 2>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane);
+      phase_j_gp<P, XLDS, 2, false>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane);
   }
 }
 
@@ -749,10 +795,11 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       phase_v<P>(gpl, g0, tab, NC, NpadMax, kb, part, wv, lane);
       lds_barrier();
       RF_STAMP(4);
-      phase_vsum<P>(gpl, g0, gn, tab, NC, NpadMax, part, vb, tid);
+      phase_vsum<P, XLDS, MAXDEG>(gpl, g0, gn, tab, NC, NpadMax, part, kb, al_l, vb, tid);
       lds_barrier();
       RF_STAMP(5);
-      phase_j<P, XLDS, MAXDEG>(gpl, g0, gn, D, NpadMax, xt_l, al_l, kb, ks, pa, pb, vb, red, wv, lane);
+      phase_j<P, XLDS, MAXDEG>(gpl, g0, gn, D, NpadMax, xt_l, al_l, kb, ks, pa, pb, vb, red, wv, lane,
+                               (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
       lds_barrier();
       RF_STAMP(6);
       // ---- phase F: sample delta_g and fold the sampling into d delta/dz ------------------------
@@ -853,7 +900,7 @@ __global__ __launch_bounds__(RF_NT) void posterior_fwd_kernel(PostArgs a) {
   __syncthreads();
   phase_v<P>(gpl, 0, tab, NC, NpadMax, kb, part, wv, lane);
   __syncthreads();
-  phase_vsum<P>(gpl, 0, 1, tab, NC, NpadMax, part, vb, tid);
+  phase_vsum<P, false, 2>(gpl, 0, 1, tab, NC, NpadMax, part, kb, nullptr, vb, tid);
   __syncthreads();
   phase_j<P, false, 2>(gpl, 0, 1, D, NpadMax, nullptr, nullptr, kb, ks, pa, pb, vb, red, wv, lane);
   __syncthreads();
