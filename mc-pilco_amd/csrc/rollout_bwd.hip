@@ -71,6 +71,9 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
   return L;
 }
 
+#ifndef BW_WPE_A
+#define BW_WPE_A 2
+#endif
 #define BW_RPT 5  // record elements a thread prefetches at most (record <= 304 doubles, >= 64 threads)
 
 // Per particle and time step the record is  [x_t (S) | u_t (U) | dJ/dx_t (S) | dJ/du_t (U) | d delta/dz (G*D)].
@@ -78,8 +81,8 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
 // parked in a double-buffered LDS copy.  The short dependent chain of tiny stages (integrator adjoint,
 // GP-Jacobian product, feature-map adjoints, squashing) runs in wave 0 alone with wave-level ordering;
 // only the RBF network stage uses the whole workgroup: two workgroup barriers per time step.
-template <int PFM, int UM, int MAXNT>
-__global__ __launch_bounds__(MAXNT) void rollout_bwd_kernel(BwdArgs a) {
+template <int PFM, int UM, int MAXNT, int WPE>
+__global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
@@ -417,10 +420,10 @@ extern "C" size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_
   return sizeof(double) * nparam * (size_t)bwd_blocks(M);
 }
 
-template <int PFM, int UM, int MAXNT>
+template <int PFM, int UM, int MAXNT, int WPE>
 static int launch_bwd(const BwdArgs& a, int grid, int NT, size_t lds, hipStream_t st) {
   if (NT > MAXNT) return MCP_ERR_LIMIT;
-  hipLaunchKernelGGL((rollout_bwd_kernel<PFM, UM, MAXNT>), dim3(grid), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL((rollout_bwd_kernel<PFM, UM, MAXNT, WPE>), dim3(grid), dim3(NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }
@@ -466,12 +469,12 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   // launch bound is the tightest that fits the thread count so the allocator gets 256-512 VGPRs
   // (at __launch_bounds__(1024) the kernel spilled ~600 B/lane to scratch)
   if (PF <= 8 && U <= 2)
-    rc = NT <= 256 ? launch_bwd<8, 2, 256>(a, grid, NT, lds, st) : launch_bwd<8, 2, 1024>(a, grid, NT, lds, st);
+    rc = NT <= 256 ? launch_bwd<8, 2, 256, BW_WPE_A>(a, grid, NT, lds, st) : launch_bwd<8, 2, 1024, 4>(a, grid, NT, lds, st);
   else if (PF <= 16 && U <= 4)
-    rc = NT <= 256 ? launch_bwd<16, 4, 256>(a, grid, NT, lds, st) : launch_bwd<16, 4, 1024>(a, grid, NT, lds, st);
+    rc = NT <= 256 ? launch_bwd<16, 4, 256, BW_WPE_A>(a, grid, NT, lds, st) : launch_bwd<16, 4, 1024, 4>(a, grid, NT, lds, st);
   else
-    rc = NT <= 256 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 256>(a, grid, NT, lds, st)
-                   : launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 512>(a, grid, NT, lds, st);
+    rc = NT <= 256 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 256, BW_WPE_A>(a, grid, NT, lds, st)
+                   : launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 512, 2>(a, grid, NT, lds, st);
   if (rc != MCP_OK) return rc;
   const int nparam = PF + policy->B * PF + U * policy->B;
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((nparam + 255) / 256), dim3(256), 0, st, grid, nparam, PF, policy->B * PF, a.slab, g_log_ls,
