@@ -21,12 +21,10 @@
 // small and re-read every step (X^T, alpha, policy centres/weights) is copied to LDS once per
 // launch when it fits (template XLDS).  Reductions over the training index use wave64 DPP sums,
 // partial results meet in LDS; 8 workgroup barriers per time step.
-#include "rollout_common.h"
+#include "rollout_fwd_shared.h"
 
 using namespace mcp;
 
-#define RF_NT 512
-#define RF_NW (RF_NT / 64)
 #define RF_MAX_NA 7  // accumulators per Jacobian item: 2 (SE), 3 (SE+P1), 7 (SE+P2)
 #define RF_MAX_CHUNKS (MCP_MAX_GP * (MCP_MAX_TRAIN / 128))
 #define RF_GS 8  // rows of Kinv per register buffer (two buffers in flight per wave)
@@ -44,28 +42,6 @@ struct FwdLayout {
 #define TAB_WC0 (TAB_GCB + MCP_MAX_GP)
 #define TAB_INTS (TAB_WC0 + RF_NW)
 #define RF_CW 128  // rows of v per column chunk: 64 lanes x 2 rows (one 16-byte load per lane)
-
-// LDS-resident copy of what the kernels need from mcp_gp.  The descriptors arrive by value in the
-// kernel argument; indexing that copy with a per-lane GP index would make the compiler spill the
-// whole argument to scratch (global-latency loads in every phase), so it is staged here once.
-typedef const double __attribute__((address_space(1))) * gptr_t;  // explicit global pointer: loads become global_load, not flat_load
-typedef double v2d __attribute__((ext_vector_type(2)));            // native vector: loadable through an address-space pointer
-typedef const v2d __attribute__((address_space(1))) * gptr2_t;
-struct GpL {
-  const double* Kinv;
-  const double* Xt;
-  const double* alpha;
-  double lambda, mean, var_scale;
-  int N, Npad, deg, pad_;
-};
-#define GPL_DOUBLES ((int)(sizeof(GpL) / sizeof(double)))
-// kernel hyper-parameters per GP in LDS: inv_ls[D] | w1[D+1] | w20[D] | w21[D] | aX[D]
-#define KP_INVLS(D) 0
-#define KP_W1(D) (D)
-#define KP_W20(D) (2 * (D) + 1)
-#define KP_W21(D) (3 * (D) + 1)
-#define KP_AX(D) (4 * (D) + 1)
-#define KP_STRIDE(D) (5 * (D) + 1)
 
 __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int G, int PF, int B, int NpadMax, int maxdeg, int GB,
                                                 int NCmax, bool xlds) {
@@ -100,29 +76,6 @@ __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int 
   return L;
 }
 
-struct FwdArgs {
-  mcp_model model;
-  mcp_policy pol;
-  mcp_noise nz;
-  int M, T, particle_pred;
-  int NpadMax, maxdeg, GB, NCmax;
-  const double* x0;
-  double* states;
-  double* inputs;
-  double* jac;
-  uint32_t* status;
-  unsigned long long* stamps;  // diagnostic only (mcp_debug_set_stamp_buffer): per-phase cycle totals of workgroup 0
-};
-
-#define RF_STAMP(k)                                 \
-  do {                                              \
-    if (a.stamps && tid == 0 && blockIdx.x == 0) {  \
-      unsigned long long now_ = clock64();          \
-      a.stamps[k] += now_ - last_stamp;             \
-      last_stamp = now_;                            \
-    }                                               \
-  } while (0)
-
 __device__ __forceinline__ int gp_num_acc(int deg) { return deg == 0 ? 2 : (deg == 1 ? 3 : RF_MAX_NA); }
 
 // ---------------------------------------------------------------------------------------
@@ -130,43 +83,6 @@ __device__ __forceinline__ int gp_num_acc(int deg) { return deg == 0 ? 2 : (deg 
 // column chunks (g, ic), each N_g row segments ("units") long
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ int chunks_of(int Npad) { return (Npad + RF_CW - 1) / RF_CW; }
-
-// one-time staging of the GP descriptors and kernel hyper-parameters into LDS (uniform indices only)
-__device__ __forceinline__ void stage_gp_tables(const mcp_gp* gps, const double* var_scale, int G, int D, GpL* gpl, double* kpar, int tid) {
-  for (int g = 0; g < G; ++g) {
-    const mcp_gp& gp = gps[g];
-    if (tid == 0) {
-      GpL e;
-      e.Kinv = gp.Kinv;
-      e.Xt = gp.Xt;
-      e.alpha = gp.alpha;
-      e.lambda = gp.kern.lambda;
-      e.mean = gp.kern.mean;
-      e.var_scale = var_scale ? var_scale[g] : 1.0;
-      e.N = gp.N;
-      e.Npad = gp.Npad;
-      e.deg = gp.kern.poly_deg;
-      e.pad_ = 0;
-      gpl[g] = e;
-    }
-    double* kp = kpar + (size_t)g * KP_STRIDE(D);
-    const int deg = gp.kern.poly_deg;
-    for (int it = tid; it < KP_STRIDE(D); it += RF_NT) {
-      double v = 0.0;
-      if (it < D)
-        v = gp.kern.inv_ls[it];
-      else if (it < 2 * D + 1)
-        v = deg >= 1 ? gp.kern.w1[it - D] : 0.0;
-      else if (it < 3 * D + 1)
-        v = deg >= 2 ? gp.kern.w20[it - KP_W20(D)] : 0.0;
-      else if (it < 4 * D + 1)
-        v = deg >= 2 ? gp.kern.w21[it - KP_W21(D)] : 0.0;
-      else
-        v = deg >= 1 ? gp.aX[it - KP_AX(D)] : 0.0;
-      kp[it] = v;
-    }
-  }
-}
 
 // the Kinv stream of one pass over GPs [g0, g0+gn): the list of column chunks, each N_g (or N_g/2) units long
 __device__ __forceinline__ int build_chunk_table(const GpL* gpl, int g0, int gn, int* tab, int tid) {
@@ -942,13 +858,15 @@ static int pick_particles_per_wg(int M) {
   // per-CU L2->L1 rate is the bound); large swarms: amortise the Kinv stream over more particles
   if (M <= 256) return 1;
   if (M <= 1024) return 2;
-  return 4;
+  return 16;  // falls back to 4 when the model does not fit the tile kernel
 }
 
 static int g_force_ppw = 0;   // test hook: force particles per workgroup (0 = automatic)
 static int g_force_xlds = -1; // test hook: -1 automatic, 0 never stage small operands in LDS, 1 = automatic
 static int g_force_gb = 0;    // test hook: GPs per pass (0 = as many as fit)
+static int g_last_ppw = 0;    // test hook: particles per workgroup of the last forward launch (16 = tile kernel)
 extern "C" void mcp_debug_set_particles_per_wg(int p) { g_force_ppw = p; }
+extern "C" int mcp_debug_last_particles_per_wg(void) { return g_last_ppw; }
 extern "C" void mcp_debug_set_fwd_mode(int xlds, int gb) {
   g_force_xlds = xlds;
   g_force_gb = gb;
@@ -1022,7 +940,15 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   hipStream_t st = (hipStream_t)stream;
   // configuration search: most particles per workgroup first, operands in LDS if they fit, all GPs per pass if they fit
   int P0 = g_force_ppw ? g_force_ppw : pick_particles_per_wg(M);
-  if (P0 != 1 && P0 != 2 && P0 != 4) return MCP_ERR_ARG;
+  if (P0 != 1 && P0 != 2 && P0 != 4 && P0 != 16) return MCP_ERR_ARG;
+  if (P0 == 16) {
+    // large swarms: 16-particle tiles on the matrix cores (rollout_fwd_tile.hip) when the problem fits that kernel
+    if (model->G >= 1 && T > 1 && fwd_tile_fits(model, policy)) {
+      g_last_ppw = 16;
+      return launch_fwd_tile(a, st);
+    }
+    P0 = 4;
+  }
   for (int P = P0; P >= 1; P >>= 1) {
     for (int xl = (g_force_xlds == 0 ? 0 : 1); xl >= 0; --xl) {
       for (int GB = imax(1, (g_force_gb > 0 ? imin(g_force_gb, model->G) : model->G)); GB >= 1; --GB) {
@@ -1033,6 +959,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
         if (lds > MCP_LDS_LIMIT) continue;
         a.GB = GB;
         a.NCmax = NCmax;
+        g_last_ppw = P;
         if (P == 4) return xl ? launch_fwd<4, true>(a, lds, st) : launch_fwd<4, false>(a, lds, st);
         if (P == 2) return xl ? launch_fwd<2, true>(a, lds, st) : launch_fwd<2, false>(a, lds, st);
         return xl ? launch_fwd<1, true>(a, lds, st) : launch_fwd<1, false>(a, lds, st);

@@ -1,0 +1,103 @@
+// Shared by the two forward rollout kernels (rollout_fwd.hip: 1/2/4 particles per workgroup, VALU matvec;
+// rollout_fwd_tile.hip: 16 particles per workgroup, matrix-core contractions): kernel arguments, the LDS copy of
+// the GP descriptors, kernel hyper-parameter tables.
+#pragma once
+#include "rollout_common.h"
+
+#define RF_NT 512
+#define RF_NW (RF_NT / 64)
+
+namespace mcp {
+
+// LDS-resident copy of what the kernels need from mcp_gp.  The descriptors arrive by value in the
+// kernel argument; indexing that copy with a per-lane GP index would make the compiler spill the
+// whole argument to scratch (global-latency loads in every phase), so it is staged here once.
+typedef const double __attribute__((address_space(1))) * gptr_t;  // explicit global pointer: loads become global_load, not flat_load
+typedef double v2d __attribute__((ext_vector_type(2)));            // native vector: loadable through an address-space pointer
+typedef const v2d __attribute__((address_space(1))) * gptr2_t;
+struct GpL {
+  const double* Kinv;
+  const double* Xt;
+  const double* X;
+  const double* alpha;
+  double lambda, mean, var_scale;
+  int N, Npad, deg, pad_;
+};
+#define GPL_DOUBLES ((int)(sizeof(GpL) / sizeof(double)))
+// kernel hyper-parameters per GP in LDS: inv_ls[D] | w1[D+1] | w20[D] | w21[D] | aX[D]
+#define KP_INVLS(D) 0
+#define KP_W1(D) (D)
+#define KP_W20(D) (2 * (D) + 1)
+#define KP_W21(D) (3 * (D) + 1)
+#define KP_AX(D) (4 * (D) + 1)
+#define KP_STRIDE(D) (5 * (D) + 1)
+
+
+struct FwdArgs {
+  mcp_model model;
+  mcp_policy pol;
+  mcp_noise nz;
+  int M, T, particle_pred;
+  int NpadMax, maxdeg, GB, NCmax;
+  const double* x0;
+  double* states;
+  double* inputs;
+  double* jac;
+  uint32_t* status;
+  unsigned long long* stamps;  // diagnostic only (mcp_debug_set_stamp_buffer): per-phase cycle totals of workgroup 0
+};
+
+#define RF_STAMP(k)                                 \
+  do {                                              \
+    if (a.stamps && tid == 0 && blockIdx.x == 0) {  \
+      unsigned long long now_ = clock64();          \
+      a.stamps[k] += now_ - last_stamp;             \
+      last_stamp = now_;                            \
+    }                                               \
+  } while (0)
+
+
+// one-time staging of the GP descriptors and kernel hyper-parameters into LDS (uniform indices only)
+__device__ __forceinline__ void stage_gp_tables(const mcp_gp* gps, const double* var_scale, int G, int D, GpL* gpl, double* kpar, int tid) {
+  for (int g = 0; g < G; ++g) {
+    const mcp_gp& gp = gps[g];
+    if (tid == 0) {
+      GpL e;
+      e.Kinv = gp.Kinv;
+      e.Xt = gp.Xt;
+      e.X = gp.X;
+      e.alpha = gp.alpha;
+      e.lambda = gp.kern.lambda;
+      e.mean = gp.kern.mean;
+      e.var_scale = var_scale ? var_scale[g] : 1.0;
+      e.N = gp.N;
+      e.Npad = gp.Npad;
+      e.deg = gp.kern.poly_deg;
+      e.pad_ = 0;
+      gpl[g] = e;
+    }
+    double* kp = kpar + (size_t)g * KP_STRIDE(D);
+    const int deg = gp.kern.poly_deg;
+    for (int it = tid; it < KP_STRIDE(D); it += RF_NT) {
+      double v = 0.0;
+      if (it < D)
+        v = gp.kern.inv_ls[it];
+      else if (it < 2 * D + 1)
+        v = deg >= 1 ? gp.kern.w1[it - D] : 0.0;
+      else if (it < 3 * D + 1)
+        v = deg >= 2 ? gp.kern.w20[it - KP_W20(D)] : 0.0;
+      else if (it < 4 * D + 1)
+        v = deg >= 2 ? gp.kern.w21[it - KP_W21(D)] : 0.0;
+      else
+        v = deg >= 1 ? gp.aX[it - KP_AX(D)] : 0.0;
+      kp[it] = v;
+    }
+  }
+}
+
+
+// forward rollout with 16 particles per workgroup (rollout_fwd_tile.hip); MCP_ERR_LIMIT when the problem does not fit it
+int launch_fwd_tile(const FwdArgs& a, hipStream_t st);
+bool fwd_tile_fits(const mcp_model* model, const mcp_policy* policy);
+
+}  // namespace mcp

@@ -163,7 +163,7 @@ def test_next_state_step(golden):
     assert abserr(torch.stack([var0, var1], 1), fx["var"]) < 1e-11
 
 
-@pytest.mark.parametrize("ppw", [0, 1, 2, 4])
+@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16])
 @pytest.mark.parametrize("name,kind", ROLLOUT_FIXTURES)
 def test_rollout_cost_gradient_vs_reference(golden, name, kind, ppw):
     """apply_policy + expected cost + backward on the reference's recorded noise."""
@@ -184,8 +184,11 @@ def test_rollout_cost_gradient_vs_reference(golden, name, kind, ppw):
         st, inp, status = ops.rollout(model, pol, noise_from(fx), x0, Tn, p)
         c, s = ops.expected_cost(cost, st)
         c.backward()
+        used = hipabi.lib().mcp_debug_last_particles_per_wg()
     finally:
         hipabi.lib().mcp_debug_set_particles_per_wg(0)
+    if ppw:
+        assert used == ppw, "forced kernel variant was not the one launched"
     assert int(status.item()) == 0
     long = Tn > 12
     assert abserr(st, fx["states"]) < (1e-6 if long else 1e-9)

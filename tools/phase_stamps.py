@@ -7,7 +7,9 @@ from mc_pilco_amd import hipabi, ops, workloads
 name = sys.argv[1] if len(sys.argv) > 1 else "c1"
 ppw = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device("cuda", 0)
-w = workloads.build(name, device=dev)
+Mo = int(sys.argv[3]) if len(sys.argv) > 3 else None
+To = int(sys.argv[4]) if len(sys.argv) > 4 else None
+w = workloads.build(name, device=dev, M=Mo, T=To)
 buf = torch.zeros(16, dtype=torch.int64, device=dev)
 x0 = w.sample_x0()
 hipabi.lib().mcp_debug_set_particles_per_wg(ppw)

@@ -3,13 +3,13 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mcp_boot, torch
 from mc_pilco_amd import hipabi, ops, workloads
-name = sys.argv[1]; M = int(sys.argv[2])
+name = sys.argv[1]; M = int(sys.argv[2]); Tn = int(sys.argv[3]) if len(sys.argv) > 3 else None
 dev = torch.device("cuda", 0)
-w = workloads.build(name, device=dev, M=M)
+w = workloads.build(name, device=dev, M=M, T=Tn)
 x0 = w.sample_x0()
 lib = hipabi.lib()
-for ppw in (1, 2, 4):
-    for xl in (1, 0):
+for ppw in (2, 4, 16):
+    for xl in ((1,) if ppw == 16 else (1, 0)):
         lib.mcp_debug_set_particles_per_wg(ppw); lib.mcp_debug_set_fwd_mode(xl, 0)
         try:
             for i in range(2):
