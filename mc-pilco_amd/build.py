@@ -13,7 +13,10 @@ HEADERS = [os.path.join(CSRC, "mcp_device.h"), os.path.join(CSRC, "rollout_commo
            os.path.join(os.path.dirname(HERE), "include", "mcpilco_hip.h")]
 LIB = os.path.join(HERE, "libmcpilco_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -disable-machine-licm: the machine-level loop-invariant hoisting pulls the ~60 double-precision literals of exp / sincos / log /
+# tanh out of the time-step loop into VGPRs, which then spill to scratch and are reloaded (global-latency) in every phase
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-mllvm", "-disable-machine-licm"]
 
 
 def _stale(target, deps):

@@ -35,7 +35,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define TL_NCOL(deg) ((deg) == 0 ? 2 : ((deg) == 1 ? 3 : 5))
 
 struct TileLayout {
-  int invl, xs, us, z, sf, dl, eps, ks, kv, R, qa, sal, gpl, kpar, scr, total;  // offsets in doubles
+  int invl, xs, us, z, sf, dl, eps, ks, kv, qa, sal, gpl, kpar, scr, total;  // offsets in doubles
   int nslot;   // phase-J partial-tile slots in scr
   int vslots;  // phase-V partial (32x16) slots in scr
 };
@@ -58,17 +58,17 @@ __host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, in
   L.ks = take(NpadMax * TL_KR);
   L.kv = take(NpadMax * TL_KR);  // directly after ks: the phi buffer of the policy phase aliases both
   const int RT = (D + 1 + 15) / 16, CT = TL_NCOL(maxdeg);
-  L.R = take(RT * CT * 256);
   L.qa = take(maxdeg >= 2 ? G * D * D : 0);
   L.sal = take(G);
   L.gpl = take(G * GPL_DOUBLES);
   L.kpar = take(G * KP_STRIDE(D));
   const int slot = RT * CT * 256;
   const int avail = MCP_LDS_LIMIT / 8 - o;
-  int nslot = 4;
+  int nslot = 8;
   while (nslot > 1 && nslot * slot > avail) nslot >>= 1;
   int scr = nslot * slot;
   if (scr < 7 * 512 && 7 * 512 <= avail) scr = 7 * 512;
+  if (scr < RF_NW * 16 + RF_NW * TL_PT * U) scr = RF_NW * 16 + RF_NW * TL_PT * U;  // per-wave exchange slots + policy partial sums
   L.nslot = nslot;
   L.vslots = scr / 512;
   L.scr = take(scr);
@@ -79,95 +79,120 @@ __host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, in
 #define TL_STAMP(k) RF_STAMP(k)
 
 // ---------------------------------------------------------------------------------------
-// phase K: wave w computes k(z_p, X_j) for p in {2w, 2w+1} and all j (lanes over j)
+// phase K: k[j][p] = k(z_p, X_j) for the 16 particles and all training points of one GP
 // ---------------------------------------------------------------------------------------
-// The training inputs come from global memory (L1/L2 hits, one coalesced row segment per feature); the loads of a
-// step (64 training points x 8 features) are issued unconditionally, one step ahead of their use.
-#define TL_KD 8  // features per step
-struct TileKAcc {
-  double d0, d1, p10, p11, A0, A1, B0, B1;
+// The weighted squared distance in the reference's own expanded form (Stationary_GP.py:65-109)
+//     dist[p][j] = sum_d (z_pd/l_d)^2 + sum_d (X_jd/l_d)^2 - 2 sum_d (z_pd/l_d^2) X_jd
+// makes the cross term -- and the bilinear forms of the polynomial kernel, sum_d w_d z_pd X_jd -- a [16 x D] x [D x 16]
+// product per 16 training points: v_mfma_f64_16x16x4_f64 with
+//   A operand  lane (m = l&15, kk = l>>4) : weight_d * z_md,  d = 4 i + kk   (one register per group i of 4 features)
+//   B operand  lane (kk = l>>4, n = l&15) : X[j0 + n][d = 4 i + kk]          (raw training inputs: shared by all products)
+//   result     lane (kq = l>>4, n = l&15), register r : particle kq + 4 r, training point j0 + n
+// so a lane finishes 4 particles of one training point: 4 exp() per MFMA group instead of one per 2*D multiply-adds.
+// |z_p|^2 and |X_j|^2 are partial sums over the lane's own features, folded across the 4 feature lanes by two
+// lane exchanges.  Tiles of 16 training points are dealt round-robin to the 8 waves, the B operands of the next tile
+// are loaded (unconditionally) before the current tile is consumed.
+__device__ __forceinline__ double fold_kk(double v) {  // sum over the 4 lanes l, l^16, l^32, l^48
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+template <int NDQ>
+__device__ __forceinline__ void tile_k_load(double (&bx)[NDQ], gptr_t Xt, int Npad, int D, int tile, int kk, int n) {
+#pragma unroll
+  for (int i = 0; i < NDQ; ++i) bx[i] = Xt[(size_t)imin(4 * i + kk, D - 1) * Npad + 16 * tile + n];
+}
+template <int MAXDEG, int NDQ>
+struct TileKConst {
+  double a_se[NDQ], ilq[NDQ];
+  double a_p1[MAXDEG >= 1 ? NDQ : 1], a_A[MAXDEG >= 2 ? NDQ : 1], a_B[MAXDEG >= 2 ? NDQ : 1];
+  double zz4[4], lam, w1D;
+  int deg, N;
 };
-__device__ __forceinline__ void tile_k_load(double (&xv)[TL_KD], gptr_t Xt, int Npad, int D, int nbd, int step, int lane) {
-  const int chunk = step / nbd, db = (step - chunk * nbd) * TL_KD;
-  const int jl = imin(chunk * 64 + lane, Npad - 1);
+template <int MAXDEG, int NDQ>
+__device__ __forceinline__ void tile_k_consume(const double (&bx)[NDQ], const TileKConst<MAXDEG, NDQ>& c, int tile, int kk, int n, double* ks,
+                                               double* kv) {
+  double sxx = 0.0;
 #pragma unroll
-  for (int i = 0; i < TL_KD; ++i) xv[i] = Xt[(size_t)imin(db + i, D - 1) * Npad + jl];
-}
-template <int MAXDEG>
-__device__ __forceinline__ void tile_k_consume(const double (&xv)[TL_KD], TileKAcc& q, const GpL& gp, const double* kp, int deg, int N, int Npad, int D,
-                                               int nbd, int step, const double* za, const double* zb, double* ks, double* kv, int wv, int lane) {
-  const int chunk = step / nbd, db = (step - chunk * nbd) * TL_KD;
-  const int j = chunk * 64 + lane;
-  if (db == 0) {
-    q.d0 = q.d1 = q.A0 = q.A1 = q.B0 = q.B1 = 0.0;
-    q.p10 = q.p11 = (MAXDEG >= 1 && deg >= 1) ? kp[KP_W1(D) + D] : 0.0;
+  for (int i = 0; i < NDQ; ++i) {
+    const double t = c.ilq[i] * bx[i];  // ilq is 0 for the padding features
+    sxx = fma(t, t, sxx);
   }
+  const double xx = fold_kk(sxx);
+  v4d Cse = (v4d){0.0, 0.0, 0.0, 0.0}, Cp1 = Cse, CA = Cse, CB = Cse;
 #pragma unroll
-  for (int i = 0; i < TL_KD; ++i) {
-    const int d = db + i;
-    if (d < D) {  // wave-uniform
-      const double x = xv[i];
-      const double il = kp[KP_INVLS(D) + d];
-      const double z0 = za[d], z1 = zb[d];
-      const double r0 = (z0 - x) * il, r1 = (z1 - x) * il;
-      q.d0 = fma(r0, r0, q.d0);
-      q.d1 = fma(r1, r1, q.d1);
-      if (MAXDEG >= 1 && deg >= 1) {
-        const double w1 = kp[KP_W1(D) + d];
-        q.p10 = fma(w1 * z0, x, q.p10);
-        q.p11 = fma(w1 * z1, x, q.p11);
-        if (deg >= 2) {
-          const double zx0 = z0 * x, zx1 = z1 * x;
-          const double wa = kp[KP_W20(D) + d], wb = kp[KP_W21(D) + d];
-          q.A0 = fma(wa, zx0, q.A0);
-          q.B0 = fma(wb, zx0, q.B0);
-          q.A1 = fma(wa, zx1, q.A1);
-          q.B1 = fma(wb, zx1, q.B1);
-        }
-      }
+  for (int i = 0; i < NDQ; ++i) {
+    Cse = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a_se[i], bx[i], Cse, 0, 0, 0);
+    if (MAXDEG >= 1 && c.deg >= 1) Cp1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a_p1[i], bx[i], Cp1, 0, 0, 0);
+    if (MAXDEG >= 2 && c.deg >= 2) {
+      CA = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a_A[i], bx[i], CA, 0, 0, 0);
+      CB = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a_B[i], bx[i], CB, 0, 0, 0);
     }
   }
-  if (db + TL_KD >= D && j < Npad) {
-    v2d s2, t2;
-    s2.x = s2.y = t2.x = t2.y = 0.0;
-    if (j < N) {
-      const double lam = gp.lambda;
-      s2.x = lam * exp(-q.d0);
-      s2.y = lam * exp(-q.d1);
-      t2 = s2;
-      if (MAXDEG >= 1 && deg >= 1) {
-        t2.x += q.p10;
-        t2.y += q.p11;
-        if (deg >= 2) {
-          t2.x = fma(q.A0, q.B0, t2.x);
-          t2.y = fma(q.A1, q.B1, t2.y);
-        }
-      }
+  const int j = 16 * tile + n;
+  const bool live = j < c.N;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double dist = (c.zz4[r] + xx) + Cse[r];
+    double kse = c.lam * exp(-dist);
+    double kt = kse;
+    if (MAXDEG >= 1 && c.deg >= 1) {
+      kt += Cp1[r] + c.w1D;
+      if (MAXDEG >= 2 && c.deg >= 2) kt = fma(CA[r], CB[r], kt);
     }
-    *reinterpret_cast<v2d*>(ks + j * TL_KR + 2 * wv) = s2;
-    *reinterpret_cast<v2d*>(kv + j * TL_KR + 2 * wv) = t2;
+    if (!live) kse = kt = 0.0;
+    const int o = j * TL_KR + kk + 4 * r;
+    ks[o] = kse;
+    kv[o] = kt;
   }
 }
-template <int MAXDEG>
-__device__ __forceinline__ void tile_phase_k(const GpL& gp, const double* kp, int D, const double* z, double* ks, double* kv, int wv, int lane) {
-  const int N = __builtin_amdgcn_readfirstlane(gp.N), Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
-  const int deg = MAXDEG == 0 ? 0 : __builtin_amdgcn_readfirstlane(gp.deg);
+template <int MAXDEG, int NDQ>
+__device__ __forceinline__ void tile_phase_k(const GpL& gp, const double* kp, int D, const double* z, double* ks, double* kv, double* wslot, int wv,
+                                             int lane) {
+  const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
+  const int kk = lane >> 4, n = lane & 15;
   gptr_t Xt = (gptr_t)gp.Xt;
-  const double* za = z + (2 * wv) * D;
-  const double* zb = za + D;
-  const int nbd = (D + TL_KD - 1) / TL_KD;
-  const int nsteps = ((Npad + 63) >> 6) * nbd;
-  double xa[TL_KD], xb[TL_KD];
-  TileKAcc q;
-  q.d0 = q.d1 = q.p10 = q.p11 = q.A0 = q.A1 = q.B0 = q.B1 = 0.0;
-  tile_k_load(xa, Xt, Npad, D, nbd, 0, lane);
-  for (int st = 0; st + 1 < nsteps; st += 2) {
-    tile_k_load(xb, Xt, Npad, D, nbd, st + 1, lane);
-    tile_k_consume<MAXDEG>(xa, q, gp, kp, deg, N, Npad, D, nbd, st, za, zb, ks, kv, wv, lane);
-    tile_k_load(xa, Xt, Npad, D, nbd, imin(st + 2, nsteps - 1), lane);
-    tile_k_consume<MAXDEG>(xb, q, gp, kp, deg, N, Npad, D, nbd, st + 1, za, zb, ks, kv, wv, lane);
+  TileKConst<MAXDEG, NDQ> c;
+  c.N = __builtin_amdgcn_readfirstlane(gp.N);
+  c.deg = MAXDEG == 0 ? 0 : __builtin_amdgcn_readfirstlane(gp.deg);
+  c.lam = gp.lambda;
+  c.w1D = (MAXDEG >= 1 && c.deg >= 1) ? kp[KP_W1(D) + D] : 0.0;
+  double szz = 0.0;
+#pragma unroll
+  for (int i = 0; i < NDQ; ++i) {
+    const int d = 4 * i + kk;
+    const bool dv = d < D;
+    const double zv = dv ? z[n * D + d] : 0.0;
+    const double il = dv ? kp[KP_INVLS(D) + d] : 0.0;
+    const double il2z = il * il * zv;
+    c.ilq[i] = il;
+    c.a_se[i] = -2.0 * il2z;
+    szz = fma(il2z, zv, szz);
+    if (MAXDEG >= 1) c.a_p1[i] = (dv && c.deg >= 1) ? kp[KP_W1(D) + d] * zv : 0.0;
+    if (MAXDEG >= 2) {
+      c.a_A[i] = (dv && c.deg >= 2) ? kp[KP_W20(D) + d] * zv : 0.0;
+      c.a_B[i] = (dv && c.deg >= 2) ? kp[KP_W21(D) + d] * zv : 0.0;
+    }
   }
-  if (nsteps & 1) tile_k_consume<MAXDEG>(xa, q, gp, kp, deg, N, Npad, D, nbd, nsteps - 1, za, zb, ks, kv, wv, lane);
+  szz = fold_kk(szz);
+  // |z_p|^2 goes from the operand layout (lane = particle) to the result layout (4 particles per lane) through 16 doubles of
+  // this wave's own LDS slot (same wave writes and reads: program order, no barrier)
+  if (kk == 0) wslot[n] = szz;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c.zz4[r] = wslot[kk + 4 * r];
+  const int ntile = Npad >> 4;
+  if (wv >= ntile) return;
+  const int nt = (ntile - wv + RF_NW - 1) / RF_NW;
+  double b0[NDQ], b1[NDQ];
+  tile_k_load<NDQ>(b0, Xt, Npad, D, wv, kk, n);
+  for (int sI = 0; sI + 1 < nt; sI += 2) {
+    tile_k_load<NDQ>(b1, Xt, Npad, D, wv + RF_NW * (sI + 1), kk, n);
+    tile_k_consume<MAXDEG, NDQ>(b0, c, wv + RF_NW * sI, kk, n, ks, kv);
+    tile_k_load<NDQ>(b0, Xt, Npad, D, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
+    tile_k_consume<MAXDEG, NDQ>(b1, c, wv + RF_NW * (sI + 1), kk, n, ks, kv);
+  }
+  if (nt & 1) tile_k_consume<MAXDEG, NDQ>(b0, c, wv + RF_NW * (nt - 1), kk, n, ks, kv);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -308,9 +333,8 @@ __device__ __forceinline__ void tile_j_consume(const TileJBatch<DEG, NDQ>& b, co
 }
 template <int DEG, int NDQ>
 __device__ __forceinline__ void tile_phase_j(const GpL& gp, const double* kp, int D, const double* z, const double* ks, const double* kv,
-                                             v4d (&acc)[2][TL_NCOL(DEG)], int wv, int lane) {
+                                             v4d (&acc)[2][TL_NCOL(DEG)], int RT, int wv, int lane) {
   constexpr int CT = TL_NCOL(DEG);
-  const int RT = (D + 1 + 15) >> 4;
   const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
   const int per = ((Npad + RF_NW * 4 - 1) / (RF_NW * 4)) * 4;
   const int j0 = imin(wv * per, Npad), j1 = imin(Npad, j0 + per);
@@ -344,26 +368,29 @@ __device__ __forceinline__ void tile_phase_j(const GpL& gp, const double* kp, in
   if (nbat & 1) tile_j_consume<DEG, NDQ>(b0, zwa, zwb, D, RT, Npad, j0 + 16 * (nbat - 1), j1, kk, n, ks, kv, acc);
 }
 
-// add the 8 waves' partial tiles in a fixed order (pairwise tree through `nslot` LDS slots), result -> R
+// The 8 waves' partial tiles meet in `nslot` (1, 2, 4 or 8, whatever fits the LDS) slots: while more waves than slots hold a
+// partial, the upper half hands its tiles to the lower half through the slots (fixed pairing, fixed order); the
+// remaining min(8, nslot) partials stay in the slots and phase F adds them as it reads.  With 8 slots: no exchange at all.
 template <int CT>
-__device__ __forceinline__ void tile_j_reduce(v4d (&acc)[2][CT], int RT, double* scr, int nslot, double* R, int wv, int lane) {
-  const int ntile = RT * CT;
-  const int slot = ntile * 256;
-  for (int active = RF_NW; active > 1; active >>= 1) {
+__device__ __forceinline__ void tile_j_store(const v4d (&acc)[2][CT], int RT, double* s, int lane) {
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+    if (rt < RT)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[(rt * CT + ct) * 256 + r * 64 + lane] = acc[rt][ct][r];
+}
+template <int CT>
+__device__ __forceinline__ int tile_j_reduce(v4d (&acc)[2][CT], int RT, double* scr, int nslot, int wv, int lane) {
+  const int slot = RT * CT * 256;
+  int active = RF_NW;
+  for (; active > nslot; active >>= 1) {
     const int half = active >> 1;
     for (int base = 0; base < half; base += nslot) {
       // writers: waves half+base .. half+base+nslot-1 ; readers: waves base .. base+nslot-1
       const int wi = wv - half - base, ri = wv - base;
-      if (wi >= 0 && wi < nslot && wv < active) {
-        double* s = scr + wi * slot;
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-          if (rt < RT)
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) s[(rt * CT + ct) * 256 + r * 64 + lane] = acc[rt][ct][r];
-      }
+      if (wi >= 0 && wi < nslot && wv < active) tile_j_store<CT>(acc, RT, scr + wi * slot, lane);
       lds_barrier();
       if (ri >= 0 && ri < nslot && ri + base < half) {
         const double* s = scr + ri * slot;
@@ -378,27 +405,176 @@ __device__ __forceinline__ void tile_j_reduce(v4d (&acc)[2][CT], int RT, double*
       lds_barrier();
     }
   }
-  if (wv == 0) {
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-      if (rt < RT)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) R[(rt * CT + ct) * 256 + r * 64 + lane] = acc[rt][ct][r];
-  }
+  if (wv < active) tile_j_store<CT>(acc, RT, scr + wv * slot, lane);
+  return active;  // partials left in the slots
 }
 
-// R[c][kind][p]: tile (c>>4, kind), element (row c&15, col p) in the accumulator layout  row = (lane>>4) + 4 r, col = lane & 15
-__device__ __forceinline__ double tile_r(const double* R, int CT, int c, int kind, int p) {
-  return R[((c >> 4) * CT + kind) * 256 + ((c & 15) >> 2) * 64 + ((c & 3) << 4) + p];
+// R[c][kind][p] = sum of the nfin partials; tile (c>>4, kind), element (row c&15, col p) in the accumulator layout
+// row = (lane>>4) + 4 r, col = lane & 15
+struct TileR {
+  const double* base;
+  int CT, nfin, slot;
+};
+__device__ __forceinline__ double tile_r(const TileR& R, int c, int kind, int p) {
+  const double* q = R.base + ((c >> 4) * R.CT + kind) * 256 + ((c & 15) >> 2) * 64 + ((c & 3) << 4) + p;
+  double s = q[0];
+  for (int w = 1; w < R.nfin; ++w) s += q[w * R.slot];
+  return s;
+}
+
+// ---------------------------------------------------------------------------------------
+// policy phase: u = u_max tanh((W (phi o mask)) / u_max),  phi_b = exp(-|| (s - c_b)/l ||^2)   (Policy.py:242-265)
+// Same expanded-distance product as phase K, the 16 particles against 16 basis functions per tile:
+//   A operand  lane (m, kk) : -2 s_mq / l_q^2,  q = 4 i + kk      B operand  lane (kk, n) : c[b0 + n][q]
+//   result     lane (kq, n), register r : particle kq + 4 r, basis b0 + n
+// A lane therefore holds phi of 4 particles for one basis function and folds it straight into its partial sums of
+// W phi (U inputs x 4 particles): phi never goes to memory.  The dropout keep bits of (particle, basis) come from one
+// Philox draw per (particle, 4 consecutive bases) as in philox_keep(); a lane draws for particle kq + 4 (n & 3) and the
+// four lanes of a quad exchange words so that each ends up with the bit of its own basis for its 4 particles.
+// Partial sums meet through a 16-lane DPP row reduction and an 8-wave LDS reduction.
+// ---------------------------------------------------------------------------------------
+template <int NQ, int UM>
+__device__ __forceinline__ void tile_pol_load(double (&cb)[NQ], double (&wk)[UM], gptr_t cen, gptr_t wgt, int B, int PF, int U, int tile, int kk, int n) {
+  const int b = imin(16 * tile + n, B - 1);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) cb[i] = cen[(size_t)b * PF + imin(4 * i + kk, PF - 1)];
+#pragma unroll
+  for (int k = 0; k < UM; ++k) wk[k] = wgt[(size_t)imin(k, U - 1) * B + b];
+}
+template <int NQ>
+struct TilePolConst {
+  double a_s[NQ], ilq[NQ], ss4[4];
+};
+template <int NQ, int UM>
+__device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const double (&wk)[UM], const TilePolConst<NQ>& c, const FwdArgs& a,
+                                                 int B, int U, int t, int m0, int tile, int kk, int n, int lane, bool drop, double keep_scale,
+                                                 uint32_t drop_thr, double (&uacc)[4][UM]) {
+  double scc = 0.0;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const double v = c.ilq[i] * cb[i];
+    scc = fma(v, v, scc);
+  }
+  const double cc = fold_kk(scc);
+  v4d C = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) C = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a_s[i], cb[i], C, 0, 0, 0);
+  const int b = 16 * tile + n;
+  const bool bvalid = b < B;
+  const int bc = imin(b, B - 1);
+  bool keep[4] = {true, true, true, true};
+  if (drop) {
+    if (a.nz.masks) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = imin(m0 + kk + 4 * r, a.M - 1);
+        keep[r] = a.nz.masks[((size_t)t * a.M + mm) * B + bc] != 0;
+      }
+    } else {
+      const int cq = n & 3;
+      const int mm = imin(m0 + kk + 4 * cq, a.M - 1);
+      const u32x4 rnd = philox_draw(a.nz, mm, t, MCP_STREAM_MASK, (uint32_t)(bc >> 2));
+      uint32_t wr[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const int ws = (cq + k4) & 3;  // the word lane (cq - k4) needs from me: its basis index is ... see below
+        // round k4: lane cq sends word[(cq + k4) & 3] to the lane of the quad whose basis offset is (cq + k4) & 3;
+        // equivalently lane c' receives, from lane r = (c' - k4) & 3 (the drawer for particle kq + 4 r), word[c']
+        const uint32_t snd = ws == 0 ? rnd.x : ws == 1 ? rnd.y : ws == 2 ? rnd.z : rnd.w;
+        const int src = (cq - k4) & 3;
+        const uint32_t rcv = (uint32_t)__shfl((int)snd, (lane & ~3) | src);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wr[r] = (src == r) ? rcv : wr[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) keep[r] = wr[r] >= drop_thr;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double dist = (c.ss4[r] + cc) + C[r];
+    double phi = exp(-dist);
+    if (drop) phi = keep[r] ? phi * keep_scale : 0.0;
+    if (!bvalid) phi = 0.0;
+#pragma unroll
+    for (int k = 0; k < UM; ++k)
+      if (k < U) uacc[r][k] = fma(wk[k], phi, uacc[r][k]);
+  }
+}
+template <int NQ, int UM>
+__device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* upart,
+                                            int B, int PF, int U, int t, int m0, int wv, int lane, bool drop, double keep_scale, uint32_t drop_thr) {
+  const int kk = lane >> 4, n = lane & 15;
+  unsigned long long* dbg = (a.stamps && blockIdx.x == 0 && wv == 0 && lane == 0) ? a.stamps : nullptr;
+  unsigned long long tq0 = clock64();
+  TilePolConst<NQ> c;
+  double sss = 0.0;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = 4 * i + kk;
+    const bool qv = q < PF;
+    const double sv = qv ? sf[n * PF + q] : 0.0;
+    const double il = qv ? invl[q] : 0.0;
+    const double il2s = il * il * sv;
+    c.ilq[i] = il;
+    c.a_s[i] = -2.0 * il2s;
+    sss = fma(il2s, sv, sss);
+  }
+  sss = fold_kk(sss);
+  if (kk == 0) wslot[n] = sss;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c.ss4[r] = wslot[kk + 4 * r];
+  double uacc[4][UM];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < UM; ++k) uacc[r][k] = 0.0;
+  if (dbg) { unsigned long long now = clock64(); dbg[12] += now - tq0; tq0 = now; }
+  const int ntile = (B + 15) >> 4;
+  if (wv < ntile) {
+    const int nt = (ntile - wv + RF_NW - 1) / RF_NW;
+    double c0[NQ], c1[NQ], w0[UM], w1[UM];
+    tile_pol_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, wv, kk, n);
+    for (int sI = 0; sI + 1 < nt; sI += 2) {
+      tile_pol_load<NQ, UM>(c1, w1, cen, wgt, B, PF, U, wv + RF_NW * (sI + 1), kk, n);
+      tile_pol_consume<NQ, UM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, uacc);
+      tile_pol_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
+      tile_pol_consume<NQ, UM>(c1, w1, c, a, B, U, t, m0, wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
+    }
+    if (nt & 1) tile_pol_consume<NQ, UM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
+  }
+  if (dbg) { unsigned long long now = clock64(); dbg[13] += now - tq0; tq0 = now; }
+  // sum over the 16 basis lanes of each row; lane 15 of row kq holds the partial of particles kq + 4 r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int k = 0; k < UM; ++k) {
+      if (k < U) {
+        double v = uacc[r][k];
+        v += dpp_take<0x111, 0xf>(v);
+        v += dpp_take<0x112, 0xf>(v);
+        v += dpp_take<0x114, 0xf>(v);
+        v += dpp_take<0x118, 0xf>(v);
+        if (n == 15) upart[(wv * TL_PT + kk + 4 * r) * U + k] = v;
+      }
+    }
+  }
+  if (dbg) { unsigned long long now = clock64(); dbg[14] += now - tq0; tq0 = now; }
 }
 
 // ---------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------
-template <int MAXDEG>
+// BIG selects the operand-group counts: small problems (D <= 8, policy features <= 8, inputs <= 2: cart-pole class) keep two
+// feature groups per product in registers, everything else eight.  One kernel per class: compiling both paths into one
+// function made the register allocator spill the small path's long-lived values for the benefit of the big one.
+// CLS: 0 = cart-pole class (D, policy features <= 8, inputs <= 2, N <= 512), 1 = UR5 class (<= 24, <= 24, <= 6, N <= 512), 2 = any
+template <int MAXDEG, int CLS>
 __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
+  constexpr int NG = CLS == 0 ? 2 : (CLS == 1 ? 6 : 8);              // feature groups of 4 (GP inputs, policy features)
+  constexpr int UM = CLS == 0 ? 2 : (CLS == 1 ? 6 : MCP_MAX_INPUT);  // inputs
+  constexpr int MAXTASK = CLS == 2 ? TL_MAXTASK : 2;                  // 32-row blocks of Kinv per wave
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
@@ -416,8 +592,6 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   double* epsb = smem + L.eps;
   double* ks = smem + L.ks;
   double* kv = smem + L.kv;
-  double* ph = ks;  // policy phase only
-  double* R = smem + L.R;
   double* qa = smem + L.qa;
   double* sal = smem + L.sal;
   double* scr = smem + L.scr;
@@ -429,7 +603,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   const double keep_scale = 1.0 / (1.0 - pl.p_drop);
   const uint32_t drop_thr = drop_threshold(pl.p_drop);
   const int nna = md.n_not_angle, na = md.n_angle;
-  const int RT = (D + 1 + 15) >> 4;
+  const int RT = CLS == 0 ? 1 : ((D + 1 + 15) >> 4);  // row tiles of [X^T;1]: a compile-time 1 for the small class
 
   // ---- one-time staging ------------------------------------------------------------------
   for (int it = tid; it < PF; it += RF_NT) invl[it] = exp(-pl.log_ls[it]);
@@ -499,7 +673,6 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     epsb[(tt & 1) * P * G + et] = e;
   };
   if (edraw && T > 1) draw_eps(0);
-  const int B4 = (B + 3) >> 2;
   unsigned long long last_stamp = clock64();
   lds_barrier();
 
@@ -534,66 +707,24 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     }
     lds_barrier();
     TL_STAMP(0);
-    // ---- phase PHI: four basis functions per thread share one Philox draw -------------------------
-    for (int it = tid; it < P * B4; it += RF_NT) {
-      const int p = it / B4, bq = it - p * B4;
-      const int mm = imin(m0 + p, M - 1);
-      u32x4 rnd = {0, 0, 0, 0};
-      if (drop && !a.nz.masks) rnd = philox_draw(a.nz, mm, t, MCP_STREAM_MASK, (uint32_t)bq);
-      double dist[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int qb = 0; qb < PF; qb += 8) {
-        double cv[4][8];  // centres of the 4 basis functions, 8 features: 32 loads in flight
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const size_t row = (size_t)imin(4 * bq + i, B - 1) * PF;
-#pragma unroll
-          for (int q = 0; q < 8; ++q) cv[i][q] = cen[row + imin(qb + q, PF - 1)];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          if (qb + q < PF) {
-            const double sv = sf[p * PF + qb + q], il = invl[qb + q];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const double r = (sv - cv[i][q]) * il;
-              dist[i] = fma(r, r, dist[i]);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int b = 4 * bq + i;
-        if (b < B) {
-          double phi = exp(-dist[i]);
-          if (drop) {
-            const uint32_t word = i == 0 ? rnd.x : i == 1 ? rnd.y : i == 2 ? rnd.z : rnd.w;
-            const bool keep = a.nz.masks ? (a.nz.masks[((size_t)t * M + mm) * B + b] != 0) : (word >= drop_thr);
-            phi = keep ? phi * keep_scale : 0.0;
-          }
-          ph[p * B + b] = phi;
-        }
-      }
-    }
+    // ---- policy: phi and W phi on the matrix cores, partial sums per wave -> LDS ----------------------
+    tile_policy<NG, UM>(a, invl, sf, cen, wgt, scr + wv * 16, scr + RF_NW * 16, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
     lds_barrier();
     TL_STAMP(1);
-    // ---- phase U: one wave per (particle, input) -----------------------------------------------
-    for (int task = wv; task < P * U; task += RF_NW) {
-      const int p = task / U, k = task - p * U;
-      gptr_t wk = wgt + (size_t)k * B;
-      double s = 0.0;
-#pragma unroll 4
-      for (int b = lane; b < B; b += 64) s = fma(wk[b], ph[p * B + b], s);
-      s = wave_sum(s);
-      if (lane == 0) {
-        const double um = pl.u_max[k];
-        const double u = pl.squash ? um * tanh(s / um) : s;
-        us[p * U + k] = u;
-        z[p * D + nna + 2 * na + k] = u;
-        if (m0 + p < M) {
-          a.inputs[((size_t)t * M + m0 + p) * U + k] = u;
-          if (is_bad(u)) bad |= MCP_STATUS_NAN;
-        }
+    // ---- squash, publish u ----------------------------------------------------------------------------
+    if (tid < P * U) {
+      const int p = tid / U, k = tid - p * U;
+      const double* up = scr + RF_NW * 16;
+      double sacc = 0.0;
+#pragma unroll
+      for (int w = 0; w < RF_NW; ++w) sacc += up[(w * P + p) * U + k];
+      const double um = pl.u_max[k];
+      const double u = pl.squash ? um * tanh(sacc / um) : sacc;
+      us[p * U + k] = u;
+      z[p * D + nna + 2 * na + k] = u;
+      if (m0 + p < M) {
+        a.inputs[((size_t)t * M + m0 + p) * U + k] = u;
+        if (is_bad(u)) bad |= MCP_STATUS_NAN;
       }
     }
     lds_barrier();
@@ -605,16 +736,16 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       const double* kp = kpar + g * KP_STRIDE(D);
       const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
       const int deg = MAXDEG == 0 ? 0 : __builtin_amdgcn_readfirstlane(gp.deg);
-      tile_phase_k<MAXDEG>(gp, kp, D, z, ks, kv, wv, lane);
+      tile_phase_k<MAXDEG, NG>(gp, kp, D, z, ks, kv, scr + wv * 16, wv, lane);
       lds_barrier();
       TL_STAMP(3);
       // ---- phase V ---------------------------------------------------------------------------
       {
         const VSched q = tile_v_sched(Npad, L.vslots);
-        v4d acc[TL_MAXTASK][2];
-        int blk[TL_MAXTASK];
+        v4d acc[MAXTASK][2];
+        int blk[MAXTASK];
 #pragma unroll
-        for (int r = 0; r < TL_MAXTASK; ++r) {
+        for (int r = 0; r < MAXTASK; ++r) {
           acc[r][0] = (v4d){0.0, 0.0, 0.0, 0.0};
           acc[r][1] = (v4d){0.0, 0.0, 0.0, 0.0};
           blk[r] = -1;
@@ -622,7 +753,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         const bool in_rem = q.rem > 0 && wv < q.rem * q.s;
         const int part = in_rem ? wv % q.s : 0;
 #pragma unroll
-        for (int r = 0; r < TL_MAXTASK; ++r) {
+        for (int r = 0; r < MAXTASK; ++r) {
           if (r < q.nfull) {
             blk[r] = r * RF_NW + wv;
             tile_v_block(gp.Kinv, Npad, blk[r] * 32, 0, Npad, kv, lane, acc[r][0], acc[r][1]);
@@ -634,7 +765,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         }
         // partial tiles of the split blocks -> scratch (slot = block-in-remainder * (s-1) + part-1)
 #pragma unroll
-        for (int r = 0; r < TL_MAXTASK; ++r) {
+        for (int r = 0; r < MAXTASK; ++r) {
           if (r == q.nfull && in_rem && part > 0) {
             double* s = scr + ((wv / q.s) * (q.s - 1) + part - 1) * 512;
 #pragma unroll
@@ -647,7 +778,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         lds_barrier();  // every wave is done reading k: v may overwrite it
         TL_STAMP(4);
 #pragma unroll
-        for (int r = 0; r < TL_MAXTASK; ++r) {
+        for (int r = 0; r < MAXTASK; ++r) {
           if (blk[r] < 0) continue;
           if (r == q.nfull && in_rem) {
             if (part > 0) continue;
@@ -674,44 +805,51 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       lds_barrier();
       TL_STAMP(5);
       // ---- phase J -----------------------------------------------------------------------------
-      int CTg;
+      int CTg, nfin;
       if (MAXDEG == 0 || deg == 0) {
         v4d acc[2][TL_NCOL(0)];
-        tile_phase_j<0, 1>(gp, kp, D, z, ks, kv, acc, wv, lane);
-        tile_j_reduce<TL_NCOL(0)>(acc, RT, scr, L.nslot, R, wv, lane);
+        tile_phase_j<0, 1>(gp, kp, D, z, ks, kv, acc, RT, wv, lane);
+        nfin = tile_j_reduce<TL_NCOL(0)>(acc, RT, scr, L.nslot, wv, lane);
         CTg = TL_NCOL(0);
       } else if (deg == 1) {
         v4d acc[2][TL_NCOL(1)];
-        tile_phase_j<1, 1>(gp, kp, D, z, ks, kv, acc, wv, lane);
-        tile_j_reduce<TL_NCOL(1)>(acc, RT, scr, L.nslot, R, wv, lane);
+        tile_phase_j<1, 1>(gp, kp, D, z, ks, kv, acc, RT, wv, lane);
+        nfin = tile_j_reduce<TL_NCOL(1)>(acc, RT, scr, L.nslot, wv, lane);
         CTg = TL_NCOL(1);
       } else {
         v4d acc[2][TL_NCOL(2)];
-        if (D <= 8)
-          tile_phase_j<2, 2>(gp, kp, D, z, ks, kv, acc, wv, lane);
-        else
-          tile_phase_j<2, 8>(gp, kp, D, z, ks, kv, acc, wv, lane);
-        tile_j_reduce<TL_NCOL(2)>(acc, RT, scr, L.nslot, R, wv, lane);
+        tile_phase_j<2, NG>(gp, kp, D, z, ks, kv, acc, RT, wv, lane);
+        nfin = tile_j_reduce<TL_NCOL(2)>(acc, RT, scr, L.nslot, wv, lane);
         CTg = TL_NCOL(2);
       }
       lds_barrier();
+      if (nfin > 1) {  // add the partials with all threads (fixed order), result in slot 0
+        const int slot = RT * CTg * 256;
+        for (int e = tid; e < slot; e += RF_NT) {
+          double sacc = scr[e];
+          for (int w = 1; w < nfin; ++w) sacc += scr[w * slot + e];
+          scr[e] = sacc;
+        }
+        lds_barrier();
+      }
       TL_STAMP(6);
       // ---- phase F: moments, sample, d delta/dz -------------------------------------------------
+      const TileR Rr = {scr, CTg, 1, RT * CTg * 256};
       for (int it = tid; it < P * (D + 1); it += RF_NT) {
         const int p = it / (D + 1), c = it - p * (D + 1);
         const double* zp = z + p * D;
         const double vscale = gp.var_scale;
         // k(z,z) and the v-weighted sum  k^T Kinv k
         double kzz = gp.lambda;
-        double ktv = tile_r(R, CTg, D, 1, p);
+        double ktv = tile_r(Rr, D, 1, p);
         double Sa = 0.0, Sb = 0.0;
         if (MAXDEG >= 1 && deg >= 1) {
           double p1 = kp[KP_W1(D) + D];
-          double pv = kp[KP_W1(D) + D] * tile_r(R, CTg, D, 2, p);
+          double pv = kp[KP_W1(D) + D] * tile_r(Rr, D, 2, p);
           for (int d = 0; d < D; ++d) {
             const double wz = kp[KP_W1(D) + d] * zp[d];
             p1 = fma(wz, zp[d], p1);
-            pv = fma(wz, tile_r(R, CTg, d, 2, p), pv);
+            pv = fma(wz, tile_r(Rr, d, 2, p), pv);
           }
           kzz += p1;
           ktv += pv;
@@ -721,7 +859,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
               const double zz = zp[d] * zp[d];
               Sa = fma(kp[KP_W20(D) + d], zz, Sa);
               Sb = fma(kp[KP_W21(D) + d], zz, Sb);
-              qv = fma(kp[KP_W20(D) + d] * zp[d], tile_r(R, CTg, d, 3, p), qv);
+              qv = fma(kp[KP_W20(D) + d] * zp[d], tile_r(Rr, d, 3, p), qv);
             }
             kzz = fma(Sa, Sb, kzz);
             ktv += qv;
@@ -735,7 +873,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           wj = eps / (2.0 * sd);
         }
         if (c == D) {
-          double mu = gp.mean + tile_r(R, CTg, D, 0, p);
+          double mu = gp.mean + tile_r(Rr, D, 0, p);
           if (MAXDEG >= 1 && deg >= 1) {
             double pm = kp[KP_W1(D) + D] * sal[g];
             for (int d = 0; d < D; ++d) pm = fma(kp[KP_W1(D) + d] * zp[d], kp[KP_AX(D) + d], pm);
@@ -759,14 +897,14 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         } else if (a.jac && m0 + p < M) {
           const double il = kp[KP_INVLS(D) + c];
           const double il2 = il * il;
-          const double r0 = fma(zp[c], tile_r(R, CTg, D, 0, p), -tile_r(R, CTg, c, 0, p));
-          const double r1 = fma(zp[c], tile_r(R, CTg, D, 1, p), -tile_r(R, CTg, c, 1, p));
+          const double r0 = fma(zp[c], tile_r(Rr, D, 0, p), -tile_r(Rr, c, 0, p));
+          const double r1 = fma(zp[c], tile_r(Rr, D, 1, p), -tile_r(Rr, c, 1, p));
           double Jmu = -2.0 * il2 * r0;
           double Jvar = 4.0 * il2 * r1;
           if (MAXDEG >= 1 && deg >= 1) {
             const double w1c = kp[KP_W1(D) + c];
             Jmu = fma(w1c, kp[KP_AX(D) + c], Jmu);
-            Jvar += 2.0 * w1c * (zp[c] - tile_r(R, CTg, c, 2, p));
+            Jvar += 2.0 * w1c * (zp[c] - tile_r(Rr, c, 2, p));
             if (deg >= 2) {
               const double* Q = qa + g * D * D;
               const double a_ = kp[KP_W20(D) + c], b_ = kp[KP_W21(D) + c];
@@ -776,7 +914,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
                 qb_ = fma(kp[KP_W20(D) + e] * zp[e], Q[c * D + e], qb_);
               }
               Jmu += a_ * qa_ + b_ * qb_;
-              Jvar += 2.0 * zp[c] * (a_ * Sb + b_ * Sa) - 2.0 * (a_ * tile_r(R, CTg, c, 3, p) + b_ * tile_r(R, CTg, c, 4, p));
+              Jvar += 2.0 * zp[c] * (a_ * Sb + b_ * Sa) - 2.0 * (a_ * tile_r(Rr, c, 3, p) + b_ * tile_r(Rr, c, 4, p));
             }
           }
           a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
@@ -813,23 +951,23 @@ bool fwd_tile_fits(const mcp_model* model, const mcp_policy* policy) {
     maxdeg = imax(maxdeg, model->gp[g].kern.poly_deg);
     if (((model->gp[g].Npad + 31) / 32 + RF_NW - 1) / RF_NW > TL_MAXTASK) return false;
   }
-  if (TL_PT * policy->B > 2 * NpadMax * TL_KR) return false;  // the phi buffer aliases the k / v panels
   TileLayout L = tile_layout(model->S, model->U, model->D, model->G, policy->P, NpadMax, maxdeg);
   const int RT = (model->D + 1 + 15) / 16;
   if (L.nslot * RT * TL_NCOL(maxdeg) * 256 > (L.total - L.scr)) return false;
+  if (policy->P > 32) return false;
   return sizeof(double) * (size_t)L.total <= MCP_LDS_LIMIT;
 }
 
-template <int MAXDEG>
+template <int MAXDEG, int CLS>
 static int launch_tile_deg(const FwdArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_tile_kernel<MAXDEG>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_tile_kernel<MAXDEG, CLS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               MCP_LDS_LIMIT);
     attr_set = true;
   }
   const int grid = (a.M + TL_PT - 1) / TL_PT;
-  hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG>), dim3(grid), dim3(RF_NT), lds, st, a);
+  hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, CLS>), dim3(grid), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }
@@ -838,7 +976,11 @@ int launch_fwd_tile(const FwdArgs& a, hipStream_t st) {
   if (!fwd_tile_fits(&a.model, &a.pol)) return MCP_ERR_LIMIT;
   TileLayout L = tile_layout(a.model.S, a.model.U, a.model.D, a.model.G, a.pol.P, a.NpadMax, a.maxdeg);
   const size_t lds = sizeof(double) * (size_t)L.total;
-  return a.maxdeg == 0 ? launch_tile_deg<0>(a, lds, st) : launch_tile_deg<2>(a, lds, st);
+  const int D = a.model.D, PF = a.pol.P, U = a.model.U;
+  const int cls = a.NpadMax > 512 ? 2 : ((D <= 8 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2));
+  if (cls == 0) return a.maxdeg == 0 ? launch_tile_deg<0, 0>(a, lds, st) : launch_tile_deg<2, 0>(a, lds, st);
+  if (cls == 1) return a.maxdeg == 0 ? launch_tile_deg<0, 1>(a, lds, st) : launch_tile_deg<2, 1>(a, lds, st);
+  return a.maxdeg == 0 ? launch_tile_deg<0, 2>(a, lds, st) : launch_tile_deg<2, 2>(a, lds, st);
 }
 
 }  // namespace mcp

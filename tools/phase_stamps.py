@@ -9,7 +9,8 @@ ppw = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 dev = torch.device("cuda", 0)
 Mo = int(sys.argv[3]) if len(sys.argv) > 3 else None
 To = int(sys.argv[4]) if len(sys.argv) > 4 else None
-w = workloads.build(name, device=dev, M=Mo, T=To)
+pd = float(sys.argv[5]) if len(sys.argv) > 5 else 0.25
+w = workloads.build(name, device=dev, M=Mo, T=To, p_drop=pd)
 buf = torch.zeros(16, dtype=torch.int64, device=dev)
 x0 = w.sample_x0()
 hipabi.lib().mcp_debug_set_particles_per_wg(ppw)
@@ -34,6 +35,6 @@ hipabi.lib().mcp_debug_set_bwd_stamp_buffer(None)
 v2 = buf2.cpu().tolist()
 print("bwd per step cycles: serial(wave0) %.0f | barrier1 %.0f | RBF stage %.0f | park+barrier2 %.0f" % tuple(x / w.T for x in (v2[8], v2[9], v2[10], v2[11])))
 print("workload", name, "T", w.T, "M", w.M, "ppw", ppw, "total cycles", tot, "-> per step", tot / (w.T - 1))
-print("J detail (wave 0, per step): mfma loops %.0f cyc, tile stores %.0f cyc" % (v[12] / (w.T - 1), v[13] / (w.T - 1)))
+print("detail slots 12/13/14 (wave 0, per step): %.0f | %.0f | %.0f cyc" % (v[12] / (w.T - 1), v[13] / (w.T - 1), v[14] / (w.T - 1)))
 for n, c in zip(names, v):
     print("%-14s %12d  %5.1f%%  %8.0f cyc/step" % (n, c, 100.0 * c / tot, c / (w.T - 1)))
