@@ -62,6 +62,37 @@ __device__ __forceinline__ void wave_sum_multi(double (&v)[N]) {
   }
 }
 
+// the first n (wave-uniform, <= N) of N values: same interleaving, no work for the unused tail
+template <int N>
+__device__ __forceinline__ void wave_sum_first(double (&v)[N], int n) {
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n) v[i] += dpp_take<0x111, 0xf>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n) v[i] += dpp_take<0x112, 0xf>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n) v[i] += dpp_take<0x114, 0xf>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n) v[i] += dpp_take<0x118, 0xf>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n) v[i] += dpp_take<0x142, 0xa>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n) v[i] += dpp_take<0x143, 0xc>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (i < n) {
+      int lo = __builtin_amdgcn_readlane(__double2loint(v[i]), 63);
+      int hi = __builtin_amdgcn_readlane(__double2hiint(v[i]), 63);
+      v[i] = __hiloint2double(hi, lo);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), counter-based: draws depend only on
 // (seed, call, global particle, time step, stream, index) -- never on launch geometry.

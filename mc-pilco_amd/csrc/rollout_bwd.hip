@@ -44,9 +44,10 @@ struct BwdArgs {
 
 struct BwdLayout {
   int invl, rec, xn, xb, zb, db, ab, sf, sb, sn, cs, red, itab, total;
+  int pstride;  // doubles between the per-particle copies of xn..cs
 };
 __host__ __device__ inline int bwd_rec_len(int S, int U, int D, int G) { return 2 * S + 2 * U + G * D; }
-__host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int PF, int NW) {
+__host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int PF, int NW, int PB) {
   BwdLayout L;
   int o = 0;
   auto take = [&](int n) {
@@ -55,7 +56,9 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
     return r;
   };
   L.invl = take(PF);
-  L.rec = take(2 * bwd_rec_len(S, U, D, G));
+  L.rec = take(2 * PB * bwd_rec_len(S, U, D, G));
+  // per-particle working set of the serial section (particle p at + p * pstride)
+  const int o0 = o;
   L.xn = take(S);
   L.xb = take(S);
   L.zb = take(D);
@@ -65,7 +68,9 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
   L.sb = take(PF);
   L.sn = take(S);
   L.cs = take(S);
-  L.red = take(NW * PF);
+  L.pstride = o - o0;
+  o = o0 + PB * L.pstride;
+  L.red = take(PB * NW * PF);
   L.itab = take((2 * MCP_MAX_GP + 2 * MCP_MAX_STATE + MCP_MAX_INPUT + 1) / 2 + 1);
   L.total = o;
   return L;
@@ -74,14 +79,16 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
 #ifndef BW_WPE_A
 #define BW_WPE_A 2
 #endif
-#define BW_RPT 5  // record elements a thread prefetches at most (record <= 304 doubles, >= 64 threads)
+#define BW_RPT 5  // record elements a thread prefetches at most (PB * record length <= BW_RPT * threads)
 
 // Per particle and time step the record is  [x_t (S) | u_t (U) | dJ/dx_t (S) | dJ/du_t (U) | d delta/dz (G*D)].
 // It is prefetched into registers one step ahead (global/L2 latency hidden behind the current step) and
-// parked in a double-buffered LDS copy.  The short dependent chain of tiny stages (integrator adjoint,
-// GP-Jacobian product, feature-map adjoints, squashing) runs in wave 0 alone with wave-level ordering;
-// only the RBF network stage uses the whole workgroup: two workgroup barriers per time step.
-template <int PFM, int UM, int MAXNT, int WPE>
+// parked in a double-buffered LDS copy.  A workgroup sweeps PB particles in lockstep: the short dependent chain of
+// tiny stages (integrator adjoint, GP-Jacobian product, feature-map adjoints, squashing) of particle p runs in wave p
+// alone with wave-level ordering (latency bound, so PB chains on PB waves cost the time of one); the RBF network stage
+// uses the whole workgroup, thread b looping over the PB particles (its gradient accumulators are shared by all
+// particles anyway): two workgroup barriers per time step for PB particle-steps.
+template <int PFM, int UM, int MAXNT, int WPE, int PB>
 __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
@@ -89,20 +96,24 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   const int tid = threadIdx.x, NT = blockDim.x, NW = NT >> 6, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
-  const BwdLayout L = bwd_layout(S, U, D, G, PF, NW);
+  const BwdLayout L = bwd_layout(S, U, D, G, PF, NW, PB);
   const int NR = bwd_rec_len(S, U, D, G);
+  const int PS = L.pstride;
+  const int sp = wv < PB ? wv : 0;  // the particle slot whose serial chain this wave runs
   double* invl = smem + L.invl;
-  volatile double* rec = smem + L.rec;  // [2][NR]
-  volatile double* xn = smem + L.xn;    // adjoint of x_{t+1}
-  volatile double* xb = smem + L.xb;    // adjoint of x_t without the policy path
-  volatile double* zb = smem + L.zb;
-  volatile double* db = smem + L.db;
-  volatile double* ab = smem + L.ab;
-  volatile double* sf = smem + L.sf;
-  volatile double* sb = smem + L.sb;
-  volatile double* sn = smem + L.sn;
-  volatile double* cs = smem + L.cs;
-  volatile double* red = smem + L.red;
+  volatile double* rec = smem + L.rec;  // [2][PB][NR]
+  volatile double* xn = smem + L.xn + sp * PS;  // adjoint of x_{t+1}
+  volatile double* xb = smem + L.xb + sp * PS;  // adjoint of x_t without the policy path
+  volatile double* zb = smem + L.zb + sp * PS;
+  volatile double* db = smem + L.db + sp * PS;
+  volatile double* ab = smem + L.ab + sp * PS;
+  volatile double* sf = smem + L.sf + sp * PS;
+  volatile double* sb = smem + L.sb + sp * PS;
+  volatile double* sn = smem + L.sn + sp * PS;
+  volatile double* cs = smem + L.cs + sp * PS;
+  const volatile double* sf_all = smem + L.sf;  // particle p at + p * PS
+  const volatile double* ab_all = smem + L.ab;
+  volatile double* red = smem + L.red;  // [PB][NW][PF]
   // integer / per-input tables in LDS: indexing the by-value kernel argument with a per-lane index would
   // make the compiler spill it to scratch
   int* t_vel = reinterpret_cast<int*>(smem + L.itab);
@@ -139,8 +150,9 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     gw[k] = 0.0;
   }
   // lane-private index tables of the serial section (lane = state / feature index)
+  const bool serial = wv < PB;
   int zi_plain = -1, zi_ang = -1, pi_plain = -1, pi_ang = -1, g_vel = -1, g_pos = -1;
-  if (wv == 0 && lane < S) {
+  if (serial && lane < S) {
     for (int i = 0; i < nna_g; ++i)
       if (md.not_angle[i] == lane) zi_plain = i;
     for (int i = 0; i < na_g; ++i)
@@ -159,17 +171,20 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   int pos_of_vel = 0;  // the position state integrated from this lane's velocity state
   for (int g = 0; g < G; ++g)
     if (md.vel[g] == lane) pos_of_vel = md.not_vel[g];
-  const double umax_lane = (wv == 0 && lane < U) ? pl.u_max[lane] : 1.0;
+  const double umax_lane = (serial && lane < U) ? pl.u_max[lane] : 1.0;
   const bool need_trig = (zi_ang >= 0) || (pi_ang >= 0);
   lds_barrier();
 
-  auto prefetch = [&](double (&pre)[BW_RPT], int t, int m) {
-    const size_t tm = (size_t)t * M + m;
+  const int NRP = PB * NR;
+  // particles of this sweep: m_p = mbase + p (clamped for the loads; slots past M contribute nothing)
+  auto prefetch = [&](double (&pre)[BW_RPT], int t, int mbase) {
 #pragma unroll
     for (int k = 0; k < BW_RPT; ++k) {
-      int i = tid + k * NT;
+      const int e = tid + k * NT;
       double v = 0.0;
-      if (i < NR) {
+      if (e < NRP) {
+        const int p = e / NR, i = e - p * NR;
+        const size_t tm = (size_t)t * M + imin(mbase + p, M - 1);
         if (i < oU)
           v = a.states[tm * S + i];
         else if (i < oGX)
@@ -187,30 +202,33 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   auto park = [&](const double (&pre)[BW_RPT], int buf) {
 #pragma unroll
     for (int k = 0; k < BW_RPT; ++k) {
-      int i = tid + k * NT;
-      if (i < NR) rec[buf * NR + i] = pre[k];
+      const int e = tid + k * NT;
+      if (e < NRP) rec[buf * NRP + e] = pre[k];
     }
   };
 
   unsigned long long last_stamp = clock64();
-  for (int m = blockIdx.x; m < M; m += gridDim.x) {
+  for (int mbase = blockIdx.x * PB; mbase < M; mbase += gridDim.x * PB) {
+    const int msp = imin(mbase + sp, M - 1);  // particle of this wave's serial chain
+    const bool spvalid = mbase + sp < M;
     double pre[BW_RPT];
     int cur = 0;
-    prefetch(pre, T - 1, m);
+    prefetch(pre, T - 1, mbase);
     park(pre, cur);
     lds_barrier();
     for (int t = T - 1; t >= 0; --t) {
       BW_STAMP(11);
-      if (t > 0) prefetch(pre, t - 1, m);
-      // ---- serial section: wave 0 ---------------------------------------------------------------
-      if (wv == 0) {
-        const volatile double* r = rec + cur * NR;
+      if (t > 0) prefetch(pre, t - 1, mbase);
+      // ---- serial section: wave p for particle slot p -----------------------------------------------
+      if (serial) {
+        const volatile double* r = rec + cur * NRP + sp * NR;
+        const volatile double* redp = red + sp * NW * PF;
         const bool last = (t == T - 1);
         if (!last) {
           // finish step t+1: adjoint of the policy features -> adjoint of x_{t+1}
           if (lane < PF) {
             double s = 0.0;
-            for (int w = 0; w < NW; ++w) s += red[w * PF + lane];
+            for (int w = 0; w < NW; ++w) s += redp[w * PF + lane];
             sb[lane] = s;
           }
           __builtin_amdgcn_wave_barrier();
@@ -287,43 +305,81 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       BW_STAMP(8);
       lds_barrier();
       BW_STAMP(9);
-      // ---- RBF network, thread b owns basis b ---------------------------------------------------------
-      double dd = 0.0;  // adjoint of dist_b (0 for idle threads, so they add nothing below)
-      if (act) {
-        double dist = 0.0;
+      // ---- RBF network, thread b owns basis b, loops over the particle slots -----------------------------
+      // dropout keep bits: one Philox draw serves 4 consecutive bases of one particle (philox_keep); the lanes of a quad
+      // draw for particle slots (b & 3) % PB and pass each other the word of the receiver's basis
+      uint32_t kw[PB];
 #pragma unroll
-        for (int q = 0; q < PFM; ++q) {
-          if (q < PF) {
-            double rr = (sf[q] - cen[q]) * invl[q];
-            dist = fma(rr, rr, dist);
+      for (int p = 0; p < PB; ++p) kw[p] = 0xFFFFFFFFu;
+      if (drop && !a.nz.masks) {
+        const int cq = b & 3;
+        const int bq = imin(b, B - 1) >> 2;
+        const u32x4 rnd = philox_draw(a.nz, imin(mbase + (cq % PB), M - 1), t, MCP_STREAM_MASK, (uint32_t)bq);
+        if (PB == 1) {
+          kw[0] = cq == 0 ? rnd.x : cq == 1 ? rnd.y : cq == 2 ? rnd.z : rnd.w;
+        } else {
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const int ws = (cq + k4) & 3;
+            const uint32_t snd = ws == 0 ? rnd.x : ws == 1 ? rnd.y : ws == 2 ? rnd.z : rnd.w;
+            const int src = (cq - k4) & 3;  // lane of the quad that drew for slot src % PB; it sends word[cq]
+            const uint32_t rcv = (uint32_t)__shfl((int)snd, (lane & ~3) | src);
+#pragma unroll
+            for (int p = 0; p < PB; ++p)
+              if ((src % PB) == p) kw[p] = rcv;
           }
         }
-        double phi = exp(-dist);
-        double mk = 1.0;
-        if (drop) {
-          bool keep = a.nz.masks ? (a.nz.masks[((size_t)t * M + m) * B + b] != 0) : philox_keep(a.nz, m, t, b, drop_thr);
-          mk = keep ? keep_scale : 0.0;
-        }
-        double phibar = 0.0;
-#pragma unroll
-        for (int k = 0; k < UM; ++k) {
-          if (k < U) {
-            double abk = ab[k];
-            gw[k] = fma(abk, phi * mk, gw[k]);
-            phibar = fma(wgt[k], abk, phibar);
-          }
-        }
-        dd = -phi * mk * phibar;
       }
 #pragma unroll
-      for (int q = 0; q < PFM; ++q) {
-        if (q < PF) {
-          double rr = (sf[q] - cen[q]) * invl[q];
-          double t2 = 2.0 * dd * rr;
-          gc[q] = fma(-t2, invl[q], gc[q]);
-          gl[q] = fma(-t2, rr, gl[q]);
-          double sm = wave_sum(t2 * invl[q]);
-          if (lane == 0) red[wv * PF + q] = sm;
+      for (int p = 0; p < PB; ++p) {
+        const volatile double* sfp = sf_all + p * PS;
+        const volatile double* abp = ab_all + p * PS;
+        const bool pv = mbase + p < M;
+        double t2v[PFM];   // 2 dd rr / l: the adjoint of the policy feature, before the sum over bases
+        double dd = 0.0;  // adjoint of dist_b (0 for idle threads and empty slots, so they add nothing below)
+        if (act && pv) {
+          double dist = 0.0;
+#pragma unroll
+          for (int q = 0; q < PFM; ++q) {
+            if (q < PF) {
+              double rr = (sfp[q] - cen[q]) * invl[q];
+              dist = fma(rr, rr, dist);
+            }
+          }
+          double phi = exp(-dist);
+          double mk = 1.0;
+          if (drop) {
+            bool keep = a.nz.masks ? (a.nz.masks[((size_t)t * M + mbase + p) * B + b] != 0) : (kw[p] >= drop_thr);
+            mk = keep ? keep_scale : 0.0;
+          }
+          double phibar = 0.0;
+#pragma unroll
+          for (int k = 0; k < UM; ++k) {
+            if (k < U) {
+              double abk = abp[k];
+              gw[k] = fma(abk, phi * mk, gw[k]);
+              phibar = fma(wgt[k], abk, phibar);
+            }
+          }
+          dd = -phi * mk * phibar;
+        }
+#pragma unroll
+        for (int q = 0; q < PFM; ++q) {
+          double v = 0.0;
+          if (q < PF) {
+            double rr = (sfp[q] - cen[q]) * invl[q];
+            double t2 = 2.0 * dd * rr;
+            gc[q] = fma(-t2, invl[q], gc[q]);
+            gl[q] = fma(-t2, rr, gl[q]);
+            v = t2 * invl[q];
+          }
+          t2v[q] = v;
+        }
+        wave_sum_first<PFM>(t2v, PF);
+        if (lane == 0) {
+#pragma unroll
+          for (int q = 0; q < PFM; ++q)
+            if (q < PF) red[(p * NW + wv) * PF + q] = t2v[q];
         }
       }
       BW_STAMP(10);
@@ -332,10 +388,11 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       lds_barrier();
     }
     // finish step 0: adjoint of x_0
-    if (wv == 0) {
+    if (serial) {
+      const volatile double* redp = red + sp * NW * PF;
       if (lane < PF) {
         double s = 0.0;
-        for (int w = 0; w < NW; ++w) s += red[w * PF + lane];
+        for (int w = 0; w < NW; ++w) s += redp[w * PF + lane];
         sb[lane] = s;
       }
       __builtin_amdgcn_wave_barrier();
@@ -349,7 +406,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         } else {
           s = sb[lane];
         }
-        if (a.g_x0) a.g_x0[(size_t)m * S + lane] = xb[lane] + s;
+        if (a.g_x0 && spvalid) a.g_x0[(size_t)msp * S + lane] = xb[lane] + s;
       }
     }
     lds_barrier();
@@ -410,6 +467,8 @@ __global__ void grad_reduce_kernel(int nblk, int nparam, int PF, int BPF, const 
 // ---------------------------------------------------------------------------------------
 static unsigned long long* g_bwd_stamps = nullptr;  // diagnostic hook
 extern "C" void mcp_debug_set_bwd_stamp_buffer(void* p) { g_bwd_stamps = (unsigned long long*)p; }
+static int g_force_bwd_pb = 0;  // test hook: particles per workgroup of the backward sweep (0 = automatic)
+extern "C" void mcp_debug_set_bwd_particles(int pb) { g_force_bwd_pb = pb; }
 static int bwd_threads(int B) { return imax(64, ((B + 63) / 64) * 64); }
 static int bwd_blocks(int M) { return imin(M, 1024); }
 
@@ -420,12 +479,17 @@ extern "C" size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_
   return sizeof(double) * nparam * (size_t)bwd_blocks(M);
 }
 
-template <int PFM, int UM, int MAXNT, int WPE>
-static int launch_bwd(const BwdArgs& a, int grid, int NT, size_t lds, hipStream_t st) {
-  if (NT > MAXNT) return MCP_ERR_LIMIT;
-  hipLaunchKernelGGL((rollout_bwd_kernel<PFM, UM, MAXNT, WPE>), dim3(grid), dim3(NT), lds, st, a);
+template <int PFM, int UM, int MAXNT, int WPE, int PB>
+static int launch_bwd(const BwdArgs& a, int NT, hipStream_t st) {
+  if (NT > MAXNT || NT < 64 * PB) return MCP_ERR_LIMIT;
+  const mcp_model& md = a.model;
+  if (PB * bwd_rec_len(md.S, md.U, md.D, md.G) > BW_RPT * NT) return MCP_ERR_LIMIT;
+  const int grid = imin((a.M + PB - 1) / PB, 1024);
+  BwdLayout L = bwd_layout(md.S, md.U, md.D, md.G, a.pol.P, NT / 64, PB);
+  const size_t lds = sizeof(double) * (size_t)L.total;
+  hipLaunchKernelGGL((rollout_bwd_kernel<PFM, UM, MAXNT, WPE, PB>), dim3(grid), dim3(NT), lds, st, a);
   MCP_LAUNCH_CHECK();
-  return MCP_OK;
+  return grid;
 }
 
 extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T,
@@ -458,24 +522,40 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   a.slab = (double*)workspace;
   a.g_x0 = g_x0;
   a.stamps = g_bwd_stamps;
-  const int NT = bwd_threads(policy->B);
-  const int grid = bwd_blocks(M);
-  BwdLayout L = bwd_layout(model->S, model->U, model->D, model->G, policy->P, NT / 64);
-  size_t lds = sizeof(double) * (size_t)L.total;
   hipStream_t st = (hipStream_t)stream;
-  int rc;
   const int PF = policy->P, U = policy->U;
-  // register budget: 3*PFM + 2*UM doubles of per-thread accumulators plus the prefetched record; the
-  // launch bound is the tightest that fits the thread count so the allocator gets 256-512 VGPRs
-  // (at __launch_bounds__(1024) the kernel spilled ~600 B/lane to scratch)
-  if (PF <= 8 && U <= 2)
-    rc = NT <= 256 ? launch_bwd<8, 2, 256, BW_WPE_A>(a, grid, NT, lds, st) : launch_bwd<8, 2, 1024, 4>(a, grid, NT, lds, st);
-  else if (PF <= 16 && U <= 4)
-    rc = NT <= 256 ? launch_bwd<16, 4, 256, BW_WPE_A>(a, grid, NT, lds, st) : launch_bwd<16, 4, 1024, 4>(a, grid, NT, lds, st);
-  else
-    rc = NT <= 256 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 256, BW_WPE_A>(a, grid, NT, lds, st)
-                   : launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 512, 2>(a, grid, NT, lds, st);
-  if (rc != MCP_OK) return rc;
+  // particles per workgroup: large swarms are latency bound per workgroup, so several particles share one sweep; small
+  // swarms keep one particle per workgroup to spread over the CUs
+  int PB = g_force_bwd_pb ? g_force_bwd_pb : (M >= 2048 ? 4 : (M >= 1024 ? 2 : 1));
+  if (!g_force_bwd_pb && (PF > 16 || U > 4)) PB = 1;  // the wide-policy instantiations are register bound already
+  if (PB != 1 && PB != 2 && PB != 4) return MCP_ERR_ARG;
+  int NT = imax(bwd_threads(policy->B), 64 * PB);
+  int rc = MCP_ERR_LIMIT;
+  // register budget: 3*PFM + 2*UM doubles of per-thread accumulators plus the prefetched record; the launch bound is the
+  // tightest that fits the thread count, capped so that two 256-thread workgroups share a CU
+  for (; PB >= 1 && rc == MCP_ERR_LIMIT; PB >>= 1) {
+    if (PF <= 8 && U <= 2) {
+      if (NT <= 256)
+        rc = PB == 4 ? launch_bwd<8, 2, 256, BW_WPE_A, 4>(a, NT, st) : PB == 2 ? launch_bwd<8, 2, 256, BW_WPE_A, 2>(a, NT, st) : launch_bwd<8, 2, 256, BW_WPE_A, 1>(a, NT, st);
+      else
+        rc = PB == 1 ? launch_bwd<8, 2, 1024, 4, 1>(a, NT, st) : MCP_ERR_LIMIT;
+    } else if (PF <= 16 && U <= 4) {
+      if (NT <= 256)
+        rc = PB == 2 ? launch_bwd<16, 4, 256, BW_WPE_A, 2>(a, NT, st) : PB == 1 ? launch_bwd<16, 4, 256, BW_WPE_A, 1>(a, NT, st) : MCP_ERR_LIMIT;
+      else
+        rc = PB == 1 ? launch_bwd<16, 4, 1024, 4, 1>(a, NT, st) : MCP_ERR_LIMIT;
+    } else {
+      if (NT <= 256)
+        rc = PB == 2 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 256, BW_WPE_A, 2>(a, NT, st)
+                     : PB == 1 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 256, BW_WPE_A, 1>(a, NT, st) : MCP_ERR_LIMIT;
+      else
+        rc = PB == 2 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 512, 2, 2>(a, NT, st)
+                     : PB == 1 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 512, 2, 1>(a, NT, st) : MCP_ERR_LIMIT;
+    }
+    if (rc == MCP_ERR_LIMIT && PB > 1) NT = imax(bwd_threads(policy->B), 64 * (PB >> 1));
+  }
+  if (rc < 0) return rc;
+  const int grid = rc;
   const int nparam = PF + policy->B * PF + U * policy->B;
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((nparam + 255) / 256), dim3(256), 0, st, grid, nparam, PF, policy->B * PF, a.slab, g_log_ls,
                      g_centers, g_weight);

@@ -82,6 +82,7 @@ _SIGS = {
     "mcp_cost_bwd": (C.c_int, [C.POINTER(Cost), C.c_int, C.c_int, dptr, dptr, C.c_double, dptr, dptr]),
     "mcp_debug_set_particles_per_wg": (None, [C.c_int]),
     "mcp_debug_last_particles_per_wg": (C.c_int, []),
+    "mcp_debug_set_bwd_particles": (None, [C.c_int]),
     "mcp_debug_set_stamp_buffer": (None, [dptr]),
     "mcp_debug_set_fwd_mode": (None, [C.c_int, C.c_int]),
     "mcp_debug_set_bwd_stamp_buffer": (None, [dptr]),

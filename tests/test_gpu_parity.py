@@ -180,6 +180,7 @@ def test_rollout_cost_gradient_vs_reference(golden, name, kind, ppw):
     Tn = fx["states"].shape[0]
     p = float(fx["p_drop"])
     hipabi.lib().mcp_debug_set_particles_per_wg(ppw)
+    hipabi.lib().mcp_debug_set_bwd_particles({0: 0, 1: 1, 2: 2, 4: 4, 16: 4}[ppw])  # the backward sweep's own tile sizes ride along
     try:
         st, inp, status = ops.rollout(model, pol, noise_from(fx), x0, Tn, p)
         c, s = ops.expected_cost(cost, st)
@@ -187,6 +188,7 @@ def test_rollout_cost_gradient_vs_reference(golden, name, kind, ppw):
         used = hipabi.lib().mcp_debug_last_particles_per_wg()
     finally:
         hipabi.lib().mcp_debug_set_particles_per_wg(0)
+        hipabi.lib().mcp_debug_set_bwd_particles(0)
     if ppw:
         assert used == ppw, "forced kernel variant was not the one launched"
     assert int(status.item()) == 0
