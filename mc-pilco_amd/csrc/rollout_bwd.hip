@@ -137,13 +137,18 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     for (int i = 0; i < pl.n_non_angle; ++i) t_pna[i] = pl.non_angle[i];
     for (int i = 0; i < pl.n_angle; ++i) t_pan[i] = pl.angle[i];
   }
-  double cen[PFM], gc[PFM], gl[PFM], wgt[UM], gw[UM];
+  // the widest policies (PFM > 24) re-read their centres every step (L1/L2 hits) instead of holding 64 more VGPRs
+  constexpr bool CENREG = PFM <= 24;
+  typedef const double __attribute__((address_space(1))) * gcptr_t;
+  gcptr_t cenrow = (gcptr_t)pl.centers + (size_t)imin(b, B - 1) * PF;
+  double cen[CENREG ? PFM : 1], gc[PFM], gl[PFM], wgt[UM], gw[UM];
 #pragma unroll
   for (int q = 0; q < PFM; ++q) {
-    cen[q] = (act && q < PF) ? pl.centers[(size_t)b * PF + q] : 0.0;
+    if (CENREG) cen[q] = (act && q < PF) ? pl.centers[(size_t)b * PF + q] : 0.0;
     gc[q] = 0.0;
     gl[q] = 0.0;
   }
+#define BW_CEN(q) (CENREG ? cen[CENREG ? (q) : 0] : cenrow[q])
 #pragma unroll
   for (int k = 0; k < UM; ++k) {
     wgt[k] = (act && k < U) ? pl.weight[(size_t)k * B + b] : 0.0;
@@ -335,14 +340,13 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         const volatile double* sfp = sf_all + p * PS;
         const volatile double* abp = ab_all + p * PS;
         const bool pv = mbase + p < M;
-        double t2v[PFM];   // 2 dd rr / l: the adjoint of the policy feature, before the sum over bases
         double dd = 0.0;  // adjoint of dist_b (0 for idle threads and empty slots, so they add nothing below)
         if (act && pv) {
           double dist = 0.0;
 #pragma unroll
           for (int q = 0; q < PFM; ++q) {
             if (q < PF) {
-              double rr = (sfp[q] - cen[q]) * invl[q];
+              double rr = (sfp[q] - BW_CEN(q)) * invl[q];
               dist = fma(rr, rr, dist);
             }
           }
@@ -363,23 +367,31 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
           }
           dd = -phi * mk * phibar;
         }
+        // 8 features at a time: their wave sums interleave (ILP) without keeping all PFM partial products live
 #pragma unroll
-        for (int q = 0; q < PFM; ++q) {
-          double v = 0.0;
-          if (q < PF) {
-            double rr = (sfp[q] - cen[q]) * invl[q];
-            double t2 = 2.0 * dd * rr;
-            gc[q] = fma(-t2, invl[q], gc[q]);
-            gl[q] = fma(-t2, rr, gl[q]);
-            v = t2 * invl[q];
+        for (int q0 = 0; q0 < PFM; q0 += 8) {
+          if (q0 < PF) {
+            double t2v[8];  // 2 dd rr / l: the adjoint of the policy feature, before the sum over bases
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int q = q0 + i;
+              double v = 0.0;
+              if (q < PFM && q < PF) {
+                double rr = (sfp[q] - BW_CEN(q)) * invl[q];
+                double t2 = 2.0 * dd * rr;
+                gc[q] = fma(-t2, invl[q], gc[q]);
+                gl[q] = fma(-t2, rr, gl[q]);
+                v = t2 * invl[q];
+              }
+              t2v[i] = v;
+            }
+            wave_sum_first<8>(t2v, PF - q0);
+            if (lane == 0) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i)
+                if (q0 + i < PF) red[(p * NW + wv) * PF + q0 + i] = t2v[i];
+            }
           }
-          t2v[q] = v;
-        }
-        wave_sum_first<PFM>(t2v, PF);
-        if (lane == 0) {
-#pragma unroll
-          for (int q = 0; q < PFM; ++q)
-            if (q < PF) red[(p * NW + wv) * PF + q] = t2v[q];
         }
       }
       BW_STAMP(10);
@@ -544,6 +556,11 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
         rc = PB == 2 ? launch_bwd<16, 4, 256, BW_WPE_A, 2>(a, NT, st) : PB == 1 ? launch_bwd<16, 4, 256, BW_WPE_A, 1>(a, NT, st) : MCP_ERR_LIMIT;
       else
         rc = PB == 1 ? launch_bwd<16, 4, 1024, 4, 1>(a, NT, st) : MCP_ERR_LIMIT;
+    } else if (PF <= 24 && U <= 6) {  // UR5 class
+      if (NT <= 256)
+        rc = PB == 2 ? launch_bwd<24, 6, 256, BW_WPE_A, 2>(a, NT, st) : PB == 1 ? launch_bwd<24, 6, 256, BW_WPE_A, 1>(a, NT, st) : MCP_ERR_LIMIT;
+      else
+        rc = PB == 2 ? launch_bwd<24, 6, 512, 2, 2>(a, NT, st) : PB == 1 ? launch_bwd<24, 6, 512, 2, 1>(a, NT, st) : MCP_ERR_LIMIT;
     } else {
       if (NT <= 256)
         rc = PB == 2 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 256, BW_WPE_A, 2>(a, NT, st)

@@ -505,8 +505,6 @@ template <int NQ, int UM>
 __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* upart,
                                             int B, int PF, int U, int t, int m0, int wv, int lane, bool drop, double keep_scale, uint32_t drop_thr) {
   const int kk = lane >> 4, n = lane & 15;
-  unsigned long long* dbg = (a.stamps && blockIdx.x == 0 && wv == 0 && lane == 0) ? a.stamps : nullptr;
-  unsigned long long tq0 = clock64();
   TilePolConst<NQ> c;
   double sss = 0.0;
 #pragma unroll
@@ -530,7 +528,6 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int k = 0; k < UM; ++k) uacc[r][k] = 0.0;
-  if (dbg) { unsigned long long now = clock64(); dbg[12] += now - tq0; tq0 = now; }
   const int ntile = (B + 15) >> 4;
   if (wv < ntile) {
     const int nt = (ntile - wv + RF_NW - 1) / RF_NW;
@@ -544,7 +541,6 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
     }
     if (nt & 1) tile_pol_consume<NQ, UM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
   }
-  if (dbg) { unsigned long long now = clock64(); dbg[13] += now - tq0; tq0 = now; }
   // sum over the 16 basis lanes of each row; lane 15 of row kq holds the partial of particles kq + 4 r
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -560,7 +556,6 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
       }
     }
   }
-  if (dbg) { unsigned long long now = clock64(); dbg[14] += now - tq0; tq0 = now; }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -978,9 +973,18 @@ int launch_fwd_tile(const FwdArgs& a, hipStream_t st) {
   const size_t lds = sizeof(double) * (size_t)L.total;
   const int D = a.model.D, PF = a.pol.P, U = a.model.U;
   const int cls = a.NpadMax > 512 ? 2 : ((D <= 8 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2));
-  if (cls == 0) return a.maxdeg == 0 ? launch_tile_deg<0, 0>(a, lds, st) : launch_tile_deg<2, 0>(a, lds, st);
-  if (cls == 1) return a.maxdeg == 0 ? launch_tile_deg<0, 1>(a, lds, st) : launch_tile_deg<2, 1>(a, lds, st);
-  return a.maxdeg == 0 ? launch_tile_deg<0, 2>(a, lds, st) : launch_tile_deg<2, 2>(a, lds, st);
+  // one instantiation per (highest polynomial degree, class): no code or registers for kernel terms the model does not have
+  switch (cls * 3 + a.maxdeg) {
+    case 0: return launch_tile_deg<0, 0>(a, lds, st);
+    case 1: return launch_tile_deg<1, 0>(a, lds, st);
+    case 2: return launch_tile_deg<2, 0>(a, lds, st);
+    case 3: return launch_tile_deg<0, 1>(a, lds, st);
+    case 4: return launch_tile_deg<1, 1>(a, lds, st);
+    case 5: return launch_tile_deg<2, 1>(a, lds, st);
+    case 6: return launch_tile_deg<0, 2>(a, lds, st);
+    case 7: return launch_tile_deg<1, 2>(a, lds, st);
+    default: return launch_tile_deg<2, 2>(a, lds, st);
+  }
 }
 
 }  // namespace mcp
