@@ -7,13 +7,16 @@
 // the small-tile kernel re-streams Kinv (720 KB per GP at N=300) for every 4 particles and every per-particle
 // phase runs at a fraction of a wave.  Here a 512-thread workgroup owns a 16-particle tile:
 //
-//   K   k[j][p] = k(z_p, X_j)                  wave w <-> particles (2w, 2w+1), lanes <-> j, X_j read once per lane
+//   pol u = u_max tanh(W (phi o mask)/u_max)    squared distances in the reference's expanded form: the cross term is a
+//                                              [16 x PF] x [PF x 16] MFMA product per 16 basis functions; W phi is folded in
+//   K   k[j][p] = k(z_p, X_j)                  same product against 16 training points per tile ([16 x D] x [D x 16]), also
+//                                              for the bilinear forms of the polynomial kernel; 4 exp() per lane and tile
 //   V   v = Kinv k  ([N x N] x [N x 16])       v_mfma_f64_16x16x4_f64: A = 32x4 panel of Kinv (one 16-byte load per
 //                                              lane feeds two MFMAs: even / odd rows), B = k[j..j+3][0..15] from LDS;
 //                                              32-row blocks are dealt to the 8 waves, accumulators stay in registers
 //                                              and overwrite k in LDS once every wave is done reading it
 //   J   R = [X^T;1] W  ((D+1) x N x 16*ncol)   the moment / Jacobian sums as one skinny matrix product per GP, the 8
-//                                              waves split N and add their partial tiles through LDS in a fixed order
+//                                              waves split N, their partial tiles meet in LDS slots and are added once
 //   F   mu, var, d mu/dz, d var/dz from R; sample; fold the sampling into d delta/dz; integrate
 //
 // GPs are processed one after the other (k and v panels of one GP: 2 x N x 18 doubles of LDS).  Polynomial kernel
