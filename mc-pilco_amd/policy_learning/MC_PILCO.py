@@ -11,7 +11,9 @@ Additions (all optional): ``noise_mode`` -- "philox" (in-kernel generator, defau
 CPU with the reference's torch calls in its order, for seed-for-seed parity); ``shard_particles(group)`` -- split the
 particles over the ranks of a torch.distributed group (one all-gather of cost moments and one all-reduce of the
 policy gradient per optimizer step; every rank then applies the identical update).
-Out of scope: MC_PILCO4PMS, MC_PILCO_Experiment, MuJoCo environments.
+``MC_PILCO4PMS`` (MC_PILCO.py:755-958, partially measurable systems) is provided on the step-wise HIP operators (posterior
+and policy launches per time step, the measurement filter in torch on the device); its rollout is not fused yet.
+Out of scope: MC_PILCO_Experiment, MuJoCo environments.
 """
 import copy
 import pickle as pkl
@@ -395,3 +397,100 @@ class MC_PILCO(torch.nn.Module):
         with torch.no_grad():
             for k in range(ml.num_gp):
                 ml.pretrain_gp(k)
+
+
+class MC_PILCO4PMS(MC_PILCO):
+    """MC-PILCO for partially measurable systems -- drop-in for ``MC_PILCO4PMS`` (MC_PILCO.py:755-958).
+
+    Particles evolve on their true states; the policy is evaluated on a simulated *measurement*: positions plus Gaussian
+    noise, velocities by backward difference of the noisy positions, smoothed online by a first-order Butterworth filter
+    (``filtering_dict["fc"]``).  The rollout runs step by step on the HIP operators (``mcp_posterior_fwd`` for the GP
+    moments, the T=1 policy launch) with the filter as torch device ops, so autograd supplies the adjoint of the filter;
+    fusing it into the rollout kernels is listed as next work in DESIGN.md.
+    """
+
+    def __init__(self, T_sampling, state_dim, input_dim, f_sim, f_model_learning, model_learning_par, f_rand_exploration_policy,
+                 rand_exploration_policy_par, f_control_policy, control_policy_par, f_cost_function, cost_function_par, pos_indeces,
+                 vel_indeces, std_meas_noise=None, log_path=None, filtering_dict={}, std_meas_noise_sim=None, dtype=torch.float64,
+                 device=torch.device("cuda")):
+        super().__init__(T_sampling=T_sampling, state_dim=state_dim, input_dim=input_dim, f_sim=f_sim, f_model_learning=f_model_learning,
+                         model_learning_par=model_learning_par, f_rand_exploration_policy=f_rand_exploration_policy,
+                         rand_exploration_policy_par=rand_exploration_policy_par, f_control_policy=f_control_policy,
+                         control_policy_par=control_policy_par, f_cost_function=f_cost_function, cost_function_par=cost_function_par,
+                         std_meas_noise=std_meas_noise, log_path=log_path, dtype=dtype, device=device)
+        self.system = _sim.PMS_Model(f_sim, filtering_dict)
+        self.filtering_dict = filtering_dict
+        self.pos_indeces = pos_indeces
+        self.vel_indeces = vel_indeces
+        # (the reference leaves the attribute unset when a value is passed, MC_PILCO.py:802-803; here it is always defined)
+        self.std_meas_noise_sim = std_meas_noise if std_meas_noise_sim is None else std_meas_noise_sim
+
+    def apply_policy(self, particles_initial_state_mean, particles_initial_state_var, flg_particles_init_uniform, particles_init_up_bound,
+                     particles_init_low_bound, flg_particles_init_multi_gauss, num_particles, T_control, p_dropout=0.0):
+        from scipy import signal
+
+        world, rank = self._world()
+        self._shard = sharding.shard_range(int(num_particles), world, rank)
+        self._m_total = int(num_particles)
+        M, T = self._shard[1], int(T_control)
+        pol, ml = self.control_policy, self.model_learning
+        ref = self.noise_mode == "reference"  # draw on the CPU with the reference's calls, in its order
+        ndev = torch.device("cpu") if ref else self.device
+        x = self.sample_initial_particles(particles_initial_state_mean, particles_initial_state_var, flg_particles_init_uniform,
+                                          particles_init_up_bound, particles_init_low_bound, flg_particles_init_multi_gauss, M)
+        b, a = signal.butter(1, self.filtering_dict["fc"])
+        pos, vel = list(self.pos_indeces), list(self.vel_indeces)
+        std_pos = torch.tensor(np.asarray(self.std_meas_noise_sim)[pos], dtype=self.dtype, device=self.device)
+        saved_mode = getattr(pol, "noise_mode", None)
+        if ref and saved_mode is not None:
+            pol.noise_mode = "torch_cpu"
+        try:
+            xs = [x]
+            noisy_prev, meas_prev = x, x
+            us = [pol(x, t=0, p_dropout=p_dropout)]
+            for t in range(1, T):
+                _, _, mean_list, var_list = ml.get_one_step_gp_out(states=xs[-1], inputs=us[-1])
+                var_list = [v * ml.norm_list[i] ** 2 for i, v in enumerate(var_list)]
+                mean, var = torch.cat(mean_list, 1), torch.cat(var_list, 1)
+                eps = torch.empty(M, ml.num_gp, dtype=self.dtype, device=ndev).normal_().to(self.device)
+                delta = mean + torch.sqrt(var) * eps
+                x, _, _ = ml.get_next_state_from_gp_output(current_state=xs[-1], current_input=us[-1],
+                                                           gp_output_mean_list=[delta[:, g:g + 1] for g in range(ml.num_gp)],
+                                                           gp_output_var_list=var_list, particle_pred=False)
+                xs.append(x)
+                n = torch.randn(M, len(pos), dtype=self.dtype, device=ndev).to(self.device)
+                noisy = x.clone()
+                noisy[:, pos] = noisy[:, pos] + std_pos * n
+                noisy[:, vel] = (noisy[:, pos] - noisy_prev[:, pos]) / self.T_sampling
+                meas = noisy.clone()
+                meas[:, vel] = (b[0] * noisy[:, vel] + b[1] * noisy_prev[:, vel] - a[1] * meas_prev[:, vel]) / a[0]
+                us.append(pol(meas, t=t, p_dropout=p_dropout))
+                noisy_prev, meas_prev = noisy, meas
+        finally:
+            if saved_mode is not None:
+                pol.noise_mode = saved_mode
+        return torch.stack(xs), torch.stack(us)
+
+    def get_data_from_system(self, initial_state, T_exploration, trial_index, flg_exploration=False):
+        policy = self.rand_exploration_policy if flg_exploration else self.control_policy
+        meas, inputs, clean, noisy = self.system.rollout(s0=initial_state, policy=policy.get_np_policy(), T=T_exploration, dt=self.T_sampling,
+                                                         noise=self.std_meas_noise, vel_indeces=self.vel_indeces, pos_indeces=self.pos_indeces)
+        states, meas, inputs, clean, noisy = self.get_velocities(meas, inputs, clean, noisy)
+        self.state_samples_history.append(states)
+        self.input_samples_history.append(inputs)
+        self.noiseless_states_history.append(clean)
+        self.num_data_collection += 1
+        self.model_learning.add_data(new_state_samples=states, new_input_samples=inputs)
+
+    def get_velocities(self, meas_states, input_samples, noiseless_samples, noisy_samples):
+        """Offline filtering of the collected data for model learning (MC_PILCO.py:938-958): zero-phase second-order Butterworth
+        on the positions, central-difference velocities, first and last sample dropped."""
+        from scipy import signal
+
+        states = np.zeros([noisy_samples.shape[0] - 2, noisy_samples.shape[1]])
+        bb, aa = signal.butter(2, 0.5)
+        for i in range(len(self.pos_indeces)):
+            pos = signal.filtfilt(bb, aa, noisy_samples[:, self.pos_indeces[i]])
+            states[:, self.pos_indeces[i]] = pos[1:-1]
+            states[:, self.vel_indeces[i]] = (pos[2:] - pos[:-2]) / (2 * self.T_sampling)
+        return states, meas_states[1:-1, :], input_samples[1:-1, :], noiseless_samples[1:-1, :], noisy_samples[1:-1, :]

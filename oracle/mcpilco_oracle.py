@@ -379,6 +379,58 @@ def apply_policy(
     return torch.stack(xs), torch.stack(us)
 
 
+def butter1(fc: float):
+    """First-order digital Butterworth low-pass, cutoff ``fc`` as a fraction of Nyquist (what ``scipy.signal.butter(1, fc)``
+    returns, MC_PILCO.py:859): bilinear transform of 1/(s+1) pre-warped to tan(pi fc / 2)."""
+    import math
+    w = math.tan(math.pi * fc / 2.0)
+    return [w / (1.0 + w), w / (1.0 + w)], [1.0, (w - 1.0) / (w + 1.0)]
+
+
+def apply_policy_pms(
+    m: SpeedModel,
+    pp: PolicyPar,
+    x0: torch.Tensor,
+    T: int,
+    pos: Sequence[int],
+    vel: Sequence[int],
+    std_pos: torch.Tensor,
+    fc: float,
+    p_drop: float = 0.0,
+    eps: Optional[torch.Tensor] = None,
+    masks: Optional[torch.Tensor] = None,
+    pos_noise: Optional[torch.Tensor] = None,
+):
+    """policy_learning/MC_PILCO.py:808-906 (MC_PILCO4PMS.apply_policy, the T-loop after x0 has been sampled).
+
+    The particles evolve on their true states; the policy is fed a *measured* state: positions plus Gaussian noise
+    (:881-885), velocities by backward difference of the noisy positions (:888-891) passed through the first-order
+    Butterworth filter (:895-899); at t=0 measured = true (:856).  eps [T-1,M,G], pos_noise [T-1,M,len(pos)] (standard
+    normal, scaled here by std_pos) and masks [T,M,B] are injected; None draws from the torch CPU generator in the
+    reference's order (mask_0; per step: eps_t, position noise, mask_t).
+    """
+    b, a = butter1(fc)
+    Ts = m.Ts
+    pos, vel = list(pos), list(vel)
+    xs = [x0]
+    noisy_prev = x0.clone()
+    meas_prev = x0.clone()
+    us = [policy_forward(pp, meas_prev, 0, None if masks is None else masks[0], p_drop)]
+    for t in range(1, T):
+        e = None if eps is None else eps[t - 1]
+        x, _, _ = next_state(m, xs[-1], us[-1], e, True)
+        xs.append(x)
+        n = torch.randn(x.shape[0], len(pos), dtype=DT) if pos_noise is None else pos_noise[t - 1]
+        noisy = x.clone()
+        noisy[:, pos] = noisy[:, pos] + std_pos * n
+        noisy[:, vel] = (noisy[:, pos] - noisy_prev[:, pos]) / Ts
+        meas = noisy.clone()
+        meas[:, vel] = (b[0] * noisy[:, vel] + b[1] * noisy_prev[:, vel] - a[1] * meas_prev[:, vel]) / a[0]
+        us.append(policy_forward(pp, meas, t, None if masks is None else masks[t], p_drop))
+        noisy_prev, meas_prev = noisy, meas
+    return torch.stack(xs), torch.stack(us)
+
+
 def draw_noise(M: int, S: int, G: int, B: int, T: int, p_drop: float):
     """Draws (eps0 [M,S], eps [T-1,M,G], masks [T,M,B] or None) from the torch CPU generator
     in exactly the order ``MC_PILCO.apply_policy`` consumes it (verified by

@@ -422,6 +422,62 @@ rollout_fixture("rollout_se_long", "se", M=32, Tn=60, p=0.25, seed=106, B=64)
 
 
 # ---------------------------------------------------------------------------------------
+# (8b) MC_PILCO4PMS.apply_policy (MC_PILCO.py:808-906): the policy sees noisy positions, finite-difference velocities
+#      and a first-order Butterworth filter; RNG order: x0, mask_0, then per step eps_t, position noise, mask_t
+# ---------------------------------------------------------------------------------------
+def pms_fixture(name="rollout_pms", M=16, Tn=9, p=0.25, seed=107, B=32):
+    from scipy import signal
+    c = sy.CARTPOLE
+    ml, xtr, utr, sig = build_cartpole_model(100, 0, sod=False)
+    pi = sy.cartpole_policy_init(B=B, seed=6)
+    ppar = dict(state_dim=4, input_dim=1, num_basis=B, angle_indices=np.array([2]), non_angle_indices=np.array([0, 1, 3]),
+                lengthscales_init=pi["lengthscales"], centers_init=pi["centers"], weight_init=pi["weight"], flg_squash=True,
+                u_max=c["u_max"], flg_drop=True, dtype=dtype, device=dev)
+    pos, vel, fc = [0, 2], [1, 3], 0.5
+    std_meas = np.array([0.01, 0.02, 0.015, 0.03])
+    with quiet:
+        obj = RMC.MC_PILCO4PMS(
+            T_sampling=c["Ts"], state_dim=4, input_dim=1, f_sim=lambda y, t, u: None,
+            f_model_learning=lambda **kw: ml, model_learning_par={},
+            f_rand_exploration_policy=RP.Random_exploration,
+            rand_exploration_policy_par=dict(state_dim=4, input_dim=1, u_max=1.0, dtype=dtype, device=dev),
+            f_control_policy=RP.Sum_of_gaussians_with_angles, control_policy_par=ppar, f_cost_function=RC.Cart_pole_cost,
+            cost_function_par=dict(target_state=T(c["cost_target"]), lengthscales=T(c["cost_ls"]), angle_index=2, pos_index=0),
+            pos_indeces=pos, vel_indeces=vel, std_meas_noise=std_meas, log_path=None, filtering_dict={"fc": fc}, dtype=dtype, device=dev)
+    pol = obj.control_policy
+    x0m, x0v = T(c["x0_mean"]), T(np.array([1e-2, 1e-2, 4e-2, 1e-2]))
+    torch.manual_seed(seed)
+    st, inp = obj.apply_policy(particles_initial_state_mean=x0m, particles_initial_state_var=x0v, flg_particles_init_uniform=False,
+                               particles_init_up_bound=None, particles_init_low_bound=None, flg_particles_init_multi_gauss=False,
+                               num_particles=M, T_control=Tn, p_dropout=p)
+    cost, std = obj.cost_function(st, inp, 0)
+    cost.backward()
+    # replay the draw order
+    torch.manual_seed(seed)
+    eps0 = torch.empty(M, 4, dtype=dtype).normal_()
+    masks = [torch.empty(M, 1, B, dtype=dtype).bernoulli_(1 - p).reshape(M, B)]
+    eps, pn = [], []
+    for _ in range(1, Tn):
+        eps.append(torch.empty(M, 2, dtype=dtype).normal_())
+        pn.append(torch.randn(M, len(pos), dtype=dtype))
+        masks.append(torch.empty(M, 1, B, dtype=dtype).bernoulli_(1 - p).reshape(M, B))
+    x0 = x0m.reshape(1, -1) + torch.sqrt(x0v).reshape(1, -1) * eps0
+    assert torch.allclose(x0, st[0].detach(), rtol=0, atol=1e-15), "noise replay does not reproduce the reference's x0"
+    b, a = signal.butter(1, fc)
+    out = dict(states_tr=xtr, inputs_tr=utr, sigma_n=sig, x0_mean=N(x0m), x0_var=N(x0v), x0=N(st[0]), eps=N(torch.stack(eps)),
+               pos_noise=N(torch.stack(pn)), masks=N(torch.stack(masks)).astype(np.uint8), p_drop=p, states=N(st), inputs=N(inp),
+               cost=N(cost), std=N(std), pos_indeces=np.array(pos), vel_indeces=np.array(vel), std_meas_noise=std_meas, fc=fc,
+               butter_b=np.asarray(b), butter_a=np.asarray(a),
+               pol_ls=N(torch.exp(pol.log_lengthscales)), pol_centers=N(pol.centers), pol_weight=N(pol.f_linear.weight),
+               g_log_ls=N(pol.log_lengthscales.grad), g_centers=N(pol.centers.grad), g_weight=N(pol.f_linear.weight.grad))
+    out.update(model_arrays(ml))
+    save(name, **out)
+
+
+pms_fixture()
+
+
+# ---------------------------------------------------------------------------------------
 # (9) multi-Gaussian and uniform initial distributions (indices bit-exact)
 # ---------------------------------------------------------------------------------------
 def init_fixture():

@@ -260,3 +260,42 @@ def test_reinforce_runs_end_to_end():
     for k in ("parameters_gp_0", "gp_inputs_0", "cost_trial_list", "parameters_trial_list", "state_samples_history"):
         assert k in log
     assert len(obj.state_samples_history) == 3  # one exploration + the policy applied after each of the two trials
+
+
+def test_pms_seed_for_seed_parity_with_reference(golden):
+    """MC_PILCO4PMS.apply_policy (MC_PILCO.py:808-906) on the drop-in: same seed, same draws, same trajectories and gradient."""
+    from mc_pilco_amd.policy_learning import MC_PILCO, Cost_function, Policy
+
+    fx = golden("rollout_pms")
+    ml = build_cartpole(fx, 0, False)
+    c = sy.CARTPOLE
+    B = fx["pol_centers"].shape[0]
+    ppar = dict(state_dim=4, input_dim=1, num_basis=B, angle_indices=np.array([2]), non_angle_indices=np.array([0, 1, 3]),
+                lengthscales_init=fx["pol_ls"].reshape(-1), centers_init=fx["pol_centers"], weight_init=fx["pol_weight"], flg_squash=True,
+                u_max=c["u_max"], flg_drop=True, dtype=dtype, device=dev())
+    with quiet():
+        obj = MC_PILCO.MC_PILCO4PMS(T_sampling=c["Ts"], state_dim=4, input_dim=1, f_sim=lambda y, t, u: None, f_model_learning=lambda **kw: ml,
+                                    model_learning_par={}, f_rand_exploration_policy=Policy.Random_exploration,
+                                    rand_exploration_policy_par=dict(state_dim=4, input_dim=1, u_max=1.0, dtype=dtype),
+                                    f_control_policy=Policy.Sum_of_gaussians_with_angles, control_policy_par=ppar,
+                                    f_cost_function=Cost_function.Cart_pole_cost,
+                                    cost_function_par=dict(target_state=T(c["cost_target"]), lengthscales=T(c["cost_ls"]), angle_index=2, pos_index=0),
+                                    pos_indeces=[int(i) for i in fx["pos_indeces"]], vel_indeces=[int(i) for i in fx["vel_indeces"]],
+                                    std_meas_noise=fx["std_meas_noise"], log_path=None, filtering_dict={"fc": float(fx["fc"])}, dtype=dtype,
+                                    device=dev())
+    obj.noise_mode = "reference"
+    M, Tn, p = fx["states"].shape[1], fx["states"].shape[0], float(fx["p_drop"])
+    torch.manual_seed(107)
+    st, inp = obj.apply_policy(particles_initial_state_mean=T(fx["x0_mean"]), particles_initial_state_var=T(fx["x0_var"]),
+                               flg_particles_init_uniform=False, particles_init_up_bound=None, particles_init_low_bound=None,
+                               flg_particles_init_multi_gauss=False, num_particles=M, T_control=Tn, p_dropout=p)
+    cost, std = obj.cost_function(st, inp, 0)
+    cost.backward()
+    assert float((st[0].detach().cpu() - torch.as_tensor(fx["states"][0])).abs().max()) < 1e-15
+    assert float((st.detach().cpu() - torch.as_tensor(fx["states"])).abs().max()) < 1e-8
+    assert float((inp.detach().cpu() - torch.as_tensor(fx["inputs"])).abs().max()) < 1e-8
+    assert abs(float(cost) - float(fx["cost"])) < 1e-10 * abs(float(fx["cost"]))
+    pol = obj.control_policy
+    assert relerr(pol.log_lengthscales.grad, fx["g_log_ls"]) < 1e-7
+    assert relerr(pol.centers.grad, fx["g_centers"]) < 1e-7
+    assert relerr(pol.f_linear.weight.grad, fx["g_weight"]) < 1e-7

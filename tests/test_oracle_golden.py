@@ -154,3 +154,25 @@ def test_initial_distributions(golden):
     r = torch.rand(fx["un_x0"].shape, dtype=torch.float64)
     xu = T(fx["lb"]) + r * (T(fx["ub"]) - T(fx["lb"]))
     assert np.array_equal(xu.numpy(), fx["un_x0"])
+
+
+def test_pms_rollout_cost_gradient(golden):
+    """MC_PILCO4PMS.apply_policy (noisy positions, finite-difference + Butterworth-filtered velocities feed the policy)."""
+    fx = golden("rollout_pms")
+    m = oracle_model(fx, "se", from_cache=True)
+    pp = oracle_policy(fx, "se")
+    for k in ("log_ls", "centers", "weight"):
+        getattr(pp, k).requires_grad_(True)
+    b, a = orc.butter1(float(fx["fc"]))
+    assert np.allclose(b, fx["butter_b"], rtol=1e-14, atol=0) and np.allclose(a, fx["butter_a"], rtol=1e-14, atol=0)
+    pos, vel = [int(i) for i in fx["pos_indeces"]], [int(i) for i in fx["vel_indeces"]]
+    st, inp = orc.apply_policy_pms(m, pp, T(fx["x0"]), fx["states"].shape[0], pos, vel, T(fx["std_meas_noise"][pos]), float(fx["fc"]),
+                                   float(fx["p_drop"]), T(fx["eps"]), T(fx["masks"]), T(fx["pos_noise"]))
+    cost, std = orc.expected_cost(oracle_cost_fn(fx, "se")(st))
+    cost.backward()
+    assert np.max(np.abs(st.detach().numpy() - fx["states"])) < 1e-9
+    assert np.max(np.abs(inp.detach().numpy() - fx["inputs"])) < 1e-9
+    assert abs(float(cost) - float(fx["cost"])) < 1e-11 * abs(float(fx["cost"]))
+    assert relerr(pp.log_ls.grad, fx["g_log_ls"]) < 1e-8
+    assert relerr(pp.centers.grad, fx["g_centers"]) < 1e-8
+    assert relerr(pp.weight.grad, fx["g_weight"]) < 1e-8
