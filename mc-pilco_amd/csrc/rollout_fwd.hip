@@ -57,7 +57,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int 
   L.us = take(P * U);
   L.z = take(P * D);
   L.sf = take(P * PF);
-  L.dl = take(P * G);
+  L.dl = take(2 * P * G);  // delta_g | process noise of the step (drawn in phase S by otherwise idle threads)
   L.kb = take(GB * NpadMax * P);
   L.ks = maxdeg > 0 ? take(GB * NpadMax * P) : L.kb;
   L.pa = maxdeg > 1 ? take(GB * NpadMax * P) : L.kb;
@@ -547,6 +547,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   double* z = smem + L.z;
   double* sf = smem + L.sf;
   double* dl = smem + L.dl;
+  double* epsb = dl + P * G;
   double* kb = smem + L.kb;
   double* ks = smem + L.ks;
   double* pa = smem + L.pa;
@@ -652,6 +653,16 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         sf[op * PF + os] = xn;
       }
     }
+    else if (tid >= 64 && tid < 64 + P * G && t < T - 1) {
+      // wave 1 is idle here: draw the process noise of this step now instead of on phase F's critical path
+      const int e = tid - 64, p = e / G, g = e - p * G;
+      double ev = 0.0;
+      if (a.particle_pred) {
+        const int mm = imin(m0 + p, M - 1);
+        ev = a.nz.eps ? a.nz.eps[((size_t)t * M + mm) * G + g] : philox_normal(a.nz, mm, t, g);
+      }
+      epsb[e] = ev;
+    }
     lds_barrier();
     RF_STAMP(0);
     // ---- phase PHI: phi_b = exp(-sum_q ((s_q - c_bq)/l_q)^2) * keep/(1-p) -------------------------
@@ -736,7 +747,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         var *= vscale;
         double eps = 0.0, wj = 0.0, sd = 0.0;
         if (a.particle_pred) {
-          eps = a.nz.eps ? a.nz.eps[((size_t)t * M + mm) * G + g] : philox_normal(a.nz, mm, t, g);
+          eps = epsb[p * G + g];
           sd = sqrt(var);
           wj = eps / (2.0 * sd);
         }

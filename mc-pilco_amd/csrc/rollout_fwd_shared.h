@@ -96,6 +96,14 @@ __device__ __forceinline__ void stage_gp_tables(const mcp_gp* gps, const double*
 }
 
 
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+// sum over the 4 lanes l, l^16, l^32, l^48 (the 4 feature groups of an MFMA operand column)
+__device__ __forceinline__ double fold_kk(double v) {
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
 // forward rollout with 16 particles per workgroup (rollout_fwd_tile.hip); MCP_ERR_LIMIT when the problem does not fit it
 int launch_fwd_tile(const FwdArgs& a, hipStream_t st);
 bool fwd_tile_fits(const mcp_model* model, const mcp_policy* policy);

@@ -95,11 +95,6 @@ __host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, in
 // |z_p|^2 and |X_j|^2 are partial sums over the lane's own features, folded across the 4 feature lanes by two
 // lane exchanges.  Tiles of 16 training points are dealt round-robin to the 8 waves, the B operands of the next tile
 // are loaded (unconditionally) before the current tile is consumed.
-__device__ __forceinline__ double fold_kk(double v) {  // sum over the 4 lanes l, l^16, l^32, l^48
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
-}
 template <int NDQ>
 __device__ __forceinline__ void tile_k_load(double (&bx)[NDQ], gptr_t Xt, int Npad, int D, int tile, int kk, int n) {
 #pragma unroll
