@@ -173,6 +173,10 @@ def main():
     value = world * M * T / (el / args.steps)
 
     if rank == 0:
+        from mc_pilco_amd import hipabi
+
+        # which forward kernel the library dispatched (16 particles per workgroup = the MFMA tile kernel, M > 1024)
+        fwd_kernel_name = "rollout_fwd_tile_kernel" if hipabi.lib().mcp_debug_last_particles_per_wg() == 16 else "rollout_fwd_kernel"
         F = workloads.flops_per_particle_step(w)
         achieved = F * M * T / (fwd_avg_ms * 1e-3) / 1e12
         out = {
@@ -186,7 +190,7 @@ def main():
                                                             w.p_drop, " + RCCL all-reduce" if world > 1 else ""),
                        "particles_per_gpu": M, "horizon": T, "parallelism": "particle-dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                         "traffic": None, "kernel": "rollout_fwd_kernel", "kernel_ms": fwd_avg_ms,
+                         "traffic": None, "kernel": fwd_kernel_name, "kernel_ms": fwd_avg_ms,
                          "alg_flops_per_particle_step": F, "units_per_launch": M * T},
             "final_cost": float(last_cost),
         }
