@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--horizon", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--noise", default="philox", choices=["philox", "buffers"])
+    ap.add_argument("--pms", action="store_true", help="partially measurable system: the policy sees noisy positions and filtered "
+                    "finite-difference velocities (MC_PILCO4PMS.apply_policy); cart-pole workloads")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -114,6 +116,12 @@ def main():
 
     w = workloads.build(args.workload, device=dev, M=args.particles or None, T=args.horizon or None)
     M, T = w.M, w.T
+    meas = None
+    if args.pms:
+        from scipy import signal
+
+        bb, aa = signal.butter(1, 0.5)  # test_mcpilco4pms_cartpole.py:155-157: pos [0,2], vel [1,3], fc 0.5
+        meas = ops.MeasSpec(pos=[0, 2], vel=[1, 3], std_pos=[0.01, 0.01], b=bb, a=aa)
     opt = torch.optim.Adam(w.params, lr=0.01)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -134,7 +142,7 @@ def main():
             p.grad = None
         if ev is not None:
             ev[0].record()
-        states, inputs, status = ops.rollout(w.model, w.policy, nz, x0, T, w.p_drop)
+        states, inputs, status = ops.rollout(w.model, w.policy, nz, x0, T, w.p_drop, meas=meas)
         if ev is not None:
             ev[1].record()
         cost, std = ops.expected_cost(w.cost, states, group)
@@ -186,8 +194,9 @@ def main():
             "data": "synthetic (RK4 cart-pole rollouts, N=%d training points/GP, fixed trained-like hyper-parameters, on-device %s noise)"
                     % (w.model.gps[0].N, "Philox" if args.noise == "philox" else "torch.randn buffers"),
             "config": {"workload": "%s: %s, %d GPs, D=%d, N=%d, B=%d, M=%d particles/GPU, T=%d, p_dropout=%.2f; step = rollout fwd + cost + "
-                                   "adjoint bwd%s + Adam" % (args.workload, w.problem["system"], w.model.G, w.model.D, w.model.gps[0].N, w.policy.B, M, T,
-                                                            w.p_drop, " + RCCL all-reduce" if world > 1 else ""),
+                                   "adjoint bwd%s + Adam%s" % (args.workload, w.problem["system"], w.model.G, w.model.D, w.model.gps[0].N, w.policy.B, M, T,
+                                                            w.p_drop, " + RCCL all-reduce" if world > 1 else "",
+                                                            "; policy on measured states (MC_PILCO4PMS)" if args.pms else ""),
                        "particles_per_gpu": M, "horizon": T, "parallelism": "particle-dp%d" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
                          "traffic": None, "kernel": fwd_kernel_name, "kernel_ms": fwd_avg_ms,

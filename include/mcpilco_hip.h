@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCP_ABI_VERSION 1
+#define MCP_ABI_VERSION 2
 
 #define MCP_OK 0
 #define MCP_ERR_ARG (-1)       /* null pointer / non-positive size                       */
@@ -100,6 +100,22 @@ typedef struct mcp_model {
 #define MCP_POLICY_ANGLES 1 /* Sum_of_gaussians_with_angles            Policy.py:268-335  s=[x_na,cos,sin] */
 #define MCP_POLICY_TRAJ 2   /* Sum_of_gaussians_with_target_trajectory Policy.py:338-403  s=[x, x*_t-x]    */
 
+/* Measurement model of MC_PILCO4PMS.apply_policy (policy_learning/MC_PILCO.py:808-906): the particles evolve on their true
+ * states, the policy is evaluated on a simulated measurement -- positions plus Gaussian noise (:881-885), velocities by
+ * backward difference of the noisy positions (:888-891) passed through the first-order filter (b0 nv_t + b1 nv_{t-1} -
+ * a1 mv_{t-1}) / a0 (:895-899); at t = 0 the measurement is the true state (:856).  n == 0: the policy sees the true state
+ * (MC_PILCO.apply_policy). */
+typedef struct mcp_meas {
+  int32_t n;                      /* (position, velocity) pairs                                        */
+  int32_t pos[MCP_MAX_STATE];     /* pos_indeces                                                       */
+  int32_t vel[MCP_MAX_STATE];     /* vel_indeces                                                       */
+  double std_pos[MCP_MAX_STATE];  /* std of the position measurement noise, std_meas_noise_sim[pos]    */
+  double b0, b1, a0, a1;          /* scipy.signal.butter(1, fc)                                        */
+  const double* pos_noise;        /* [T-1][M][n] standard normals (step t at row t-1), or NULL: Philox  */
+  double* meas;                   /* [T][M][S] measured states: written by mcp_rollout_fwd, read by
+                                     mcp_rollout_bwd (caller-owned, required when n > 0)               */
+} mcp_meas;
+
 typedef struct mcp_policy {
   int32_t kind;
   int32_t S;              /* state dim of the system                                   */
@@ -116,6 +132,7 @@ typedef struct mcp_policy {
   const double* weight;   /* [U][B]  f_linear.weight (no bias)                         */
   const double* u_max;    /* [U]                                                       */
   const double* target_traj; /* [traj_len][S] or NULL                                  */
+  mcp_meas meas;          /* what the policy is evaluated on (n == 0: the true state)  */
 } mcp_policy;
 
 /* Where the rollout's random numbers come from.  Parity mode: the host draws them with the

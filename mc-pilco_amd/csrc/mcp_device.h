@@ -120,6 +120,7 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
 
 #define MCP_STREAM_EPS 0u
 #define MCP_STREAM_MASK 1u
+#define MCP_STREAM_POS 2u  // position measurement noise of the partially-measurable-system rollout
 
 __device__ __forceinline__ u32x4 philox_draw(const mcp_noise& nz, int64_t particle, int t, uint32_t stream, uint32_t index) {
   uint64_t gp = (uint64_t)(particle + nz.particle_offset);
@@ -134,8 +135,8 @@ __device__ __forceinline__ u32x4 philox_draw(const mcp_noise& nz, int64_t partic
 }
 
 // standard normal for (particle, t, gp index g): Box-Muller on two 52-bit uniforms
-__device__ __forceinline__ double philox_normal(const mcp_noise& nz, int64_t particle, int t, int g) {
-  u32x4 r = philox_draw(nz, particle, t, MCP_STREAM_EPS, (uint32_t)g);
+__device__ __forceinline__ double philox_normal(const mcp_noise& nz, int64_t particle, int t, int g, uint32_t stream = MCP_STREAM_EPS) {
+  u32x4 r = philox_draw(nz, particle, t, stream, (uint32_t)g);
   const double two_m52 = 2.220446049250313e-16;
   double u1 = ((double)(((uint64_t)r.x << 20) | (r.y >> 12)) + 0.5) * two_m52;  // (0,1)
   double u2 = ((double)(((uint64_t)r.z << 20) | (r.w >> 12)) + 0.5) * two_m52;

@@ -43,11 +43,11 @@ struct BwdArgs {
   } while (0)
 
 struct BwdLayout {
-  int invl, rec, xn, xb, zb, db, ab, sf, sb, sn, cs, red, itab, total;
+  int invl, rec, xn, xb, zb, db, ab, sf, sb, sn, cs, snm, csm, cmv, cnv, nvx, red, itab, total;
   int pstride;  // doubles between the per-particle copies of xn..cs
 };
-__host__ __device__ inline int bwd_rec_len(int S, int U, int D, int G) { return 2 * S + 2 * U + G * D; }
-__host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int PF, int NW, int PB) {
+__host__ __device__ inline int bwd_rec_len(int S, int U, int D, int G, bool pms = false) { return 2 * S + 2 * U + G * D + (pms ? S : 0); }
+__host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int PF, int NW, int PB, bool pms = false) {
   BwdLayout L;
   int o = 0;
   auto take = [&](int n) {
@@ -56,7 +56,7 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
     return r;
   };
   L.invl = take(PF);
-  L.rec = take(2 * PB * bwd_rec_len(S, U, D, G));
+  L.rec = take(2 * PB * bwd_rec_len(S, U, D, G, pms));
   // per-particle working set of the serial section (particle p at + p * pstride)
   const int o0 = o;
   L.xn = take(S);
@@ -68,6 +68,11 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
   L.sb = take(PF);
   L.sn = take(S);
   L.cs = take(S);
+  L.snm = take(pms ? S : 0);  // trig of the measured angles (policy features of a partially measurable system)
+  L.csm = take(pms ? S : 0);
+  L.cmv = take(pms ? S : 0);  // adjoints carried backward through the velocity filter: filtered / finite-difference velocity
+  L.cnv = take(pms ? S : 0);
+  L.nvx = take(pms ? S : 0);  // hand-over of d/d(noisy velocity) from a velocity lane to its position lane
   L.pstride = o - o0;
   o = o0 + PB * L.pstride;
   L.red = take(PB * NW * PF);
@@ -96,8 +101,10 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   const int tid = threadIdx.x, NT = blockDim.x, NW = NT >> 6, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
-  const BwdLayout L = bwd_layout(S, U, D, G, PF, NW, PB);
-  const int NR = bwd_rec_len(S, U, D, G);
+  const mcp_meas& ms = pl.meas;
+  const bool pms = ms.n > 0;
+  const BwdLayout L = bwd_layout(S, U, D, G, PF, NW, PB, pms);
+  const int NR = bwd_rec_len(S, U, D, G, pms);
   const int PS = L.pstride;
   const int sp = wv < PB ? wv : 0;  // the particle slot whose serial chain this wave runs
   double* invl = smem + L.invl;
@@ -111,6 +118,11 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   volatile double* sb = smem + L.sb + sp * PS;
   volatile double* sn = smem + L.sn + sp * PS;
   volatile double* cs = smem + L.cs + sp * PS;
+  volatile double* snm = pms ? smem + L.snm + sp * PS : sn;  // measured angles' trig (== sn/cs without a measurement model)
+  volatile double* csm = pms ? smem + L.csm + sp * PS : cs;
+  volatile double* cmv = smem + L.cmv + sp * PS;
+  volatile double* cnv = smem + L.cnv + sp * PS;
+  volatile double* nvx = smem + L.nvx + sp * PS;
   const volatile double* sf_all = smem + L.sf;  // particle p at + p * PS
   const volatile double* ab_all = smem + L.ab;
   volatile double* red = smem + L.red;  // [PB][NW][PF]
@@ -127,6 +139,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   const uint32_t drop_thr = drop_threshold(pl.p_drop);
   const int nna_g = md.n_not_angle, na_g = md.n_angle;
   const int oX = 0, oU = S, oGX = S + U, oGU = 2 * S + U, oJ = 2 * S + 2 * U;
+  const int oM = pms ? oJ + G * D : oX;  // measured state (what the policy was evaluated on)
 
   for (int it = tid; it < PF; it += NT) invl[it] = exp(-pl.log_ls[it]);
   if (tid == 0) {
@@ -173,6 +186,14 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       if (md.not_vel[g] == lane) g_pos = g;
     }
   }
+  int pm_pos = -1, pm_vel = -1;  // measurement model: index of this lane's state in pos_indeces / vel_indeces
+  if (pms && serial && lane < S) {
+    for (int i = 0; i < ms.n; ++i) {
+      if (ms.pos[i] == lane) pm_pos = i;
+      if (ms.vel[i] == lane) pm_vel = i;
+    }
+  }
+  const double pm_a = pms ? -ms.a1 / ms.a0 : 0.0, pm_b0 = pms ? ms.b0 / ms.a0 : 0.0, pm_b1 = pms ? ms.b1 / ms.a0 : 0.0;
   int pos_of_vel = 0;  // the position state integrated from this lane's velocity state
   for (int g = 0; g < G; ++g)
     if (md.vel[g] == lane) pos_of_vel = md.not_vel[g];
@@ -198,8 +219,10 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
           v = a.g_states ? a.g_states[tm * S + (i - oGX)] : 0.0;
         else if (i < oJ)
           v = a.g_inputs ? a.g_inputs[tm * U + (i - oGU)] : 0.0;
-        else if (t < T - 1)
-          v = a.jac[tm * G * D + (i - oJ)];
+        else if (i < oJ + G * D)
+          v = (t < T - 1) ? a.jac[tm * G * D + (i - oJ)] : 0.0;
+        else
+          v = ms.meas[tm * S + (i - oJ - G * D)];
       }
       pre[k] = v;
     }
@@ -212,12 +235,40 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     }
   };
 
+  // Adjoint of the measurement model (MC_PILCO.py:881-899) at step tt, lane = state index.  In: s = dJ/d(measured state);
+  // out: the part of dJ/dx_tt that flows through the measurement.  With mv_t = (b0 nv_t + b1 nv_{t-1} - a1 mv_{t-1})/a0 and
+  // nv_t = (np_t - np_{t-1})/Ts, np_t = x_t[pos] + noise:   mvb_t = s_vel - a1/a0 mvb_{t+1};   nvb_t = b0/a0 mvb_t + b1/a0 mvb_{t+1};
+  // x_t[pos] gets s_pos + (nvb_t - nvb_{t+1})/Ts, x_t[vel] nothing -- except at t = 0, where the measurement is the true
+  // state: x_0[vel] gets mvb_0 + b1/a0 mvb_1 and x_0[pos] gets s_pos - nvb_1/Ts.  cmv / cnv carry mvb_{t+1}, nvb_{t+1}.
+  auto meas_adjoint = [&](double s_in, int tt) -> double {
+    double sx = s_in, mvb = 0.0, nvb = 0.0;
+    if (pm_vel >= 0) {
+      const double c1 = cmv[pm_vel];
+      mvb = fma(pm_a, c1, s_in);
+      nvb = tt >= 1 ? fma(pm_b0, mvb, pm_b1 * c1) : 0.0;
+      sx = tt == 0 ? fma(pm_b1, c1, mvb) : 0.0;
+      nvx[pm_vel] = nvb;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (pm_pos >= 0) sx = s_in + (nvx[pm_pos] - cnv[pm_pos]) / md.Ts;
+    __builtin_amdgcn_wave_barrier();
+    if (pm_vel >= 0) {
+      cmv[pm_vel] = mvb;
+      cnv[pm_vel] = nvb;
+    }
+    return sx;
+  };
+
   unsigned long long last_stamp = clock64();
   for (int mbase = blockIdx.x * PB; mbase < M; mbase += gridDim.x * PB) {
     const int msp = imin(mbase + sp, M - 1);  // particle of this wave's serial chain
     const bool spvalid = mbase + sp < M;
     double pre[BW_RPT];
     int cur = 0;
+    if (pms && serial && lane < S) {
+      cmv[lane] = 0.0;
+      cnv[lane] = 0.0;
+    }
     prefetch(pre, T - 1, mbase);
     park(pre, cur);
     lds_barrier();
@@ -241,12 +292,13 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
             double s;
             if (pl.kind == MCP_POLICY_ANGLES) {
               s = (pi_plain >= 0) ? sb[pi_plain] : 0.0;
-              if (pi_ang >= 0) s += -sb[pl.n_non_angle + pi_ang] * sn[lane] + sb[pl.n_non_angle + pl.n_angle + pi_ang] * cs[lane];
+              if (pi_ang >= 0) s += -sb[pl.n_non_angle + pi_ang] * snm[lane] + sb[pl.n_non_angle + pl.n_angle + pi_ang] * csm[lane];
             } else if (pl.kind == MCP_POLICY_TRAJ) {
               s = sb[lane] - sb[S + lane];
             } else {
               s = sb[lane];
             }
+            if (pms) s = meas_adjoint(s, t + 1);
             xn[lane] = xb[lane] + s;
           }
           __builtin_amdgcn_wave_barrier();
@@ -259,6 +311,12 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
           sincos(r[oX + lane], &sv, &cv);
           sn[lane] = sv;
           cs[lane] = cv;
+        }
+        if (pms && lane < S && pi_ang >= 0) {
+          double sv, cv;
+          sincos(r[oM + lane], &sv, &cv);
+          snm[lane] = sv;
+          csm[lane] = cv;
         }
         __builtin_amdgcn_wave_barrier();
         // through the GP Jacobian and the integrator's direct paths
@@ -282,15 +340,15 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
           if (pl.kind == MCP_POLICY_ANGLES) {
             const int pn = pl.n_non_angle, pa_ = pl.n_angle;
             if (lane < pn)
-              f = r[oX + t_pna[lane]];
+              f = r[oM + t_pna[lane]];
             else if (lane < pn + pa_)
-              f = cs[t_pan[lane - pn]];
+              f = csm[t_pan[lane - pn]];
             else
-              f = sn[t_pan[lane - pn - pa_]];
+              f = snm[t_pan[lane - pn - pa_]];
           } else if (pl.kind == MCP_POLICY_TRAJ) {
-            f = (lane < S) ? r[oX + lane] : pl.target_traj[(size_t)t * S + (lane - S)] - r[oX + lane - S];
+            f = (lane < S) ? r[oM + lane] : pl.target_traj[(size_t)t * S + (lane - S)] - r[oM + lane - S];
           } else {
-            f = r[oX + lane];
+            f = r[oM + lane];
           }
           sf[lane] = f;
         }
@@ -412,12 +470,13 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         double s;
         if (pl.kind == MCP_POLICY_ANGLES) {
           s = (pi_plain >= 0) ? sb[pi_plain] : 0.0;
-          if (pi_ang >= 0) s += -sb[pl.n_non_angle + pi_ang] * sn[lane] + sb[pl.n_non_angle + pl.n_angle + pi_ang] * cs[lane];
+          if (pi_ang >= 0) s += -sb[pl.n_non_angle + pi_ang] * snm[lane] + sb[pl.n_non_angle + pl.n_angle + pi_ang] * csm[lane];
         } else if (pl.kind == MCP_POLICY_TRAJ) {
           s = sb[lane] - sb[S + lane];
         } else {
           s = sb[lane];
         }
+        if (pms) s = meas_adjoint(s, 0);
         if (a.g_x0 && spvalid) a.g_x0[(size_t)msp * S + lane] = xb[lane] + s;
       }
     }
@@ -495,9 +554,10 @@ template <int PFM, int UM, int MAXNT, int WPE, int PB>
 static int launch_bwd(const BwdArgs& a, int NT, hipStream_t st) {
   if (NT > MAXNT || NT < 64 * PB) return MCP_ERR_LIMIT;
   const mcp_model& md = a.model;
-  if (PB * bwd_rec_len(md.S, md.U, md.D, md.G) > BW_RPT * NT) return MCP_ERR_LIMIT;
+  const bool pms = a.pol.meas.n > 0;
+  if (PB * bwd_rec_len(md.S, md.U, md.D, md.G, pms) > BW_RPT * NT) return MCP_ERR_LIMIT;
   const int grid = imin((a.M + PB - 1) / PB, 1024);
-  BwdLayout L = bwd_layout(md.S, md.U, md.D, md.G, a.pol.P, NT / 64, PB);
+  BwdLayout L = bwd_layout(md.S, md.U, md.D, md.G, a.pol.P, NT / 64, PB, pms);
   const size_t lds = sizeof(double) * (size_t)L.total;
   hipLaunchKernelGGL((rollout_bwd_kernel<PFM, UM, MAXNT, WPE, PB>), dim3(grid), dim3(NT), lds, st, a);
   MCP_LAUNCH_CHECK();
@@ -510,6 +570,7 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
                                void* workspace, size_t workspace_bytes, void* stream) {
   if (!noise || !states || !inputs || !g_log_ls || !g_centers || !g_weight || !workspace || !policy || M <= 0 || T <= 0) return MCP_ERR_ARG;
   if (T > 1 && !jac) return MCP_ERR_ARG;
+  if (policy->meas.n > 0 && !policy->meas.meas) return MCP_ERR_ARG;
   mcp_model stub;
   if (!model) {
     if (T != 1) return MCP_ERR_ARG;

@@ -68,6 +68,10 @@ static inline bool policy_ok(const mcp_policy* p, int S, int U, int T) {
   if (p->B <= 0 || p->B > MCP_MAX_BASIS || p->P <= 0 || p->P > MCP_MAX_PFEAT) return false;
   if (!p->log_ls || !p->centers || !p->weight || !p->u_max) return false;
   if (!(p->p_drop >= 0.0 && p->p_drop < 1.0)) return false;
+  if (p->meas.n < 0 || 2 * p->meas.n > S) return false;
+  for (int i = 0; i < p->meas.n; ++i)
+    if (p->meas.pos[i] < 0 || p->meas.pos[i] >= S || p->meas.vel[i] < 0 || p->meas.vel[i] >= S || p->meas.pos[i] == p->meas.vel[i]) return false;
+  if (p->meas.n > 0 && !(p->meas.a0 != 0.0)) return false;
   if (p->kind == MCP_POLICY_PLAIN) return p->P == S;
   if (p->kind == MCP_POLICY_ANGLES) {
     if (p->n_non_angle + 2 * p->n_angle != p->P) return false;

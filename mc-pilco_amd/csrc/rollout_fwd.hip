@@ -616,6 +616,27 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
     }
   }
   const int pol_nna = pl.n_non_angle, pol_na = pl.n_angle;
+  // partially measurable system (MC_PILCO4PMS.apply_policy, MC_PILCO.py:808-906): the policy sees a measured state.  Thread (p, s)
+  // produces the measurement of its own component; a velocity thread rebuilds the noisy position of its pair (same draw) and
+  // carries the previous noisy position, noisy velocity and filtered velocity.
+  const mcp_meas& ms = pl.meas;
+  const bool pms = ms.n > 0;
+  int pm_pos = -1, pm_vel = -1, pm_pairlane = lane;
+  double pm_std = 0.0;  // (looked up here with a uniform index: per-lane indexing of the by-value argument would spill it)
+  if (pms && own) {
+    for (int i = 0; i < ms.n; ++i) {
+      if (ms.pos[i] == os) {
+        pm_pos = i;
+        pm_std = ms.std_pos[i];
+      }
+      if (ms.vel[i] == os) {
+        pm_vel = i;
+        pm_pairlane = op * S + ms.pos[i];
+        pm_std = ms.std_pos[i];
+      }
+    }
+  }
+  double pm_prev_np = 0.0, pm_prev_nv = 0.0, pm_prev_mv = 0.0;
   int vel_of_pos = 0;
   for (int g = 0; g < G; ++g)
     if (own && md.not_vel[g] == os) vel_of_pos = md.vel[g];
@@ -624,15 +645,43 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
 
   for (int t = 0; t < T; ++t) {
     // ---- phase S: publish x_t and everything derived from a single state component --------------
+    double xm = xn;  // what the policy sees of this component
+    if (pms && wv == 0) {
+      const double xpair = __shfl(xn, pm_pairlane);  // all of wave 0 takes part (the state threads live in it)
+      if (own) {
+        const int pi = pm_pos >= 0 ? pm_pos : pm_vel;
+        double npos = pm_pos >= 0 ? xn : xpair;
+        if (pi >= 0 && t > 0) {
+          const double nn = ms.pos_noise ? ms.pos_noise[((size_t)(t - 1) * M + om) * ms.n + pi] : philox_normal(a.nz, om, t, pi, MCP_STREAM_POS);
+          npos = fma(pm_std, nn, npos);
+        }
+        if (pm_pos >= 0) xm = npos;
+        if (pm_vel >= 0) {
+          if (t == 0) {
+            pm_prev_nv = xn;
+            pm_prev_mv = xn;
+          } else {
+            const double nv = (npos - pm_prev_np) / Ts;
+            xm = (ms.b0 * nv + ms.b1 * pm_prev_nv - ms.a1 * pm_prev_mv) / ms.a0;
+            pm_prev_nv = nv;
+            pm_prev_mv = xm;
+          }
+          pm_prev_np = npos;
+        }
+      }
+    }
     if (own) {
       double* xc = xs + cur * P * S;
       xc[op * S + os] = xn;
       if (ovalid) {
         a.states[((size_t)t * M + m0 + op) * S + os] = xn;
-        if (is_bad(xn)) bad |= MCP_STATUS_NAN;
+        if (pms) ms.meas[((size_t)t * M + m0 + op) * S + os] = xm;
+        if (is_bad(xn) || is_bad(xm)) bad |= MCP_STATUS_NAN;
       }
       double sn = 0.0, cs = 0.0;
       if (zi_ang >= 0 || pi_ang >= 0) sincos(xn, &sn, &cs);
+      double snm = sn, csm = cs;  // trig of the measured value (policy features)
+      if (pms && pi_ang >= 0 && xm != xn) sincos(xm, &snm, &csm);
       // GP input z = [x[not_angle], sin x[angle], cos x[angle], u]   (Model_learning.py:670-683)
       if (zi_plain >= 0) z[op * D + zi_plain] = xn;
       if (zi_ang >= 0) {
@@ -641,16 +690,16 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       }
       // policy features (Policy.py:326-333: [x_nonangle, COS, SIN];  :397-399: [x, x*_t - x])
       if (pl.kind == MCP_POLICY_ANGLES) {
-        if (pi_plain >= 0) sf[op * PF + pi_plain] = xn;
+        if (pi_plain >= 0) sf[op * PF + pi_plain] = xm;
         if (pi_ang >= 0) {
-          sf[op * PF + pol_nna + pi_ang] = cs;
-          sf[op * PF + pol_nna + pol_na + pi_ang] = sn;
+          sf[op * PF + pol_nna + pi_ang] = csm;
+          sf[op * PF + pol_nna + pol_na + pi_ang] = snm;
         }
       } else if (pl.kind == MCP_POLICY_TRAJ) {
-        sf[op * PF + os] = xn;
-        sf[op * PF + S + os] = pl.target_traj[(size_t)t * S + os] - xn;
+        sf[op * PF + os] = xm;
+        sf[op * PF + S + os] = pl.target_traj[(size_t)t * S + os] - xm;
       } else {
-        sf[op * PF + os] = xn;
+        sf[op * PF + os] = xm;
       }
     }
     else if (tid >= 64 && tid < 64 + P * G && t < T - 1) {
@@ -952,9 +1001,11 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   // configuration search: most particles per workgroup first, operands in LDS if they fit, all GPs per pass if they fit
   int P0 = g_force_ppw ? g_force_ppw : pick_particles_per_wg(M);
   if (P0 != 1 && P0 != 2 && P0 != 4 && P0 != 16) return MCP_ERR_ARG;
+  if (policy->meas.n > 0 && !policy->meas.meas) return MCP_ERR_ARG;
   if (P0 == 16) {
     // large swarms: 16-particle tiles on the matrix cores (rollout_fwd_tile.hip) when the problem fits that kernel
-    if (model->G >= 1 && T > 1 && fwd_tile_fits(model, policy)) {
+    // (the measurement filter of partially measurable systems is implemented in the small-tile kernel only)
+    if (model->G >= 1 && T > 1 && policy->meas.n == 0 && fwd_tile_fits(model, policy)) {
       g_last_ppw = 16;
       return launch_fwd_tile(a, st);
     }

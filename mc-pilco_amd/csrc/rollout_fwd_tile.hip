@@ -146,7 +146,8 @@ __device__ __forceinline__ void tile_k_consume(const double (&bx)[NDQ], const Ti
 }
 template <int MAXDEG, int NDQ>
 __device__ __forceinline__ void tile_phase_k(const GpL& gp, const double* kp, int D, const double* z, double* ks, double* kv, double* wslot, int wv,
-                                             int lane) {
+                                             int lane, unsigned long long* dbg = nullptr) {
+  unsigned long long tq0 = dbg ? clock64() : 0;
   const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
   const int kk = lane >> 4, n = lane & 15;
   gptr_t Xt = (gptr_t)gp.Xt;
@@ -180,6 +181,7 @@ __device__ __forceinline__ void tile_phase_k(const GpL& gp, const double* kp, in
 #pragma unroll
   for (int r = 0; r < 4; ++r) c.zz4[r] = wslot[kk + 4 * r];
   const int ntile = Npad >> 4;
+  if (dbg && lane == 0) { unsigned long long now = clock64(); dbg[12] += now - tq0; tq0 = now; }
   if (wv >= ntile) return;
   const int nt = (ntile - wv + RF_NW - 1) / RF_NW;
   double b0[NDQ], b1[NDQ];
@@ -191,6 +193,7 @@ __device__ __forceinline__ void tile_phase_k(const GpL& gp, const double* kp, in
     tile_k_consume<MAXDEG, NDQ>(b1, c, wv + RF_NW * (sI + 1), kk, n, ks, kv);
   }
   if (nt & 1) tile_k_consume<MAXDEG, NDQ>(b0, c, wv + RF_NW * (nt - 1), kk, n, ks, kv);
+  if (dbg && lane == 0) dbg[13] += clock64() - tq0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -331,8 +334,9 @@ __device__ __forceinline__ void tile_j_consume(const TileJBatch<DEG, NDQ>& b, co
 }
 template <int DEG, int NDQ>
 __device__ __forceinline__ void tile_phase_j(const GpL& gp, const double* kp, int D, const double* z, const double* ks, const double* kv,
-                                             v4d (&acc)[2][TL_NCOL(DEG)], int RT, int wv, int lane) {
+                                             v4d (&acc)[2][TL_NCOL(DEG)], int RT, int wv, int lane, unsigned long long* dbg = nullptr) {
   constexpr int CT = TL_NCOL(DEG);
+  unsigned long long tq0 = dbg ? clock64() : 0;
   const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
   const int per = ((Npad + RF_NW * 4 - 1) / (RF_NW * 4)) * 4;
   const int j0 = imin(wv * per, Npad), j1 = imin(Npad, j0 + per);
@@ -354,6 +358,7 @@ __device__ __forceinline__ void tile_phase_j(const GpL& gp, const double* kp, in
   }
   const int cc0 = imin(n, D - 1), cc1 = imin(16 + n, D - 1);
   const int nbat = (j1 - j0 + 15) >> 4;
+  if (dbg && lane == 0) { unsigned long long now = clock64(); dbg[14] += now - tq0; tq0 = now; }
   TileJBatch<DEG, NDQ> b0, b1;
   tile_j_load<DEG, NDQ>(b0, Xt, al, Npad, D, RT, cc0, cc1, j0, kk, n);
   for (int b = 0; b + 1 < nbat; b += 2) {
@@ -364,6 +369,7 @@ __device__ __forceinline__ void tile_phase_j(const GpL& gp, const double* kp, in
     tile_j_consume<DEG, NDQ>(b1, zwa, zwb, D, RT, Npad, ja + 16, j1, kk, n, ks, kv, acc);
   }
   if (nbat & 1) tile_j_consume<DEG, NDQ>(b0, zwa, zwb, D, RT, Npad, j0 + 16 * (nbat - 1), j1, kk, n, ks, kv, acc);
+  if (dbg && lane == 0) dbg[15] += clock64() - tq0;
 }
 
 // The 8 waves' partial tiles meet in `nslot` (1, 2, 4 or 8, whatever fits the LDS) slots: while more waves than slots hold a
@@ -729,7 +735,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       const double* kp = kpar + g * KP_STRIDE(D);
       const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
       const int deg = MAXDEG == 0 ? 0 : __builtin_amdgcn_readfirstlane(gp.deg);
-      tile_phase_k<MAXDEG, NG>(gp, kp, D, z, ks, kv, scr + wv * 16, wv, lane);
+      tile_phase_k<MAXDEG, NG>(gp, kp, D, z, ks, kv, scr + wv * 16, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
       lds_barrier();
       TL_STAMP(3);
       // ---- phase V ---------------------------------------------------------------------------
@@ -801,17 +807,17 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       int CTg, nfin;
       if (MAXDEG == 0 || deg == 0) {
         v4d acc[2][TL_NCOL(0)];
-        tile_phase_j<0, 1>(gp, kp, D, z, ks, kv, acc, RT, wv, lane);
+        tile_phase_j<0, 1>(gp, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
         nfin = tile_j_reduce<TL_NCOL(0)>(acc, RT, scr, L.nslot, wv, lane);
         CTg = TL_NCOL(0);
       } else if (deg == 1) {
         v4d acc[2][TL_NCOL(1)];
-        tile_phase_j<1, 1>(gp, kp, D, z, ks, kv, acc, RT, wv, lane);
+        tile_phase_j<1, 1>(gp, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
         nfin = tile_j_reduce<TL_NCOL(1)>(acc, RT, scr, L.nslot, wv, lane);
         CTg = TL_NCOL(1);
       } else {
         v4d acc[2][TL_NCOL(2)];
-        tile_phase_j<2, NG>(gp, kp, D, z, ks, kv, acc, RT, wv, lane);
+        tile_phase_j<2, NG>(gp, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
         nfin = tile_j_reduce<TL_NCOL(2)>(acc, RT, scr, L.nslot, wv, lane);
         CTg = TL_NCOL(2);
       }
@@ -915,8 +921,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       }
       if (g == 0 && edraw && t + 1 < T - 1) draw_eps(t + 1);
       lds_barrier();  // R, k/v panels and the scratch are reused by the next GP
+      TL_STAMP(7);
     }
-    TL_STAMP(7);
     // ---- integrate:  v' = v + delta ;  q' = q + Ts v + Ts/2 delta   (Model_learning.py:711-716) ----
     if (own) {
       const double* xc = xs + cur * P * S + op * S;

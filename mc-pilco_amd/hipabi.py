@@ -40,11 +40,16 @@ class Model(C.Structure):
                 ("gp", GP * MAX_GP)]
 
 
+class Meas(C.Structure):
+    _fields_ = [("n", C.c_int32), ("pos", C.c_int32 * MAX_STATE), ("vel", C.c_int32 * MAX_STATE), ("std_pos", C.c_double * MAX_STATE),
+                ("b0", C.c_double), ("b1", C.c_double), ("a0", C.c_double), ("a1", C.c_double), ("pos_noise", dptr), ("meas", dptr)]
+
+
 class Policy(C.Structure):
     _fields_ = [("kind", C.c_int32), ("S", C.c_int32), ("P", C.c_int32), ("B", C.c_int32), ("U", C.c_int32), ("squash", C.c_int32),
                 ("n_angle", C.c_int32), ("n_non_angle", C.c_int32), ("angle", C.c_int32 * MAX_STATE),
                 ("non_angle", C.c_int32 * MAX_STATE), ("traj_len", C.c_int32), ("p_drop", C.c_double), ("log_ls", dptr),
-                ("centers", dptr), ("weight", dptr), ("u_max", dptr), ("target_traj", dptr)]
+                ("centers", dptr), ("weight", dptr), ("u_max", dptr), ("target_traj", dptr), ("meas", Meas)]
 
 
 class Noise(C.Structure):
@@ -105,7 +110,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if handle.mcp_abi_version() != 1:
+        if handle.mcp_abi_version() != 2:
             raise RuntimeError("libmcpilco_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -277,6 +277,45 @@ class NoiseSpec:
         return n
 
 
+@dataclass
+class MeasSpec:
+    """Measurement model of ``MC_PILCO4PMS.apply_policy`` (MC_PILCO.py:808-906) for the fused rollout: the policy is fed
+    noisy positions and backward-difference velocities smoothed by the first-order filter (b, a) = butter(1, fc).
+    ``pos_noise`` [T-1,M,n] standard normals on the GPU (parity mode) or None (in-kernel Philox)."""
+
+    pos: Sequence[int]
+    vel: Sequence[int]
+    std_pos: Sequence[float]
+    b: Sequence[float]
+    a: Sequence[float]
+    pos_noise: Optional[torch.Tensor] = None
+
+    def fill(self, m, T, M, meas_buf):
+        n = len(self.pos)
+        if len(self.vel) != n or len(self.std_pos) != n or n > abi.MAX_STATE:
+            raise RuntimeError("pos / vel / std_pos must have the same length")
+        m.n = n
+        for i in range(n):
+            m.pos[i], m.vel[i], m.std_pos[i] = int(self.pos[i]), int(self.vel[i]), float(self.std_pos[i])
+        m.b0, m.b1, m.a0, m.a1 = float(self.b[0]), float(self.b[1]), float(self.a[0]), float(self.a[1])
+        if self.pos_noise is not None:
+            q = self.pos_noise
+            if q.dtype != DT or not q.is_cuda or not q.is_contiguous() or tuple(q.shape) != (max(T - 1, 0), M, n):
+                raise RuntimeError("pos_noise must be a contiguous float64 GPU tensor of shape [T-1,M,n]")
+        m.pos_noise = None if self.pos_noise is None else self.pos_noise.data_ptr()
+        m.meas = meas_buf.data_ptr()
+
+
+def _set_meas(policy, meas, T, M, buf):
+    """Points policy.c.meas at the measurement model for the next launch (n = 0: the policy sees the true state)."""
+    if meas is None:
+        policy.c.meas.n = 0
+        policy.c.meas.meas = None
+        policy.c.meas.pos_noise = None
+    else:
+        meas.fill(policy.c.meas, T, M, buf)
+
+
 # --------------------------------------------------------------------------------------
 # fused rollout (autograd)
 # --------------------------------------------------------------------------------------
@@ -295,7 +334,8 @@ def _mc(model):
     return None if model is None else C.byref(model.c)
 
 
-def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, noise: NoiseSpec, x0, T, p_drop, particle_pred=True, need_jac=True):
+def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, noise: NoiseSpec, x0, T, p_drop, particle_pred=True, need_jac=True,
+                        meas: Optional[MeasSpec] = None):
     """model None (only with T == 1) evaluates the policy alone."""
     dev = policy.device if model is None else model.device
     x0 = x0.detach().to(device=dev, dtype=DT).contiguous()
@@ -308,14 +348,21 @@ def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, nois
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     pc = policy.bind(p_drop)
     nz = noise.to_c()
-    abi.check(abi.lib().mcp_rollout_fwd(_mc(model), C.byref(pc), C.byref(nz), M, T, int(bool(particle_pred)), abi.ptr(x0),
-                                        abi.ptr(states), abi.ptr(inputs), abi.ptr(jac), abi.ptr(status), None, 0, abi.stream()),
-              "mcp_rollout_fwd")
+    meas_buf = torch.empty(T, M, policy.S, dtype=DT, device=dev) if meas is not None else None
+    _set_meas(policy, meas, T, M, meas_buf)
+    try:
+        abi.check(abi.lib().mcp_rollout_fwd(_mc(model), C.byref(pc), C.byref(nz), M, T, int(bool(particle_pred)), abi.ptr(x0),
+                                            abi.ptr(states), abi.ptr(inputs), abi.ptr(jac), abi.ptr(status), None, 0, abi.stream()),
+                  "mcp_rollout_fwd")
+    finally:
+        _set_meas(policy, None, T, M, None)
+    if meas is not None:
+        return states, inputs, jac, status, meas_buf
     return states, inputs, jac, status
 
 
 def rollout_backward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseSpec, states, inputs, jac, g_states, g_inputs, p_drop,
-                         want_gx0=False):
+                         want_gx0=False, meas: Optional[MeasSpec] = None, meas_buf=None):
     dev = policy.device
     T, M = states.shape[0], states.shape[1]
     pc = policy.bind(p_drop)
@@ -328,9 +375,13 @@ def rollout_backward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseS
     g_x0 = torch.empty(M, policy.S, dtype=DT, device=dev) if want_gx0 else None
     gs = None if g_states is None else g_states.to(dtype=DT).contiguous()
     gi = None if g_inputs is None else g_inputs.to(dtype=DT).contiguous()
-    abi.check(abi.lib().mcp_rollout_bwd(_mc(model), C.byref(pc), C.byref(nz), M, T, abi.ptr(states), abi.ptr(inputs), abi.ptr(jac),
-                                        abi.ptr(gs), abi.ptr(gi), abi.ptr(g_ls), abi.ptr(g_c), abi.ptr(g_w), abi.ptr(g_x0), abi.ptr(ws),
-                                        nbytes, abi.stream()), "mcp_rollout_bwd")
+    _set_meas(policy, meas, T, M, meas_buf)
+    try:
+        abi.check(abi.lib().mcp_rollout_bwd(_mc(model), C.byref(pc), C.byref(nz), M, T, abi.ptr(states), abi.ptr(inputs), abi.ptr(jac),
+                                            abi.ptr(gs), abi.ptr(gi), abi.ptr(g_ls), abi.ptr(g_c), abi.ptr(g_w), abi.ptr(g_x0), abi.ptr(ws),
+                                            nbytes, abi.stream()), "mcp_rollout_bwd")
+    finally:
+        _set_meas(policy, None, T, M, None)
     return g_ls, g_c, g_w, g_x0
 
 
@@ -340,10 +391,12 @@ class RolloutFunction(torch.autograd.Function):
     parameters (and x0); the GP model is frozen, as after ``Model_learning.set_eval_mode``."""
 
     @staticmethod
-    def forward(ctx, x0, log_ls, centers, weight, model, policy, noise, T, p_drop, particle_pred):
+    def forward(ctx, x0, log_ls, centers, weight, model, policy, noise, T, p_drop, particle_pred, meas=None):
         need = any(ctx.needs_input_grad[:4])
-        states, inputs, jac, status = rollout_forward_raw(model, policy, noise, x0, T, p_drop, particle_pred, need_jac=need)
+        out = rollout_forward_raw(model, policy, noise, x0, T, p_drop, particle_pred, need_jac=need, meas=meas)
+        states, inputs, jac, status = out[:4]
         ctx.model, ctx.policy, ctx.noise, ctx.p_drop = model, policy, noise, p_drop
+        ctx.meas, ctx.meas_buf = meas, (out[4] if meas is not None else None)
         ctx.has_jac = jac is not None
         ctx.save_for_backward(states, inputs, jac if jac is not None else torch.empty(0, device=states.device))
         ctx.mark_non_differentiable(status)
@@ -355,14 +408,15 @@ class RolloutFunction(torch.autograd.Function):
         if not ctx.has_jac:
             jac = None
         g_ls, g_c, g_w, g_x0 = rollout_backward_raw(ctx.model, ctx.policy, ctx.noise, states, inputs, jac, g_states, g_inputs, ctx.p_drop,
-                                                    want_gx0=ctx.needs_input_grad[0])
-        return g_x0, g_ls.reshape(ctx.policy.log_ls.shape), g_c, g_w, None, None, None, None, None, None
+                                                    want_gx0=ctx.needs_input_grad[0], meas=ctx.meas, meas_buf=ctx.meas_buf)
+        return g_x0, g_ls.reshape(ctx.policy.log_ls.shape), g_c, g_w, None, None, None, None, None, None, None
 
 
-def rollout(model, policy, noise, x0, T, p_drop=0.0, particle_pred=True):
-    """Differentiable fused rollout.  Returns (states, inputs, status)."""
+def rollout(model, policy, noise, x0, T, p_drop=0.0, particle_pred=True, meas: Optional[MeasSpec] = None):
+    """Differentiable fused rollout.  Returns (states, inputs, status).  ``meas``: measurement model between the particles and
+    the policy (partially measurable systems); None = the policy sees the true state."""
     return RolloutFunction.apply(x0, policy.log_ls, policy.centers, policy.weight, model, policy, noise, int(T), float(p_drop),
-                                 bool(particle_pred))
+                                 bool(particle_pred), meas)
 
 
 # --------------------------------------------------------------------------------------

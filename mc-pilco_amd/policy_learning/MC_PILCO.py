@@ -11,8 +11,8 @@ Additions (all optional): ``noise_mode`` -- "philox" (in-kernel generator, defau
 CPU with the reference's torch calls in its order, for seed-for-seed parity); ``shard_particles(group)`` -- split the
 particles over the ranks of a torch.distributed group (one all-gather of cost moments and one all-reduce of the
 policy gradient per optimizer step; every rank then applies the identical update).
-``MC_PILCO4PMS`` (MC_PILCO.py:755-958, partially measurable systems) is provided on the step-wise HIP operators (posterior
-and policy launches per time step, the measurement filter in torch on the device); its rollout is not fused yet.
+``MC_PILCO4PMS`` (MC_PILCO.py:755-958, partially measurable systems): the measurement filter between particles and policy is
+part of the fused rollout kernels (``mcp_meas``); a step-wise path on the posterior / policy operators remains as fallback.
 Out of scope: MC_PILCO_Experiment, MuJoCo environments.
 """
 import copy
@@ -404,9 +404,10 @@ class MC_PILCO4PMS(MC_PILCO):
 
     Particles evolve on their true states; the policy is evaluated on a simulated *measurement*: positions plus Gaussian
     noise, velocities by backward difference of the noisy positions, smoothed online by a first-order Butterworth filter
-    (``filtering_dict["fc"]``).  The rollout runs step by step on the HIP operators (``mcp_posterior_fwd`` for the GP
-    moments, the T=1 policy launch) with the filter as torch device ops, so autograd supplies the adjoint of the filter;
-    fusing it into the rollout kernels is listed as next work in DESIGN.md.
+    (``filtering_dict["fc"]``).  With the speed-integration models and the RBF policies the rollout is the same single fused
+    launch as ``MC_PILCO.apply_policy``: the kernels carry the filter's states per particle and the reverse sweep its adjoint
+    recursion (``mcp_meas``).  ``fused = False`` (or any other model / policy object) runs step by step on the posterior and
+    policy operators with the filter as torch device ops.
     """
 
     def __init__(self, T_sampling, state_dim, input_dim, f_sim, f_model_learning, model_learning_par, f_rand_exploration_policy,
@@ -424,6 +425,7 @@ class MC_PILCO4PMS(MC_PILCO):
         self.vel_indeces = vel_indeces
         # (the reference leaves the attribute unset when a value is passed, MC_PILCO.py:802-803; here it is always defined)
         self.std_meas_noise_sim = std_meas_noise if std_meas_noise_sim is None else std_meas_noise_sim
+        self.fused = True  # False: step-by-step rollout on the posterior / policy operators (any model or policy object)
 
     def apply_policy(self, particles_initial_state_mean, particles_initial_state_var, flg_particles_init_uniform, particles_init_up_bound,
                      particles_init_low_bound, flg_particles_init_multi_gauss, num_particles, T_control, p_dropout=0.0):
@@ -440,6 +442,30 @@ class MC_PILCO4PMS(MC_PILCO):
                                           particles_init_up_bound, particles_init_low_bound, flg_particles_init_multi_gauss, M)
         b, a = signal.butter(1, self.filtering_dict["fc"])
         pos, vel = list(self.pos_indeces), list(self.vel_indeces)
+        if self.fused and isinstance(pol, _Policy.Sum_of_gaussians) and hasattr(ml, "vel_indeces"):
+            # one fused launch: the kernels carry the measurement filter's states per particle (mcp_meas)
+            p = float(p_dropout) if getattr(pol, "flg_drop", True) else 0.0
+            G, B = ml.num_gp, pol.num_basis
+            self._rollout_calls += 1
+            if ref:  # the reference's draw order: mask_0; per step: eps_t, position noise, mask_t
+                masks = [torch.empty(M, 1, B, dtype=self.dtype).bernoulli_(1 - p).reshape(M, B)] if p > 0 else None
+                eps, pn = [], []
+                for _ in range(1, T):
+                    eps.append(torch.empty(M, G, dtype=self.dtype).normal_())
+                    pn.append(torch.randn(M, len(pos), dtype=self.dtype))
+                    if p > 0:
+                        masks.append(torch.empty(M, 1, B, dtype=self.dtype).bernoulli_(1 - p).reshape(M, B))
+                stack = lambda l, w: (torch.stack(l) if l else torch.zeros(0, M, w, dtype=self.dtype)).to(self.device).contiguous()
+                noise = ops.NoiseSpec(eps=stack(eps, G), masks=None if masks is None else torch.stack(masks).to(torch.uint8).to(self.device).contiguous())
+                pos_noise = stack(pn, len(pos))
+            else:
+                noise = ops.NoiseSpec(seed=self.seed, call=self._rollout_calls, particle_offset=self._shard[0])
+                pos_noise = None
+            meas = ops.MeasSpec(pos=pos, vel=vel, std_pos=[float(v) for v in np.asarray(self.std_meas_noise_sim)[pos]], b=b, a=a,
+                                pos_noise=pos_noise)
+            states, inputs, status = ops.rollout(ml.packed(), pol.packed(), noise, x, T, p, meas=meas)
+            self.last_status = status
+            return states, inputs
         std_pos = torch.tensor(np.asarray(self.std_meas_noise_sim)[pos], dtype=self.dtype, device=self.device)
         saved_mode = getattr(pol, "noise_mode", None)
         if ref and saved_mode is not None:

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libmcpilco_hip.so does not export %s" % n
     assert set(hipabi.EXPORTED) == set(names)
-    assert lib.mcp_abi_version() == 1
+    assert lib.mcp_abi_version() == 2
     assert b"gfx950" in lib.mcp_build_info()
 
 
@@ -38,15 +38,16 @@ def test_struct_layout_matches_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "mcpilco_hip.h"\n'
-        "int main(){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(mcp_kernel), sizeof(mcp_gp), sizeof(mcp_model),"
+        "int main(){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(mcp_kernel), sizeof(mcp_gp), sizeof(mcp_model),"
         " sizeof(mcp_policy), sizeof(mcp_noise), sizeof(mcp_cost), offsetof(mcp_model, gp), offsetof(mcp_policy, log_ls),"
-        " offsetof(mcp_cost, target_traj)); return 0;}\n"
+        " offsetof(mcp_cost, target_traj), sizeof(mcp_meas), offsetof(mcp_policy, meas), offsetof(mcp_meas, pos_noise)); return 0;}\n"
     )
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(hipabi.Kernel), C.sizeof(hipabi.GP), C.sizeof(hipabi.Model), C.sizeof(hipabi.Policy), C.sizeof(hipabi.Noise),
-            C.sizeof(hipabi.Cost), hipabi.Model.gp.offset, hipabi.Policy.log_ls.offset, hipabi.Cost.target_traj.offset]
+            C.sizeof(hipabi.Cost), hipabi.Model.gp.offset, hipabi.Policy.log_ls.offset, hipabi.Cost.target_traj.offset,
+            C.sizeof(hipabi.Meas), hipabi.Policy.meas.offset, hipabi.Meas.pos_noise.offset]
     assert got == want
 
 

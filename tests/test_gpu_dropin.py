@@ -262,8 +262,11 @@ def test_reinforce_runs_end_to_end():
     assert len(obj.state_samples_history) == 3  # one exploration + the policy applied after each of the two trials
 
 
-def test_pms_seed_for_seed_parity_with_reference(golden):
-    """MC_PILCO4PMS.apply_policy (MC_PILCO.py:808-906) on the drop-in: same seed, same draws, same trajectories and gradient."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_pms_seed_for_seed_parity_with_reference(golden, fused):
+    """MC_PILCO4PMS.apply_policy (MC_PILCO.py:808-906) on the drop-in: same seed, same draws, same trajectories and gradient --
+    through the fused kernels (measurement filter carried per particle, adjoint recursion in the reverse sweep) and through
+    the step-wise operator path."""
     from mc_pilco_amd.policy_learning import MC_PILCO, Cost_function, Policy
 
     fx = golden("rollout_pms")
@@ -284,6 +287,7 @@ def test_pms_seed_for_seed_parity_with_reference(golden):
                                     std_meas_noise=fx["std_meas_noise"], log_path=None, filtering_dict={"fc": float(fx["fc"])}, dtype=dtype,
                                     device=dev())
     obj.noise_mode = "reference"
+    obj.fused = fused
     M, Tn, p = fx["states"].shape[1], fx["states"].shape[0], float(fx["p_drop"])
     torch.manual_seed(107)
     st, inp = obj.apply_policy(particles_initial_state_mean=T(fx["x0_mean"]), particles_initial_state_var=T(fx["x0_var"]),

@@ -273,3 +273,57 @@ def test_philox_mode_properties():
     # all particles start at the same point: the spread after one step is the GP's predictive std
     d = a[1, :, 1] - a[1, :, 1].mean()
     assert 0.5 < float(d.std() / a[1, :, 1].std()) < 1.5 and float(a[1, :, 1].std()) > 0
+
+
+@pytest.mark.parametrize("ppw", [0, 1, 2, 4])
+def test_pms_rollout_cost_gradient_vs_reference(golden, ppw):
+    """MC_PILCO4PMS.apply_policy + cost + backward through the C ABI (mcp_meas): the measurement filter between particles and
+    policy is carried inside the fused kernels; the reference's recorded eps / position noise / masks are injected."""
+    from gpu_helpers import G, dev, packed_cost, packed_model, packed_policy
+    from mc_pilco_amd import hipabi, ops
+
+    fx = golden("rollout_pms")
+    model, pol, cost = packed_model(fx, "se"), packed_policy(fx, "se"), packed_cost(fx, "se")
+    pos = [int(i) for i in fx["pos_indeces"]]
+    meas = ops.MeasSpec(pos=pos, vel=[int(i) for i in fx["vel_indeces"]], std_pos=[float(v) for v in fx["std_meas_noise"][pos]],
+                        b=fx["butter_b"], a=fx["butter_a"], pos_noise=G(fx["pos_noise"]))
+    nz = ops.NoiseSpec(eps=G(fx["eps"]), masks=torch.as_tensor(fx["masks"]).to(dev()).contiguous())
+    Tn, p = fx["states"].shape[0], float(fx["p_drop"])
+    hipabi.lib().mcp_debug_set_particles_per_wg(ppw)
+    hipabi.lib().mcp_debug_set_bwd_particles(ppw)
+    try:
+        st, inp, status = ops.rollout(model, pol, nz, G(fx["x0"]), Tn, p, meas=meas)
+        c, s = ops.expected_cost(cost, st)
+        c.backward()
+    finally:
+        hipabi.lib().mcp_debug_set_particles_per_wg(0)
+        hipabi.lib().mcp_debug_set_bwd_particles(0)
+    assert int(status.item()) == 0
+    assert abserr(st, fx["states"]) < 1e-9
+    assert abserr(inp, fx["inputs"]) < 1e-9
+    assert abs(float(c) - float(fx["cost"])) < 1e-11 * abs(float(fx["cost"]))
+    assert relerr(pol.log_ls.grad, fx["g_log_ls"]) < 1e-8
+    assert relerr(pol.centers.grad, fx["g_centers"]) < 1e-8
+    assert relerr(pol.weight.grad, fx["g_weight"]) < 1e-8
+
+
+def test_pms_philox_mode_is_reproducible_and_shard_invariant():
+    """Performance-mode position noise: Philox stream counted by the global particle id, like eps and the masks."""
+    from gpu_helpers import G, packed_model, packed_policy
+    from conftest import load_golden
+    from mc_pilco_amd import ops
+
+    fx = load_golden("rollout_pms")
+    model, pol = packed_model(fx, "se"), packed_policy(fx, "se", requires_grad=False)
+    meas = ops.MeasSpec(pos=[0, 2], vel=[1, 3], std_pos=[0.01, 0.015], b=fx["butter_b"], a=fx["butter_a"])
+    M, Tn = 96, 7
+    x0 = G(0.01 * np.random.RandomState(0).randn(M, 4))
+    a = ops.rollout(model, pol, ops.NoiseSpec(seed=5, call=2), x0, Tn, 0.25, meas=meas)
+    b = ops.rollout(model, pol, ops.NoiseSpec(seed=5, call=2), x0, Tn, 0.25, meas=meas)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    h = M // 2
+    lo = ops.rollout(model, pol, ops.NoiseSpec(seed=5, call=2, particle_offset=0), x0[:h].contiguous(), Tn, 0.25, meas=meas)
+    hi = ops.rollout(model, pol, ops.NoiseSpec(seed=5, call=2, particle_offset=h), x0[h:].contiguous(), Tn, 0.25, meas=meas)
+    assert torch.equal(torch.cat([lo[0], hi[0]], 1), a[0])
+    plain = ops.rollout(model, pol, ops.NoiseSpec(seed=5, call=2), x0, Tn, 0.25)
+    assert float((plain[1] - a[1]).abs().max()) > 1e-6  # the measurement noise does reach the policy
