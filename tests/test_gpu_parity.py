@@ -327,3 +327,39 @@ def test_pms_philox_mode_is_reproducible_and_shard_invariant():
     assert torch.equal(torch.cat([lo[0], hi[0]], 1), a[0])
     plain = ops.rollout(model, pol, ops.NoiseSpec(seed=5, call=2), x0, Tn, 0.25)
     assert float((plain[1] - a[1]).abs().max()) > 1e-6  # the measurement noise does reach the policy
+
+
+@pytest.mark.parametrize("case", [("cartpole", 0, 20, 17, 3), ("cartpole", 2, 33, 5, 2), ("cartpole", 1, 16, 1, 4), ("ur5", 1, 17, 3, 3),
+                                  ("cartpole", 0, 130, 35, 4)])
+def test_kernel_variants_agree_on_odd_shapes(case):
+    """Every forward tile size (1, 2, 4, 16 particles per workgroup) and backward sweep width (1, 2, 4) on shapes that exercise
+    the edges: N not a multiple of 16 or 32, a single 16-row block, M smaller than / not a multiple of the tile, T = 2."""
+    from gpu_helpers import dev
+    from mc_pilco_amd import hipabi, ops, workloads
+
+    workloads.CONFIGS["edge"] = case
+    w = workloads.build("edge", device=dev())
+    torch.manual_seed(11)
+    x0 = w.sample_x0()
+    ref = None
+    for ppw, pb in [(1, 1), (2, 2), (4, 4), (16, 4)]:
+        hipabi.lib().mcp_debug_set_particles_per_wg(ppw)
+        hipabi.lib().mcp_debug_set_bwd_particles(pb)
+        try:
+            for q in w.params:
+                q.grad = None
+            st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=9, call=3), x0, w.T, w.p_drop)
+            c, s = ops.expected_cost(w.cost, st)
+            c.backward()
+            used = hipabi.lib().mcp_debug_last_particles_per_wg()
+        finally:
+            hipabi.lib().mcp_debug_set_particles_per_wg(0)
+            hipabi.lib().mcp_debug_set_bwd_particles(0)
+        assert used == ppw and int(status.item()) == 0
+        got = (st.detach().clone(), inp.detach().clone(), [q.grad.detach().clone() for q in w.params])
+        if ref is None:
+            ref = got
+            continue
+        assert float((got[0] - ref[0]).abs().max()) < 1e-9 and float((got[1] - ref[1]).abs().max()) < 1e-9
+        for ga, gb in zip(got[2], ref[2]):
+            assert float((ga - gb).abs().max()) <= 1e-8 * max(1e-30, float(gb.abs().max()))
