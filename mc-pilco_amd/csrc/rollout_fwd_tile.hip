@@ -38,7 +38,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define TL_NCOL(deg) ((deg) == 0 ? 2 : ((deg) == 1 ? 3 : 5))
 
 struct TileLayout {
-  int invl, xs, us, z, sf, dl, eps, ks, kv, qa, sal, gpl, kpar, scr, total;  // offsets in doubles
+  int invl, xs, us, z, sf, dl, eps, ks, kv, qa, mup, gpl, kpar, scr, total;  // offsets in doubles
   int nslot;   // phase-J partial-tile slots in scr
   int vslots;  // phase-V partial (32x16) slots in scr
 };
@@ -62,7 +62,7 @@ __host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, in
   L.kv = take(NpadMax * TL_KR);  // directly after ks: the phi buffer of the policy phase aliases both
   const int RT = (D + 1 + 15) / 16, CT = TL_NCOL(maxdeg);
   L.qa = take(maxdeg >= 2 ? G * D * D : 0);
-  L.sal = take(G);
+  L.mup = take(RF_NW * TL_PT);  // per-wave partial sums of  sum_j alpha_j k_j  (the posterior mean, accumulated in phase K)
   L.gpl = take(G * GPL_DOUBLES);
   L.kpar = take(G * KP_STRIDE(D));
   const int slot = RT * CT * 256;
@@ -96,9 +96,10 @@ __host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, in
 // lane exchanges.  Tiles of 16 training points are dealt round-robin to the 8 waves, the B operands of the next tile
 // are loaded (unconditionally) before the current tile is consumed.
 template <int NDQ>
-__device__ __forceinline__ void tile_k_load(double (&bx)[NDQ], gptr_t Xt, int Npad, int D, int tile, int kk, int n) {
+__device__ __forceinline__ void tile_k_load(double (&bx)[NDQ], double& alj, gptr_t Xt, gptr_t al, int Npad, int D, int tile, int kk, int n) {
 #pragma unroll
   for (int i = 0; i < NDQ; ++i) bx[i] = Xt[(size_t)imin(4 * i + kk, D - 1) * Npad + 16 * tile + n];
+  alj = al[16 * tile + n];  // zero on the padding rows (unused, and optimised away, for SE-only models)
 }
 template <int MAXDEG, int NDQ>
 struct TileKConst {
@@ -108,8 +109,8 @@ struct TileKConst {
   int deg, N;
 };
 template <int MAXDEG, int NDQ>
-__device__ __forceinline__ void tile_k_consume(const double (&bx)[NDQ], const TileKConst<MAXDEG, NDQ>& c, int tile, int kk, int n, double* ks,
-                                               double* kv) {
+__device__ __forceinline__ void tile_k_consume(const double (&bx)[NDQ], double alj, const TileKConst<MAXDEG, NDQ>& c, int tile, int kk, int n,
+                                               double* ks, double* kv, double (&macc)[4]) {
   double sxx = 0.0;
 #pragma unroll
   for (int i = 0; i < NDQ; ++i) {
@@ -139,14 +140,15 @@ __device__ __forceinline__ void tile_k_consume(const double (&bx)[NDQ], const Ti
       if (MAXDEG >= 2 && c.deg >= 2) kt = fma(CA[r], CB[r], kt);
     }
     if (!live) kse = kt = 0.0;
+    if (MAXDEG >= 1) macc[r] = fma(alj, kt, macc[r]);  // posterior mean  sum_j alpha_j k_j  (GP_prior.py:145), all kernel terms at once
     const int o = j * TL_KR + kk + 4 * r;
     ks[o] = kse;
     kv[o] = kt;
   }
 }
 template <int MAXDEG, int NDQ>
-__device__ __forceinline__ void tile_phase_k(const GpL& gp, const double* kp, int D, const double* z, double* ks, double* kv, double* wslot, int wv,
-                                             int lane, unsigned long long* dbg = nullptr) {
+__device__ __forceinline__ void tile_phase_k(const GpL& gp, const double* kp, int D, const double* z, double* ks, double* kv, double* wslot,
+                                             double* mup, int wv, int lane, unsigned long long* dbg = nullptr) {
   unsigned long long tq0 = dbg ? clock64() : 0;
   const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
   const int kk = lane >> 4, n = lane & 15;
@@ -182,17 +184,31 @@ __device__ __forceinline__ void tile_phase_k(const GpL& gp, const double* kp, in
   for (int r = 0; r < 4; ++r) c.zz4[r] = wslot[kk + 4 * r];
   const int ntile = Npad >> 4;
   if (dbg && lane == 0) { unsigned long long now = clock64(); dbg[12] += now - tq0; tq0 = now; }
-  if (wv >= ntile) return;
-  const int nt = (ntile - wv + RF_NW - 1) / RF_NW;
-  double b0[NDQ], b1[NDQ];
-  tile_k_load<NDQ>(b0, Xt, Npad, D, wv, kk, n);
-  for (int sI = 0; sI + 1 < nt; sI += 2) {
-    tile_k_load<NDQ>(b1, Xt, Npad, D, wv + RF_NW * (sI + 1), kk, n);
-    tile_k_consume<MAXDEG, NDQ>(b0, c, wv + RF_NW * sI, kk, n, ks, kv);
-    tile_k_load<NDQ>(b0, Xt, Npad, D, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
-    tile_k_consume<MAXDEG, NDQ>(b1, c, wv + RF_NW * (sI + 1), kk, n, ks, kv);
+  double macc[4] = {0.0, 0.0, 0.0, 0.0};
+  if (wv < ntile) {
+    gptr_t al = (gptr_t)gp.alpha;
+    const int nt = (ntile - wv + RF_NW - 1) / RF_NW;
+    double b0[NDQ], b1[NDQ], al0, al1;
+    tile_k_load<NDQ>(b0, al0, Xt, al, Npad, D, wv, kk, n);
+    for (int sI = 0; sI + 1 < nt; sI += 2) {
+      tile_k_load<NDQ>(b1, al1, Xt, al, Npad, D, wv + RF_NW * (sI + 1), kk, n);
+      tile_k_consume<MAXDEG, NDQ>(b0, al0, c, wv + RF_NW * sI, kk, n, ks, kv, macc);
+      tile_k_load<NDQ>(b0, al0, Xt, al, Npad, D, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
+      tile_k_consume<MAXDEG, NDQ>(b1, al1, c, wv + RF_NW * (sI + 1), kk, n, ks, kv, macc);
+    }
+    if (nt & 1) tile_k_consume<MAXDEG, NDQ>(b0, al0, c, wv + RF_NW * (nt - 1), kk, n, ks, kv, macc);
   }
-  if (nt & 1) tile_k_consume<MAXDEG, NDQ>(b0, c, wv + RF_NW * (nt - 1), kk, n, ks, kv);
+  // this wave's share of the mean: sum over its 16 training-point lanes, one partial per particle.  (SE-only models read the
+  // mean off the ones-row of phase J's product instead, which costs nothing there.)
+#pragma unroll
+  for (int r = 0; r < (MAXDEG >= 1 ? 4 : 0); ++r) {
+    double v = macc[r];
+    v += dpp_take<0x111, 0xf>(v);
+    v += dpp_take<0x112, 0xf>(v);
+    v += dpp_take<0x114, 0xf>(v);
+    v += dpp_take<0x118, 0xf>(v);
+    if (n == 15) mup[wv * TL_PT + kk + 4 * r] = v;
+  }
   if (dbg && lane == 0) dbg[13] += clock64() - tq0;
 }
 
@@ -592,7 +608,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   double* ks = smem + L.ks;
   double* kv = smem + L.kv;
   double* qa = smem + L.qa;
-  double* sal = smem + L.sal;
+  double* mup = smem + L.mup;
   double* scr = smem + L.scr;
   GpL* gpl = reinterpret_cast<GpL*>(smem + L.gpl);
   double* kpar = smem + L.kpar;
@@ -608,23 +624,15 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   for (int it = tid; it < PF; it += RF_NT) invl[it] = exp(-pl.log_ls[it]);
   stage_gp_tables(md.gp, md.var_scale, G, D, gpl, kpar, tid);
   lds_barrier();
-  // launch constants of the polynomial terms: sum_j alpha_j and (degree 2) sum_j alpha_j X_jc X_je
-  if (MAXDEG >= 1) {
-    for (int it = tid; it < G; it += RF_NT) {
-      const GpL& gp = gpl[it];
+  // launch constants of the degree-2 polynomial term: sum_j alpha_j X_jc X_je (for d mu/dz)
+  if (MAXDEG >= 2 && a.maxdeg >= 2) {  // (qa has no storage when maxdeg < 2)
+    for (int it = tid; it < G * D * D; it += RF_NT) {
+      const int g = it / (D * D), r = it - g * D * D, c = r / D, e = r - c * D;
+      const GpL& gp = gpl[g];
       double s = 0.0;
-      for (int j = 0; j < gp.N; ++j) s += gp.alpha[j];
-      sal[it] = s;
-    }
-    if (MAXDEG >= 2 && a.maxdeg >= 2) {  // (the template is instantiated for 0 and 2 only; qa has no storage when maxdeg == 1)
-      for (int it = tid; it < G * D * D; it += RF_NT) {
-        const int g = it / (D * D), r = it - g * D * D, c = r / D, e = r - c * D;
-        const GpL& gp = gpl[g];
-        double s = 0.0;
-        if (gp.deg >= 2)
-          for (int j = 0; j < gp.N; ++j) s = fma(gp.alpha[j] * gp.X[(size_t)j * D + c], gp.X[(size_t)j * D + e], s);
-        qa[it] = s;
-      }
+      if (gp.deg >= 2)
+        for (int j = 0; j < gp.N; ++j) s = fma(gp.alpha[j] * gp.X[(size_t)j * D + c], gp.X[(size_t)j * D + e], s);
+      qa[it] = s;
     }
   }
   gptr_t cen = (gptr_t)pl.centers;
@@ -735,7 +743,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       const double* kp = kpar + g * KP_STRIDE(D);
       const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
       const int deg = MAXDEG == 0 ? 0 : __builtin_amdgcn_readfirstlane(gp.deg);
-      tile_phase_k<MAXDEG, NG>(gp, kp, D, z, ks, kv, scr + wv * 16, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+      tile_phase_k<MAXDEG, NG>(gp, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
       lds_barrier();
       TL_STAMP(3);
       // ---- phase V ---------------------------------------------------------------------------
@@ -872,21 +880,12 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           wj = eps / (2.0 * sd);
         }
         if (c == D) {
-          double mu = gp.mean + tile_r(Rr, D, 0, p);
-          if (MAXDEG >= 1 && deg >= 1) {
-            double pm = kp[KP_W1(D) + D] * sal[g];
-            for (int d = 0; d < D; ++d) pm = fma(kp[KP_W1(D) + d] * zp[d], kp[KP_AX(D) + d], pm);
-            mu += pm;
-            if (deg >= 2) {
-              const double* Q = qa + g * D * D;
-              double qm = 0.0;
-              for (int d = 0; d < D; ++d) {
-                double row = 0.0;
-                for (int e = 0; e < D; ++e) row = fma(kp[KP_W21(D) + e] * zp[e], Q[d * D + e], row);
-                qm = fma(kp[KP_W20(D) + d] * zp[d], row, qm);
-              }
-              mu += qm;
-            }
+          double mu = gp.mean;
+          if (MAXDEG >= 1) {
+#pragma unroll
+            for (int w = 0; w < RF_NW; ++w) mu += mup[w * P + p];
+          } else {
+            mu += tile_r(Rr, D, 0, p);
           }
           dl[p * G + g] = a.particle_pred ? fma(sd, eps, mu) : mu;
           if (m0 + p < M) {
