@@ -37,6 +37,8 @@ __global__ void cov_diag_kernel(mcp_kernel kn, int N, const double* __restrict__
 #define CH_NB 16
 #define CH_NT 1024
 
+__device__ __forceinline__ int imin_d(int a, int b) { return a < b ? a : b; }
+
 __global__ __launch_bounds__(CH_NT) void chol_factor_kernel(int N, double* __restrict__ A, int lda, double* __restrict__ logdet,
                                                             uint32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -97,16 +99,44 @@ __global__ __launch_bounds__(CH_NT) void chol_factor_kernel(int N, double* __res
       }
     }
     __syncthreads();
-    // (3) trailing update over the upper triangle (i <= j): flat index space so that every thread
-    //     has several independent read-modify-writes in flight
-    for (int idx = tid; idx < nc * nc; idx += CH_NT) {
-      int i = idx / nc, j = idx - i * nc;
-      if (j < i) continue;
-      double s = A[(size_t)(j0 + i) * lda + j0 + j];
+    // (3) trailing update over the upper triangle (i <= j)
+    //     4x4 register tiles: per panel row m a thread reads 4 + 4 panel values from LDS for 16 multiply-adds (one element per
+    //     thread needed 2 LDS reads per multiply-add and made the phase instruction bound); only tiles on or above the diagonal
+    const int nts = (nc + 3) >> 2;
+    for (int t = tid; t < nts * nts; t += CH_NT) {
+      const int ti = t / nts, tj = t - ti * nts;
+      if (tj < ti) continue;
+      const int i0 = 4 * ti, jj0 = 4 * tj;
+      double acc[4][4];
 #pragma unroll
-      for (int m = 0; m < CH_NB; ++m)
-        if (m < nb) s = fma(-pn[(size_t)m * nc + i], pn[(size_t)m * nc + j], s);
-      A[(size_t)(j0 + i) * lda + j0 + j] = s;
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = imin_d(i0 + r, nc - 1), j = imin_d(jj0 + c, nc - 1);
+          acc[r][c] = A[(size_t)(j0 + i) * lda + j0 + j];
+        }
+#pragma unroll
+      for (int m = 0; m < CH_NB; ++m) {
+        if (m < nb) {
+          double pi[4], pj[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pi[r] = pn[(size_t)m * nc + imin_d(i0 + r, nc - 1)];
+            pj[r] = pn[(size_t)m * nc + imin_d(jj0 + r, nc - 1)];
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = fma(-pi[r], pj[c], acc[r][c]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = i0 + r, j = jj0 + c;
+          if (i < nc && j < nc && j >= i) A[(size_t)(j0 + i) * lda + j0 + j] = acc[r][c];
+        }
     }
     __syncthreads();
   }
@@ -154,6 +184,56 @@ __global__ __launch_bounds__(TI_NT) void tri_inverse_kernel(int N, const double*
   // rows below the block's last column are zero for these columns
   if (j < N)
     for (int i = jmax + 1; i < N; ++i) Ui[(size_t)i * ldi + j] = 0.0;
+}
+
+// Uinv = U^-1 for N <= 1024: one WAVE per column j.  Back substitution x_i = (delta_ij - sum_{i<m<=j} U[i][m] x_m) / U[i][i],
+// i = j .. 0: lane l keeps x_m for m = l (mod 64) in registers, the row of U is one coalesced read per 64 columns (the next
+// row is fetched while the current dot product is reduced), the dot product a wave64 DPP sum.  N columns run in parallel
+// (the thread-per-column kernel above walks its own earlier results through global memory: 2 ms at N=300 against ~0.1 ms).
+#define TW_KM 16  // 64 * TW_KM >= N
+__global__ __launch_bounds__(256) void tri_inverse_wave_kernel(int N, const double* __restrict__ U, int ldu, double* __restrict__ Ui, int ldi) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);  // this wave's column
+  if (j >= N) return;
+  double x[TW_KM];
+#pragma unroll
+  for (int k = 0; k < TW_KM; ++k) x[k] = 0.0;
+  const int kj = j >> 6;  // register slots 0..kj can hold a nonzero
+  double urow[TW_KM], unext[TW_KM];
+  auto load_row = [&](double (&r)[TW_KM], int i) {
+#pragma unroll
+    for (int k = 0; k < TW_KM; ++k) {
+      const int m = k * 64 + lane;
+      r[k] = (k <= kj && i >= 0 && m <= j) ? U[(size_t)i * ldu + m] : 0.0;
+    }
+  };
+  load_row(urow, j);
+  for (int i = j; i >= 0; --i) {
+    load_row(unext, i - 1);
+    double part = 0.0, uii = 0.0;
+#pragma unroll
+    for (int k = 0; k < TW_KM; ++k) {
+      if (k <= kj) {
+        const int m = k * 64 + lane;
+        if (m > i) part = fma(urow[k], x[k], part);  // x_m is still 0 for m > j
+        if (m == i) uii = urow[k];
+      }
+    }
+    const double dot = wave_sum(part);
+    const double d = wave_sum(uii);  // the diagonal element, from the lane that owns column i
+    const double xi = ((i == j ? 1.0 : 0.0) - dot) / d;
+#pragma unroll
+    for (int k = 0; k < TW_KM; ++k)
+      if (k * 64 + lane == i) x[k] = xi;
+#pragma unroll
+    for (int k = 0; k < TW_KM; ++k) urow[k] = unext[k];
+  }
+  // column j of the result: rows <= j from the registers, zeros below
+#pragma unroll
+  for (int k = 0; k < TW_KM; ++k) {
+    const int m = k * 64 + lane;
+    if (m < N) Ui[(size_t)m * ldi + j] = m <= j ? x[k] : 0.0;
+  }
 }
 
 // Kinv[i][j] = sum_{m >= max(i,j)} Ui[i][m] Ui[j][m]
@@ -392,8 +472,11 @@ extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32
 extern "C" int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream) {
   if (!U || !Uinv || !Kinv || N <= 0 || ldu < N || ldi < N || ldk < N) return MCP_ERR_ARG;
   if (N > 16384) return MCP_ERR_LIMIT;
-  hipLaunchKernelGGL(tri_inverse_kernel, dim3((N + TI_NT - 1) / TI_NT), dim3(TI_NT), sizeof(double) * N, (hipStream_t)stream, N, U,
-                     ldu, Uinv, ldi);
+  if (N <= 64 * TW_KM)
+    hipLaunchKernelGGL(tri_inverse_wave_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, U, ldu, Uinv, ldi);
+  else
+    hipLaunchKernelGGL(tri_inverse_kernel, dim3((N + TI_NT - 1) / TI_NT), dim3(TI_NT), sizeof(double) * N, (hipStream_t)stream, N, U,
+                       ldu, Uinv, ldi);
   MCP_LAUNCH_CHECK();
   dim3 grid((N + 255) / 256, N);
   hipLaunchKernelGGL(kinv_from_uinv_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, Uinv, ldi, Kinv, ldk);
