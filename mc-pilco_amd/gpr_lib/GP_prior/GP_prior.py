@@ -171,24 +171,28 @@ class GP_prior(torch.nn.Module):
         print("\nInitial parameters:")
         self.print_model()
         t0 = time.time()
+        from mc_pilco_amd import nll
+
         for epoch in range(N_epoch):
-            running, nb = 0.0, 0
+            running, nb = None, 0  # the loss stays on the device: one host sync per epoch (the kernel descriptor's scalars), not three
             for inputs, labels in trainloader:
                 optimizer.zero_grad()
                 loss = criterion.loss_and_grad(self, inputs, labels)
                 optimizer.step()
-                running += float(loss)
+                running = loss if running is None else running + loss
                 nb += 1
             if epoch % N_epoch_print == 0:
+                nll.check_status(self)
                 print("\nEPOCH:", epoch)
                 self.print_model()
-                print("Running loss:", running / max(nb, 1))
+                print("Running loss:", (float(running) if running is not None else 0.0) / max(nb, 1))
                 print("Time elapsed:", time.time() - t0)
                 t0 = time.time()
                 if f_saving_model is not None:
                     f_saving_model(epoch)
                 if f_print is not None:
                     f_print()
+        nll.check_status(self)
         print("\nFinal parameters:")
         self.print_model()
 

@@ -60,6 +60,8 @@ class RBF(Stationary_GP):
         return self.mean_par.detach().reshape(1, -1).repeat(X.shape[0], 1)
 
     def kernel_spec(self) -> ops.KernelSpec:
-        sig2 = float(self.get_sigma_n_2()) if self.GP_with_noise else 0.0
-        return ops.KernelSpec(self.lengthscales().to(torch.float64), float(torch.exp(self.log_lambda_par.detach()).reshape(-1)[0]), sig2,
-                              float(self.mean_par.detach().reshape(-1)[0]))
+        # the three scalars of the descriptor in ONE device->host transfer
+        sig2_t = self.get_sigma_n_2().detach().reshape(-1)[:1] if self.GP_with_noise else torch.zeros(1, dtype=self.dtype, device=self.device)
+        sc = torch.cat([sig2_t.to(torch.float64), torch.exp(self.log_lambda_par.detach()).reshape(-1)[:1].to(torch.float64),
+                        self.mean_par.detach().reshape(-1)[:1].to(torch.float64)]).cpu()
+        return ops.KernelSpec(self.lengthscales().to(torch.float64), float(sc[1]), float(sc[0]), float(sc[2]))

@@ -33,8 +33,10 @@ def nll_loss_and_grad(gp, X, Y):
     N, D = Xc.shape
     K = ops.cov_build(spec, Xc, None, noise=gp.GP_with_noise)
     U, logdet, status = ops.chol_factor(K)
-    if ops.status_flags(status)["not_spd"]:
-        raise RuntimeError("cholesky: the covariance matrix is not positive-definite")
+    # the not-positive-definite flag is checked by the caller at its next host sync point (``check_status``): reading it
+    # here would stall the launch queue in the middle of every epoch
+    prev = getattr(gp, "_nll_status", None)
+    gp._nll_status = status if prev is None else torch.bitwise_or(prev, status)
     _, Kinv = ops.chol_inverse(U)
     r = (Y.to(dev) - gp.get_mean(X)).reshape(-1).contiguous()
     alpha = ops.gp_alpha(Kinv, r, 0.0).reshape(-1).contiguous()
@@ -68,3 +70,12 @@ def nll_loss_and_grad(gp, X, Y):
                 put(leaf.Sigma_pos_par, torch.cat([g[2 * D + 3:3 * D + 3], g[3 * D + 3:4 * D + 3]]))
         first = False
     return loss.detach()
+
+
+def check_status(gp):
+    """Raises if any Cholesky since the last check met a matrix that is not positive definite (torch.cholesky's error in the
+    reference, GP_prior.py:106)."""
+    st = getattr(gp, "_nll_status", None)
+    gp._nll_status = None
+    if st is not None and ops.status_flags(st)["not_spd"]:
+        raise RuntimeError("cholesky: the covariance matrix is not positive-definite")
