@@ -86,6 +86,11 @@ class MC_PILCO(torch.nn.Module):
     def sample_initial_particles(self, mean, var, flg_uniform, up_bound, low_bound, flg_multi_gauss, num_particles):
         """x_0 ~ uniform / mixture of Gaussians / Gaussian.  In "reference" noise mode the draw is made on the CPU with
         the reference's own distribution calls (bit-exact for a given torch seed)."""
+        if self.noise_mode != "reference" and not flg_uniform and not flg_multi_gauss:
+            # same distribution as MultivariateNormal(mean, diag(var)) without building M covariance matrices and their Cholesky
+            # factors on every optimizer step
+            mean, var = mean.to(self.device).reshape(1, -1), var.to(self.device).reshape(1, -1)
+            return mean + torch.sqrt(var) * torch.randn(num_particles, mean.shape[1], dtype=mean.dtype, device=self.device)
         on = torch.device("cpu") if self.noise_mode == "reference" else self.device
         mean, var = mean.to(on), var.to(on)
         if flg_uniform:
@@ -206,8 +211,12 @@ class MC_PILCO(torch.nn.Module):
             for _ in range(10):
                 states, inputs = self.apply_policy(p_dropout=s["p_drop"], **sim)
                 cost, std = self._cost(states, inputs, trial_index)
+                # the adjoint sweep is queued before the host looks at the cost (the NaN test is a sync point: checking first would
+                # leave the GPU idle while the backward launches are prepared); gradients of a NaN rollout are simply discarded
+                cost.backward(retain_graph=False)
                 if bool(torch.isnan(cost)):
                     print("\nCost is NaN: try sampling again")
+                    opt.zero_grad()
                 else:
                     nan = False
                     break
@@ -219,7 +228,6 @@ class MC_PILCO(torch.nn.Module):
                 es2 = alpha_diff_cost * (es2 + (1 - alpha_diff_cost) * (diff - s["es1"][step]) ** 2)
                 cost_prev = s["cost"][step]
                 s["ratio"][step + 1] = alpha_diff_cost * s["ratio"][step] + (1 - alpha_diff_cost) * (s["es1"][step + 1] / es2.sqrt())
-            cost.backward(retain_graph=False)
             self._allreduce_grads()
             opt.step()
             if step % num_step_print == 0:
