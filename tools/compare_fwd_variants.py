@@ -1,4 +1,5 @@
-"""Diagnostic: 16-particle tile kernel against the small-tile kernel on synthetic workloads of varied shape (same Philox noise)."""
+"""Diagnostic: the 16-particle MFMA tile kernel against the small-tile forward kernel on synthetic workloads of varied shape
+(same Philox noise): max differences of states, inputs and stored Jacobians, with and without sampling."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mcp_boot, torch
