@@ -19,8 +19,12 @@
 // "column i" is read as 64-double row segments (coalesced 512-B wave loads), double-buffered in
 // registers, the stream cut into equal contiguous shares for the 8 waves (phase V).  Everything
 // small and re-read every step (X^T, alpha, policy centres/weights) is copied to LDS once per
-// launch when it fits (template XLDS).  Reductions over the training index use wave64 DPP sums,
-// partial results meet in LDS; 8 workgroup barriers per time step.
+// launch when it fits (template XLDS).  The moment / Jacobian sums over the training index are one
+// skinny MFMA product per GP (phase J), the other reductions wave64 DPP sums; partial results meet in
+// LDS; 8 LDS-only workgroup barriers per time step.  Swarms above 1024 particles are handed to the
+// 16-particle tile kernel (rollout_fwd_tile.hip).  With a measurement model (mcp_meas: partially
+// measurable systems, MC_PILCO.py:808-906) phase S also produces what the policy sees: noisy
+// positions, backward-difference velocities, first-order filter, three carried values per pair.
 #include "rollout_fwd_shared.h"
 
 using namespace mcp;
