@@ -303,3 +303,26 @@ def test_pms_seed_for_seed_parity_with_reference(golden, fused):
     assert relerr(pol.log_lengthscales.grad, fx["g_log_ls"]) < 1e-7
     assert relerr(pol.centers.grad, fx["g_centers"]) < 1e-7
     assert relerr(pol.f_linear.weight.grad, fx["g_weight"]) < 1e-7
+
+
+def test_initial_particle_distributions_match_reference(golden):
+    """MC_PILCO.apply_policy's three initial distributions (MC_PILCO.py:634-660) in reference noise mode: the multi-Gaussian
+    component indices and the uniform draw reproduce the reference's for the same seed."""
+    fx = golden("init_dists")
+    fr = golden("rollout_se")
+    ml = build_cartpole(fr, 0, False)
+    obj = build_mcpilco(fr, ml, fr["pol_centers"].shape[0])
+    obj.noise_mode = "reference"
+    M = fx["mg_x0"].shape[0]
+    torch.manual_seed(int(fx["mg_seed"]))
+    x0 = obj.sample_initial_particles(T(fx["means"]), T(fx["vars"]), False, None, None, True, M)
+    assert float((x0.cpu() - torch.as_tensor(fx["mg_x0"])).abs().max()) < 1e-15
+    torch.manual_seed(int(fx["un_seed"]))
+    x0 = obj.sample_initial_particles(T(fx["means"][0]), T(fx["vars"][0]), True, T(fx["ub"]), T(fx["lb"]), False, M)
+    assert float((x0.cpu() - torch.as_tensor(fx["un_x0"])).abs().max()) < 1e-15
+    # performance mode: same moments (Gaussian), on the device
+    obj.noise_mode = "philox"
+    torch.manual_seed(0)
+    x0 = obj.sample_initial_particles(T(fx["means"][0]), T(fx["vars"][0]), False, None, None, False, 20000)
+    assert x0.is_cuda and float((x0.mean(0).cpu() - torch.as_tensor(fx["means"][0])).abs().max()) < 0.01
+    assert float((x0.var(0).cpu() / torch.as_tensor(fx["vars"][0]) - 1).abs().max()) < 0.05
