@@ -395,8 +395,10 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       }
 #pragma unroll
       for (int p = 0; p < PB; ++p) {
-        const volatile double* sfp = sf_all + p * PS;
-        const volatile double* abp = ab_all + p * PS;
+        // (plain reads: the serial waves' writes are ordered by the workgroup barrier above, and volatile would force a
+        // separate LDS round trip for every use)
+        const double* sfp = const_cast<const double*>(sf_all) + p * PS;
+        const double* abp = const_cast<const double*>(ab_all) + p * PS;
         const bool pv = mbase + p < M;
         double dd = 0.0;  // adjoint of dist_b (0 for idle threads and empty slots, so they add nothing below)
         if (act && pv) {
