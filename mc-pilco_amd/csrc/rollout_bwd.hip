@@ -277,7 +277,9 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       if (t > 0) prefetch(pre, t - 1, mbase);
       // ---- serial section: wave p for particle slot p -----------------------------------------------
       if (serial) {
-        const volatile double* r = rec + cur * NRP + sp * NR;
+        // the record of this step was parked before the last workgroup barrier and is not written again until the next one:
+        // plain loads (the compiler may batch them), unlike the section's own scratch arrays, which need program order
+        const double* r = const_cast<const double*>(rec) + cur * NRP + sp * NR;
         const volatile double* redp = red + sp * NW * PF;
         const bool last = (t == T - 1);
         if (!last) {
