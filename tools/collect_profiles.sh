@@ -17,6 +17,8 @@ rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/c1_write" -o c1 -- pytho
 echo "c1 write done"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c3_stats" -o c3 -- python3 "$R/bench.py" --workload c3 --steps 5 --warmup 2 --no-cpu > "$OUT/c3_stats.log" 2>&1 || exit 1
 echo "c3 stats done"
+rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/c3_mfma" -o c3 -- python3 "$R/bench.py" --workload c3 --steps 3 --warmup 1 --no-cpu > "$OUT/c3_mfma.log" 2>&1 || exit 1
+echo "c3 mfma counters done"
 rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5_stats" -o c5 -- python3 "$R/bench.py" --workload c5 --horizon 100 --steps 3 --warmup 1 --no-cpu > "$OUT/c5_stats.log" 2>&1 || exit 1
 echo "c5 stats done"
 # keep what is cited: the per-kernel statistics, and of the counter passes only the rollout kernels' rows

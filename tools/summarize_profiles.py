@@ -19,6 +19,15 @@ for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     v = [float(r["Counter_Value"]) for r in rows]
     vals[name] = sum(v[1:]) / max(1, len(v) - 1)  # skip the first (cold L2) launch
     print(counter, "launches", len(v), "steady-state mean KB", vals[name], "first", v[0])
+f = os.path.join(src, "c3_mfma", "c3_counter_collection.csv.rollout")
+if os.path.exists(f):
+    shutil.copy(f, os.path.join(dst, "%s_c3_pmc_mfma_busy.csv" % rnd))
+    rows = [r for r in csv.DictReader(open(f)) if "rollout_fwd_tile" in r["Kernel_Name"]]
+    busy = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES"]
+    act = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
+    if busy and act:  # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs in total
+        print("tile kernel (c3): MFMA busy %.3e cycles per launch, %.3e MFMAs at 64 cycles, pipe utilisation %.1f %%"
+              % (busy[-1], busy[-1] / 64, 100 * busy[-1] / (act[-1] / 8 * 1024)))
 M, T = 400, 150
 out = {"c1": (2.0 * vals["fetch"] + vals["write"]) * 1024.0,
        "_note": "rollout_fwd_kernel, bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (gfx950 FETCH_SIZE "
