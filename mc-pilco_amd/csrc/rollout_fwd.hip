@@ -1008,8 +1008,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   if (policy->meas.n > 0 && !policy->meas.meas) return MCP_ERR_ARG;
   if (P0 == 16) {
     // large swarms: 16-particle tiles on the matrix cores (rollout_fwd_tile.hip) when the problem fits that kernel
-    // (the measurement filter of partially measurable systems is implemented in the small-tile kernel only)
-    if (model->G >= 1 && T > 1 && policy->meas.n == 0 && fwd_tile_fits(model, policy)) {
+    if (model->G >= 1 && T > 1 && fwd_tile_fits(model, policy)) {
       g_last_ppw = 16;
       return launch_fwd_tile(a, st);
     }

@@ -585,7 +585,8 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
 // feature groups per product in registers, everything else eight.  One kernel per class: compiling both paths into one
 // function made the register allocator spill the small path's long-lived values for the benefit of the big one.
 // CLS: 0 = cart-pole class (D, policy features <= 8, inputs <= 2, N <= 512), 1 = UR5 class (<= 24, <= 24, <= 6, N <= 512), 2 = any
-template <int MAXDEG, int CLS>
+// PMS: the policy is evaluated on a simulated measurement (mcp_meas, MC_PILCO4PMS.apply_policy) instead of the true state
+template <int MAXDEG, int CLS, bool PMS>
 __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   constexpr int NG = CLS == 0 ? 2 : (CLS == 1 ? 6 : 8);              // feature groups of 4 (GP inputs, policy features)
   constexpr int UM = CLS == 0 ? 2 : (CLS == 1 ? 6 : MCP_MAX_INPUT);  // inputs
@@ -667,6 +668,24 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   for (int g = 0; g < G; ++g)
     if (own && md.not_vel[g] == os) vel_of_pos = md.vel[g];
   const double Ts = md.Ts;
+  // measurement model (see rollout_fwd.hip): thread (p, s) produces the measured value of its own component; a velocity thread
+  // rebuilds the noisy position of its pair (same draw) and carries the filter's three values
+  const mcp_meas& ms = pl.meas;
+  int pm_pos = -1, pm_vel = -1, pm_pair = 0;
+  double pm_std = 0.0, pm_prev_np = 0.0, pm_prev_nv = 0.0, pm_prev_mv = 0.0;
+  if (PMS && own) {
+    for (int i = 0; i < ms.n; ++i) {
+      if (ms.pos[i] == os) {
+        pm_pos = i;
+        pm_std = ms.std_pos[i];
+      }
+      if (ms.vel[i] == os) {
+        pm_vel = i;
+        pm_pair = ms.pos[i];
+        pm_std = ms.std_pos[i];
+      }
+    }
+  }
   // the last P*G threads draw the process noise of step t+1 while phase F of the first GP keeps only a few waves busy
   const int et = tid - (RF_NT - P * G);
   const bool edraw = et >= 0;
@@ -684,7 +703,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   lds_barrier();
 
   for (int t = 0; t < T; ++t) {
-    // ---- phase S: publish x_t, the GP / policy features of each state component; draw eps_t ------
+    // ---- phase S: publish x_t, the GP / policy features of each state component ------------------
+    double xm = xn;  // what the policy sees of this component
     if (own) {
       double* xc = xs + cur * P * S;
       xc[op * S + os] = xn;
@@ -692,24 +712,56 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         a.states[((size_t)t * M + m0 + op) * S + os] = xn;
         if (is_bad(xn)) bad |= MCP_STATUS_NAN;
       }
+    }
+    if (PMS) {
+      lds_barrier();  // a velocity thread reads its pair's position (the state threads span several waves)
+      if (own) {
+        const int pi = pm_pos >= 0 ? pm_pos : pm_vel;
+        double npos = pm_pos >= 0 ? xn : xs[cur * P * S + op * S + pm_pair];
+        if (pi >= 0 && t > 0) {
+          const double nn = ms.pos_noise ? ms.pos_noise[((size_t)(t - 1) * M + om) * ms.n + pi] : philox_normal(a.nz, om, t, pi, MCP_STREAM_POS);
+          npos = fma(pm_std, nn, npos);
+        }
+        if (pm_pos >= 0) xm = npos;
+        if (pm_vel >= 0) {
+          if (t == 0) {
+            pm_prev_nv = xn;
+            pm_prev_mv = xn;
+          } else {
+            const double nv = (npos - pm_prev_np) / Ts;
+            xm = (ms.b0 * nv + ms.b1 * pm_prev_nv - ms.a1 * pm_prev_mv) / ms.a0;
+            pm_prev_nv = nv;
+            pm_prev_mv = xm;
+          }
+          pm_prev_np = npos;
+        }
+        if (ovalid) {
+          ms.meas[((size_t)t * M + m0 + op) * S + os] = xm;
+          if (is_bad(xm)) bad |= MCP_STATUS_NAN;
+        }
+      }
+    }
+    if (own) {
       double sn = 0.0, cs = 0.0;
       if (zi_ang >= 0 || pi_ang >= 0) sincos(xn, &sn, &cs);
+      double snm = sn, csm = cs;  // trig of the measured value (policy features)
+      if (PMS && pi_ang >= 0 && xm != xn) sincos(xm, &snm, &csm);
       if (zi_plain >= 0) z[op * D + zi_plain] = xn;
       if (zi_ang >= 0) {
         z[op * D + nna + zi_ang] = sn;
         z[op * D + nna + na + zi_ang] = cs;
       }
       if (pl.kind == MCP_POLICY_ANGLES) {
-        if (pi_plain >= 0) sf[op * PF + pi_plain] = xn;
+        if (pi_plain >= 0) sf[op * PF + pi_plain] = xm;
         if (pi_ang >= 0) {
-          sf[op * PF + pol_nna + pi_ang] = cs;
-          sf[op * PF + pol_nna + pol_na + pi_ang] = sn;
+          sf[op * PF + pol_nna + pi_ang] = csm;
+          sf[op * PF + pol_nna + pol_na + pi_ang] = snm;
         }
       } else if (pl.kind == MCP_POLICY_TRAJ) {
-        sf[op * PF + os] = xn;
-        sf[op * PF + S + os] = pl.target_traj[(size_t)t * S + os] - xn;
+        sf[op * PF + os] = xm;
+        sf[op * PF + S + os] = pl.target_traj[(size_t)t * S + os] - xm;
       } else {
-        sf[op * PF + os] = xn;
+        sf[op * PF + os] = xm;
       }
     }
     lds_barrier();
@@ -956,18 +1008,23 @@ bool fwd_tile_fits(const mcp_model* model, const mcp_policy* policy) {
   return sizeof(double) * (size_t)L.total <= MCP_LDS_LIMIT;
 }
 
-template <int MAXDEG, int CLS>
-static int launch_tile_deg(const FwdArgs& a, size_t lds, hipStream_t st) {
+template <int MAXDEG, int CLS, bool PMS>
+static int launch_tile_pms(const FwdArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_tile_kernel<MAXDEG, CLS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_tile_kernel<MAXDEG, CLS, PMS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               MCP_LDS_LIMIT);
     attr_set = true;
   }
   const int grid = (a.M + TL_PT - 1) / TL_PT;
-  hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, CLS>), dim3(grid), dim3(RF_NT), lds, st, a);
+  hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, CLS, PMS>), dim3(grid), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
+}
+
+template <int MAXDEG, int CLS>
+static int launch_tile_deg(const FwdArgs& a, size_t lds, hipStream_t st) {
+  return a.pol.meas.n > 0 ? launch_tile_pms<MAXDEG, CLS, true>(a, lds, st) : launch_tile_pms<MAXDEG, CLS, false>(a, lds, st);
 }
 
 int launch_fwd_tile(const FwdArgs& a, hipStream_t st) {

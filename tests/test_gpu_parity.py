@@ -275,7 +275,7 @@ def test_philox_mode_properties():
     assert 0.5 < float(d.std() / a[1, :, 1].std()) < 1.5 and float(a[1, :, 1].std()) > 0
 
 
-@pytest.mark.parametrize("ppw", [0, 1, 2, 4])
+@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16])
 def test_pms_rollout_cost_gradient_vs_reference(golden, ppw):
     """MC_PILCO4PMS.apply_policy + cost + backward through the C ABI (mcp_meas): the measurement filter between particles and
     policy is carried inside the fused kernels; the reference's recorded eps / position noise / masks are injected."""
@@ -290,9 +290,11 @@ def test_pms_rollout_cost_gradient_vs_reference(golden, ppw):
     nz = ops.NoiseSpec(eps=G(fx["eps"]), masks=torch.as_tensor(fx["masks"]).to(dev()).contiguous())
     Tn, p = fx["states"].shape[0], float(fx["p_drop"])
     hipabi.lib().mcp_debug_set_particles_per_wg(ppw)
-    hipabi.lib().mcp_debug_set_bwd_particles(ppw)
+    hipabi.lib().mcp_debug_set_bwd_particles(min(ppw, 4))
     try:
         st, inp, status = ops.rollout(model, pol, nz, G(fx["x0"]), Tn, p, meas=meas)
+        if ppw:
+            assert hipabi.lib().mcp_debug_last_particles_per_wg() == ppw
         c, s = ops.expected_cost(cost, st)
         c.backward()
     finally:
@@ -327,6 +329,16 @@ def test_pms_philox_mode_is_reproducible_and_shard_invariant():
     assert torch.equal(torch.cat([lo[0], hi[0]], 1), a[0])
     plain = ops.rollout(model, pol, ops.NoiseSpec(seed=5, call=2), x0, Tn, 0.25)
     assert float((plain[1] - a[1]).abs().max()) > 1e-6  # the measurement noise does reach the policy
+    # the 16-particle tile kernel draws the same numbers (same trajectories to rounding)
+    from mc_pilco_amd import hipabi
+
+    hipabi.lib().mcp_debug_set_particles_per_wg(16)
+    try:
+        t16 = ops.rollout(model, pol, ops.NoiseSpec(seed=5, call=2), x0, Tn, 0.25, meas=meas)
+        assert hipabi.lib().mcp_debug_last_particles_per_wg() == 16
+    finally:
+        hipabi.lib().mcp_debug_set_particles_per_wg(0)
+    assert float((t16[0] - a[0]).abs().max()) < 1e-9 and float((t16[1] - a[1]).abs().max()) < 1e-9
 
 
 @pytest.mark.parametrize("case", [("cartpole", 0, 20, 17, 3), ("cartpole", 2, 33, 5, 2), ("cartpole", 1, 16, 1, 4), ("ur5", 1, 17, 3, 3),
