@@ -375,3 +375,90 @@ def test_kernel_variants_agree_on_odd_shapes(case):
         assert float((got[0] - ref[0]).abs().max()) < 1e-9 and float((got[1] - ref[1]).abs().max()) < 1e-9
         for ga, gb in zip(got[2], ref[2]):
             assert float((ga - gb).abs().max()) <= 1e-8 * max(1e-30, float(gb.abs().max()))
+
+
+@pytest.mark.parametrize("name,M", [("c1", 400), ("c3", 4096)])
+def test_full_size_properties(name, M):
+    """BASELINE.json's full shapes (N=300, T=150; c1: M=400 on the small-tile kernels, c3: SE+poly(2) on the 16-particle MFMA
+    tile kernel and the 4-particle backward sweep), checked through size-independent properties: bitwise determinism, shard
+    invariance (two half swarms with their global particle offsets reproduce the full swarm bit for bit), and the adjoint
+    gradient against a central finite difference of the expected cost along a random direction (noise held fixed)."""
+    from gpu_helpers import dev
+    from mc_pilco_amd import ops, workloads
+
+    w = workloads.build(name, device=dev(), M=M)
+    torch.manual_seed(21)
+    x0 = w.sample_x0()
+    nz = lambda off=0: ops.NoiseSpec(seed=77, call=5, particle_offset=off)
+
+    def cost_of():
+        st, inp, status = ops.rollout(w.model, w.policy, nz(), x0, w.T, w.p_drop)
+        c, s = ops.expected_cost(w.cost, st)
+        return st, c, status
+
+    st_a, c_a, status = cost_of()
+    st_b, c_b, _ = cost_of()
+    assert int(status.item()) == 0
+    assert torch.equal(st_a, st_b) and torch.equal(c_a.detach(), c_b.detach())
+    h = M // 2
+    lo = ops.rollout(w.model, w.policy, nz(0), x0[:h].contiguous(), w.T, w.p_drop)[0]
+    hi = ops.rollout(w.model, w.policy, nz(h), x0[h:].contiguous(), w.T, w.p_drop)[0]
+    assert (h > 1024) == (M > 1024)  # the halves run the same kernel variant as the whole: bit-identical
+    assert torch.equal(torch.cat([lo, hi], 1), st_a)
+    for q in w.params:
+        q.grad = None
+    c_a.backward()
+    g = [q.grad.detach().clone() for q in w.params]
+    gen = torch.Generator(device=dev())
+    gen.manual_seed(5)
+    dirs = [torch.randn(q.shape, dtype=q.dtype, device=q.device, generator=gen) for q in w.params]
+    gd = sum(float((a * b).sum()) for a, b in zip(g, dirs))
+    eps = 1e-6
+    with torch.no_grad():
+        for q, d in zip(w.params, dirs):
+            q.add_(eps * d)
+        cp = float(cost_of()[1])
+        for q, d in zip(w.params, dirs):
+            q.sub_(2 * eps * d)
+        cm = float(cost_of()[1])
+        for q, d in zip(w.params, dirs):
+            q.add_(eps * d)
+    fd = (cp - cm) / (2 * eps)
+    # over 150 steps the expected cost is violently nonlinear in the policy parameters (the difference quotient changes sign
+    # at eps = 1e-4 and is itself only good to ~1e-3): a coarse bound here, the tight one on the 40-step horizon below
+    assert abs(fd - gd) < 5e-3 * max(abs(gd), 1e-3), (fd, gd)
+
+
+@pytest.mark.parametrize("name,M", [("c1", 400), ("c3", 2048)])
+def test_adjoint_matches_finite_difference_at_full_width(name, M):
+    """Same swarms and training sets as above on a 40-step horizon, where a central difference is accurate: the adjoint
+    gradient's directional derivative agrees to 1e-5."""
+    from gpu_helpers import dev
+    from mc_pilco_amd import ops, workloads
+
+    w = workloads.build(name, device=dev(), M=M, T=40)
+    torch.manual_seed(21)
+    x0 = w.sample_x0()
+
+    def cost_of():
+        st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=77, call=5), x0, w.T, w.p_drop)
+        return ops.expected_cost(w.cost, st)[0]
+
+    for q in w.params:
+        q.grad = None
+    cost_of().backward()
+    g = [q.grad.detach().clone() for q in w.params]
+    gen = torch.Generator(device=dev())
+    gen.manual_seed(5)
+    dirs = [torch.randn(q.shape, dtype=q.dtype, device=q.device, generator=gen) for q in w.params]
+    gd = sum(float((a * b).sum()) for a, b in zip(g, dirs))
+    eps = 1e-6
+    with torch.no_grad():
+        for q, d in zip(w.params, dirs):
+            q.add_(eps * d)
+        cp = float(cost_of())
+        for q, d in zip(w.params, dirs):
+            q.sub_(2 * eps * d)
+        cm = float(cost_of())
+    fd = (cp - cm) / (2 * eps)
+    assert abs(fd - gd) < 1e-5 * max(abs(gd), 1e-3), (fd, gd)
