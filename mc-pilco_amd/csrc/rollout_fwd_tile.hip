@@ -71,7 +71,7 @@ __host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, in
   while (nslot > 1 && nslot * slot > avail) nslot >>= 1;
   int scr = nslot * slot;
   if (scr < 7 * 512 && 7 * 512 <= avail) scr = 7 * 512;
-  if (scr < RF_NW * 16 + RF_NW * TL_PT * U) scr = RF_NW * 16 + RF_NW * TL_PT * U;  // per-wave exchange slots + policy partial sums
+  if (scr < RF_NW * 16 + RF_NW * 16 * 17 + RF_NW * TL_PT * U) scr = RF_NW * 16 + RF_NW * 16 * 17 + RF_NW * TL_PT * U;  // exchange slots, phi tiles, partial sums  // per-wave exchange slots + policy partial sums
   L.nslot = nslot;
   L.vslots = scr / 512;
   L.scr = take(scr);
@@ -453,8 +453,10 @@ __device__ __forceinline__ double tile_r(const TileR& R, int c, int kind, int p)
 // four lanes of a quad exchange words so that each ends up with the bit of its own basis for its 4 particles.
 // Partial sums meet through a 16-lane DPP row reduction and an 8-wave LDS reduction.
 // ---------------------------------------------------------------------------------------
+// Narrow shapes (at most 2 inputs): W phi accumulated in registers (4 particles x U per lane) and reduced over the 16 basis
+// lanes by DPP at the end -- cheaper than the round trip through LDS of the two-product form below.
 template <int NQ, int UM>
-__device__ __forceinline__ void tile_pol_load(double (&cb)[NQ], double (&wk)[UM], gptr_t cen, gptr_t wgt, int B, int PF, int U, int tile, int kk, int n) {
+__device__ __forceinline__ void tile_polr_load(double (&cb)[NQ], double (&wk)[UM], gptr_t cen, gptr_t wgt, int B, int PF, int U, int tile, int kk, int n) {
   const int b = imin(16 * tile + n, B - 1);
 #pragma unroll
   for (int i = 0; i < NQ; ++i) cb[i] = cen[(size_t)b * PF + imin(4 * i + kk, PF - 1)];
@@ -462,11 +464,11 @@ __device__ __forceinline__ void tile_pol_load(double (&cb)[NQ], double (&wk)[UM]
   for (int k = 0; k < UM; ++k) wk[k] = wgt[(size_t)imin(k, U - 1) * B + b];
 }
 template <int NQ>
-struct TilePolConst {
+struct TilePolRConst {
   double a_s[NQ], ilq[NQ], ss4[4];
 };
 template <int NQ, int UM>
-__device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const double (&wk)[UM], const TilePolConst<NQ>& c, const FwdArgs& a,
+__device__ __forceinline__ void tile_polr_consume(const double (&cb)[NQ], const double (&wk)[UM], const TilePolRConst<NQ>& c, const FwdArgs& a,
                                                  int B, int U, int t, int m0, int tile, int kk, int n, int lane, bool drop, double keep_scale,
                                                  uint32_t drop_thr, double (&uacc)[4][UM]) {
   double scc = 0.0;
@@ -522,10 +524,10 @@ __device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const d
   }
 }
 template <int NQ, int UM>
-__device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* upart,
+__device__ __forceinline__ void tile_policy_reg(const FwdArgs& a, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* upart,
                                             int B, int PF, int U, int t, int m0, int wv, int lane, bool drop, double keep_scale, uint32_t drop_thr) {
   const int kk = lane >> 4, n = lane & 15;
-  TilePolConst<NQ> c;
+  TilePolRConst<NQ> c;
   double sss = 0.0;
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
@@ -552,14 +554,14 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
   if (wv < ntile) {
     const int nt = (ntile - wv + RF_NW - 1) / RF_NW;
     double c0[NQ], c1[NQ], w0[UM], w1[UM];
-    tile_pol_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, wv, kk, n);
+    tile_polr_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, wv, kk, n);
     for (int sI = 0; sI + 1 < nt; sI += 2) {
-      tile_pol_load<NQ, UM>(c1, w1, cen, wgt, B, PF, U, wv + RF_NW * (sI + 1), kk, n);
-      tile_pol_consume<NQ, UM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, uacc);
-      tile_pol_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
-      tile_pol_consume<NQ, UM>(c1, w1, c, a, B, U, t, m0, wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
+      tile_polr_load<NQ, UM>(c1, w1, cen, wgt, B, PF, U, wv + RF_NW * (sI + 1), kk, n);
+      tile_polr_consume<NQ, UM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, uacc);
+      tile_polr_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
+      tile_polr_consume<NQ, UM>(c1, w1, c, a, B, U, t, m0, wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
     }
-    if (nt & 1) tile_pol_consume<NQ, UM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
+    if (nt & 1) tile_polr_consume<NQ, UM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
   }
   // sum over the 16 basis lanes of each row; lane 15 of row kq holds the partial of particles kq + 4 r
 #pragma unroll
@@ -578,6 +580,126 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
   }
 }
 
+// Wide shapes: W phi as a second matrix product per tile (the accumulator is one 16x16 tile instead of 4 x U registers).
+#define TL_PHP 17  // row pitch (doubles) of the per-wave 16 x 16 phi tile
+template <int NQ>
+__device__ __forceinline__ void tile_pol_load(double (&cb)[NQ], double (&wb)[4], gptr_t cen, gptr_t wgt, int B, int PF, int U, int tile, int kk, int n) {
+  const int b = imin(16 * tile + n, B - 1);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) cb[i] = cen[(size_t)b * PF + imin(4 * i + kk, PF - 1)];
+  // B operand of the second product: W[k = n][16 tile + 4 s + kk]
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) wb[s4] = wgt[(size_t)imin(n, U - 1) * B + imin(16 * tile + 4 * s4 + kk, B - 1)];
+}
+template <int NQ>
+struct TilePolConst {
+  double a_s[NQ], ilq[NQ], ss4[4];
+};
+template <int NQ>
+__device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const double (&wb)[4], const TilePolConst<NQ>& c, const FwdArgs& a, int B,
+                                                 int U, int t, int m0, int tile, int kk, int n, int lane, bool drop, double keep_scale,
+                                                 uint32_t drop_thr, double* ptile, v4d& uacc) {
+  double scc = 0.0;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const double v = c.ilq[i] * cb[i];
+    scc = fma(v, v, scc);
+  }
+  const double cc = fold_kk(scc);
+  v4d C = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) C = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a_s[i], cb[i], C, 0, 0, 0);
+  const int b = 16 * tile + n;
+  const bool bvalid = b < B;
+  const int bc = imin(b, B - 1);
+  bool keep[4] = {true, true, true, true};
+  if (drop) {
+    if (a.nz.masks) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mm = imin(m0 + kk + 4 * r, a.M - 1);
+        keep[r] = a.nz.masks[((size_t)t * a.M + mm) * B + bc] != 0;
+      }
+    } else {
+      const int cq = n & 3;
+      const int mm = imin(m0 + kk + 4 * cq, a.M - 1);
+      const u32x4 rnd = philox_draw(a.nz, mm, t, MCP_STREAM_MASK, (uint32_t)(bc >> 2));
+      uint32_t wr[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        // round k4: lane cq sends word[(cq + k4) & 3]; lane c' receives, from lane r = (c' - k4) & 3 (the drawer for particle
+        // kq + 4 r), word[c'] -- the keep bit of its own basis for that particle
+        const int ws = (cq + k4) & 3;
+        const uint32_t snd = ws == 0 ? rnd.x : ws == 1 ? rnd.y : ws == 2 ? rnd.z : rnd.w;
+        const int src = (cq - k4) & 3;
+        const uint32_t rcv = (uint32_t)__shfl((int)snd, (lane & ~3) | src);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wr[r] = (src == r) ? rcv : wr[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) keep[r] = wr[r] >= drop_thr;
+    }
+  }
+  // phi tile (particle x basis) -> this wave's LDS scratch, then W phi as a second product: A = phi[p][b], B = W[k][b]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const double dist = (c.ss4[r] + cc) + C[r];
+    double phi = exp(-dist);
+    if (drop) phi = keep[r] ? phi * keep_scale : 0.0;
+    if (!bvalid) phi = 0.0;
+    ptile[(kk + 4 * r) * TL_PHP + n] = phi;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same wave writes and reads: program order is enough
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const double av = ptile[n * TL_PHP + 4 * s4 + kk];
+    const double bw = n < U ? wb[s4] : 0.0;
+    uacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bw, uacc, 0, 0, 0);
+  }
+}
+template <int NQ>
+__device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* ptile,
+                                            double* upart, int B, int PF, int U, int t, int m0, int wv, int lane, bool drop, double keep_scale,
+                                            uint32_t drop_thr) {
+  const int kk = lane >> 4, n = lane & 15;
+  TilePolConst<NQ> c;
+  double sss = 0.0;
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int q = 4 * i + kk;
+    const bool qv = q < PF;
+    const double sv = qv ? sf[n * PF + q] : 0.0;
+    const double il = qv ? invl[q] : 0.0;
+    const double il2s = il * il * sv;
+    c.ilq[i] = il;
+    c.a_s[i] = -2.0 * il2s;
+    sss = fma(il2s, sv, sss);
+  }
+  sss = fold_kk(sss);
+  if (kk == 0) wslot[n] = sss;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c.ss4[r] = wslot[kk + 4 * r];
+  v4d uacc = (v4d){0.0, 0.0, 0.0, 0.0};  // rows: particles kq + 4 r, column n: input k = n
+  const int ntile = (B + 15) >> 4;
+  if (wv < ntile) {
+    const int nt = (ntile - wv + RF_NW - 1) / RF_NW;
+    double c0[NQ], c1[NQ], w0[4], w1[4];
+    tile_pol_load<NQ>(c0, w0, cen, wgt, B, PF, U, wv, kk, n);
+    for (int sI = 0; sI + 1 < nt; sI += 2) {
+      tile_pol_load<NQ>(c1, w1, cen, wgt, B, PF, U, wv + RF_NW * (sI + 1), kk, n);
+      tile_pol_consume<NQ>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
+      tile_pol_load<NQ>(c0, w0, cen, wgt, B, PF, U, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
+      tile_pol_consume<NQ>(c1, w1, c, a, B, U, t, m0, wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
+    }
+    if (nt & 1) tile_pol_consume<NQ>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
+  }
+  if (n < U) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) upart[(wv * TL_PT + kk + 4 * r) * U + n] = uacc[r];
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // kernel
 // ---------------------------------------------------------------------------------------
@@ -589,7 +711,6 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
 template <int MAXDEG, int CLS, bool PMS>
 __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   constexpr int NG = CLS == 0 ? 2 : (CLS == 1 ? 6 : 8);              // feature groups of 4 (GP inputs, policy features)
-  constexpr int UM = CLS == 0 ? 2 : (CLS == 1 ? 6 : MCP_MAX_INPUT);  // inputs
   constexpr int MAXTASK = CLS == 2 ? TL_MAXTASK : 2;                  // 32-row blocks of Kinv per wave
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
@@ -767,13 +888,18 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     lds_barrier();
     TL_STAMP(0);
     // ---- policy: phi and W phi on the matrix cores, partial sums per wave -> LDS ----------------------
-    tile_policy<NG, UM>(a, invl, sf, cen, wgt, scr + wv * 16, scr + RF_NW * 16, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+    if (CLS == 0)
+      tile_policy_reg<NG, 2>(a, invl, sf, cen, wgt, scr + wv * 16, scr + RF_NW * 16 + RF_NW * 16 * TL_PHP, B, PF, U, t, m0, wv, lane, drop, keep_scale,
+                             drop_thr);
+    else
+      tile_policy<NG>(a, invl, sf, cen, wgt, scr + wv * 16, scr + RF_NW * 16 + wv * 16 * TL_PHP, scr + RF_NW * 16 + RF_NW * 16 * TL_PHP, B, PF, U, t, m0,
+                      wv, lane, drop, keep_scale, drop_thr);
     lds_barrier();
     TL_STAMP(1);
     // ---- squash, publish u ----------------------------------------------------------------------------
     if (tid < P * U) {
       const int p = tid / U, k = tid - p * U;
-      const double* up = scr + RF_NW * 16;
+      const double* up = scr + RF_NW * 16 + RF_NW * 16 * TL_PHP;
       double sacc = 0.0;
 #pragma unroll
       for (int w = 0; w < RF_NW; ++w) sacc += up[(w * P + p) * U + k];
