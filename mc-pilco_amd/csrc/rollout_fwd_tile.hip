@@ -38,7 +38,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define TL_NCOL(deg) ((deg) == 0 ? 2 : ((deg) == 1 ? 3 : 5))
 
 struct TileLayout {
-  int invl, xs, us, z, sf, dl, eps, ks, kv, qa, mup, gpl, kpar, scr, total;  // offsets in doubles
+  int invl, xs, us, z, sf, dl, eps, ks, kv, qa, mup, gpl, kpar, scr, total;
+  int ptile, upart;  // policy phase: per-wave phi tiles (alias the k / v panels, idle then, when those are large enough) and partial sums  // offsets in doubles
   int nslot;   // phase-J partial-tile slots in scr
   int vslots;  // phase-V partial (32x16) slots in scr
 };
@@ -71,10 +72,15 @@ __host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, in
   while (nslot > 1 && nslot * slot > avail) nslot >>= 1;
   int scr = nslot * slot;
   if (scr < 7 * 512 && 7 * 512 <= avail) scr = 7 * 512;
-  if (scr < RF_NW * 16 + RF_NW * 16 * 17 + RF_NW * TL_PT * U) scr = RF_NW * 16 + RF_NW * 16 * 17 + RF_NW * TL_PT * U;  // exchange slots, phi tiles, partial sums  // per-wave exchange slots + policy partial sums
+  const int ptiles = RF_NW * 16 * 17;
+  const bool pt_in_scr = 2 * NpadMax * TL_KR < ptiles;
+  const int polneed = RF_NW * 16 + (pt_in_scr ? ptiles : 0) + RF_NW * TL_PT * U;  // exchange slots, [phi tiles,] partial sums
+  if (scr < polneed) scr = polneed;  // per-wave exchange slots + policy partial sums
   L.nslot = nslot;
   L.vslots = scr / 512;
   L.scr = take(scr);
+  L.ptile = pt_in_scr ? L.scr + RF_NW * 16 : L.ks;
+  L.upart = L.scr + RF_NW * 16 + (pt_in_scr ? ptiles : 0);
   L.total = o;
   return L;
 }
@@ -889,17 +895,16 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     TL_STAMP(0);
     // ---- policy: phi and W phi on the matrix cores, partial sums per wave -> LDS ----------------------
     if (CLS == 0)
-      tile_policy_reg<NG, 2>(a, invl, sf, cen, wgt, scr + wv * 16, scr + RF_NW * 16 + RF_NW * 16 * TL_PHP, B, PF, U, t, m0, wv, lane, drop, keep_scale,
-                             drop_thr);
+      tile_policy_reg<NG, 2>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
     else
-      tile_policy<NG>(a, invl, sf, cen, wgt, scr + wv * 16, scr + RF_NW * 16 + wv * 16 * TL_PHP, scr + RF_NW * 16 + RF_NW * 16 * TL_PHP, B, PF, U, t, m0,
-                      wv, lane, drop, keep_scale, drop_thr);
+      tile_policy<NG>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.ptile + wv * 16 * TL_PHP, smem + L.upart, B, PF, U, t, m0, wv, lane, drop,
+                      keep_scale, drop_thr);
     lds_barrier();
     TL_STAMP(1);
     // ---- squash, publish u ----------------------------------------------------------------------------
     if (tid < P * U) {
       const int p = tid / U, k = tid - p * U;
-      const double* up = scr + RF_NW * 16 + RF_NW * 16 * TL_PHP;
+      const double* up = smem + L.upart;
       double sacc = 0.0;
 #pragma unroll
       for (int w = 0; w < RF_NW; ++w) sacc += up[(w * P + p) * U + k];
