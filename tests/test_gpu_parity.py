@@ -462,3 +462,16 @@ def test_adjoint_matches_finite_difference_at_full_width(name, M):
         cm = float(cost_of())
     fd = (cp - cm) / (2 * eps)
     assert abs(fd - gd) < 1e-5 * max(abs(gd), 1e-3), (fd, gd)
+
+
+@pytest.mark.parametrize("name,M,expect", [("c1", 400, 2), ("c3", 4000, 16), ("c5", 2000, 16)])
+def test_baseline_shapes_run_on_the_intended_kernel(name, M, expect):
+    """The automatic dispatch puts BASELINE.json's shapes where DESIGN.md says they run (a shape that overflows the tile kernel's
+    LDS budget would silently fall back to the 4-particle kernel)."""
+    from gpu_helpers import dev
+    from mc_pilco_amd import hipabi, ops, workloads
+
+    w = workloads.build(name, device=dev(), M=M, T=3)
+    st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=1), w.sample_x0(), w.T, w.p_drop)
+    assert int(status.item()) == 0
+    assert hipabi.lib().mcp_debug_last_particles_per_wg() == expect
