@@ -40,6 +40,7 @@ extern "C" {
 #define MCP_STATUS_NAN 1u         /* a NaN was produced in a state / input / cost          */
 #define MCP_STATUS_NONPOS_VAR 2u  /* a GP posterior variance <= 0 (torch Normal would raise) */
 #define MCP_STATUS_NOT_SPD 4u     /* Cholesky met a non-positive pivot                     */
+#define MCP_STATUS_SYNC 8u        /* GP-sharded rollout: a partner workgroup never arrived   */
 
 #define MCP_MAX_GP 8
 #define MCP_MAX_STATE 16

@@ -548,10 +548,11 @@ static int bwd_threads(int B) { return imax(64, ((B + 63) / 64) * 64); }
 static int bwd_blocks(int M) { return imin(M, 1024); }
 
 extern "C" size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_policy* policy, int M, int T) {
-  (void)model;
   if (!policy || M <= 0 || T <= 0) return 0;
   size_t nparam = (size_t)policy->P + (size_t)policy->B * policy->P + (size_t)policy->U * policy->B;
-  return sizeof(double) * nparam * (size_t)bwd_blocks(M);
+  const size_t bwd = sizeof(double) * nparam * (size_t)bwd_blocks(M);   // mcp_rollout_bwd: per-workgroup gradient slabs
+  const size_t fwd = model ? rollout_xch_bytes(M, model->G) : 0;         // mcp_rollout_fwd: hand-off granules (GP-sharded launch)
+  return bwd > fwd ? bwd : fwd;
 }
 
 template <int PFM, int UM, int MAXNT, int WPE, int PB>

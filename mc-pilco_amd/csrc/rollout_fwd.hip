@@ -47,8 +47,10 @@ struct FwdLayout {
 #define TAB_INTS (TAB_WC0 + RF_NW)
 #define RF_CW 128  // rows of v per column chunk: 64 lanes x 2 rows (one 16-byte load per lane)
 
+// GX = number of GPs whose operands are staged in LDS (G, or 1 in a GP-sharded launch)
 __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int G, int PF, int B, int NpadMax, int maxdeg, int GB,
-                                                int NCmax, bool xlds) {
+                                                int NCmax, bool xlds, int GX = -1) {
+  if (GX < 0) GX = G;
   FwdLayout L;
   int o = 0;
   auto take = [&](int n) {
@@ -61,7 +63,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int 
   L.us = take(P * U);
   L.z = take(P * D);
   L.sf = take(P * PF);
-  L.dl = take(2 * P * G);  // delta_g | process noise of the step (drawn in phase S by otherwise idle threads)
+  L.dl = take(2 * P * G + 2);  // delta_g | process noise of the step (drawn in phase S by otherwise idle threads) | abort word (GSH)
   L.kb = take(GB * NpadMax * P);
   L.ks = maxdeg > 0 ? take(GB * NpadMax * P) : L.kb;
   L.pa = maxdeg > 1 ? take(GB * NpadMax * P) : L.kb;
@@ -69,8 +71,8 @@ __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int 
   L.vb = take(GB * NpadMax * P * (maxdeg == 0 ? 2 : 1));  // SE-only models store the phase-J weight matrix W[j][2p+a] instead of v
   L.part = take(imax((NCmax + RF_NW) * 128 * P, P * B));
   L.red = take(GB * RF_NW * (D + 1) * P * (maxdeg == 0 ? 2 : 9));
-  L.xt = xlds ? take(G * D * NpadMax) : 0;
-  L.al = xlds ? take(G * NpadMax) : 0;
+  L.xt = xlds ? take(GX * D * NpadMax) : 0;
+  L.al = xlds ? take(GX * NpadMax) : 0;
   L.cen = xlds ? take(B * PF) : 0;
   L.wgt = xlds ? take(U * B) : 0;
   L.tab = take((TAB_INTS + 1) / 2);
@@ -182,15 +184,26 @@ __device__ __forceinline__ void phase_k(const GpL* gpl, const double* kpar, int 
 // end.  RF_GS loads per register buffer, two buffers in flight.  k_j[0..P) is an LDS broadcast read.
 // The stream (all chunks of all GPs of the pass) is cut into RF_NW equal contiguous shares.
 // ---------------------------------------------------------------------------------------
+// (the k values are read from LDS ahead of their use, a whole register buffer or a rolling half of it: left at their uses, the
+//  compiler emits read -> wait -> 2 FMAs per value and the LDS latency, ~64 cycles, is paid P times per row)
 template <int P>
 __device__ __forceinline__ void consume_rows(const v2d (&A)[RF_GS], const double* __restrict__ kk, int kstride, double (&acc)[2][P]) {
+  constexpr int KB = P >= 4 ? RF_GS / 2 : RF_GS;  // rows of k in flight (a rolling window: 4 rows of 4 particles cover the latency)
+  double kr[KB][P];
+#pragma unroll
+  for (int u = 0; u < KB; ++u)
+#pragma unroll
+    for (int p = 0; p < P; ++p) kr[u][p] = kk[u * kstride + p];
 #pragma unroll
   for (int u = 0; u < RF_GS; ++u) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-      double kv = kk[u * kstride + p];
-      acc[0][p] = fma(A[u].x, kv, acc[0][p]);
-      acc[1][p] = fma(A[u].y, kv, acc[1][p]);
+      acc[0][p] = fma(A[u].x, kr[u % KB][p], acc[0][p]);
+      acc[1][p] = fma(A[u].y, kr[u % KB][p], acc[1][p]);
+    }
+    if (u + KB < RF_GS) {
+#pragma unroll
+      for (int p = 0; p < P; ++p) kr[u % KB][p] = kk[(u + KB) * kstride + p];
     }
   }
 }
@@ -532,9 +545,27 @@ __device__ __forceinline__ void gp_jac(const GpL& gp, const double* kp, int D, c
 }
 
 // ---------------------------------------------------------------------------------------
-// forward rollout
+// GP-sharded launch (GSH): hand-off of the sampled increments between the G workgroups of a particle cluster.
+// The data is the flag: every double travels as two naturally aligned 8-byte {tag = t + 1, 32-bit half} granules, each
+// written by ONE agent-scope (write-through) store and re-read by agent-scope loads until its tag matches; no fence, no
+// ordering between granules.  Slots alternate with the parity of t: a workgroup can only be one hand-off ahead of its
+// partners, so slot (t & 1) is not rewritten before every partner has consumed step t.  The buffer is zeroed by the
+// launch function on the stream (tags start at 1).  Spins are bounded: a partner that never shows up (a grid larger
+// than the device can hold would be the only reason) ends the rollout with MCP_STATUS_SYNC instead of hanging.
 // ---------------------------------------------------------------------------------------
-template <int P, bool XLDS, int MAXDEG>
+typedef unsigned long long __attribute__((address_space(1))) * gu64_t;
+#define RF_SPIN_LIMIT (1u << 20)
+__device__ __forceinline__ void store_granule(gu64_t g, unsigned epoch, unsigned value) {
+  __hip_atomic_store(g, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ size_t xch_slot(int cluster, int t, int G, int g, int P) { return ((((size_t)cluster * 2 + (t & 1)) * G + g) * P) * 2; }
+
+// ---------------------------------------------------------------------------------------
+// forward rollout.  GSH = false: one workgroup per P particles, all GPs.  GSH = true: G workgroups per P particles, each
+// evaluates ONE GP (streams one Kinv) and the policy; they meet once per step in the hand-off above.  Blocks b and b + 8
+// are dealt to the same XCD, so the members of a cluster sit 8 apart (a speed matter only).
+// ---------------------------------------------------------------------------------------
+template <int P, bool XLDS, int MAXDEG, bool GSH>
 __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
@@ -544,7 +575,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
   const int NpadMax = a.NpadMax, GB = a.GB;
-  const FwdLayout L = fwd_layout(P, S, U, D, G, PF, B, NpadMax, a.maxdeg, GB, a.NCmax, XLDS);
+  const FwdLayout L = fwd_layout(P, S, U, D, G, PF, B, NpadMax, a.maxdeg, GB, a.NCmax, XLDS, GSH ? 1 : G);
   double* invl = smem + L.invl;
   double* xs = smem + L.xs;  // [2][P][S] double-buffered
   double* us = smem + L.us;
@@ -566,7 +597,17 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   int* tab = reinterpret_cast<int*>(smem + L.tab);
   GpL* gpl = reinterpret_cast<GpL*>(smem + L.gpl);
   double* kpar = smem + L.kpar;
-  const int m0 = blockIdx.x * P;
+  int cluster = blockIdx.x, myg = 0;
+  if (GSH) {
+    const int b = blockIdx.x, grp = b / (8 * G), r = b - grp * 8 * G;
+    cluster = grp * 8 + (r & 7);
+    myg = r >> 3;
+    if (cluster >= a.nclusters) return;  // padding blocks of the last group of 8 clusters
+  }
+  const bool writer = !GSH || myg == 0;  // states / inputs are identical in the workgroups of a cluster: one of them stores
+  int* abortw = reinterpret_cast<int*>(dl + 2 * P * G);
+  if (GSH && tid == 0) *abortw = 0;
+  const int m0 = cluster * P;
   uint32_t bad = 0;
   const bool drop = pl.p_drop > 0.0;
   const double keep_scale = 1.0 / (1.0 - pl.p_drop);
@@ -575,10 +616,13 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
 
   // ---- one-time staging ------------------------------------------------------------------
   for (int it = tid; it < PF; it += RF_NT) invl[it] = exp(-pl.log_ls[it]);
-  stage_gp_tables(gps, md.var_scale, G, D, gpl, kpar, tid);
+  // the GPs this workgroup evaluates: all of them, or (GSH) its own one, which then lives in slot 0 of every LDS table
+  const int GL = GSH ? 1 : G;
+  const mcp_gp* gps_l = gps + myg;
+  stage_gp_tables(gps_l, md.var_scale + myg, GL, D, gpl, kpar, tid);
   if (XLDS) {
-    for (int g = 0; g < G; ++g) {
-      const mcp_gp& gp = gps[g];
+    for (int g = 0; g < GL; ++g) {
+      const mcp_gp& gp = gps_l[g];
       for (int it = tid; it < D * gp.Npad; it += RF_NT) {
         int d = it / gp.Npad, j = it - d * gp.Npad;
         xt_l[(g * D + d) * NpadMax + j] = gp.Xt[it];
@@ -592,7 +636,10 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   const double* wgt = XLDS ? wgt_l : pl.weight;
   lds_barrier();
   int NC = 0;
-  if (GB >= G) NC = build_chunk_table(gpl, 0, G, tab, tid);
+  if (GSH)
+    NC = build_chunk_table(gpl, 0, 1, tab, tid);
+  else if (GB >= G)
+    NC = build_chunk_table(gpl, 0, G, tab, tid);
 
   // thread (p, s) owns state component s of particle p
   const bool own = tid < P * S;
@@ -678,8 +725,10 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       double* xc = xs + cur * P * S;
       xc[op * S + os] = xn;
       if (ovalid) {
-        a.states[((size_t)t * M + m0 + op) * S + os] = xn;
-        if (pms) ms.meas[((size_t)t * M + m0 + op) * S + os] = xm;
+        if (writer) {
+          a.states[((size_t)t * M + m0 + op) * S + os] = xn;
+          if (pms) ms.meas[((size_t)t * M + m0 + op) * S + os] = xm;
+        }
         if (is_bad(xn) || is_bad(xm)) bad |= MCP_STATUS_NAN;
       }
       double sn = 0.0, cs = 0.0;
@@ -753,7 +802,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         us[p * U + k] = u;
         z[p * D + nna + 2 * na + k] = u;
         if (m0 + p < M) {
-          a.inputs[((size_t)t * M + m0 + p) * U + k] = u;
+          if (writer) a.inputs[((size_t)t * M + m0 + p) * U + k] = u;
           if (is_bad(u)) bad |= MCP_STATUS_NAN;
         }
       }
@@ -762,9 +811,9 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
     RF_STAMP(2);
     if (t == T - 1) break;
     // ---- GPs, GB at a time ---------------------------------------------------------------------
-    for (int g0 = 0; g0 < G; g0 += GB) {
-      const int gn = imin(GB, G - g0);
-      if (GB < G) {
+    for (int g0 = 0; g0 < GL; g0 += GB) {
+      const int gn = imin(GB, GL - g0);
+      if (!GSH && GB < G) {
         lds_barrier();
         NC = build_chunk_table(gpl, g0, gn, tab, tid);
         lds_barrier();
@@ -787,9 +836,9 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         int gl = it / (P * (D + 1));
         int r = it - gl * P * (D + 1);
         int p = r / (D + 1), c = r - p * (D + 1);
-        const int g = g0 + gl;
-        const GpL& gp = gpl[g];
-        const double* kp = kpar + g * KP_STRIDE(D);
+        const int g = GSH ? myg : g0 + gl;  // global GP index (noise, increments, Jacobian rows)
+        const GpL& gp = gpl[g0 + gl];
+        const double* kp = kpar + (g0 + gl) * KP_STRIDE(D);
         const double vscale = gp.var_scale;
         constexpr int NCOLMAX = P * RF_NAX(MAXDEG);
         const double* Rg = red + gl * RF_NW * (D + 1) * NCOLMAX;
@@ -805,7 +854,14 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
           wj = eps / (2.0 * sd);
         }
         if (c == D) {
-          dl[p * G + g] = a.particle_pred ? fma(sd, eps, mu) : mu;
+          const double dv = a.particle_pred ? fma(sd, eps, mu) : mu;
+          dl[p * G + g] = dv;
+          if (GSH) {  // publish straight from the register: two granules
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(dv);
+            gu64_t slot = (gu64_t)a.xch + xch_slot(cluster, t, G, g, P) + 2 * p;
+            store_granule(slot, (unsigned)t + 1u, (unsigned)bits);
+            store_granule(slot + 1, (unsigned)t + 1u, (unsigned)(bits >> 32));
+          }
           if (m0 + p < M) {
             if (a.particle_pred && !(var > 0.0)) bad |= MCP_STATUS_NONPOS_VAR;
             if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
@@ -817,7 +873,38 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         }
       }
     }
+    if (GSH && wv == 0) {
+      // collect the other GPs' increments: lane -> (other GP, particle, half); every pass re-reads every granule
+      const unsigned long long tx0_ = (a.stamps && blockIdx.x == 0) ? clock64() : 0;
+      const int ngr = (G - 1) * P * 2;
+      const bool act = lane < ngr;
+      const int go = act ? lane / (2 * P) : 0, r = act ? lane - go * 2 * P : 0;
+      const int gq = go < myg ? go : go + 1;
+      gu64_t slot = (gu64_t)a.xch + xch_slot(cluster, t, G, gq, P) + r;
+      unsigned val = 0;
+      bool done = false;
+      for (unsigned spins = 0; spins < RF_SPIN_LIMIT; ++spins) {
+        bool ok = true;
+        if (act) {
+          const unsigned long long x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          val = (unsigned)x;
+          ok = (unsigned)(x >> 32) == (unsigned)t + 1u;
+        }
+        if (__all(ok)) {
+          done = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (act) reinterpret_cast<unsigned*>(dl)[2 * ((r >> 1) * G + gq) + (r & 1)] = val;
+      if (!done && lane == 0) *abortw = 1;
+      if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[8] += clock64() - tx0_;
+    }
     lds_barrier();
+    if (GSH && *abortw) {  // uniform (the barrier's memory clobber forces the re-read): a partner never arrived
+      bad |= MCP_STATUS_SYNC;
+      break;
+    }
     RF_STAMP(7);
     // ---- integrate:  v' = v + delta ;  q' = q + Ts v + Ts/2 delta   (Model_learning.py:711-716) ----
     if (own) {
@@ -938,6 +1025,26 @@ extern "C" void mcp_debug_set_fwd_mode(int xlds, int gb) {
 static unsigned long long* g_stamps = nullptr;  // diagnostic hook: device buffer of 16 u64 phase-cycle totals
 extern "C" void mcp_debug_set_stamp_buffer(void* p) { g_stamps = (unsigned long long*)p; }
 
+// ---- GP-sharded launch: G workgroups per particle cluster ----------------------------------------------------------
+static int g_gp_sharding = -1;  // test hook: -1 automatic, 0 never, 1 whenever the grid fits the device
+static int g_last_sharded = 0;  // test hook: whether the last forward launch was GP-sharded
+extern "C" void mcp_debug_set_gp_sharding(int mode) { g_gp_sharding = mode; }
+extern "C" int mcp_debug_last_gp_sharded(void) { return g_last_sharded; }
+static int gsh_grid(int nclusters, int G) { return ((nclusters + 7) / 8) * 8 * G; }
+// every workgroup of a GP-sharded grid waits for its partners, so the whole grid must be resident: one 512-thread
+// workgroup per CU (the LDS footprint allows no more)
+static int device_cu_count() {
+  static int cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cus[dev] = n;
+  }
+  return cus[dev];
+}
+
 static int chunks_in_pass(const mcp_model* m, int GB) {
   int best = 0;
   for (int g0 = 0; g0 < m->G; g0 += GB) {
@@ -948,30 +1055,32 @@ static int chunks_in_pass(const mcp_model* m, int GB) {
   return best;
 }
 
-template <int P, bool XLDS, int MAXDEG>
+template <int P, bool XLDS, int MAXDEG, bool GSH>
 static int launch_fwd_deg(const FwdArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_kernel<P, XLDS, MAXDEG>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              MCP_LDS_LIMIT);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_kernel<P, XLDS, MAXDEG, GSH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, MCP_LDS_LIMIT);
     attr_set = true;
   }
-  int grid = (a.M + P - 1) / P;
-  hipLaunchKernelGGL((rollout_fwd_kernel<P, XLDS, MAXDEG>), dim3(grid), dim3(RF_NT), lds, st, a);
+  const int grid = GSH ? gsh_grid(a.nclusters, a.model.G) : (a.M + P - 1) / P;
+  hipLaunchKernelGGL((rollout_fwd_kernel<P, XLDS, MAXDEG, GSH>), dim3(grid), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }
 // the SE-only instantiation carries no polynomial code: a markedly smaller kernel (instruction-cache footprint)
 template <int P, bool XLDS>
 static int launch_fwd(const FwdArgs& a, size_t lds, hipStream_t st) {
-  return a.maxdeg == 0 ? launch_fwd_deg<P, XLDS, 0>(a, lds, st) : launch_fwd_deg<P, XLDS, 2>(a, lds, st);
+  return a.maxdeg == 0 ? launch_fwd_deg<P, XLDS, 0, false>(a, lds, st) : launch_fwd_deg<P, XLDS, 2, false>(a, lds, st);
+}
+template <int P>
+static int launch_fwd_sharded(const FwdArgs& a, size_t lds, hipStream_t st) {
+  return a.maxdeg == 0 ? launch_fwd_deg<P, true, 0, true>(a, lds, st) : launch_fwd_deg<P, true, 2, true>(a, lds, st);
 }
 
 extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
                                const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
                                size_t workspace_bytes, void* stream) {
-  (void)workspace;
-  (void)workspace_bytes;
   if (!noise || !x0 || !states || !inputs || !status || !policy || M <= 0 || T <= 0) return MCP_ERR_ARG;
   mcp_model stub;
   if (!model) {
@@ -1001,11 +1110,41 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   a.jac = jac;
   a.status = status;
   a.stamps = g_stamps;
+  a.xch = nullptr;
+  a.nclusters = 0;
   hipStream_t st = (hipStream_t)stream;
   // configuration search: most particles per workgroup first, operands in LDS if they fit, all GPs per pass if they fit
   int P0 = g_force_ppw ? g_force_ppw : pick_particles_per_wg(M);
   if (P0 != 1 && P0 != 2 && P0 != 4 && P0 != 16) return MCP_ERR_ARG;
   if (policy->meas.n > 0 && !policy->meas.meas) return MCP_ERR_ARG;
+  // small swarms: shard the GPs of a particle cluster over G workgroups (each streams one Kinv) when the whole grid is
+  // resident at one workgroup per CU; smallest cluster size first (most CUs busy)
+  g_last_sharded = 0;
+  if (g_gp_sharding != 0 && model->G >= 2 && T > 1 && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
+      (g_force_ppw == 0 || g_gp_sharding == 1)) {
+    const int cus = device_cu_count();
+    int NC1 = 0;
+    for (int g = 0; g < model->G; ++g) NC1 = imax(NC1, (model->gp[g].Npad + RF_CW - 1) / RF_CW);
+    const bool forced = g_force_ppw == 1 || g_force_ppw == 2 || g_force_ppw == 4;
+    for (int P = forced ? g_force_ppw : 1; P <= (forced ? g_force_ppw : 4) && NC1 <= RF_MAX_CHUNKS; P <<= 1) {
+      const int ncl = (M + P - 1) / P;
+      if (gsh_grid(ncl, model->G) > cus) continue;
+      FwdLayout L = fwd_layout(P, model->S, model->U, model->D, model->G, policy->P, policy->B, a.NpadMax, a.maxdeg, 1, NC1, true, 1);
+      const size_t lds = sizeof(double) * (size_t)L.total;
+      if (lds > MCP_LDS_LIMIT) break;
+      a.GB = 1;
+      a.NCmax = NC1;
+      a.nclusters = ncl;
+      a.xch = (unsigned long long*)workspace;
+      if (hipMemsetAsync(workspace, 0, ((size_t)ncl * 2 * model->G * P * 2 * sizeof(unsigned long long) + 15) & ~(size_t)15, st) != hipSuccess)
+        return MCP_ERR_LAUNCH;
+      g_last_ppw = P;
+      g_last_sharded = 1;
+      if (P == 4) return launch_fwd_sharded<4>(a, lds, st);
+      if (P == 2) return launch_fwd_sharded<2>(a, lds, st);
+      return launch_fwd_sharded<1>(a, lds, st);
+    }
+  }
   if (P0 == 16) {
     // large swarms: 16-particle tiles on the matrix cores (rollout_fwd_tile.hip) when the problem fits that kernel
     if (model->G >= 1 && T > 1 && fwd_tile_fits(model, policy)) {

@@ -45,6 +45,10 @@ struct FwdArgs {
   double* jac;
   uint32_t* status;
   unsigned long long* stamps;  // diagnostic only (mcp_debug_set_stamp_buffer): per-phase cycle totals of workgroup 0
+  // GP-sharded launch (rollout_fwd.hip, GSH): the G workgroups of a particle cluster hand each other their GP's sampled
+  // increment once per step through 8-byte {tag, value} granules  xch[cluster][t & 1][g][p][half]  (zeroed per launch)
+  unsigned long long* xch;
+  int nclusters;
 };
 
 #define RF_STAMP(k)                                 \

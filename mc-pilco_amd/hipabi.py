@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libmcpilco_hip.so")
 MAX_GP, MAX_STATE, MAX_INPUT, MAX_GPDIM, MAX_PFEAT, MAX_BASIS, MAX_TRAIN = 8, 16, 8, 32, 32, 1024, 1024
 OK = 0
 ERRORS = {-1: "MCP_ERR_ARG", -2: "MCP_ERR_LIMIT", -3: "MCP_ERR_WORKSPACE", -4: "MCP_ERR_LAUNCH"}
-STATUS_NAN, STATUS_NONPOS_VAR, STATUS_NOT_SPD = 1, 2, 4
+STATUS_NAN, STATUS_NONPOS_VAR, STATUS_NOT_SPD, STATUS_SYNC = 1, 2, 4, 8
 POLICY_PLAIN, POLICY_ANGLES, POLICY_TRAJ = 0, 1, 2
 COST_CARTPOLE, COST_TRAJ = 0, 1
 
@@ -91,6 +91,8 @@ _SIGS = {
     "mcp_debug_set_stamp_buffer": (None, [dptr]),
     "mcp_debug_set_fwd_mode": (None, [C.c_int, C.c_int]),
     "mcp_debug_set_bwd_stamp_buffer": (None, [dptr]),
+    "mcp_debug_set_gp_sharding": (None, [C.c_int]),
+    "mcp_debug_last_gp_sharded": (C.c_int, []),
 }
 EXPORTED = [k for k in _SIGS if not k.startswith("mcp_debug")]
 

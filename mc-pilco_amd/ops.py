@@ -350,9 +350,12 @@ def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, nois
     nz = noise.to_c()
     meas_buf = torch.empty(T, M, policy.S, dtype=DT, device=dev) if meas is not None else None
     _set_meas(policy, meas, T, M, meas_buf)
+    # workspace: the hand-off granules of the GP-sharded launch (small swarms); the library zeroes what it uses
+    nbytes = abi.lib().mcp_rollout_workspace_bytes(_mc(model), C.byref(pc), M, T) if (model is not None and T > 1) else 0
+    ws = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev) if nbytes else None
     try:
         abi.check(abi.lib().mcp_rollout_fwd(_mc(model), C.byref(pc), C.byref(nz), M, T, int(bool(particle_pred)), abi.ptr(x0),
-                                            abi.ptr(states), abi.ptr(inputs), abi.ptr(jac), abi.ptr(status), None, 0, abi.stream()),
+                                            abi.ptr(states), abi.ptr(inputs), abi.ptr(jac), abi.ptr(status), abi.ptr(ws), nbytes, abi.stream()),
                   "mcp_rollout_fwd")
     finally:
         _set_meas(policy, None, T, M, None)
@@ -555,4 +558,5 @@ def posterior(gp: PackedGP, Z):
 def status_flags(status):
     """Decodes a device status word (synchronises)."""
     v = int(status.item())
-    return {"nan": bool(v & abi.STATUS_NAN), "nonpos_var": bool(v & abi.STATUS_NONPOS_VAR), "not_spd": bool(v & abi.STATUS_NOT_SPD)}
+    return {"nan": bool(v & abi.STATUS_NAN), "nonpos_var": bool(v & abi.STATUS_NONPOS_VAR), "not_spd": bool(v & abi.STATUS_NOT_SPD),
+            "sync": bool(v & abi.STATUS_SYNC)}

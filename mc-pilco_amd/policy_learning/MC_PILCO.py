@@ -164,6 +164,22 @@ class MC_PILCO(torch.nn.Module):
     # ------------------------------------------------------------------------------------------------------------
     # policy optimisation
     # ------------------------------------------------------------------------------------------------------------
+    def _rollout_failed(self, cost):
+        """True when the cost is NaN (data, not an error: MC_PILCO.py:497).  The same device->host transfer carries the
+        hand-off bit of the last fused rollout's status word: a GP-sharded launch whose partner workgroups never met is a
+        hard error, never a silently wrong trajectory."""
+        from mc_pilco_amd import hipabi
+
+        flag = torch.isnan(cost.detach())
+        st = self.last_status
+        if st is not None and st.device == flag.device:
+            flag = flag | ((st.reshape(-1)[0] & hipabi.STATUS_SYNC) != 0)
+        if not bool(flag):
+            return False
+        if st is not None and (int(st.reshape(-1)[0]) & hipabi.STATUS_SYNC):
+            raise RuntimeError("mcp_rollout_fwd: GP-sharded launch timed out waiting for a partner workgroup (MCP_STATUS_SYNC)")
+        return True
+
     def reinforce_policy(self, T_control, num_particles, trial_index, particles_initial_state_mean, particles_initial_state_var,
                          flg_particles_init_uniform, particles_init_up_bound, particles_init_low_bound, flg_particles_init_multi_gauss,
                          opt_steps_list, lr_list, f_optimizer, num_step_print=10, policy_reinit_dict=None, p_dropout_list=None,
@@ -194,7 +210,7 @@ class MC_PILCO(torch.nn.Module):
             for _ in range(10):
                 st0, in0 = self.apply_policy(p_dropout=p_drop0, **sim)
                 cost0, _ = self._cost(st0, in0, trial_index)
-                if not bool(torch.isnan(cost0)):
+                if not self._rollout_failed(cost0):
                     break
                 print("\nSE filter initialization: Cost is NaN - reinit the policy")
                 self.control_policy.reinit(**policy_reinit_dict)
@@ -214,7 +230,7 @@ class MC_PILCO(torch.nn.Module):
                 # the adjoint sweep is queued before the host looks at the cost (the NaN test is a sync point: checking first would
                 # leave the GPU idle while the backward launches are prepared); gradients of a NaN rollout are simply discarded
                 cost.backward(retain_graph=False)
-                if bool(torch.isnan(cost)):
+                if self._rollout_failed(cost):
                     print("\nCost is NaN: try sampling again")
                     opt.zero_grad()
                 else:

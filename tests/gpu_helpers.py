@@ -58,3 +58,48 @@ def noise_from(fx):
     eps = G(fx["eps"])
     masks = torch.as_tensor(fx["masks"]).to(dev()).contiguous() if "masks" in fx else None
     return ops.NoiseSpec(eps=eps, masks=masks)
+
+
+class forced_variant:
+    """Context manager over the library's test hooks: ``code`` 0 = automatic dispatch; 1 / 2 / 4 = that many particles per
+    workgroup, all GPs in the workgroup; 16 = the 16-particle matrix-core kernel; 101 / 102 / 104 = the GP-sharded launch
+    (G workgroups per cluster of 1 / 2 / 4 particles, met by a per-step hand-off).  ``check()`` asserts that the forced
+    variant is the one that ran."""
+
+    def __init__(self, code, bwd_particles=None):
+        self.code = code
+        self.ppw = code % 100
+        self.sharded = code >= 100
+        self.pb = bwd_particles if bwd_particles is not None else {0: 0, 1: 1, 2: 2, 4: 4, 16: 4}[self.ppw]
+
+    def __enter__(self):
+        from mc_pilco_amd import hipabi
+
+        L = hipabi.lib()
+        L.mcp_debug_set_particles_per_wg(self.ppw)
+        L.mcp_debug_set_bwd_particles(self.pb)
+        L.mcp_debug_set_gp_sharding(1 if self.sharded else (-1 if self.code == 0 else 0))
+        return self
+
+    def check(self, sharding_optional=False):
+        """``sharding_optional``: wide shapes whose operands do not fit the LDS beside the policy's cannot be GP-sharded; the
+        library then runs the unsharded kernel of the same tile size."""
+        from mc_pilco_amd import hipabi
+
+        L = hipabi.lib()
+        if self.code:
+            assert L.mcp_debug_last_particles_per_wg() == self.ppw, "forced kernel variant was not the one launched"
+            if not (sharding_optional and self.sharded):
+                assert bool(L.mcp_debug_last_gp_sharded()) == self.sharded, "GP sharding was not what the test forced"
+
+    def __exit__(self, *exc):
+        from mc_pilco_amd import hipabi
+
+        L = hipabi.lib()
+        L.mcp_debug_set_particles_per_wg(0)
+        L.mcp_debug_set_bwd_particles(0)
+        L.mcp_debug_set_gp_sharding(-1)
+        return False
+
+
+VARIANTS = [0, 1, 2, 4, 16, 101, 102, 104]

@@ -163,34 +163,27 @@ def test_next_state_step(golden):
     assert abserr(torch.stack([var0, var1], 1), fx["var"]) < 1e-11
 
 
-@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16])
+@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16, 101, 102, 104])
 @pytest.mark.parametrize("name,kind", ROLLOUT_FIXTURES)
 def test_rollout_cost_gradient_vs_reference(golden, name, kind, ppw):
-    """apply_policy + expected cost + backward on the reference's recorded noise."""
-    from gpu_helpers import G, noise_from, packed_cost, packed_model, packed_policy
-    from mc_pilco_amd import hipabi, ops
+    """apply_policy + expected cost + backward on the reference's recorded noise, on every kernel variant (gpu_helpers.forced_variant)."""
+    from gpu_helpers import G, forced_variant, noise_from, packed_cost, packed_model, packed_policy
+    from mc_pilco_amd import ops
 
     fx = golden(name)
-    if ppw and name == "rollout_se_long" and ppw != 2:
-        pytest.skip("long rollout checked at one forced tile size")
+    if ppw and name == "rollout_se_long" and ppw not in (2, 104):
+        pytest.skip("long rollout checked at one forced tile size per launch kind")
     model = packed_model(fx, kind)
     pol = packed_policy(fx, kind)
     cost = packed_cost(fx, kind)
     x0 = G(fx["states"][0])
     Tn = fx["states"].shape[0]
     p = float(fx["p_drop"])
-    hipabi.lib().mcp_debug_set_particles_per_wg(ppw)
-    hipabi.lib().mcp_debug_set_bwd_particles({0: 0, 1: 1, 2: 2, 4: 4, 16: 4}[ppw])  # the backward sweep's own tile sizes ride along
-    try:
+    with forced_variant(ppw) as fv:
         st, inp, status = ops.rollout(model, pol, noise_from(fx), x0, Tn, p)
         c, s = ops.expected_cost(cost, st)
         c.backward()
-        used = hipabi.lib().mcp_debug_last_particles_per_wg()
-    finally:
-        hipabi.lib().mcp_debug_set_particles_per_wg(0)
-        hipabi.lib().mcp_debug_set_bwd_particles(0)
-    if ppw:
-        assert used == ppw, "forced kernel variant was not the one launched"
+        fv.check()
     assert int(status.item()) == 0
     long = Tn > 12
     assert abserr(st, fx["states"]) < (1e-6 if long else 1e-9)
@@ -275,12 +268,12 @@ def test_philox_mode_properties():
     assert 0.5 < float(d.std() / a[1, :, 1].std()) < 1.5 and float(a[1, :, 1].std()) > 0
 
 
-@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16])
+@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16, 101, 102, 104])
 def test_pms_rollout_cost_gradient_vs_reference(golden, ppw):
     """MC_PILCO4PMS.apply_policy + cost + backward through the C ABI (mcp_meas): the measurement filter between particles and
     policy is carried inside the fused kernels; the reference's recorded eps / position noise / masks are injected."""
-    from gpu_helpers import G, dev, packed_cost, packed_model, packed_policy
-    from mc_pilco_amd import hipabi, ops
+    from gpu_helpers import G, dev, forced_variant, packed_cost, packed_model, packed_policy
+    from mc_pilco_amd import ops
 
     fx = golden("rollout_pms")
     model, pol, cost = packed_model(fx, "se"), packed_policy(fx, "se"), packed_cost(fx, "se")
@@ -289,17 +282,11 @@ def test_pms_rollout_cost_gradient_vs_reference(golden, ppw):
                         b=fx["butter_b"], a=fx["butter_a"], pos_noise=G(fx["pos_noise"]))
     nz = ops.NoiseSpec(eps=G(fx["eps"]), masks=torch.as_tensor(fx["masks"]).to(dev()).contiguous())
     Tn, p = fx["states"].shape[0], float(fx["p_drop"])
-    hipabi.lib().mcp_debug_set_particles_per_wg(ppw)
-    hipabi.lib().mcp_debug_set_bwd_particles(min(ppw, 4))
-    try:
+    with forced_variant(ppw) as fv:
         st, inp, status = ops.rollout(model, pol, nz, G(fx["x0"]), Tn, p, meas=meas)
-        if ppw:
-            assert hipabi.lib().mcp_debug_last_particles_per_wg() == ppw
+        fv.check()
         c, s = ops.expected_cost(cost, st)
         c.backward()
-    finally:
-        hipabi.lib().mcp_debug_set_particles_per_wg(0)
-        hipabi.lib().mcp_debug_set_bwd_particles(0)
     assert int(status.item()) == 0
     assert abserr(st, fx["states"]) < 1e-9
     assert abserr(inp, fx["inputs"]) < 1e-9
@@ -344,30 +331,25 @@ def test_pms_philox_mode_is_reproducible_and_shard_invariant():
 @pytest.mark.parametrize("case", [("cartpole", 0, 20, 17, 3), ("cartpole", 2, 33, 5, 2), ("cartpole", 1, 16, 1, 4), ("ur5", 1, 17, 3, 3),
                                   ("cartpole", 0, 130, 35, 4)])
 def test_kernel_variants_agree_on_odd_shapes(case):
-    """Every forward tile size (1, 2, 4, 16 particles per workgroup) and backward sweep width (1, 2, 4) on shapes that exercise
+    """Every forward variant (1, 2, 4, 16 particles per workgroup; GP-sharded clusters of 1, 2, 4) and backward sweep width (1, 2, 4) on shapes that exercise
     the edges: N not a multiple of 16 or 32, a single 16-row block, M smaller than / not a multiple of the tile, T = 2."""
-    from gpu_helpers import dev
-    from mc_pilco_amd import hipabi, ops, workloads
+    from gpu_helpers import dev, forced_variant
+    from mc_pilco_amd import ops, workloads
 
     workloads.CONFIGS["edge"] = case
     w = workloads.build("edge", device=dev())
     torch.manual_seed(11)
     x0 = w.sample_x0()
     ref = None
-    for ppw, pb in [(1, 1), (2, 2), (4, 4), (16, 4)]:
-        hipabi.lib().mcp_debug_set_particles_per_wg(ppw)
-        hipabi.lib().mcp_debug_set_bwd_particles(pb)
-        try:
+    for code in [1, 2, 4, 16, 101, 102, 104]:
+        with forced_variant(code) as fv:
             for q in w.params:
                 q.grad = None
             st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=9, call=3), x0, w.T, w.p_drop)
             c, s = ops.expected_cost(w.cost, st)
             c.backward()
-            used = hipabi.lib().mcp_debug_last_particles_per_wg()
-        finally:
-            hipabi.lib().mcp_debug_set_particles_per_wg(0)
-            hipabi.lib().mcp_debug_set_bwd_particles(0)
-        assert used == ppw and int(status.item()) == 0
+            fv.check(sharding_optional=(case[0] == "ur5"))
+        assert int(status.item()) == 0
         got = (st.detach().clone(), inp.detach().clone(), [q.grad.detach().clone() for q in w.params])
         if ref is None:
             ref = got
@@ -464,10 +446,12 @@ def test_adjoint_matches_finite_difference_at_full_width(name, M):
     assert abs(fd - gd) < 1e-5 * max(abs(gd), 1e-3), (fd, gd)
 
 
-@pytest.mark.parametrize("name,M,expect", [("c1", 400, 2), ("c3", 4000, 16), ("c5", 2000, 16)])
-def test_baseline_shapes_run_on_the_intended_kernel(name, M, expect):
+@pytest.mark.parametrize("name,M,expect,sharded", [("c1", 400, 4, True), ("c1", 256, 2, True), ("c1", 1000, 2, False), ("c3", 4000, 16, False),
+                                                   ("c5", 2000, 16, False)])
+def test_baseline_shapes_run_on_the_intended_kernel(name, M, expect, sharded):
     """The automatic dispatch puts BASELINE.json's shapes where DESIGN.md says they run (a shape that overflows the tile kernel's
-    LDS budget would silently fall back to the 4-particle kernel)."""
+    LDS budget would silently fall back to the 4-particle kernel; a small swarm whose GP-sharded grid does not fit the device
+    must not be sharded)."""
     from gpu_helpers import dev
     from mc_pilco_amd import hipabi, ops, workloads
 
@@ -475,3 +459,30 @@ def test_baseline_shapes_run_on_the_intended_kernel(name, M, expect):
     st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=1), w.sample_x0(), w.T, w.p_drop)
     assert int(status.item()) == 0
     assert hipabi.lib().mcp_debug_last_particles_per_wg() == expect
+    assert bool(hipabi.lib().mcp_debug_last_gp_sharded()) == sharded
+
+
+def test_gp_sharded_launch_needs_its_workspace():
+    """Without the hand-off workspace the C ABI must not shard (and must still run on the device)."""
+    from gpu_helpers import dev
+    from mc_pilco_amd import hipabi, ops, workloads
+    import ctypes as C
+
+    w = workloads.build("tiny", device=dev())
+    x0 = w.sample_x0()
+    M, T = x0.shape[0], w.T
+    pc = w.policy.bind(w.p_drop)
+    nz = ops.NoiseSpec(seed=3, call=1).to_c()
+    out = []
+    for with_ws in (True, False):
+        states = torch.empty(T, M, w.policy.S, dtype=torch.float64, device=dev())
+        inputs = torch.empty(T, M, w.policy.U, dtype=torch.float64, device=dev())
+        status = torch.zeros(1, dtype=torch.int32, device=dev())
+        nbytes = hipabi.lib().mcp_rollout_workspace_bytes(C.byref(w.model.c), C.byref(pc), M, T)
+        ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=dev())
+        rc = hipabi.lib().mcp_rollout_fwd(C.byref(w.model.c), C.byref(pc), C.byref(nz), M, T, 1, hipabi.ptr(x0), hipabi.ptr(states), hipabi.ptr(inputs),
+                                          None, hipabi.ptr(status), hipabi.ptr(ws) if with_ws else None, nbytes if with_ws else 0, hipabi.stream())
+        assert rc == 0 and int(status.item()) == 0
+        assert bool(hipabi.lib().mcp_debug_last_gp_sharded()) == with_ws
+        out.append(states.clone())
+    assert float((out[0] - out[1]).abs().max()) < 1e-9
