@@ -34,17 +34,20 @@ using namespace mcp;
 #define RF_GS 8  // rows of Kinv per register buffer (two buffers in flight per wave)
 
 struct FwdLayout {
+  int mk;  // dropout keep bits of the step, one int per (particle, 4 basis functions): drawn in phase S by idle waves
   int invl, xs, us, z, sf, dl, kb, ks, pa, pb, vb, part, red, xt, al, cen, wgt, tab, gpl, kpar, total;  // offsets in doubles
 };
 
-// integer tables (in the `tab` region): cstart[NC+1], cg[NC], cbase[NC], cR[NC], gcb[GB], wc0[NW]
+// integer tables (in the `tab` region): cstart[NC+1], cg[NC], cbase[NC], cR[NC], gcb[GB], wc0[NW], slo[NC], shi[NC]
 #define TAB_CSTART 0
 #define TAB_CG (RF_MAX_CHUNKS + 1)
 #define TAB_CBASE (TAB_CG + RF_MAX_CHUNKS)
 #define TAB_CR (TAB_CBASE + RF_MAX_CHUNKS)
 #define TAB_GCB (TAB_CR + RF_MAX_CHUNKS)
 #define TAB_WC0 (TAB_GCB + MCP_MAX_GP)
-#define TAB_INTS (TAB_WC0 + RF_NW)
+#define TAB_SLO (TAB_WC0 + RF_NW)            // first / last partial-sum slot of a chunk (phase vsum)
+#define TAB_SHI (TAB_SLO + RF_MAX_CHUNKS)
+#define TAB_INTS (TAB_SHI + RF_MAX_CHUNKS)
 #define RF_CW 128  // rows of v per column chunk: 64 lanes x 2 rows (one 16-byte load per lane)
 
 // GX = number of GPs whose operands are staged in LDS (G, or 1 in a GP-sharded launch)
@@ -76,6 +79,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int 
   L.cen = xlds ? take(B * PF) : 0;
   L.wgt = xlds ? take(U * B) : 0;
   L.tab = take((TAB_INTS + 1) / 2);
+  L.mk = take((P * ((B + 3) / 4) + 1) / 2);
   L.gpl = take(G * GPL_DOUBLES);
   L.kpar = take(G * (5 * D + 1));
   L.total = o;
@@ -118,6 +122,10 @@ __device__ __forceinline__ int build_chunk_table(const GpL* gpl, int g0, int gn,
       while (cc + 1 < c && tab[TAB_CSTART + cc + 1] <= u0) ++cc;
       tab[TAB_WC0 + w] = cc;
     }
+    for (int cc = 0; cc < c; ++cc) {
+      tab[TAB_SLO + cc] = cc + tab[TAB_CSTART + cc] / L;
+      tab[TAB_SHI + cc] = cc + (tab[TAB_CSTART + cc + 1] - 1) / L;
+    }
   }
   return NC;
 }
@@ -129,10 +137,21 @@ __device__ __forceinline__ int build_chunk_table(const GpL* gpl, int g0, int gn,
 template <int P, bool XLDS, int MAXDEG>
 __device__ __forceinline__ void phase_k(const GpL* gpl, const double* kpar, int g0, int gn, int D, int NpadMax, const double* z,
                                         const double* xt_l, double* kb, double* ks, double* pa, double* pb, int tid) {
-  for (int it = tid; it < gn * P * NpadMax; it += RF_NT) {
-    int gl = it / (P * NpadMax);
-    int r = it - gl * P * NpadMax;
-    int p = r / NpadMax, j = r - p * NpadMax;
+  // item = (training point j, GP gl, particle p), particle fastest: the decode is shifts for a single GP (integer division by
+  // a run-time value costs more VALU time here than the kernel evaluation itself)
+  const int Q = gn * P;
+  for (int it = tid; it < NpadMax * Q; it += RF_NT) {
+    int j, gl, p;
+    if (gn == 1) {
+      j = it / P;
+      gl = 0;
+      p = it - j * P;
+    } else {
+      j = it / Q;
+      const int q = it - j * Q;
+      gl = q / P;
+      p = q - gl * P;
+    }
     const GpL& gp = gpl[g0 + gl];
     const int N = gp.N, Npad = gp.Npad;
     if (j >= N) {
@@ -190,10 +209,24 @@ template <int P>
 __device__ __forceinline__ void consume_rows(const v2d (&A)[RF_GS], const double* __restrict__ kk, int kstride, double (&acc)[2][P]) {
   constexpr int KB = P >= 4 ? RF_GS / 2 : RF_GS;  // rows of k in flight (a rolling window: 4 rows of 4 particles cover the latency)
   double kr[KB][P];
+  // a row of k is P doubles at a 16-byte aligned address for even P: read it as ds_read_b128 (4 LDS cycles per 16 B;
+  // the ds_read2_b64 the compiler picks for two adjacent doubles costs 8)
+  auto read_k = [&](double (&dst)[P], int u) {
+    if (P % 2 == 0) {
+      const v2d* k2 = reinterpret_cast<const v2d*>(__builtin_assume_aligned(kk + u * kstride, 16));
 #pragma unroll
-  for (int u = 0; u < KB; ++u)
+      for (int q = 0; q < P / 2; ++q) {
+        const v2d t = k2[q];
+        dst[2 * q] = t.x;
+        dst[2 * q + 1] = t.y;
+      }
+    } else {
 #pragma unroll
-    for (int p = 0; p < P; ++p) kr[u][p] = kk[u * kstride + p];
+      for (int p = 0; p < P; ++p) dst[p] = kk[u * kstride + p];
+    }
+  };
+#pragma unroll
+  for (int u = 0; u < KB; ++u) read_k(kr[u], u);
 #pragma unroll
   for (int u = 0; u < RF_GS; ++u) {
 #pragma unroll
@@ -201,10 +234,7 @@ __device__ __forceinline__ void consume_rows(const v2d (&A)[RF_GS], const double
       acc[0][p] = fma(A[u].x, kr[u % KB][p], acc[0][p]);
       acc[1][p] = fma(A[u].y, kr[u % KB][p], acc[1][p]);
     }
-    if (u + KB < RF_GS) {
-#pragma unroll
-      for (int p = 0; p < P; ++p) kr[u % KB][p] = kk[(u + KB) * kstride + p];
-    }
+    if (u + KB < RF_GS) read_k(kr[u % KB], u + KB);
   }
 }
 
@@ -312,16 +342,24 @@ __device__ __forceinline__ void phase_v(const GpL* gpl, int g0, const int* tab, 
 template <int P, bool XLDS, int MAXDEG>
 __device__ __forceinline__ void phase_vsum(const GpL* gpl, int g0, int gn, const int* tab, int NC, int NpadMax, const double* part,
                                            const double* kb, const double* al_l, double* vb, int tid) {
-  const int total = tab[TAB_CSTART + NC];
-  const int L = (total + RF_NW - 1) / RF_NW;
-  for (int it = tid; it < gn * NpadMax * P; it += RF_NT) {
-    int gl = it / (NpadMax * P);
-    int r = it - gl * NpadMax * P;
-    int i = r / P, p = r - i * P;
+  const int Q = gn * P;
+  for (int itq = tid; itq < NpadMax * Q; itq += RF_NT) {
+    int i, gl, p;  // (row i, GP gl, particle p), particle fastest (cheap decode, see phase K)
+    if (gn == 1) {
+      i = itq / P;
+      gl = 0;
+      p = itq - i * P;
+    } else {
+      i = itq / Q;
+      const int q = itq - i * Q;
+      gl = q / P;
+      p = q - gl * P;
+    }
+    const int it = (gl * NpadMax + i) * P + p;
     const GpL& gp = gpl[g0 + gl];
     if (i >= gp.N) continue;
-    int c = tab[TAB_GCB + gl] + i / RF_CW;
-    int s_lo = c + tab[TAB_CSTART + c] / L, s_hi = c + (tab[TAB_CSTART + c + 1] - 1) / L;
+    const int c = tab[TAB_GCB + gl] + i / RF_CW;
+    const int s_lo = tab[TAB_SLO + c], s_hi = tab[TAB_SHI + c];
     double s = 0.0;
     for (int sid = s_lo; sid <= s_hi; ++sid) s += part[(sid * 128 + (i % RF_CW)) * P + p];
     if (MAXDEG == 0) {
@@ -595,6 +633,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   double* cen_l = smem + L.cen;
   double* wgt_l = smem + L.wgt;
   int* tab = reinterpret_cast<int*>(smem + L.tab);
+  int* mk = reinterpret_cast<int*>(smem + L.mk);
   GpL* gpl = reinterpret_cast<GpL*>(smem + L.gpl);
   double* kpar = smem + L.kpar;
   int cluster = blockIdx.x, myg = 0;
@@ -765,12 +804,24 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       }
       epsb[e] = ev;
     }
+    else if (tid >= 128 && drop && !a.nz.masks) {
+      // waves 2.. are idle here too: the step's dropout decisions, one Philox block per 4 basis functions (the integer
+      // multiplies of a block cost more than the exp of the feature it gates; drawn per basis function in phase PHI they
+      // were most of that phase)
+      const int BQ = (B + 3) >> 2;
+      for (int it = tid - 128; it < P * BQ; it += RF_NT - 128) {
+        const int p = it / BQ, q = it - p * BQ;
+        const u32x4 r = philox_draw(a.nz, imin(m0 + p, M - 1), t, MCP_STREAM_MASK, (uint32_t)q);
+        mk[it] = (int)(r.x >= drop_thr) | ((int)(r.y >= drop_thr) << 1) | ((int)(r.z >= drop_thr) << 2) | ((int)(r.w >= drop_thr) << 3);
+      }
+    }
     lds_barrier();
     RF_STAMP(0);
     // ---- phase PHI: phi_b = exp(-sum_q ((s_q - c_bq)/l_q)^2) * keep/(1-p) -------------------------
     double* ph = part;
-    for (int it = tid; it < P * B; it += RF_NT) {
-      int p = it / B, b = it - p * B;
+    for (int itq = tid; itq < P * B; itq += RF_NT) {
+      const int b = itq / P, p = itq - b * P;  // particle fastest: no division by a run-time value
+      const int it = p * B + b;
       const double* cb = cen + b * PF;
       double dist = 0.0;
 #pragma unroll 5
@@ -781,7 +832,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       double phi = exp(-dist);
       if (drop) {
         int mm = imin(m0 + p, M - 1);
-        bool keep = a.nz.masks ? (a.nz.masks[((size_t)t * M + mm) * B + b] != 0) : philox_keep(a.nz, mm, t, b, drop_thr);
+        bool keep = a.nz.masks ? (a.nz.masks[((size_t)t * M + mm) * B + b] != 0) : (((mk[p * ((B + 3) >> 2) + (b >> 2)] >> (b & 3)) & 1) != 0);
         phi = keep ? phi * keep_scale : 0.0;
       }
       ph[it] = phi;
