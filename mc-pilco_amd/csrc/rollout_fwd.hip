@@ -61,7 +61,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int 
     o += (n + 1) & ~1;  // keep 16-byte alignment
     return r;
   };
-  L.invl = take(PF);
+  L.invl = take(PF + MCP_MAX_INPUT);  // policy inverse lengthscales | u_max (staged once: a global load on phase U's critical path otherwise)
   L.xs = take(2 * P * S);
   L.us = take(P * U);
   L.z = take(P * D);
@@ -413,23 +413,31 @@ __device__ __forceinline__ void phase_j_gp(const GpL& gp, int ggl, int gl, int D
     for (int ct = 0; ct < CT; ++ct) acc[rt][ct] = (v4d){0.0, 0.0, 0.0, 0.0};
   if (WPRE && CT == 1 && RT == 1) {
     // fast path (SE-only model, one 16x16 tile): batch the operand reads of RF_JU steps, then issue the MFMAs back to back
-    constexpr int RF_JU = 5;
+    constexpr int RF_JU = 10;  // N = 300 over 8 waves is 10 steps of 4: one batch of operand reads, then the MFMAs back to back
     const int c = li, cc = imin(c, D - 1);
     const double* xrow = XLDS ? xt_l + (ggl * D + cc) * NpadMax : nullptr;
     const double* wrow = vb + gl * NpadMax * NCOLS + imin(li, NCOLS - 1);
     const bool nok = li < NCOLS;
     v4d a0 = (v4d){0.0, 0.0, 0.0, 0.0};
     for (int jb = j0; jb < j1; jb += 4 * RF_JU) {
+      // all 2*RF_JU operand reads are issued before anything consumes them (pinned by the asm statement): left alone, the
+      // compiler sinks every read to its use and each MFMA step pays an LDS latency
       double av[RF_JU], bw[RF_JU];
 #pragma unroll
       for (int u = 0; u < RF_JU; ++u) {
         const int j = jb + 4 * u + kq;
-        const bool jok = j < j1;
-        const int jc = jok ? j : j0;
-        const double x = XLDS ? xrow[jc] : ((gptr_t)gp.Xt)[(size_t)cc * Npad + jc];
-        const double w = wrow[jc * NCOLS];
-        av[u] = !jok ? 0.0 : (c < D ? x : (c == D ? 1.0 : 0.0));
-        bw[u] = (jok && nok) ? w : 0.0;
+        const int jc = j < j1 ? j : j0;
+        av[u] = XLDS ? xrow[jc] : ((gptr_t)gp.Xt)[(size_t)cc * Npad + jc];
+        bw[u] = wrow[jc * NCOLS];
+      }
+      static_assert(RF_JU == 10, "operand list below");
+      asm volatile("" : "+v"(av[0]) : "v"(av[1]), "v"(av[2]), "v"(av[3]), "v"(av[4]), "v"(av[5]), "v"(av[6]), "v"(av[7]), "v"(av[8]), "v"(av[9]),
+                   "v"(bw[0]), "v"(bw[1]), "v"(bw[2]), "v"(bw[3]), "v"(bw[4]), "v"(bw[5]), "v"(bw[6]), "v"(bw[7]), "v"(bw[8]), "v"(bw[9]));
+#pragma unroll
+      for (int u = 0; u < RF_JU; ++u) {
+        const bool jok = jb + 4 * u + kq < j1;
+        av[u] = !jok ? 0.0 : (c < D ? av[u] : (c == D ? 1.0 : 0.0));
+        bw[u] = (jok && nok) ? bw[u] : 0.0;
       }
 #pragma unroll
       for (int u = 0; u < RF_JU; ++u) a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bw[u], a0, 0, 0, 0);
@@ -655,6 +663,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
 
   // ---- one-time staging ------------------------------------------------------------------
   for (int it = tid; it < PF; it += RF_NT) invl[it] = exp(-pl.log_ls[it]);
+  double* umax_l = invl + PF;
+  if (tid < U) umax_l[tid] = pl.u_max[tid];
   // the GPs this workgroup evaluates: all of them, or (GSH) its own one, which then lives in slot 0 of every LDS table
   const int GL = GSH ? 1 : G;
   const mcp_gp* gps_l = gps + myg;
@@ -848,7 +858,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       for (int b = lane; b < B; b += 64) s = fma(wk[b], ph[p * B + b], s);
       s = wave_sum(s);
       if (lane == 0) {
-        double um = pl.u_max[k];
+        double um = umax_l[k];
         double u = pl.squash ? um * tanh(s / um) : s;
         us[p * U + k] = u;
         z[p * D + nna + 2 * na + k] = u;
