@@ -202,7 +202,12 @@ size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_policy* pol
 /* x0 [M][S] -> states [T][M][S], inputs [T][M][U].  jac [T-1][M][G][D] (d delta_g/d z, sampling
  * included) is written when non-NULL and is what mcp_rollout_bwd consumes.
  * particle_pred==0 -> delta = posterior mean (Model_learning.py:707-708).  T==1 evaluates the
- * policy only (Policy.forward); in that case `model` may be NULL. */
+ * policy only (Policy.forward); in that case `model` may be NULL.
+ * workspace (optional, mcp_rollout_workspace_bytes): with it, small swarms run GP-sharded -- the G
+ * workgroups of a particle cluster each evaluate one GP and hand each other the sampled increments
+ * once per step through this buffer (zeroed by the call, on `stream`); results agree with the
+ * unsharded launch to rounding.  MCP_STATUS_SYNC in `status` reports a hand-off that timed out
+ * (the trajectories are then invalid).  Without a workspace the launch is never sharded. */
 int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
                     const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
                     size_t workspace_bytes, void* stream);
