@@ -200,41 +200,82 @@ __device__ __forceinline__ void phase_k(const GpL* gpl, const double* kpar, int 
 // adjacent rows (2l, 2l+1) of a 128-row column chunk and walks the summation index j; Kinv is
 // symmetric, so element (i,j) is read from row j (contiguous).  A narrow tail chunk (<= 64 rows)
 // packs two rows j, j+1 into one wave-load (lanes 32..63 take j+1) and folds the two halves at the
-// end.  RF_GS loads per register buffer, two buffers in flight.  k_j[0..P) is an LDS broadcast read.
+// end.  RF_GS loads per register buffer, two buffers in flight.
 // The stream (all chunks of all GPs of the pass) is cut into RF_NW equal contiguous shares.
 // ---------------------------------------------------------------------------------------
-// (the k values are read from LDS ahead of their use, a whole register buffer or a rolling half of it: left at their uses, the
-//  compiler emits read -> wait -> 2 FMAs per value and the LDS latency, ~64 cycles, is paid P times per row)
+// k_j is the same for every lane, but a broadcast LDS read per row is not free: LDS returns and vector-memory returns share
+// the path into the VGPRs, and phase V's time was (stream time) + (LDS cycles of the k reads): 130 / 147 / 190 cycles per row
+// and wave round at 1 / 2 / 4 particles (halving the FMAs changed nothing).  So a group's whole k block (RF_GS rows x P
+// particles) is fetched by ONE read, spread over the 16 lanes of every DPP row, and the FMAs take their k operand through
+// DPP row_newbcast (v_fmac_f64_dpp: the lane select rides on the FMA, no extra instruction).
+template <int N>
+__device__ __forceinline__ void fmac_bcast(double& acc, double k, double a) {  // acc += k[lane N of this 16-lane row] * a
+  asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(k), "v"(a), "n"(N));
+}
 template <int P>
-__device__ __forceinline__ void consume_rows(const v2d (&A)[RF_GS], const double* __restrict__ kk, int kstride, double (&acc)[2][P]) {
-  constexpr int KB = P >= 4 ? RF_GS / 2 : RF_GS;  // rows of k in flight (a rolling window: 4 rows of 4 particles cover the latency)
-  double kr[KB][P];
-  // a row of k is P doubles at a 16-byte aligned address for even P: read it as ds_read_b128 (4 LDS cycles per 16 B;
-  // the ds_read2_b64 the compiler picks for two adjacent doubles costs 8)
-  auto read_k = [&](double (&dst)[P], int u) {
-    if (P % 2 == 0) {
-      const v2d* k2 = reinterpret_cast<const v2d*>(__builtin_assume_aligned(kk + u * kstride, 16));
-#pragma unroll
-      for (int q = 0; q < P / 2; ++q) {
-        const v2d t = k2[q];
-        dst[2 * q] = t.x;
-        dst[2 * q + 1] = t.y;
-      }
-    } else {
-#pragma unroll
-      for (int p = 0; p < P; ++p) dst[p] = kk[u * kstride + p];
-    }
-  };
-#pragma unroll
-  for (int u = 0; u < KB; ++u) read_k(kr[u], u);
-#pragma unroll
-  for (int u = 0; u < RF_GS; ++u) {
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-      acc[0][p] = fma(A[u].x, kr[u % KB][p], acc[0][p]);
-      acc[1][p] = fma(A[u].y, kr[u % KB][p], acc[1][p]);
-    }
-    if (u + KB < RF_GS) read_k(kr[u % KB], u + KB);
+struct KBlock {  // rows u = 0..RF_GS-1 of k, element e = u*P + p held by lane e/2 (component e&1) for even P, by lane e for P = 1
+  double x, y;
+};
+template <int P>
+__device__ __forceinline__ KBlock<P> read_k_block(const double* __restrict__ kk, int kstride, int n, int lane) {
+  KBlock<P> kb;
+  const int t = lane & 15;
+  if (P % 2 == 0) {
+    constexpr int H = P / 2;              // 16-byte pieces per row
+    const int u = imin(t / H, n - 1), h = t % H;
+    const v2d v = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(kk + u * kstride + 2 * h, 16));
+    kb.x = v.x;
+    kb.y = v.y;
+  } else {
+    kb.x = kk[imin(t, n - 1) * kstride];
+    kb.y = 0.0;
+  }
+  return kb;
+}
+template <int P, int U, int PP>
+__device__ __forceinline__ void fma_unit_p(const v2d& a, const KBlock<P>& kb, double (&acc)[2][P]) {
+  constexpr int e = U * P + PP;
+  if (P % 2 == 0) {
+    const double kv = (e & 1) ? kb.y : kb.x;
+    fmac_bcast<(e >> 1)>(acc[0][PP], kv, a.x);
+    fmac_bcast<(e >> 1)>(acc[1][PP], kv, a.y);
+  } else {
+    fmac_bcast<e>(acc[0][PP], kb.x, a.x);
+    fmac_bcast<e>(acc[1][PP], kb.x, a.y);
+  }
+}
+template <int P, int U>
+__device__ __forceinline__ void fma_unit(const v2d& a, const KBlock<P>& kb, double (&acc)[2][P]) {
+  fma_unit_p<P, U, 0>(a, kb, acc);
+  if (P >= 2) fma_unit_p<P, U, (P >= 2 ? 1 : 0)>(a, kb, acc);
+  if (P >= 4) {
+    fma_unit_p<P, U, (P >= 4 ? 2 : 0)>(a, kb, acc);
+    fma_unit_p<P, U, (P >= 4 ? 3 : 0)>(a, kb, acc);
+  }
+}
+// rows 0..n-1 of the register buffer (n wave-uniform; n == RF_GS: no branches)
+template <int P>
+__device__ __forceinline__ void consume_rows(const v2d (&A)[RF_GS], KBlock<P> kb, int n, double (&acc)[2][P]) {
+  static_assert(RF_GS == 8 && RF_GS * P <= 32, "k block: one 16-byte piece per lane of a 16-lane row");
+  // a VALU write of the block followed at once by a DPP read of it needs two wait states: take them here, once
+  asm volatile("s_nop 1" : "+v"(kb.x), "+v"(kb.y));
+  if (n == RF_GS) {
+    fma_unit<P, 0>(A[0], kb, acc);
+    fma_unit<P, 1>(A[1], kb, acc);
+    fma_unit<P, 2>(A[2], kb, acc);
+    fma_unit<P, 3>(A[3], kb, acc);
+    fma_unit<P, 4>(A[4], kb, acc);
+    fma_unit<P, 5>(A[5], kb, acc);
+    fma_unit<P, 6>(A[6], kb, acc);
+    fma_unit<P, 7>(A[7], kb, acc);
+  } else {
+    if (0 < n) fma_unit<P, 0>(A[0], kb, acc);
+    if (1 < n) fma_unit<P, 1>(A[1], kb, acc);
+    if (2 < n) fma_unit<P, 2>(A[2], kb, acc);
+    if (3 < n) fma_unit<P, 3>(A[3], kb, acc);
+    if (4 < n) fma_unit<P, 4>(A[4], kb, acc);
+    if (5 < n) fma_unit<P, 5>(A[5], kb, acc);
+    if (6 < n) fma_unit<P, 6>(A[6], kb, acc);
   }
 }
 
@@ -247,47 +288,44 @@ __device__ __forceinline__ void load_rows(v2d (&A)[RF_GS], gptr_t p, size_t rstr
 // `kk` at its k row; consecutive units are rstride / kstride apart
 template <int P>
 __device__ __forceinline__ void matvec_rows(gptr_t base, size_t rstride, const double* __restrict__ kk, int kstride,
-                                            int ua, int ub, double (&acc)[2][P]) {
+                                            int ua, int ub, int lane, double (&acc)[2][P]) {
   gptr_t p = base + (size_t)ua * rstride;
   const size_t gstep = (size_t)RF_GS * rstride;
   int u0 = ua;
   const int nfull = (ub - ua) / RF_GS;
   v2d A[RF_GS], Bf[RF_GS];
+  KBlock<P> kA, kB;  // the k block of a register buffer is read when the buffer's loads are issued
   if (nfull > 0) {
     load_rows(A, p, rstride);
+    kA = read_k_block<P>(kk + u0 * kstride, kstride, RF_GS, lane);
     p += gstep;
     for (int g = 0; g < nfull; g += 2) {
       const bool hasB = g + 1 < nfull;
       if (hasB) {
         load_rows(Bf, p, rstride);
+        kB = read_k_block<P>(kk + (u0 + RF_GS) * kstride, kstride, RF_GS, lane);
         p += gstep;
       }
-      consume_rows<P>(A, kk + u0 * kstride, kstride, acc);
+      consume_rows<P>(A, kA, RF_GS, acc);
       u0 += RF_GS;
       if (hasB) {
         if (g + 2 < nfull) {
           load_rows(A, p, rstride);
+          kA = read_k_block<P>(kk + (u0 + RF_GS) * kstride, kstride, RF_GS, lane);
           p += gstep;
         }
-        consume_rows<P>(Bf, kk + u0 * kstride, kstride, acc);
+        consume_rows<P>(Bf, kB, RF_GS, acc);
         u0 += RF_GS;
       }
     }
   }
   const int rem = ub - u0;  // 0 .. RF_GS-1, wave-uniform
+  if (rem > 0) {
 #pragma unroll
-  for (int u = 0; u < RF_GS - 1; ++u)
-    if (u < rem) A[u] = *(gptr2_t)(p + (size_t)u * rstride);
-#pragma unroll
-  for (int u = 0; u < RF_GS - 1; ++u) {
-    if (u < rem) {
-#pragma unroll
-      for (int q = 0; q < P; ++q) {
-        double kv = kk[(u0 + u) * kstride + q];
-        acc[0][q] = fma(A[u].x, kv, acc[0][q]);
-        acc[1][q] = fma(A[u].y, kv, acc[1][q]);
-      }
-    }
+    for (int u = 0; u < RF_GS - 1; ++u)
+      if (u < rem) A[u] = *(gptr2_t)(p + (size_t)u * rstride);
+    kA = read_k_block<P>(kk + u0 * kstride, kstride, rem, lane);
+    consume_rows<P>(A, kA, rem, acc);
   }
 }
 
@@ -314,7 +352,7 @@ __device__ __forceinline__ void phase_v(const GpL* gpl, int g0, const int* tab, 
 #pragma unroll
     for (int p = 0; p < P; ++p) acc[0][p] = acc[1][p] = 0.0;
     gptr_t base = (gptr_t)Kinv + (size_t)sub * Npad + (ok ? i : rb);
-    matvec_rows<P>(base, (size_t)R * Npad, kb + (gl * NpadMax + sub) * P, R * P, ua, ub, acc);
+    matvec_rows<P>(base, (size_t)R * Npad, kb + (gl * NpadMax + sub) * P, R * P, ua, ub, lane, acc);
     if (R == 2) {
       // fold rows j+1 (lanes 32..63) into rows j (lanes 0..31)
 #pragma unroll

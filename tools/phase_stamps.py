@@ -13,7 +13,11 @@ pd = float(sys.argv[5]) if len(sys.argv) > 5 else 0.25
 w = workloads.build(name, device=dev, M=Mo, T=To, p_drop=pd)
 buf = torch.zeros(16, dtype=torch.int64, device=dev)
 x0 = w.sample_x0()
-hipabi.lib().mcp_debug_set_particles_per_wg(ppw)
+hipabi.lib().mcp_debug_set_particles_per_wg(ppw % 100)
+if ppw >= 100:  # 101 / 102 / 104: force the GP-sharded launch with that cluster size
+    hipabi.lib().mcp_debug_set_gp_sharding(1)
+elif ppw:
+    hipabi.lib().mcp_debug_set_gp_sharding(0)
 for i in range(2):
     ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=i), x0, w.T, w.p_drop)
 hipabi.lib().mcp_debug_set_stamp_buffer(buf.data_ptr())
