@@ -374,41 +374,33 @@ __device__ __forceinline__ void phase_v(const GpL* gpl, int g0, const int* tab, 
   }
 }
 
-// v[gl][i][p] = sum of the chunk's partial slots, in a fixed order.  For SE-only models (MAXDEG == 0) the thread goes one
-// step further and stores the two phase-J weights of its (j, p):  W[j][2p] = kse_j alpha_j,  W[j][2p+1] = kse_j v_j,
-// so that phase J needs a single LDS read per MFMA operand.
+// v[gl][i][p] = sum of the chunk's partial slots, in a fixed order, for the rows [j0, j1) of one GP -- the rows whose phase-J
+// sums the calling wave forms next, so the wave needs no workgroup barrier between the two (only its own LDS order).  For
+// SE-only models (MAXDEG == 0) the lane goes one step further and stores the two phase-J weights of its (j, p):
+// W[j][2p] = kse_j alpha_j,  W[j][2p+1] = kse_j v_j,  so that phase J needs a single LDS read per MFMA operand.
 template <int P, bool XLDS, int MAXDEG>
-__device__ __forceinline__ void phase_vsum(const GpL* gpl, int g0, int gn, const int* tab, int NC, int NpadMax, const double* part,
-                                           const double* kb, const double* al_l, double* vb, int tid) {
-  const int Q = gn * P;
-  for (int itq = tid; itq < NpadMax * Q; itq += RF_NT) {
-    int i, gl, p;  // (row i, GP gl, particle p), particle fastest (cheap decode, see phase K)
-    if (gn == 1) {
-      i = itq / P;
-      gl = 0;
-      p = itq - i * P;
-    } else {
-      i = itq / Q;
-      const int q = itq - i * Q;
-      gl = q / P;
-      p = q - gl * P;
-    }
+__device__ __forceinline__ void vsum_range(const GpL& gp, int ggl, int gl, const int* tab, int NpadMax, const double* part, const double* kb,
+                                           const double* al_l, double* vb, int j0, int j1, int lane) {
+  const int cb = tab[TAB_GCB + gl];
+  for (int itq = lane; itq < (j1 - j0) * P; itq += 64) {
+    const int i = j0 + itq / P, p = itq % P;
     const int it = (gl * NpadMax + i) * P + p;
-    const GpL& gp = gpl[g0 + gl];
-    if (i >= gp.N) continue;
-    const int c = tab[TAB_GCB + gl] + i / RF_CW;
+    const int c = cb + i / RF_CW;
     const int s_lo = tab[TAB_SLO + c], s_hi = tab[TAB_SHI + c];
     double s = 0.0;
     for (int sid = s_lo; sid <= s_hi; ++sid) s += part[(sid * 128 + (i % RF_CW)) * P + p];
     if (MAXDEG == 0) {
       const double kse = kb[it];
-      const double alj = XLDS ? al_l[(g0 + gl) * NpadMax + i] : ((gptr_t)gp.alpha)[i];
+      const double alj = XLDS ? al_l[ggl * NpadMax + i] : ((gptr_t)gp.alpha)[i];
       vb[2 * it] = kse * alj;
       vb[2 * it + 1] = kse * s;
     } else {
       vb[it] = s;
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ---------------------------------------------------------------------------------------
@@ -433,7 +425,8 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 template <int P, bool XLDS, int DEG, bool WPRE>
 __device__ __forceinline__ void phase_j_gp(const GpL& gp, int ggl, int gl, int D, int NpadMax, int ncolmax, const double* xt_l,
                                            const double* al_l, const double* kb, const double* ks, const double* pa, const double* pb,
-                                           const double* vb, double* redw, int wv, int lane, unsigned long long* jst = nullptr) {
+                                           double* vb, const int* tab, const double* part, double* redw, int wv, int lane,
+                                           unsigned long long* jst = nullptr) {
   unsigned long long t0_ = jst ? clock64() : 0;
   constexpr int NAX = RF_NAX(DEG);
   constexpr int NCOLS = P * NAX;
@@ -444,6 +437,7 @@ __device__ __forceinline__ void phase_j_gp(const GpL& gp, int ggl, int gl, int D
   const int per = ((N + RF_NW * 4 - 1) / (RF_NW * 4)) * 4;  // this wave's share of j, a multiple of 4
   const int j0 = wv * per, j1 = imin(N, j0 + per);
   const int kq = lane >> 4, li = lane & 15;
+  vsum_range<P, XLDS, (WPRE ? 0 : 2)>(gp, ggl, gl, tab, NpadMax, part, kb, al_l, vb, j0, j1, lane);
   v4d acc[3][CT];
 #pragma unroll
   for (int rt = 0; rt < 3; ++rt)
@@ -549,20 +543,20 @@ __device__ __forceinline__ void phase_j_gp(const GpL& gp, int ggl, int gl, int D
 
 template <int P, bool XLDS, int MAXDEG>
 __device__ __forceinline__ void phase_j(const GpL* gpl, int g0, int gn, int D, int NpadMax, const double* xt_l, const double* al_l,
-                                        const double* kb, const double* ks, const double* pa, const double* pb, const double* vb,
-                                        double* redw, int wv, int lane, unsigned long long* jst = nullptr) {
+                                        const double* kb, const double* ks, const double* pa, const double* pb, double* vb,
+                                        const int* tab, const double* part, double* redw, int wv, int lane, unsigned long long* jst = nullptr) {
   constexpr int NCOLMAX = P * RF_NAX(MAXDEG);
   for (int gl = 0; gl < gn; ++gl) {
     const GpL& gp = gpl[g0 + gl];
     const int deg = MAXDEG == 0 ? 0 : __builtin_amdgcn_readfirstlane(gp.deg);
     if (MAXDEG == 0)
-      phase_j_gp<P, XLDS, 0, true>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane, jst);
+      phase_j_gp<P, XLDS, 0, true>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, tab, part, redw, wv, lane, jst);
     else if (deg == 0)
-      phase_j_gp<P, XLDS, 0, false>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane);
+      phase_j_gp<P, XLDS, 0, false>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, tab, part, redw, wv, lane);
     else if (deg == 1)
-      phase_j_gp<P, XLDS, 1, false>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane);
+      phase_j_gp<P, XLDS, 1, false>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, tab, part, redw, wv, lane);
     else
-      phase_j_gp<P, XLDS, 2, false>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, redw, wv, lane);
+      phase_j_gp<P, XLDS, 2, false>(gp, g0 + gl, gl, D, NpadMax, NCOLMAX, xt_l, al_l, kb, ks, pa, pb, vb, tab, part, redw, wv, lane);
   }
 }
 
@@ -923,10 +917,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       phase_v<P>(gpl, g0, tab, NC, NpadMax, kb, part, wv, lane);
       lds_barrier();
       RF_STAMP(4);
-      phase_vsum<P, XLDS, MAXDEG>(gpl, g0, gn, tab, NC, NpadMax, part, kb, al_l, vb, tid);
-      lds_barrier();
       RF_STAMP(5);
-      phase_j<P, XLDS, MAXDEG>(gpl, g0, gn, D, NpadMax, xt_l, al_l, kb, ks, pa, pb, vb, red, wv, lane,
+      phase_j<P, XLDS, MAXDEG>(gpl, g0, gn, D, NpadMax, xt_l, al_l, kb, ks, pa, pb, vb, tab, part, red, wv, lane,
                                (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
       lds_barrier();
       RF_STAMP(6);
@@ -1066,9 +1058,7 @@ __global__ __launch_bounds__(RF_NT) void posterior_fwd_kernel(PostArgs a) {
   __syncthreads();
   phase_v<P>(gpl, 0, tab, NC, NpadMax, kb, part, wv, lane);
   __syncthreads();
-  phase_vsum<P, false, 2>(gpl, 0, 1, tab, NC, NpadMax, part, kb, nullptr, vb, tid);
-  __syncthreads();
-  phase_j<P, false, 2>(gpl, 0, 1, D, NpadMax, nullptr, nullptr, kb, ks, pa, pb, vb, red, wv, lane);
+  phase_j<P, false, 2>(gpl, 0, 1, D, NpadMax, nullptr, nullptr, kb, ks, pa, pb, vb, tab, part, red, wv, lane);
   __syncthreads();
   for (int it = tid; it < P * (D + 1); it += RF_NT) {
     int p = it / (D + 1), c = it - p * (D + 1);
