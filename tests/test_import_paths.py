@@ -102,3 +102,24 @@ def test_pms_simulator_filter_matches_the_restated_formula():
         assert abs(noisy[k, 1] - nv) < 1e-14
         prev_nv = noisy[k - 1, 1]
         assert abs(meas[k, 1] - (b[0] * nv + b[1] * prev_nv - a[1] * meas[k - 1, 1]) / a[0]) < 1e-12
+
+
+def test_hand_off_timeout_is_raised_not_swallowed():
+    """A GP-sharded rollout whose workgroups never met reports MCP_STATUS_SYNC; the optimisation loop must raise on it
+    (a NaN cost alone is data: the reference re-samples, MC_PILCO.py:497)."""
+    import pytest
+    import torch
+
+    import mcp_boot  # noqa: F401
+    from mc_pilco_amd import hipabi
+    from mc_pilco_amd.policy_learning.MC_PILCO import MC_PILCO
+
+    obj = MC_PILCO.__new__(MC_PILCO)  # only the status logic is exercised
+    obj.last_status = torch.zeros(1, dtype=torch.int32)
+    assert obj._rollout_failed(torch.tensor(1.5, dtype=torch.float64)) is False
+    assert obj._rollout_failed(torch.tensor(float("nan"), dtype=torch.float64)) is True
+    obj.last_status = torch.tensor([hipabi.STATUS_NAN], dtype=torch.int32)
+    assert obj._rollout_failed(torch.tensor(float("nan"), dtype=torch.float64)) is True
+    obj.last_status = torch.tensor([hipabi.STATUS_SYNC], dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="MCP_STATUS_SYNC"):
+        obj._rollout_failed(torch.tensor(1.5, dtype=torch.float64))
