@@ -948,7 +948,6 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         constexpr int NCOLMAX = P * RF_NAX(MAXDEG);
         const double* Rg = red + gl * RF_NW * (D + 1) * NCOLMAX;
         const double* zp = z + p * D;
-        int mm = imin(m0 + p, M - 1);
         double mu, var;
         gp_point<MAXDEG>(gp, kp, D, zp, Rg, NCOLMAX, p, mu, var);
         var *= vscale;
@@ -1045,7 +1044,7 @@ __global__ __launch_bounds__(RF_NT) void posterior_fwd_kernel(PostArgs a) {
   const mcp_gp& gp = a.gp;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int D = gp.kern.D, deg = gp.kern.poly_deg, NpadMax = gp.Npad;
+  const int D = gp.kern.D, NpadMax = gp.Npad;
   const FwdLayout L = fwd_layout(P, 1, 1, D, 1, 1, 1, NpadMax, 2, 1, a.NCmax, false);
   double* z = smem + L.z;
   double* kb = smem + L.kb;
