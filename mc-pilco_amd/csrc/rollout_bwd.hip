@@ -203,12 +203,16 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
 
   const int NRP = PB * NR;
   // particles of this sweep: m_p = mbase + p (clamped for the loads; slots past M contribute nothing)
+  // the record traffic (address arithmetic for BW_RPT elements, ~1.3 k cycles per step) is kept off the serial waves when the
+  // workgroup has others: measured on wave 0's critical path before
+  const bool pf_split = NW > PB;
+  const int pf_tid = pf_split ? tid - 64 * PB : tid, pf_nt = pf_split ? NT - 64 * PB : NT;
   auto prefetch = [&](double (&pre)[BW_RPT], int t, int mbase) {
 #pragma unroll
     for (int k = 0; k < BW_RPT; ++k) {
-      const int e = tid + k * NT;
+      const int e = pf_tid + k * pf_nt;
       double v = 0.0;
-      if (e < NRP) {
+      if (pf_tid >= 0 && e < NRP) {
         const int p = e / NR, i = e - p * NR;
         const size_t tm = (size_t)t * M + imin(mbase + p, M - 1);
         if (i < oU)
@@ -230,8 +234,8 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   auto park = [&](const double (&pre)[BW_RPT], int buf) {
 #pragma unroll
     for (int k = 0; k < BW_RPT; ++k) {
-      const int e = tid + k * NT;
-      if (e < NRP) rec[buf * NRP + e] = pre[k];
+      const int e = pf_tid + k * pf_nt;
+      if (pf_tid >= 0 && e < NRP) rec[buf * NRP + e] = pre[k];
     }
   };
 
@@ -560,7 +564,7 @@ static int launch_bwd(const BwdArgs& a, int NT, hipStream_t st) {
   if (NT > MAXNT || NT < 64 * PB) return MCP_ERR_LIMIT;
   const mcp_model& md = a.model;
   const bool pms = a.pol.meas.n > 0;
-  if (PB * bwd_rec_len(md.S, md.U, md.D, md.G, pms) > BW_RPT * NT) return MCP_ERR_LIMIT;
+  if (PB * bwd_rec_len(md.S, md.U, md.D, md.G, pms) > BW_RPT * (NT / 64 > PB ? NT - 64 * PB : NT)) return MCP_ERR_LIMIT;
   const int grid = imin((a.M + PB - 1) / PB, 1024);
   BwdLayout L = bwd_layout(md.S, md.U, md.D, md.G, a.pol.P, NT / 64, PB, pms);
   const size_t lds = sizeof(double) * (size_t)L.total;
