@@ -608,7 +608,9 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   const int PF = policy->P, U = policy->U;
   // particles per workgroup: large swarms are latency bound per workgroup, so several particles share one sweep; small
   // swarms keep one particle per workgroup to spread over the CUs
-  int PB = g_force_bwd_pb ? g_force_bwd_pb : (M >= 2048 ? 4 : (M >= 1024 ? 2 : 1));
+  // (two 256-thread workgroups per CU are resident: one particle per workgroup while M of them fit in one round, then 2, then 4;
+  //  measured, tools/sweep_bwd_particles.py: M=800 1.74 / 1.34 / 1.92 ms, M=2000 3.24 / 2.51 / 2.07 ms for 1 / 2 / 4)
+  int PB = g_force_bwd_pb ? g_force_bwd_pb : (M > 1024 ? 4 : (M > 512 ? 2 : 1));
   if (!g_force_bwd_pb && (PF > 16 || U > 4)) PB = 1;  // the wide-policy instantiations are register bound already
   if (PB != 1 && PB != 2 && PB != 4) return MCP_ERR_ARG;
   int NT = imax(bwd_threads(policy->B), 64 * PB);

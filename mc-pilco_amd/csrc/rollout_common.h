@@ -30,8 +30,8 @@ __device__ __forceinline__ double policy_feature(const mcp_policy& pl, const dou
 // the rollout kernels (nobody in the kernel reads them back), so they are not drained at every barrier
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// hand-off buffer of the GP-sharded forward launch (rollout_fwd.hip): [clusters][2][G][P][2] granules of 8 bytes, clusters * P < M + 4
-static inline size_t rollout_xch_bytes(int M, int G) { return ((size_t)(M + 4) * 2 * G * 2 * sizeof(unsigned long long) + 15) & ~(size_t)15; }
+// hand-off buffer of the GP-sharded forward launch (rollout_fwd.hip): [clusters][2][G][P][2] granules of 8 bytes, clusters * P < M + 16 (a launch per chunk, each rounded up to whole clusters)
+static inline size_t rollout_xch_bytes(int M, int G) { return ((size_t)(M + 16) * 2 * G * 2 * sizeof(unsigned long long) + 15) & ~(size_t)15; }
 
 static inline bool model_ok(const mcp_model* m) {
   if (!m) return false;

@@ -697,10 +697,12 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
     myg = r >> 3;
     if (cluster >= a.nclusters) return;  // padding blocks of the last group of 8 clusters
   }
+  const int gcluster = GSH ? a.m_off / P + cluster : cluster;  // cluster index in the whole swarm (hand-off slots)
   const bool writer = !GSH || myg == 0;  // states / inputs are identical in the workgroups of a cluster: one of them stores
   int* abortw = reinterpret_cast<int*>(dl + 2 * P * G);
   if (GSH && tid == 0) *abortw = 0;
-  const int m0 = cluster * P;
+  const int m0 = (GSH ? a.m_off : 0) + cluster * P;
+  const int Mend = GSH ? a.m_off + a.m_cnt : M;  // one past the last particle of this launch (M itself: strides of the [T][M][.] arrays)
   uint32_t bad = 0;
   const bool drop = pl.p_drop > 0.0;
   const double keep_scale = 1.0 / (1.0 - pl.p_drop);
@@ -739,8 +741,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   // thread (p, s) owns state component s of particle p
   const bool own = tid < P * S;
   const int op = own ? tid / S : 0, os = own ? tid - op * S : 0;
-  const int om = imin(m0 + op, M - 1);
-  const bool ovalid = own && (m0 + op < M);
+  const int om = imin(m0 + op, Mend - 1);
+  const bool ovalid = own && (m0 + op < Mend);
   double xn = own ? a.x0[(size_t)om * S + os] : 0.0;
   int cur = 0;
   // what this state component feeds (fixed for the whole rollout): GP-feature slots, policy-feature slots, integrator role
@@ -855,7 +857,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       const int e = tid - 64, p = e / G, g = e - p * G;
       double ev = 0.0;
       if (a.particle_pred) {
-        const int mm = imin(m0 + p, M - 1);
+        const int mm = imin(m0 + p, Mend - 1);
         ev = a.nz.eps ? a.nz.eps[((size_t)t * M + mm) * G + g] : philox_normal(a.nz, mm, t, g);
       }
       epsb[e] = ev;
@@ -867,7 +869,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       const int BQ = (B + 3) >> 2;
       for (int it = tid - 128; it < P * BQ; it += RF_NT - 128) {
         const int p = it / BQ, q = it - p * BQ;
-        const u32x4 r = philox_draw(a.nz, imin(m0 + p, M - 1), t, MCP_STREAM_MASK, (uint32_t)q);
+        const u32x4 r = philox_draw(a.nz, imin(m0 + p, Mend - 1), t, MCP_STREAM_MASK, (uint32_t)q);
         mk[it] = (int)(r.x >= drop_thr) | ((int)(r.y >= drop_thr) << 1) | ((int)(r.z >= drop_thr) << 2) | ((int)(r.w >= drop_thr) << 3);
       }
     }
@@ -887,7 +889,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       }
       double phi = exp(-dist);
       if (drop) {
-        int mm = imin(m0 + p, M - 1);
+        int mm = imin(m0 + p, Mend - 1);
         bool keep = a.nz.masks ? (a.nz.masks[((size_t)t * M + mm) * B + b] != 0) : (((mk[p * ((B + 3) >> 2) + (b >> 2)] >> (b & 3)) & 1) != 0);
         phi = keep ? phi * keep_scale : 0.0;
       }
@@ -908,7 +910,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         double u = pl.squash ? um * tanh(s / um) : s;
         us[p * U + k] = u;
         z[p * D + nna + 2 * na + k] = u;
-        if (m0 + p < M) {
+        if (m0 + p < Mend) {
           if (writer) a.inputs[((size_t)t * M + m0 + p) * U + k] = u;
           if (is_bad(u)) bad |= MCP_STATUS_NAN;
         }
@@ -962,15 +964,15 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
           dl[p * G + g] = dv;
           if (GSH) {  // publish straight from the register: two granules
             const unsigned long long bits = (unsigned long long)__double_as_longlong(dv);
-            gu64_t slot = (gu64_t)a.xch + xch_slot(cluster, t, G, g, P) + 2 * p;
+            gu64_t slot = (gu64_t)a.xch + xch_slot(gcluster, t, G, g, P) + 2 * p;
             store_granule(slot, (unsigned)t + 1u, (unsigned)bits);
             store_granule(slot + 1, (unsigned)t + 1u, (unsigned)(bits >> 32));
           }
-          if (m0 + p < M) {
+          if (m0 + p < Mend) {
             if (a.particle_pred && !(var > 0.0)) bad |= MCP_STATUS_NONPOS_VAR;
             if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
           }
-        } else if (a.jac && m0 + p < M) {
+        } else if (a.jac && m0 + p < Mend) {
           double Jmu, Jvar;
           gp_jac<MAXDEG>(gp, kp, D, zp, Rg, NCOLMAX, p, c, Jmu, Jvar);
           a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
@@ -984,7 +986,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       const bool act = lane < ngr;
       const int go = act ? lane / (2 * P) : 0, r = act ? lane - go * 2 * P : 0;
       const int gq = go < myg ? go : go + 1;
-      gu64_t slot = (gu64_t)a.xch + xch_slot(cluster, t, G, gq, P) + r;
+      gu64_t slot = (gu64_t)a.xch + xch_slot(gcluster, t, G, gq, P) + r;
       unsigned val = 0;
       bool done = false;
       for (unsigned spins = 0; spins < RF_SPIN_LIMIT; ++spins) {
@@ -1129,7 +1131,9 @@ extern "C" void mcp_debug_set_stamp_buffer(void* p) { g_stamps = (unsigned long 
 
 // ---- GP-sharded launch: G workgroups per particle cluster ----------------------------------------------------------
 static int g_gp_sharding = -1;  // test hook: -1 automatic, 0 never, 1 whenever the grid fits the device
-static int g_last_sharded = 0;  // test hook: whether the last forward launch was GP-sharded
+static int g_last_sharded = 0;  // test hook: number of GP-sharded launches the last forward call made (0 = not sharded)
+static int g_gp_max_launches = 2;  // a swarm goes out GP-sharded when it fits this many resident grids (cart-pole shape, forward ms,
+                                   // tools/sweep_fwd_swarm.py: M=1024 two launches 4.9 vs 6.5 unsharded; M=1280 three launches 7.3 vs 6.9 on the tile kernel)
 extern "C" void mcp_debug_set_gp_sharding(int mode) { g_gp_sharding = mode; }
 extern "C" int mcp_debug_last_gp_sharded(void) { return g_last_sharded; }
 static int gsh_grid(int nclusters, int G) { return ((nclusters + 7) / 8) * 8 * G; }
@@ -1214,6 +1218,8 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   a.stamps = g_stamps;
   a.xch = nullptr;
   a.nclusters = 0;
+  a.m_off = 0;
+  a.m_cnt = M;
   hipStream_t st = (hipStream_t)stream;
   // configuration search: most particles per workgroup first, operands in LDS if they fit, all GPs per pass if they fit
   int P0 = g_force_ppw ? g_force_ppw : pick_particles_per_wg(M);
@@ -1228,23 +1234,32 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
     int NC1 = 0;
     for (int g = 0; g < model->G; ++g) NC1 = imax(NC1, (model->gp[g].Npad + RF_CW - 1) / RF_CW);
     const bool forced = g_force_ppw == 1 || g_force_ppw == 2 || g_force_ppw == 4;
+    a.xch = (unsigned long long*)workspace;
+    a.GB = 1;
+    a.NCmax = NC1;
     for (int P = forced ? g_force_ppw : 1; P <= (forced ? g_force_ppw : 4) && NC1 <= RF_MAX_CHUNKS; P <<= 1) {
-      const int ncl = (M + P - 1) / P;
-      if (gsh_grid(ncl, model->G) > cus) continue;
+      // particles one resident grid takes at this cluster size (whole groups of 8 clusters, G workgroups each)
+      const int cap = (cus / (8 * model->G)) * 8 * P;
+      if (cap <= 0) break;
+      // up to g_gp_max_launches launches back to back (each resident on its own; they may overlap where one drains and the next
+      // starts, which only delays a partner)
+      const int nchunk = (M + cap - 1) / cap;
+      if (nchunk > 1 && (P < 4 || nchunk > g_gp_max_launches)) continue;
       FwdLayout L = fwd_layout(P, model->S, model->U, model->D, model->G, policy->P, policy->B, a.NpadMax, a.maxdeg, 1, NC1, true, 1);
       const size_t lds = sizeof(double) * (size_t)L.total;
       if (lds > MCP_LDS_LIMIT) break;
-      a.GB = 1;
-      a.NCmax = NC1;
-      a.nclusters = ncl;
-      a.xch = (unsigned long long*)workspace;
-      if (hipMemsetAsync(workspace, 0, ((size_t)ncl * 2 * model->G * P * 2 * sizeof(unsigned long long) + 15) & ~(size_t)15, st) != hipSuccess)
-        return MCP_ERR_LAUNCH;
+      if (hipMemsetAsync(workspace, 0, rollout_xch_bytes(M, model->G), st) != hipSuccess) return MCP_ERR_LAUNCH;
       g_last_ppw = P;
-      g_last_sharded = 1;
-      if (P == 4) return launch_fwd_sharded<4>(a, lds, st);
-      if (P == 2) return launch_fwd_sharded<2>(a, lds, st);
-      return launch_fwd_sharded<1>(a, lds, st);
+      g_last_sharded = nchunk;
+      const int per = (((M + nchunk - 1) / nchunk + P - 1) / P) * P;  // particles per launch, whole clusters
+      for (int off = 0; off < M; off += per) {
+        a.m_off = off;
+        a.m_cnt = imin(per, M - off);
+        a.nclusters = (a.m_cnt + P - 1) / P;
+        const int rc = P == 4 ? launch_fwd_sharded<4>(a, lds, st) : (P == 2 ? launch_fwd_sharded<2>(a, lds, st) : launch_fwd_sharded<1>(a, lds, st));
+        if (rc != MCP_OK) return rc;
+      }
+      return MCP_OK;
     }
   }
   if (P0 == 16) {

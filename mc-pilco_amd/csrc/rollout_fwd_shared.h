@@ -49,6 +49,8 @@ struct FwdArgs {
   // increment once per step through 8-byte {tag, value} granules  xch[cluster][t & 1][g][p][half]  (zeroed per launch)
   unsigned long long* xch;
   int nclusters;
+  int m_off, m_cnt;  // the particles [m_off, m_off + m_cnt) of the swarm that this launch covers (a swarm too large for one
+                     // resident GP-sharded grid goes out as a few launches back to back on the stream)
 };
 
 #define RF_STAMP(k)                                 \

@@ -446,12 +446,12 @@ def test_adjoint_matches_finite_difference_at_full_width(name, M):
     assert abs(fd - gd) < 1e-5 * max(abs(gd), 1e-3), (fd, gd)
 
 
-@pytest.mark.parametrize("name,M,expect,sharded", [("c1", 400, 4, True), ("c1", 256, 2, True), ("c1", 1000, 2, False), ("c3", 4000, 16, False),
+@pytest.mark.parametrize("name,M,expect,sharded", [("c1", 400, 4, True), ("c1", 256, 2, True), ("c1", 1000, 4, True), ("c1", 1200, 16, False), ("c3", 4000, 16, False),
                                                    ("c5", 2000, 16, False)])
 def test_baseline_shapes_run_on_the_intended_kernel(name, M, expect, sharded):
     """The automatic dispatch puts BASELINE.json's shapes where DESIGN.md says they run (a shape that overflows the tile kernel's
-    LDS budget would silently fall back to the 4-particle kernel; a small swarm whose GP-sharded grid does not fit the device
-    must not be sharded)."""
+    LDS budget would silently fall back to the 4-particle kernel; a swarm beyond one resident GP-sharded grid goes out as two
+    such launches, a larger one on the tile kernel)."""
     from gpu_helpers import dev
     from mc_pilco_amd import hipabi, ops, workloads
 
@@ -486,3 +486,34 @@ def test_gp_sharded_launch_needs_its_workspace():
         assert bool(hipabi.lib().mcp_debug_last_gp_sharded()) == with_ws
         out.append(states.clone())
     assert float((out[0] - out[1]).abs().max()) < 1e-9
+
+
+def test_two_launch_sharding_matches_the_unsharded_kernels():
+    """A swarm beyond one resident GP-sharded grid (512 < M <= 1024 at two GPs) goes out as two sharded launches over disjoint
+    particle ranges: same trajectories and gradient as the unsharded kernels, Philox noise keyed by the global particle index."""
+    from gpu_helpers import dev
+    from mc_pilco_amd import hipabi, ops, workloads
+
+    w = workloads.build("c1", device=dev(), M=700, T=10)
+    torch.manual_seed(5)
+    x0 = w.sample_x0()
+    out = []
+    for mode in (-1, 0):
+        hipabi.lib().mcp_debug_set_gp_sharding(mode)
+        try:
+            for q in w.params:
+                q.grad = None
+            st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=4, call=2), x0, w.T, w.p_drop)
+            launches = hipabi.lib().mcp_debug_last_gp_sharded()
+            c, s = ops.expected_cost(w.cost, st)
+            c.backward()
+        finally:
+            hipabi.lib().mcp_debug_set_gp_sharding(-1)
+        assert int(status.item()) == 0
+        assert launches == (2 if mode == -1 else 0)
+        out.append((st.detach().clone(), inp.detach().clone(), [q.grad.detach().clone() for q in w.params]))
+    # (the two kernels add the V partial sums in different orders: rounding-level differences, grown by 10 steps of dynamics
+    #  over the most sensitive of 700 particles)
+    assert float((out[0][0] - out[1][0]).abs().max()) < 2e-8 and float((out[0][1] - out[1][1]).abs().max()) < 2e-8
+    for ga, gb in zip(out[0][2], out[1][2]):
+        assert float((ga - gb).abs().max()) <= 1e-7 * max(1e-30, float(gb.abs().max()))
