@@ -646,7 +646,7 @@ __device__ __forceinline__ void gp_jac(const GpL& gp, const double* kp, int D, c
 // than the device can hold would be the only reason) ends the rollout with MCP_STATUS_SYNC instead of hanging.
 // ---------------------------------------------------------------------------------------
 typedef unsigned long long __attribute__((address_space(1))) * gu64_t;
-#define RF_SPIN_LIMIT (1u << 20)
+#define RF_SPIN_LIMIT (1u << 22)  // polls of ~1-2 us each: several seconds -- far beyond any delay a partner can have while the device makes progress
 __device__ __forceinline__ void store_granule(gu64_t g, unsigned epoch, unsigned value) {
   __hip_atomic_store(g, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
