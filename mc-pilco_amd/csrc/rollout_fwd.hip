@@ -8,20 +8,22 @@
 // and also produces what autograd's backward (MC_PILCO.py:522) needs from the GP.
 //
 // Parallel axis: particles.  They never interact inside the rollout, so a 512-thread workgroup
-// owns P particles for all T steps (no inter-workgroup synchronisation anywhere) and keeps their
-// state in LDS.  Per step and GP:  k = k(z,X) [N],  v = Kinv k [N]  (the N^2 term),  mu = m + k.a,
+// owns P particles for all T steps and keeps their state in LDS.  Small swarms are launched
+// GP-sharded (template GSH): the G workgroups of a cluster of P particles each evaluate one GP and
+// hand each other the sampled increment once per step (tagged 8-byte granules, see below); larger
+// ones one workgroup per P particles with no inter-workgroup traffic at all.  Per step and GP:  k = k(z,X) [N],  v = Kinv k [N]  (the N^2 term),  mu = m + k.a,
 // var = k(z,z) - k.v,  and d mu/dz, d var/dz -- formed HERE from v (d var/dz = dk(z,z)/dz -
 // 2 sum_j v_j dk_j/dz).  Only d delta_g/dz (G x D doubles per particle-step, sampling folded in)
 // is stored, so the backward sweep never touches the GP again (rollout_bwd.hip).
 //
 // Memory plan: Kinv (N x N fp64 = 720 KB per GP at N=300) cannot live in the 160 KiB
 // LDS; it stays L2-resident and is streamed once per step per workgroup -- symmetric, so
-// "column i" is read as 64-double row segments (coalesced 512-B wave loads), double-buffered in
+// "column i" is read as 128-double row segments (one 16-byte load per lane), double-buffered in
 // registers, the stream cut into equal contiguous shares for the 8 waves (phase V).  Everything
 // small and re-read every step (X^T, alpha, policy centres/weights) is copied to LDS once per
 // launch when it fits (template XLDS).  The moment / Jacobian sums over the training index are one
 // skinny MFMA product per GP (phase J), the other reductions wave64 DPP sums; partial results meet in
-// LDS; 8 LDS-only workgroup barriers per time step.  Swarms above 1024 particles are handed to the
+// LDS; 7 LDS-only workgroup barriers per time step.  Swarms above 1024 particles are handed to the
 // 16-particle tile kernel (rollout_fwd_tile.hip).  With a measurement model (mcp_meas: partially
 // measurable systems, MC_PILCO.py:808-906) phase S also produces what the policy sees: noisy
 // positions, backward-difference velocities, first-order filter, three carried values per pair.
