@@ -647,13 +647,6 @@ __device__ __forceinline__ void gp_jac(const GpL& gp, const double* kp, int D, c
 // launch function on the stream (tags start at 1).  Spins are bounded: a partner that never shows up (a grid larger
 // than the device can hold would be the only reason) ends the rollout with MCP_STATUS_SYNC instead of hanging.
 // ---------------------------------------------------------------------------------------
-typedef unsigned long long __attribute__((address_space(1))) * gu64_t;
-#define RF_SPIN_LIMIT (1u << 22)  // polls of ~1-2 us each: several seconds -- far beyond any delay a partner can have while the device makes progress
-__device__ __forceinline__ void store_granule(gu64_t g, unsigned epoch, unsigned value) {
-  __hip_atomic_store(g, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ size_t xch_slot(int cluster, int t, int G, int g, int P) { return ((((size_t)cluster * 2 + (t & 1)) * G + g) * P) * 2; }
-
 // ---------------------------------------------------------------------------------------
 // forward rollout.  GSH = false: one workgroup per P particles, all GPs.  GSH = true: G workgroups per P particles, each
 // evaluates ONE GP (streams one Kinv) and the policy; they meet once per step in the hand-off above.  Blocks b and b + 8
@@ -1153,6 +1146,13 @@ static int device_cu_count() {
   return cus[dev];
 }
 
+// whether the GP-sharded 16-particle kernel can take the whole swarm in one resident grid (rollout_fwd_tile.hip: small class, G <= 3)
+static bool tile_sharded_possible(const mcp_model* m, const mcp_policy* p, int NpadMax, int M, int T) {
+  if (m->G < 2 || m->G > 3 || T <= 1 || NpadMax > 512) return false;
+  if (!(m->D <= 8 && p->P <= 8 && m->U <= 2) || !fwd_tile_fits(m, p)) return false;
+  return gsh_grid((M + 15) / 16, m->G) <= device_cu_count();
+}
+
 static int chunks_in_pass(const mcp_model* m, int GB) {
   int best = 0;
   for (int g0 = 0; g0 < m->G; g0 += GB) {
@@ -1231,11 +1231,12 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   // resident at one workgroup per CU; smallest cluster size first (most CUs busy)
   g_last_sharded = 0;
   if (g_gp_sharding != 0 && model->G >= 2 && T > 1 && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
-      (g_force_ppw == 0 || g_gp_sharding == 1)) {
+      (g_force_ppw == 0 || (g_gp_sharding == 1 && g_force_ppw != 16))) {
     const int cus = device_cu_count();
     int NC1 = 0;
     for (int g = 0; g < model->G; ++g) NC1 = imax(NC1, (model->gp[g].Npad + RF_CW - 1) / RF_CW);
     const bool forced = g_force_ppw == 1 || g_force_ppw == 2 || g_force_ppw == 4;
+    const bool tile_sh = tile_sharded_possible(model, policy, a.NpadMax, M, T);
     a.xch = (unsigned long long*)workspace;
     a.GB = 1;
     a.NCmax = NC1;
@@ -1246,7 +1247,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
       // up to g_gp_max_launches launches back to back (each resident on its own; they may overlap where one drains and the next
       // starts, which only delays a partner)
       const int nchunk = (M + cap - 1) / cap;
-      if (nchunk > 1 && (P < 4 || nchunk > g_gp_max_launches)) continue;
+      if (nchunk > 1 && (P < 4 || nchunk > g_gp_max_launches || (!forced && tile_sh))) continue;  // (the sharded 16-particle kernel is the faster form then)
       FwdLayout L = fwd_layout(P, model->S, model->U, model->D, model->G, policy->P, policy->B, a.NpadMax, a.maxdeg, 1, NC1, true, 1);
       const size_t lds = sizeof(double) * (size_t)L.total;
       if (lds > MCP_LDS_LIMIT) break;
@@ -1262,6 +1263,27 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
         if (rc != MCP_OK) return rc;
       }
       return MCP_OK;
+    }
+  }
+  if ((P0 == 16 || g_force_ppw == 0) && g_gp_sharding != 0 && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
+      tile_sharded_possible(model, policy, a.NpadMax, M, T)) {
+    // swarms beyond one resident grid of the small-tile kernel, up to 2048 particles at two GPs: the 16-particle kernel GP-sharded --
+    // twice the workgroups, each with one GP's contractions (tools/sweep_fwd_swarm.py, cart-pole shape, forward ms: M=1024 3.8 vs 4.9
+    // for two small-tile launches vs 6.4 unsharded; M=2048 3.9 vs 6.8 for the unsharded 16-particle kernel)
+    const int ncl = (M + 15) / 16;
+    {
+      a.xch = (unsigned long long*)workspace;
+      a.nclusters = ncl;
+      if (hipMemsetAsync(workspace, 0, rollout_xch_bytes(M, model->G), st) != hipSuccess) return MCP_ERR_LAUNCH;
+      const int rc = launch_fwd_tile_sharded(a, st);
+      if (rc == MCP_OK) {
+        g_last_ppw = 16;
+        g_last_sharded = 1;
+        return MCP_OK;
+      }
+      if (rc != MCP_ERR_LIMIT) return rc;
+      a.xch = nullptr;
+      a.nclusters = 0;
     }
   }
   if (P0 == 16) {

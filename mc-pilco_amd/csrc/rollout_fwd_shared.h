@@ -102,6 +102,14 @@ __device__ __forceinline__ void stage_gp_tables(const mcp_gp* gps, const double*
 }
 
 
+// hand-off of the GP-sharded launches (protocol: rollout_fwd.hip): granule store, slot of (cluster, step parity, GP, particle)
+typedef unsigned long long __attribute__((address_space(1))) * gu64_t;
+#define RF_SPIN_LIMIT (1u << 22)  // polls of ~1-2 us each: several seconds -- far beyond any delay a partner can have while the device makes progress
+__device__ __forceinline__ void store_granule(gu64_t g, unsigned epoch, unsigned value) {
+  __hip_atomic_store(g, ((unsigned long long)epoch << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ size_t xch_slot(int cluster, int t, int G, int g, int P) { return ((((size_t)cluster * 2 + (t & 1)) * G + g) * P) * 2; }
+
 typedef double v4d_t __attribute__((ext_vector_type(4)));
 // sum over the 4 lanes l, l^16, l^32, l^48 (the 4 feature groups of an MFMA operand column)
 __device__ __forceinline__ double fold_kk(double v) {
@@ -112,6 +120,9 @@ __device__ __forceinline__ double fold_kk(double v) {
 
 // forward rollout with 16 particles per workgroup (rollout_fwd_tile.hip); MCP_ERR_LIMIT when the problem does not fit it
 int launch_fwd_tile(const FwdArgs& a, hipStream_t st);
+// the same kernel GP-sharded (G workgroups per 16-particle tile; a.xch / a.nclusters set by the caller); MCP_ERR_LIMIT when
+// the shape has no sharded instantiation
+int launch_fwd_tile_sharded(const FwdArgs& a, hipStream_t st);
 bool fwd_tile_fits(const mcp_model* model, const mcp_policy* policy);
 
 }  // namespace mcp

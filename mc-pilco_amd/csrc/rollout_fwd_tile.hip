@@ -57,7 +57,7 @@ __host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, in
   L.us = take(TL_PT * U);
   L.z = take(TL_PT * D);
   L.sf = take(TL_PT * PF);
-  L.dl = take(TL_PT * G);
+  L.dl = take(TL_PT * G + 2);  // sampled increments | abort word of the GP-sharded launch
   L.eps = take(2 * TL_PT * G);  // process noise of steps t (read by phase F) and t+1 (drawn by idle threads of phase F)
   L.ks = take(NpadMax * TL_KR);
   L.kv = take(NpadMax * TL_KR);  // directly after ks: the phi buffer of the policy phase aliases both
@@ -714,7 +714,9 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
 // function made the register allocator spill the small path's long-lived values for the benefit of the big one.
 // CLS: 0 = cart-pole class (D, policy features <= 8, inputs <= 2, N <= 512), 1 = UR5 class (<= 24, <= 24, <= 6, N <= 512), 2 = any
 // PMS: the policy is evaluated on a simulated measurement (mcp_meas, MC_PILCO4PMS.apply_policy) instead of the true state
-template <int MAXDEG, int CLS, bool PMS>
+// GSH (small class only): G workgroups per 16-particle tile, each evaluates ONE GP (and, redundantly, the policy); they hand each
+// other the sampled increments once per step exactly as the small-tile kernel's GP-sharded launch does (rollout_fwd.hip).
+template <int MAXDEG, int CLS, bool PMS, bool GSH = false>
 __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   constexpr int NG = CLS == 0 ? 2 : (CLS == 1 ? 6 : 8);              // feature groups of 4 (GP inputs, policy features)
   constexpr int MAXTASK = CLS == 2 ? TL_MAXTASK : 2;                  // 32-row blocks of Kinv per wave
@@ -740,7 +742,17 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   double* scr = smem + L.scr;
   GpL* gpl = reinterpret_cast<GpL*>(smem + L.gpl);
   double* kpar = smem + L.kpar;
-  const int m0 = blockIdx.x * P;
+  int cluster = blockIdx.x, myg = 0;
+  if (GSH) {  // blocks b and b + 8 share an XCD: the members of a cluster sit 8 apart (speed only)
+    const int b = blockIdx.x, grp = b / (8 * G), r = b - grp * 8 * G;
+    cluster = grp * 8 + (r & 7);
+    myg = r >> 3;
+    if (cluster >= a.nclusters) return;
+  }
+  const bool writer = !GSH || myg == 0;  // states / inputs are identical in the workgroups of a cluster: one of them stores
+  int* abortw = reinterpret_cast<int*>(dl + P * G);
+  if (GSH && tid == 0) *abortw = 0;
+  const int m0 = cluster * P;
   uint32_t bad = 0;
   const bool drop = pl.p_drop > 0.0;
   const double keep_scale = 1.0 / (1.0 - pl.p_drop);
@@ -836,7 +848,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       double* xc = xs + cur * P * S;
       xc[op * S + os] = xn;
       if (ovalid) {
-        a.states[((size_t)t * M + m0 + op) * S + os] = xn;
+        if (writer) a.states[((size_t)t * M + m0 + op) * S + os] = xn;
         if (is_bad(xn)) bad |= MCP_STATUS_NAN;
       }
     }
@@ -863,7 +875,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           pm_prev_np = npos;
         }
         if (ovalid) {
-          ms.meas[((size_t)t * M + m0 + op) * S + os] = xm;
+          if (writer) ms.meas[((size_t)t * M + m0 + op) * S + os] = xm;
           if (is_bad(xm)) bad |= MCP_STATUS_NAN;
         }
       }
@@ -913,7 +925,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       us[p * U + k] = u;
       z[p * D + nna + 2 * na + k] = u;
       if (m0 + p < M) {
-        a.inputs[((size_t)t * M + m0 + p) * U + k] = u;
+        if (writer) a.inputs[((size_t)t * M + m0 + p) * U + k] = u;
         if (is_bad(u)) bad |= MCP_STATUS_NAN;
       }
     }
@@ -921,7 +933,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     TL_STAMP(2);
     if (t == T - 1) break;
 
-    for (int g = 0; g < G; ++g) {
+    for (int g = GSH ? myg : 0; g < (GSH ? myg + 1 : G); ++g) {
       const GpL& gp = gpl[g];
       const double* kp = kpar + g * KP_STRIDE(D);
       const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
@@ -1070,7 +1082,14 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           } else {
             mu += tile_r(Rr, D, 0, p);
           }
-          dl[p * G + g] = a.particle_pred ? fma(sd, eps, mu) : mu;
+          const double dv = a.particle_pred ? fma(sd, eps, mu) : mu;
+          dl[p * G + g] = dv;
+          if (GSH) {  // publish straight from the register: two granules
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(dv);
+            gu64_t slot = (gu64_t)a.xch + xch_slot(cluster, t, G, g, P) + 2 * p;
+            store_granule(slot, (unsigned)t + 1u, (unsigned)bits);
+            store_granule(slot + 1, (unsigned)t + 1u, (unsigned)(bits >> 32));
+          }
           if (m0 + p < M) {
             if (a.particle_pred && !(var > 0.0)) bad |= MCP_STATUS_NONPOS_VAR;
             if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
@@ -1101,9 +1120,38 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
         }
       }
-      if (g == 0 && edraw && t + 1 < T - 1) draw_eps(t + 1);
+      if (g == (GSH ? myg : 0) && edraw && t + 1 < T - 1) draw_eps(t + 1);
+      if (GSH && wv == 0) {
+        // collect the other GPs' increments (rollout_fwd.hip): lane -> (other GP, particle, half), re-read until every tag matches
+        const int ngr = (G - 1) * P * 2;  // <= 64 (the sharded launch is offered for G <= 3)
+        const bool act = lane < ngr;
+        const int go = act ? lane / (2 * P) : 0, r = act ? lane - go * 2 * P : 0;
+        const int gq = go < myg ? go : go + 1;
+        gu64_t slot = (gu64_t)a.xch + xch_slot(cluster, t, G, gq, P) + r;
+        unsigned val = 0;
+        bool done = false;
+        for (unsigned spins = 0; spins < RF_SPIN_LIMIT; ++spins) {
+          bool ok = true;
+          if (act) {
+            const unsigned long long x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            val = (unsigned)x;
+            ok = (unsigned)(x >> 32) == (unsigned)t + 1u;
+          }
+          if (__all(ok)) {
+            done = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (act) reinterpret_cast<unsigned*>(dl)[2 * ((r >> 1) * G + gq) + (r & 1)] = val;
+        if (!done && lane == 0) *abortw = 1;
+      }
       lds_barrier();  // R, k/v panels and the scratch are reused by the next GP
       TL_STAMP(7);
+    }
+    if (GSH && *abortw) {  // uniform: a partner never arrived
+      bad |= MCP_STATUS_SYNC;
+      break;
     }
     // ---- integrate:  v' = v + delta ;  q' = q + Ts v + Ts/2 delta   (Model_learning.py:711-716) ----
     if (own) {
@@ -1153,6 +1201,20 @@ static int launch_tile_pms(const FwdArgs& a, size_t lds, hipStream_t st) {
   return MCP_OK;
 }
 
+template <int MAXDEG, bool PMS>
+static int launch_tile_gsh(const FwdArgs& a, size_t lds, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_tile_kernel<MAXDEG, 0, PMS, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, MCP_LDS_LIMIT);
+    attr_set = true;
+  }
+  const int grid = ((a.nclusters + 7) / 8) * 8 * a.model.G;
+  hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, 0, PMS, true>), dim3(grid), dim3(RF_NT), lds, st, a);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
 template <int MAXDEG, int CLS>
 static int launch_tile_deg(const FwdArgs& a, size_t lds, hipStream_t st) {
   return a.pol.meas.n > 0 ? launch_tile_pms<MAXDEG, CLS, true>(a, lds, st) : launch_tile_pms<MAXDEG, CLS, false>(a, lds, st);
@@ -1175,6 +1237,21 @@ int launch_fwd_tile(const FwdArgs& a, hipStream_t st) {
     case 6: return launch_tile_deg<0, 2>(a, lds, st);
     case 7: return launch_tile_deg<1, 2>(a, lds, st);
     default: return launch_tile_deg<2, 2>(a, lds, st);
+  }
+}
+
+// GP-sharded launch of the 16-particle kernel: the small class (cart-pole-sized D, policy features, inputs) with G <= 3
+int launch_fwd_tile_sharded(const FwdArgs& a, hipStream_t st) {
+  if (!fwd_tile_fits(&a.model, &a.pol) || a.model.G < 2 || a.model.G > 3 || !a.xch) return MCP_ERR_LIMIT;
+  const int D = a.model.D, PF = a.pol.P, U = a.model.U;
+  if (a.NpadMax > 512 || !(D <= 8 && PF <= 8 && U <= 2)) return MCP_ERR_LIMIT;
+  TileLayout L = tile_layout(a.model.S, a.model.U, a.model.D, a.model.G, a.pol.P, a.NpadMax, a.maxdeg);
+  const size_t lds = sizeof(double) * (size_t)L.total;
+  const bool pms = a.pol.meas.n > 0;
+  switch (a.maxdeg) {
+    case 0: return pms ? launch_tile_gsh<0, true>(a, lds, st) : launch_tile_gsh<0, false>(a, lds, st);
+    case 1: return pms ? launch_tile_gsh<1, true>(a, lds, st) : launch_tile_gsh<1, false>(a, lds, st);
+    default: return pms ? launch_tile_gsh<2, true>(a, lds, st) : launch_tile_gsh<2, false>(a, lds, st);
   }
 }
 

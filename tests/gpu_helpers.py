@@ -62,8 +62,8 @@ def noise_from(fx):
 
 class forced_variant:
     """Context manager over the library's test hooks: ``code`` 0 = automatic dispatch; 1 / 2 / 4 = that many particles per
-    workgroup, all GPs in the workgroup; 16 = the 16-particle matrix-core kernel; 101 / 102 / 104 = the GP-sharded launch
-    (G workgroups per cluster of 1 / 2 / 4 particles, met by a per-step hand-off).  ``check()`` asserts that the forced
+    workgroup, all GPs in the workgroup; 16 = the 16-particle matrix-core kernel; 101 / 102 / 104 / 116 = the GP-sharded launch
+    (G workgroups per cluster of 1 / 2 / 4 / 16 particles, met by a per-step hand-off).  ``check()`` asserts that the forced
     variant is the one that ran."""
 
     def __init__(self, code, bwd_particles=None):
@@ -102,4 +102,4 @@ class forced_variant:
         return False
 
 
-VARIANTS = [0, 1, 2, 4, 16, 101, 102, 104]
+VARIANTS = [0, 1, 2, 4, 16, 101, 102, 104, 116]
