@@ -1146,11 +1146,15 @@ static int device_cu_count() {
   return cus[dev];
 }
 
-// whether the GP-sharded 16-particle kernel can take the whole swarm in one resident grid (rollout_fwd_tile.hip: small class, G <= 3)
-static bool tile_sharded_possible(const mcp_model* m, const mcp_policy* p, int NpadMax, int M, int T) {
-  if (m->G < 2 || m->G > 3 || T <= 1 || NpadMax > 512) return false;
-  if (!(m->D <= 8 && p->P <= 8 && m->U <= 2) || !fwd_tile_fits(m, p)) return false;
-  return gsh_grid((M + 15) / 16, m->G) <= device_cu_count();
+// Workgroups per tile with which the GP-sharded 16-particle kernel can take the whole swarm in one resident grid (0 = it cannot):
+// the largest divisor of G that fits, i.e. the fewest GPs per workgroup (rollout_fwd_tile.hip: cart-pole and UR5 register classes)
+static int tile_sharded_cluster(const mcp_model* m, const mcp_policy* p, int NpadMax, int M, int T) {
+  if (m->G < 2 || T <= 1 || NpadMax > 512) return 0;
+  if (!(m->D <= 24 && p->P <= 24 && m->U <= 6) || !fwd_tile_fits(m, p)) return 0;
+  const int cus = device_cu_count(), ncl = (M + 15) / 16;
+  for (int cs = m->G; cs >= 2; --cs)
+    if (m->G % cs == 0 && ((ncl + 7) / 8) * 8 * cs <= cus) return cs;
+  return 0;
 }
 
 static int chunks_in_pass(const mcp_model* m, int GB) {
@@ -1222,6 +1226,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   a.nclusters = 0;
   a.m_off = 0;
   a.m_cnt = M;
+  a.gsh_cs = 0;
   hipStream_t st = (hipStream_t)stream;
   // configuration search: most particles per workgroup first, operands in LDS if they fit, all GPs per pass if they fit
   int P0 = g_force_ppw ? g_force_ppw : pick_particles_per_wg(M);
@@ -1236,7 +1241,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
     int NC1 = 0;
     for (int g = 0; g < model->G; ++g) NC1 = imax(NC1, (model->gp[g].Npad + RF_CW - 1) / RF_CW);
     const bool forced = g_force_ppw == 1 || g_force_ppw == 2 || g_force_ppw == 4;
-    const bool tile_sh = tile_sharded_possible(model, policy, a.NpadMax, M, T);
+    const bool tile_sh = tile_sharded_cluster(model, policy, a.NpadMax, M, T) > 0;
     a.xch = (unsigned long long*)workspace;
     a.GB = 1;
     a.NCmax = NC1;
@@ -1266,7 +1271,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
     }
   }
   if ((P0 == 16 || g_force_ppw == 0) && g_gp_sharding != 0 && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
-      tile_sharded_possible(model, policy, a.NpadMax, M, T)) {
+      tile_sharded_cluster(model, policy, a.NpadMax, M, T) > 0) {
     // swarms beyond one resident grid of the small-tile kernel, up to 2048 particles at two GPs: the 16-particle kernel GP-sharded --
     // twice the workgroups, each with one GP's contractions (tools/sweep_fwd_swarm.py, cart-pole shape, forward ms: M=1024 3.8 vs 4.9
     // for two small-tile launches vs 6.4 unsharded; M=2048 3.9 vs 6.8 for the unsharded 16-particle kernel)
@@ -1274,6 +1279,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
     {
       a.xch = (unsigned long long*)workspace;
       a.nclusters = ncl;
+      a.gsh_cs = tile_sharded_cluster(model, policy, a.NpadMax, M, T);
       if (hipMemsetAsync(workspace, 0, rollout_xch_bytes(M, model->G), st) != hipSuccess) return MCP_ERR_LAUNCH;
       const int rc = launch_fwd_tile_sharded(a, st);
       if (rc == MCP_OK) {

@@ -49,6 +49,7 @@ struct FwdArgs {
   // increment once per step through 8-byte {tag, value} granules  xch[cluster][t & 1][g][p][half]  (zeroed per launch)
   unsigned long long* xch;
   int nclusters;
+  int gsh_cs;        // workgroups per cluster in the GP-sharded 16-particle kernel (each takes G / gsh_cs consecutive GPs)
   int m_off, m_cnt;  // the particles [m_off, m_off + m_cnt) of the swarm that this launch covers (a swarm too large for one
                      // resident GP-sharded grid goes out as a few launches back to back on the stream)
 };

@@ -714,8 +714,8 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
 // function made the register allocator spill the small path's long-lived values for the benefit of the big one.
 // CLS: 0 = cart-pole class (D, policy features <= 8, inputs <= 2, N <= 512), 1 = UR5 class (<= 24, <= 24, <= 6, N <= 512), 2 = any
 // PMS: the policy is evaluated on a simulated measurement (mcp_meas, MC_PILCO4PMS.apply_policy) instead of the true state
-// GSH (small class only): G workgroups per 16-particle tile, each evaluates ONE GP (and, redundantly, the policy); they hand each
-// other the sampled increments once per step exactly as the small-tile kernel's GP-sharded launch does (rollout_fwd.hip).
+// GSH: a.gsh_cs workgroups per 16-particle tile, each evaluates G / gsh_cs consecutive GPs (and, redundantly, the policy); they hand
+// each other the sampled increments once per step exactly as the small-tile kernel's GP-sharded launch does (rollout_fwd.hip).
 template <int MAXDEG, int CLS, bool PMS, bool GSH = false>
 __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   constexpr int NG = CLS == 0 ? 2 : (CLS == 1 ? 6 : 8);              // feature groups of 4 (GP inputs, policy features)
@@ -742,14 +742,17 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   double* scr = smem + L.scr;
   GpL* gpl = reinterpret_cast<GpL*>(smem + L.gpl);
   double* kpar = smem + L.kpar;
-  int cluster = blockIdx.x, myg = 0;
+  int cluster = blockIdx.x, gbeg = 0, gend = G;  // the GPs [gbeg, gend) this workgroup evaluates
   if (GSH) {  // blocks b and b + 8 share an XCD: the members of a cluster sit 8 apart (speed only)
-    const int b = blockIdx.x, grp = b / (8 * G), r = b - grp * 8 * G;
+    const int CS = a.gsh_cs;
+    const int b = blockIdx.x, grp = b / (8 * CS), r = b - grp * 8 * CS;
     cluster = grp * 8 + (r & 7);
-    myg = r >> 3;
+    const int myc = r >> 3;
     if (cluster >= a.nclusters) return;
+    gbeg = (myc * G) / CS;
+    gend = ((myc + 1) * G) / CS;
   }
-  const bool writer = !GSH || myg == 0;  // states / inputs are identical in the workgroups of a cluster: one of them stores
+  const bool writer = !GSH || gbeg == 0;  // states / inputs are identical in the workgroups of a cluster: one of them stores
   int* abortw = reinterpret_cast<int*>(dl + P * G);
   if (GSH && tid == 0) *abortw = 0;
   const int m0 = cluster * P;
@@ -933,7 +936,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     TL_STAMP(2);
     if (t == T - 1) break;
 
-    for (int g = GSH ? myg : 0; g < (GSH ? myg + 1 : G); ++g) {
+    for (int g = gbeg; g < gend; ++g) {
       const GpL& gp = gpl[g];
       const double* kp = kpar + g * KP_STRIDE(D);
       const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
@@ -1120,30 +1123,35 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
         }
       }
-      if (g == (GSH ? myg : 0) && edraw && t + 1 < T - 1) draw_eps(t + 1);
-      if (GSH && wv == 0) {
-        // collect the other GPs' increments (rollout_fwd.hip): lane -> (other GP, particle, half), re-read until every tag matches
-        const int ngr = (G - 1) * P * 2;  // <= 64 (the sharded launch is offered for G <= 3)
-        const bool act = lane < ngr;
-        const int go = act ? lane / (2 * P) : 0, r = act ? lane - go * 2 * P : 0;
-        const int gq = go < myg ? go : go + 1;
-        gu64_t slot = (gu64_t)a.xch + xch_slot(cluster, t, G, gq, P) + r;
-        unsigned val = 0;
-        bool done = false;
-        for (unsigned spins = 0; spins < RF_SPIN_LIMIT; ++spins) {
-          bool ok = true;
-          if (act) {
-            const unsigned long long x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            val = (unsigned)x;
-            ok = (unsigned)(x >> 32) == (unsigned)t + 1u;
+      if (g == gbeg && edraw && t + 1 < T - 1) draw_eps(t + 1);
+      if (GSH && wv == 0 && g == gend - 1) {
+        // collect the other workgroups' increments (rollout_fwd.hip): lane -> (other GP, particle, half), 64 granules per pass,
+        // each pass re-read until every tag matches
+        const int nown = gend - gbeg, ngr = (G - nown) * P * 2;
+        bool done = true;
+        for (int base = 0; base < ngr && done; base += 64) {
+          const int idx = base + lane;
+          const bool act = idx < ngr;
+          const int go = act ? idx / (2 * P) : 0, r = act ? idx - go * 2 * P : 0;
+          const int gq = go < gbeg ? go : go + nown;
+          gu64_t slot = (gu64_t)a.xch + xch_slot(cluster, t, G, gq, P) + r;
+          unsigned val = 0;
+          done = false;
+          for (unsigned spins = 0; spins < RF_SPIN_LIMIT; ++spins) {
+            bool ok = true;
+            if (act) {
+              const unsigned long long x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              val = (unsigned)x;
+              ok = (unsigned)(x >> 32) == (unsigned)t + 1u;
+            }
+            if (__all(ok)) {
+              done = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(2);
           }
-          if (__all(ok)) {
-            done = true;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(2);
+          if (act) reinterpret_cast<unsigned*>(dl)[2 * ((r >> 1) * G + gq) + (r & 1)] = val;
         }
-        if (act) reinterpret_cast<unsigned*>(dl)[2 * ((r >> 1) * G + gq) + (r & 1)] = val;
         if (!done && lane == 0) *abortw = 1;
       }
       lds_barrier();  // R, k/v panels and the scratch are reused by the next GP
@@ -1201,18 +1209,22 @@ static int launch_tile_pms(const FwdArgs& a, size_t lds, hipStream_t st) {
   return MCP_OK;
 }
 
-template <int MAXDEG, bool PMS>
+template <int MAXDEG, int CLS, bool PMS>
 static int launch_tile_gsh(const FwdArgs& a, size_t lds, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_tile_kernel<MAXDEG, 0, PMS, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, MCP_LDS_LIMIT);
     attr_set = true;
   }
-  const int grid = ((a.nclusters + 7) / 8) * 8 * a.model.G;
-  hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, 0, PMS, true>), dim3(grid), dim3(RF_NT), lds, st, a);
+  const int grid = ((a.nclusters + 7) / 8) * 8 * a.gsh_cs;
+  hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true>), dim3(grid), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
+}
+template <int MAXDEG, int CLS>
+static int launch_tile_gsh_deg(const FwdArgs& a, size_t lds, hipStream_t st) {
+  return a.pol.meas.n > 0 ? launch_tile_gsh<MAXDEG, CLS, true>(a, lds, st) : launch_tile_gsh<MAXDEG, CLS, false>(a, lds, st);
 }
 
 template <int MAXDEG, int CLS>
@@ -1240,18 +1252,23 @@ int launch_fwd_tile(const FwdArgs& a, hipStream_t st) {
   }
 }
 
-// GP-sharded launch of the 16-particle kernel: the small class (cart-pole-sized D, policy features, inputs) with G <= 3
+// GP-sharded launch of the 16-particle kernel (a.gsh_cs workgroups per tile, a.xch, a.nclusters set by the caller): the cart-pole
+// and the UR5 register classes
 int launch_fwd_tile_sharded(const FwdArgs& a, hipStream_t st) {
-  if (!fwd_tile_fits(&a.model, &a.pol) || a.model.G < 2 || a.model.G > 3 || !a.xch) return MCP_ERR_LIMIT;
+  if (!fwd_tile_fits(&a.model, &a.pol) || a.gsh_cs < 2 || a.gsh_cs > a.model.G || !a.xch) return MCP_ERR_LIMIT;
   const int D = a.model.D, PF = a.pol.P, U = a.model.U;
-  if (a.NpadMax > 512 || !(D <= 8 && PF <= 8 && U <= 2)) return MCP_ERR_LIMIT;
+  if (a.NpadMax > 512) return MCP_ERR_LIMIT;
+  const int cls = (D <= 8 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2);
+  if (cls == 2) return MCP_ERR_LIMIT;
   TileLayout L = tile_layout(a.model.S, a.model.U, a.model.D, a.model.G, a.pol.P, a.NpadMax, a.maxdeg);
   const size_t lds = sizeof(double) * (size_t)L.total;
-  const bool pms = a.pol.meas.n > 0;
-  switch (a.maxdeg) {
-    case 0: return pms ? launch_tile_gsh<0, true>(a, lds, st) : launch_tile_gsh<0, false>(a, lds, st);
-    case 1: return pms ? launch_tile_gsh<1, true>(a, lds, st) : launch_tile_gsh<1, false>(a, lds, st);
-    default: return pms ? launch_tile_gsh<2, true>(a, lds, st) : launch_tile_gsh<2, false>(a, lds, st);
+  switch (cls * 3 + a.maxdeg) {
+    case 0: return launch_tile_gsh_deg<0, 0>(a, lds, st);
+    case 1: return launch_tile_gsh_deg<1, 0>(a, lds, st);
+    case 2: return launch_tile_gsh_deg<2, 0>(a, lds, st);
+    case 3: return launch_tile_gsh_deg<0, 1>(a, lds, st);
+    case 4: return launch_tile_gsh_deg<1, 1>(a, lds, st);
+    default: return launch_tile_gsh_deg<2, 1>(a, lds, st);
   }
 }
 

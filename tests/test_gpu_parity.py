@@ -447,7 +447,7 @@ def test_adjoint_matches_finite_difference_at_full_width(name, M):
 
 
 @pytest.mark.parametrize("name,M,expect,sharded", [("c1", 400, 4, True), ("c1", 256, 2, True), ("c1", 1000, 16, True), ("c1", 2048, 16, True), ("c1", 2100, 16, False), ("c3", 4000, 16, False),
-                                                   ("c5", 2000, 16, False)])
+                                                   ("c5", 2000, 16, True)])
 def test_baseline_shapes_run_on_the_intended_kernel(name, M, expect, sharded):
     """The automatic dispatch puts BASELINE.json's shapes where DESIGN.md says they run (a shape that overflows the tile kernel's
     LDS budget would silently fall back to the 4-particle kernel; a swarm beyond one resident GP-sharded grid of the small-tile kernel runs on the
