@@ -29,13 +29,14 @@
 extern "C" {
 #endif
 
-#define MCP_ABI_VERSION 2
+#define MCP_ABI_VERSION 3
 
 #define MCP_OK 0
 #define MCP_ERR_ARG (-1)       /* null pointer / non-positive size                       */
 #define MCP_ERR_LIMIT (-2)     /* a dimension exceeds a compiled limit (MCP_MAX_*)        */
 #define MCP_ERR_WORKSPACE (-3) /* workspace too small                                     */
 #define MCP_ERR_LAUNCH (-4)    /* hipLaunchKernel reported an error                       */
+#define MCP_ERR_COMM (-5)      /* RCCL is not loadable / no communicator / a collective failed */
 
 #define MCP_STATUS_NAN 1u         /* a NaN was produced in a state / input / cost          */
 #define MCP_STATUS_NONPOS_VAR 2u  /* a GP posterior variance <= 0 (torch Normal would raise) */
@@ -245,6 +246,30 @@ int mcp_cost_finalize(int T, int R, const double* moments, const int64_t* counts
  * gradient of the cost (NULL = 1), so no host synchronisation is needed; gscale = 1/M_total. */
 int mcp_cost_bwd(const mcp_cost* cost, int T, int M, const double* states, const double* g_cost, double gscale, double* g_states,
                  void* stream);
+
+/* Summable form of one rank's cost moments, for the SINGLE all-reduce of a particle-sharded step:
+ * sums[t] = sum_m (c_tm - shift_t), sums[T+t] = sum_m (c_tm - shift_t)^2 over this rank's M particles, from the
+ * moments of mcp_cost_fwd.  shift [T] (the same on every rank; NULL = 0; the previous step's pooled means are the
+ * natural choice) keeps the pooled variance free of cancellation. */
+int mcp_cost_sums(int T, int M, const double* moments, const double* shift, double* sums, void* stream);
+/* sums [2T] added over all ranks (n_total particles) -> out[0] = sum_t mean_m c, out[1] = sum_t unbiased std_m c
+ * (Cost_function.py:32-36 on the pooled swarm); mean_out [T] (optional) receives the pooled mean per time step. */
+int mcp_cost_finalize_sums(int T, int64_t n_total, const double* sums, const double* shift, double* out, double* mean_out,
+                           void* stream);
+
+/* ---- particle sharding: the one collective of an optimizer step --------------------------
+ * The reference is single-process (no collective anywhere); sharding the particles over the GPUs of a node adds ONE
+ * exchange between `cost.backward()` and `optimizer.step()` (policy_learning/MC_PILCO.py:522-525): an in-place
+ * all-reduce(sum) of the flat fp64 message [dJ/dlog_lengthscales | dJ/dcenters | dJ/dweight | mcp_cost_sums (2T) | flags].
+ * Thin wrapper over RCCL (bound at run time; MCP_ERR_COMM when it cannot be loaded), ONE communicator per process created
+ * once by mcp_comm_init and reused by every step.  Rank 0 obtains `id` (MCP_COMM_ID_BYTES) from mcp_comm_unique_id and
+ * the host distributes it to the other ranks (any side channel: torch.distributed's store, MPI, a file). */
+#define MCP_COMM_ID_BYTES 128
+int mcp_comm_unique_id(void* id_out);
+int mcp_comm_init(int world, int rank, const void* id);
+int mcp_comm_world(void); /* 0 when no communicator exists */
+int mcp_allreduce_grad(double* flat, size_t n, void* stream);
+int mcp_comm_destroy(void);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,34 @@
+/*
+ * mcpilco_hip_debug.h -- test and diagnostic hooks of libmcpilco_hip.so.  NOT part of the drop-in
+ * boundary (include/mcpilco_hip.h): the product path never needs them.  They exist so that the
+ * parity tests can force every kernel variant the automatic dispatch of mcp_rollout_fwd /
+ * mcp_rollout_bwd may choose, so that bench.py / tools can report which variant ran, and so that
+ * tools/phase_stamps.py can read per-phase cycle counters.  Process-global, not thread-safe.
+ */
+#ifndef MCPILCO_HIP_DEBUG_H
+#define MCPILCO_HIP_DEBUG_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* forward rollout: particles per workgroup 1 / 2 / 4 (small-tile kernel) or 16 (matrix-core tile kernel); 0 = automatic */
+void mcp_debug_set_particles_per_wg(int p);
+/* what the last mcp_rollout_fwd / mcp_posterior_fwd launched (16 = tile kernel) */
+int mcp_debug_last_particles_per_wg(void);
+/* GP-sharded launch forms: -1 automatic, 0 never, 1 whenever the grid fits the device */
+void mcp_debug_set_gp_sharding(int mode);
+/* number of GP-sharded launches the last forward call made (0 = unsharded) */
+int mcp_debug_last_gp_sharded(void);
+/* small-tile kernel: xlds -1 automatic / 0 never stage the small operands in LDS; gb = GPs per pass (0 = as many as fit) */
+void mcp_debug_set_fwd_mode(int xlds, int gb);
+/* backward sweep: particles per workgroup 1 / 2 / 4; 0 = automatic */
+void mcp_debug_set_bwd_particles(int pb);
+/* device buffers of 16 uint64 per-phase cycle totals of workgroup 0 (NULL = off) */
+void mcp_debug_set_stamp_buffer(void* device_u64x16);
+void mcp_debug_set_bwd_stamp_buffer(void* device_u64x16);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCPILCO_HIP_DEBUG_H */

@@ -98,6 +98,48 @@ __global__ __launch_bounds__(256) void cost_finalize_kernel(int T, int R, const 
   }
 }
 
+// Summable form of one rank's moments, for the single all-reduce of a particle-sharded step:
+//   sums[t] = sum_m (c - shift_t),  sums[T + t] = sum_m (c - shift_t)^2   over this rank's M particles,
+// from the two-pass {mean, centred sum of squares} cost_fwd_kernel produced.  shift (same on every rank; NULL = 0) keeps
+// the pooled variance free of cancellation: the caller passes the previous step's pooled means.
+__global__ void cost_sums_kernel(int T, double n, const double* __restrict__ moments, const double* __restrict__ shift,
+                                 double* __restrict__ sums) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const double d = moments[2 * t] - (shift ? shift[t] : 0.0);
+  sums[t] = n * d;
+  sums[T + t] = fma(n * d, d, moments[2 * t + 1]);
+}
+
+// all ranks' sums added up (n_total particles) -> out[0] = sum_t mean, out[1] = sum_t unbiased std; mean_out[t] (optional)
+// receives the pooled mean per time step (the next step's shift).  One workgroup.
+__global__ __launch_bounds__(256) void cost_finalize_sums_kernel(int T, double n_tot, const double* __restrict__ sums,
+                                                                 const double* __restrict__ shift, double* __restrict__ out,
+                                                                 double* __restrict__ mean_out) {
+  __shared__ double red[2][4];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  double cs = 0.0, ss = 0.0;
+  for (int t = tid; t < T; t += 256) {
+    const double a = sums[t], b = sums[T + t];
+    const double mean = (shift ? shift[t] : 0.0) + a / n_tot;
+    const double m2 = b - a * a / n_tot;
+    cs += mean;
+    ss += sqrt(fmax(m2, 0.0) / (n_tot - 1.0));
+    if (mean_out) mean_out[t] = mean;
+  }
+  cs = wave_sum(cs);
+  ss = wave_sum(ss);
+  if (lane == 0) {
+    red[0][wv] = cs;
+    red[1][wv] = ss;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    out[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    out[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+
 __global__ void cost_bwd_kernel(mcp_cost c, int T, int M, const double* __restrict__ states, const double* __restrict__ g_cost,
                                 double gscale, double* __restrict__ g_states) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,6 +195,21 @@ extern "C" int mcp_cost_finalize(int T, int R, const double* moments, const int6
   RankCounts rc;
   for (int r = 0; r < 64; ++r) rc.n[r] = r < R ? counts[r] : 0;
   hipLaunchKernelGGL(cost_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, T, R, moments, rc, out);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+extern "C" int mcp_cost_sums(int T, int M, const double* moments, const double* shift, double* sums, void* stream) {
+  if (!moments || !sums || T <= 0 || M <= 0) return MCP_ERR_ARG;
+  hipLaunchKernelGGL(cost_sums_kernel, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, T, (double)M, moments, shift, sums);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+extern "C" int mcp_cost_finalize_sums(int T, int64_t n_total, const double* sums, const double* shift, double* out, double* mean_out,
+                                      void* stream) {
+  if (!sums || !out || T <= 0 || n_total <= 0) return MCP_ERR_ARG;
+  hipLaunchKernelGGL(cost_finalize_sums_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, T, (double)n_total, sums, shift, out, mean_out);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }

@@ -459,11 +459,7 @@ extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32
   if (!A || !logdet || !status || N <= 0 || lda < N) return MCP_ERR_ARG;
   if (N > 1152) return MCP_ERR_LIMIT;  // row panel [16][N] must fit the 160 KiB LDS
   size_t lds = sizeof(double) * ((size_t)CH_NB * (CH_NB + 1) + (size_t)CH_NB * N);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(chol_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  MCP_ENSURE_MAX_LDS(chol_factor_kernel);
   hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(CH_NT), lds, (hipStream_t)stream, N, A, lda, logdet, status);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
@@ -509,11 +505,7 @@ extern "C" int mcp_sod_select(const mcp_kernel* kern, int N, const double* X, do
   if (workspace_bytes < mcp_sod_workspace_bytes(N)) return MCP_ERR_WORKSPACE;
   if (N > 16384) return MCP_ERR_LIMIT;  // kv [N] lives in LDS
   double* Uw = (double*)workspace;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(sod_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  MCP_ENSURE_MAX_LDS(sod_select_kernel);
   hipLaunchKernelGGL(sod_select_kernel, dim3(1), dim3(MCP_WAVE), sizeof(double) * N, (hipStream_t)stream, *kern, N, X, threshold,
                      idx_out, n_out, Uw);
   MCP_LAUNCH_CHECK();
@@ -527,11 +519,7 @@ extern "C" int mcp_nll_grad(const mcp_kernel* kern, int N, const double* X, cons
   if (!kernel_ok(kern) || !X || !Kinv || !alpha || !grad || !workspace || N <= 0 || ldk < N) return MCP_ERR_ARG;
   if (N > 4096) return MCP_ERR_LIMIT;  // four [N] row buffers live in LDS
   if (workspace_bytes < mcp_nll_workspace_bytes(N, kern->D)) return MCP_ERR_WORKSPACE;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nll_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  MCP_ENSURE_MAX_LDS(nll_grad_kernel);
   const int NP = 4 * kern->D + 3;
   double* slab = (double*)workspace;
   hipLaunchKernelGGL(nll_grad_kernel, dim3(N), dim3(256), sizeof(double) * 4 * (size_t)N, (hipStream_t)stream, *kern, N, X, Kinv, ldk, alpha,

@@ -13,6 +13,21 @@
     if (hipGetLastError() != hipSuccess) return MCP_ERR_LAUNCH; \
   } while (0)
 
+// Opts a kernel in to the CU's full 160 KiB of dynamic LDS -- once per DEVICE (a process may drive several) and per kernel
+// (the static lives in the enclosing function, i.e. per template instantiation); the runtime's refusal is MCP_ERR_LAUNCH.
+#define MCP_ENSURE_MAX_LDS(...)                                                                                             \
+  do {                                                                                                                      \
+    static bool done_[64];                                                                                                  \
+    int dev_ = 0;                                                                                                           \
+    if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 64) return MCP_ERR_LAUNCH;                                 \
+    if (!done_[dev_]) {                                                                                                     \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                              160 * 1024) != hipSuccess)                                                                    \
+        return MCP_ERR_LAUNCH;                                                                                              \
+      done_[dev_] = true;                                                                                                   \
+    }                                                                                                                       \
+  } while (0)
+
 namespace mcp {
 
 // ---------------------------------------------------------------------------------------

@@ -1169,12 +1169,7 @@ static int chunks_in_pass(const mcp_model* m, int GB) {
 
 template <int P, bool XLDS, int MAXDEG, bool GSH>
 static int launch_fwd_deg(const FwdArgs& a, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_kernel<P, XLDS, MAXDEG, GSH>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, MCP_LDS_LIMIT);
-    attr_set = true;
-  }
+  MCP_ENSURE_MAX_LDS(rollout_fwd_kernel<P, XLDS, MAXDEG, GSH>);
   const int grid = GSH ? gsh_grid(a.nclusters, a.model.G) : (a.M + P - 1) / P;
   hipLaunchKernelGGL((rollout_fwd_kernel<P, XLDS, MAXDEG, GSH>), dim3(grid), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
@@ -1322,12 +1317,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
 
 template <int P>
 static int launch_post(const PostArgs& a, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(posterior_fwd_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              MCP_LDS_LIMIT);
-    attr_set = true;
-  }
+  MCP_ENSURE_MAX_LDS(posterior_fwd_kernel<P>);
   hipLaunchKernelGGL(posterior_fwd_kernel<P>, dim3((a.M + P - 1) / P), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return MCP_OK;

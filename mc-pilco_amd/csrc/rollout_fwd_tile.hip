@@ -1197,12 +1197,7 @@ bool fwd_tile_fits(const mcp_model* model, const mcp_policy* policy) {
 
 template <int MAXDEG, int CLS, bool PMS>
 static int launch_tile_pms(const FwdArgs& a, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_tile_kernel<MAXDEG, CLS, PMS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              MCP_LDS_LIMIT);
-    attr_set = true;
-  }
+  MCP_ENSURE_MAX_LDS(rollout_fwd_tile_kernel<MAXDEG, CLS, PMS>);
   const int grid = (a.M + TL_PT - 1) / TL_PT;
   hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, CLS, PMS>), dim3(grid), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
@@ -1211,12 +1206,7 @@ static int launch_tile_pms(const FwdArgs& a, size_t lds, hipStream_t st) {
 
 template <int MAXDEG, int CLS, bool PMS>
 static int launch_tile_gsh(const FwdArgs& a, size_t lds, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, MCP_LDS_LIMIT);
-    attr_set = true;
-  }
+  MCP_ENSURE_MAX_LDS(rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true>);
   const int grid = ((a.nclusters + 7) / 8) * 8 * a.gsh_cs;
   hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true>), dim3(grid), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();

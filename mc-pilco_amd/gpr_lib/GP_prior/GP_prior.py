@@ -113,12 +113,16 @@ class GP_prior(torch.nn.Module):
         return alpha, m_X, K_X_inv
 
     def _packed(self, X, alpha, K_X_inv):
-        key = (X.data_ptr(), alpha.data_ptr(), K_X_inv.data_ptr(), tuple(X.shape), getattr(X, "_version", 0))
+        """Packed operands of (X, alpha, K_X_inv) under the CURRENT hyper-parameters.  The one-entry cache holds strong
+        references to the three tensors and compares them by identity (an address can be reused by a new tensor once the old
+        one is freed), together with their in-place version counters and those of every hyper-parameter (optimizer steps,
+        load_state_dict and reinit all write in place and bump them)."""
+        ver = tuple(int(t._version) for t in (X, alpha, K_X_inv)) + tuple(int(p._version) for p in self.parameters())
         hit = self._packed_cache.get("last")
-        if hit is not None and hit[0] == key:
-            return hit[1]
+        if hit is not None and hit[0] is X and hit[1] is alpha and hit[2] is K_X_inv and hit[3] == ver:
+            return hit[4]
         gp = ops.PackedGP(self.kernel_spec(), self._cols(X), alpha, K_X_inv)
-        self._packed_cache["last"] = (key, gp)
+        self._packed_cache["last"] = (X, alpha, K_X_inv, ver, gp)
         return gp
 
     def get_estimate_from_alpha(self, X, X_test, alpha, m_X, K_X_inv=None, Y_test=None):

@@ -15,7 +15,9 @@ LIB_PATH = os.path.join(HERE, "libmcpilco_hip.so")
 
 MAX_GP, MAX_STATE, MAX_INPUT, MAX_GPDIM, MAX_PFEAT, MAX_BASIS, MAX_TRAIN = 8, 16, 8, 32, 32, 1024, 1024
 OK = 0
-ERRORS = {-1: "MCP_ERR_ARG", -2: "MCP_ERR_LIMIT", -3: "MCP_ERR_WORKSPACE", -4: "MCP_ERR_LAUNCH"}
+ERRORS = {-1: "MCP_ERR_ARG", -2: "MCP_ERR_LIMIT", -3: "MCP_ERR_WORKSPACE", -4: "MCP_ERR_LAUNCH", -5: "MCP_ERR_COMM"}
+ABI_VERSION = 3
+COMM_ID_BYTES = 128
 STATUS_NAN, STATUS_NONPOS_VAR, STATUS_NOT_SPD, STATUS_SYNC = 1, 2, 4, 8
 POLICY_PLAIN, POLICY_ANGLES, POLICY_TRAJ = 0, 1, 2
 COST_CARTPOLE, COST_TRAJ = 0, 1
@@ -85,6 +87,13 @@ _SIGS = {
     "mcp_cost_fwd": (C.c_int, [C.POINTER(Cost), C.c_int, C.c_int, dptr, dptr, dptr, dptr, dptr]),
     "mcp_cost_finalize": (C.c_int, [C.c_int, C.c_int, dptr, C.POINTER(C.c_int64), dptr, dptr]),
     "mcp_cost_bwd": (C.c_int, [C.POINTER(Cost), C.c_int, C.c_int, dptr, dptr, C.c_double, dptr, dptr]),
+    "mcp_cost_sums": (C.c_int, [C.c_int, C.c_int, dptr, dptr, dptr, dptr]),
+    "mcp_cost_finalize_sums": (C.c_int, [C.c_int, C.c_int64, dptr, dptr, dptr, dptr, dptr]),
+    "mcp_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "mcp_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
+    "mcp_comm_world": (C.c_int, []),
+    "mcp_allreduce_grad": (C.c_int, [dptr, C.c_size_t, dptr]),
+    "mcp_comm_destroy": (C.c_int, []),
     "mcp_debug_set_particles_per_wg": (None, [C.c_int]),
     "mcp_debug_last_particles_per_wg": (C.c_int, []),
     "mcp_debug_set_bwd_particles": (None, [C.c_int]),
@@ -112,7 +121,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if handle.mcp_abi_version() != 2:
+        if handle.mcp_abi_version() != ABI_VERSION:
             raise RuntimeError("libmcpilco_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -55,7 +55,7 @@ class KernelSpec:
     w1: Optional[torch.Tensor] = None
     w20: Optional[torch.Tensor] = None
     w21: Optional[torch.Tensor] = None
-    _keep: list = field(default_factory=list)
+    _keep: dict = field(default_factory=dict, repr=False, compare=False)
 
     @property
     def D(self):
@@ -65,26 +65,32 @@ class KernelSpec:
     def poly_deg(self):
         return 0 if self.w1 is None else (1 if self.w20 is None else 2)
 
+    def _device_operands(self, device):
+        """Device copies of the hyper-parameter vectors, uploaded ONCE per device and kept for the life of the spec: every
+        descriptor built from this spec (mcp_kernel inside mcp_gp inside mcp_model) points at the same tensors, so a later
+        to_c() can never free memory an older descriptor still refers to."""
+        key = (device.type, device.index)
+        ops_ = self._keep.get(key)
+        if ops_ is None:
+            ops_ = {"inv_ls": (1.0 / _t(self.lengthscales, device)).contiguous()}
+            for name in ("w1", "w20", "w21"):
+                v = getattr(self, name)
+                ops_[name] = None if v is None else _t(v, device)
+            self._keep[key] = ops_
+        return ops_
+
     def to_c(self, device):
         device = _dev(device)
-        inv_ls = (1.0 / _t(self.lengthscales, device)).contiguous()
+        ops_ = self._device_operands(device)
         k = abi.Kernel()
         k.D = self.D
         k.poly_deg = self.poly_deg
         k.lam = float(self.lam)
         k.sigma_n2 = float(self.sigma_n2)
         k.mean = float(self.mean)
-        keep = [inv_ls]
-        k.inv_ls = inv_ls.data_ptr()
+        k.inv_ls = ops_["inv_ls"].data_ptr()
         for name in ("w1", "w20", "w21"):
-            v = getattr(self, name)
-            if v is not None:
-                tv = _t(v, device)
-                keep.append(tv)
-                setattr(k, name, tv.data_ptr())
-            else:
-                setattr(k, name, None)
-        self._keep = keep  # device copies must outlive the descriptor
+            setattr(k, name, None if ops_[name] is None else ops_[name].data_ptr())
         return k
 
 
@@ -335,8 +341,9 @@ def _mc(model):
 
 
 def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, noise: NoiseSpec, x0, T, p_drop, particle_pred=True, need_jac=True,
-                        meas: Optional[MeasSpec] = None):
-    """model None (only with T == 1) evaluates the policy alone."""
+                        meas: Optional[MeasSpec] = None, gp_sharding=True):
+    """model None (only with T == 1) evaluates the policy alone.  gp_sharding False: no hand-off workspace is passed, so the
+    library never launches GP-sharded (the recovery path after MCP_STATUS_SYNC)."""
     dev = policy.device if model is None else model.device
     x0 = x0.detach().to(device=dev, dtype=DT).contiguous()
     M = x0.shape[0]
@@ -351,7 +358,7 @@ def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, nois
     meas_buf = torch.empty(T, M, policy.S, dtype=DT, device=dev) if meas is not None else None
     _set_meas(policy, meas, T, M, meas_buf)
     # workspace: the hand-off granules of the GP-sharded launch (small swarms); the library zeroes what it uses
-    nbytes = abi.lib().mcp_rollout_workspace_bytes(_mc(model), C.byref(pc), M, T) if (model is not None and T > 1) else 0
+    nbytes = abi.lib().mcp_rollout_workspace_bytes(_mc(model), C.byref(pc), M, T) if (model is not None and T > 1 and gp_sharding) else 0
     ws = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev) if nbytes else None
     try:
         abi.check(abi.lib().mcp_rollout_fwd(_mc(model), C.byref(pc), C.byref(nz), M, T, int(bool(particle_pred)), abi.ptr(x0),
@@ -394,9 +401,9 @@ class RolloutFunction(torch.autograd.Function):
     parameters (and x0); the GP model is frozen, as after ``Model_learning.set_eval_mode``."""
 
     @staticmethod
-    def forward(ctx, x0, log_ls, centers, weight, model, policy, noise, T, p_drop, particle_pred, meas=None):
+    def forward(ctx, x0, log_ls, centers, weight, model, policy, noise, T, p_drop, particle_pred, meas=None, gp_sharding=True):
         need = any(ctx.needs_input_grad[:4])
-        out = rollout_forward_raw(model, policy, noise, x0, T, p_drop, particle_pred, need_jac=need, meas=meas)
+        out = rollout_forward_raw(model, policy, noise, x0, T, p_drop, particle_pred, need_jac=need, meas=meas, gp_sharding=gp_sharding)
         states, inputs, jac, status = out[:4]
         ctx.model, ctx.policy, ctx.noise, ctx.p_drop = model, policy, noise, p_drop
         ctx.meas, ctx.meas_buf = meas, (out[4] if meas is not None else None)
@@ -412,14 +419,15 @@ class RolloutFunction(torch.autograd.Function):
             jac = None
         g_ls, g_c, g_w, g_x0 = rollout_backward_raw(ctx.model, ctx.policy, ctx.noise, states, inputs, jac, g_states, g_inputs, ctx.p_drop,
                                                     want_gx0=ctx.needs_input_grad[0], meas=ctx.meas, meas_buf=ctx.meas_buf)
-        return g_x0, g_ls.reshape(ctx.policy.log_ls.shape), g_c, g_w, None, None, None, None, None, None, None
+        return g_x0, g_ls.reshape(ctx.policy.log_ls.shape), g_c, g_w, None, None, None, None, None, None, None, None
 
 
-def rollout(model, policy, noise, x0, T, p_drop=0.0, particle_pred=True, meas: Optional[MeasSpec] = None):
+def rollout(model, policy, noise, x0, T, p_drop=0.0, particle_pred=True, meas: Optional[MeasSpec] = None, gp_sharding=True):
     """Differentiable fused rollout.  Returns (states, inputs, status).  ``meas``: measurement model between the particles and
-    the policy (partially measurable systems); None = the policy sees the true state."""
+    the policy (partially measurable systems); None = the policy sees the true state.  ``gp_sharding`` False forbids the
+    GP-sharded launch forms (used to repeat a step whose hand-off reported MCP_STATUS_SYNC)."""
     return RolloutFunction.apply(x0, policy.log_ls, policy.centers, policy.weight, model, policy, noise, int(T), float(p_drop),
-                                 bool(particle_pred), meas)
+                                 bool(particle_pred), meas, bool(gp_sharding))
 
 
 # --------------------------------------------------------------------------------------
@@ -514,6 +522,48 @@ class ExpectedCostFunction(torch.autograd.Function):
 
 def expected_cost(cost: PackedCost, states, group=None, counts=None):
     return ExpectedCostFunction.apply(states, cost, group, counts)
+
+
+class LocalCostFunction(torch.autograd.Function):
+    """This rank's share of a particle-sharded expected cost, in the form ONE all-reduce(sum) can pool:
+    states [T,M_local,S] -> (share = sum_t sum_m c_tm / m_total  [differentiable; its gradient is what this rank contributes to
+    d(sum_t mean_m c)/dtheta],  sums [2T] = mcp_cost_sums: per time step sum_m (c - shift_t) and sum_m (c - shift_t)^2)."""
+
+    @staticmethod
+    def forward(ctx, states, cost, m_total, shift):
+        mom, _, _ = cost_moments(cost, states)
+        T, M = states.shape[0], states.shape[1]
+        sums = torch.empty(2 * T, dtype=DT, device=states.device)
+        abi.check(abi.lib().mcp_cost_sums(T, M, abi.ptr(mom), abi.ptr(shift), abi.ptr(sums), abi.stream()), "mcp_cost_sums")
+        local = cost_finalize(mom.unsqueeze(0), [M])[0] * (float(M) / float(m_total))
+        ctx.cost, ctx.m_total = cost, int(m_total)
+        ctx.save_for_backward(states.detach())
+        ctx.mark_non_differentiable(sums)
+        return local, sums
+
+    @staticmethod
+    def backward(ctx, g_local, _g_sums):
+        (states,) = ctx.saved_tensors
+        T, M, _ = states.shape
+        g = torch.empty_like(states)
+        st = states.contiguous()
+        gc = g_local.detach().to(dtype=DT).reshape(1).contiguous()
+        abi.check(abi.lib().mcp_cost_bwd(C.byref(ctx.cost.c), T, M, abi.ptr(st), abi.ptr(gc), 1.0 / float(ctx.m_total), abi.ptr(g), abi.stream()),
+                  "mcp_cost_bwd")
+        return g, None, None, None
+
+
+def local_cost(cost: PackedCost, states, m_total, shift=None):
+    return LocalCostFunction.apply(states, cost, int(m_total), shift)
+
+
+def cost_from_sums(sums, n_total, shift=None, mean_out=None):
+    """Pooled (sum_t mean_m c, sum_t unbiased std_m c) from the all-reduced sums of ``local_cost`` -> tensor [2]."""
+    T = sums.numel() // 2
+    out = torch.empty(2, dtype=DT, device=sums.device)
+    abi.check(abi.lib().mcp_cost_finalize_sums(T, int(n_total), abi.ptr(sums.contiguous()), abi.ptr(shift), abi.ptr(out), abi.ptr(mean_out),
+                                               abi.stream()), "mcp_cost_finalize_sums")
+    return out
 
 
 # --------------------------------------------------------------------------------------

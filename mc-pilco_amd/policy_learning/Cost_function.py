@@ -26,13 +26,18 @@ class Expected_cost(torch.nn.modules.loss._Loss):
         super().__init__()
         self.cost_function = cost_function
 
-    def forward(self, states_sequence, inputs_sequence, trial_index=None, group=None):
+    def forward(self, states_sequence, inputs_sequence, trial_index=None, group=None, counts=None):
         costs = self.cost_function(states_sequence, inputs_sequence, trial_index)
         if group is not None:
             import torch.distributed as dist
 
-            R = dist.get_world_size(group)
-            n = costs.shape[1] * R
+            # pooled over the ranks' particles; shards may be uneven: the total count is reduced, never assumed
+            if counts is None:
+                n = torch.tensor([float(costs.shape[1])], dtype=costs.dtype, device=costs.device)
+                dist.all_reduce(n, group=group)
+                n = float(n.item())
+            else:
+                n = float(sum(int(c) for c in counts))
             s1 = costs.sum(1)
             s1_all = s1.detach().clone()
             dist.all_reduce(s1_all, group=group)
@@ -41,6 +46,23 @@ class Expected_cost(torch.nn.modules.loss._Loss):
             dist.all_reduce(m2, group=group)
             return torch.sum(s1) / n + (torch.sum(mean) - torch.sum(s1.detach()) / n), torch.sum(torch.sqrt(m2 / (n - 1)))
         return torch.sum(torch.mean(costs, 1)), torch.sum(torch.std(costs.detach(), 1))
+
+    def local_moments(self, states_sequence, inputs_sequence, trial_index, m_total, shift=None):
+        """This rank's share of a particle-sharded cost in summable form (sharding.StepReducer): (share = sum_t sum_m c / m_total,
+        differentiable;  sums [2T] = per time step sum_m (c - shift_t), sum_m (c - shift_t)^2, detached)."""
+        costs = self.cost_function(states_sequence, inputs_sequence, trial_index)
+        d = costs.detach() - (0.0 if shift is None else shift.reshape(-1, 1))
+        return costs.sum() / float(m_total), torch.cat([d.sum(1), (d * d).sum(1)])
+
+    @staticmethod
+    def from_sums(sums, n_total, shift=None, mean_out=None):
+        """(cost, std) of the pooled swarm from the all-reduced sums."""
+        T = sums.numel() // 2
+        a, b = sums[:T], sums[T:]
+        mean = a / n_total + (0.0 if shift is None else shift)
+        if mean_out is not None:
+            mean_out.copy_(mean)
+        return torch.sum(mean), torch.sum(torch.sqrt(torch.clamp(b - a * a / n_total, min=0.0) / (n_total - 1)))
 
 
 class _HipExpectedCost(Expected_cost):
@@ -55,6 +77,16 @@ class _HipExpectedCost(Expected_cost):
         if self._packed is None or self._packed.device != states_sequence.device:
             self._packed = self._pack(states_sequence)
         return ops.expected_cost(self._packed, states_sequence, group, counts)
+
+    def local_moments(self, states_sequence, inputs_sequence, trial_index, m_total, shift=None):
+        if self._packed is None or self._packed.device != states_sequence.device:
+            self._packed = self._pack(states_sequence)
+        return ops.local_cost(self._packed, states_sequence, m_total, shift)
+
+    @staticmethod
+    def from_sums(sums, n_total, shift=None, mean_out=None):
+        out = ops.cost_from_sums(sums, n_total, shift, mean_out)
+        return out[0], out[1]
 
 
 class Cart_pole_cost(_HipExpectedCost):

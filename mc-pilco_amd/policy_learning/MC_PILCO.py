@@ -63,15 +63,23 @@ class MC_PILCO(torch.nn.Module):
         self._rollout_calls = 0
         self.dist_group = None
         self.last_status = None
+        self.gp_sharding = True    # cleared for good once a GP-sharded launch reports MCP_STATUS_SYNC (co-residency was not there)
+        self._reducer = None       # sharding.StepReducer: the one all-reduce of a sharded optimizer step
+        self._cost_shift = None    # previous step's pooled per-time-step mean cost (the shift of the summable cost moments)
 
     # ------------------------------------------------------------------------------------------------------------
     # particle sharding
     # ------------------------------------------------------------------------------------------------------------
-    def shard_particles(self, group=None):
-        """Split ``num_particles`` over the ranks of ``group`` (default: the WORLD group)."""
+    def shard_particles(self, group=None, transport="torch"):
+        """Split ``num_particles`` over the ranks of ``group`` (default: the WORLD group).  Per optimizer step the ranks then meet
+        in ONE all-reduce (sharding.StepReducer; ``transport`` "torch" = torch.distributed, "abi" = the C ABI's RCCL communicator).
+        Every rank must seed torch identically (the launch scripts' ``torch.manual_seed(seed)``): x0 -- and in "reference"
+        noise mode eps and the masks -- are drawn for ALL particles on every rank and sliced, so a sharded run simulates
+        exactly the particles one GPU would."""
         import torch.distributed as dist
 
         self.dist_group = dist.group.WORLD if group is None else group
+        self._reducer = sharding.StepReducer(self.dist_group, transport)
 
     def _world(self):
         if self.dist_group is None:
@@ -102,22 +110,28 @@ class MC_PILCO(torch.nn.Module):
             dist_ = MultivariateNormal(loc=mean.repeat(num_particles, 1), covariance_matrix=torch.diag_embed(var.repeat(num_particles, 1)))
         return dist_.rsample().to(self.device)
 
+    def _shard_slice(self, t, dim):
+        """This rank's particles of a tensor drawn for the whole swarm (no-op on a single rank)."""
+        off, cnt = self._shard
+        return t if cnt == t.shape[dim] else t.narrow(dim, off, cnt).contiguous()
+
     def _rollout_noise(self, M, T, p_dropout):
         pol = self.control_policy
         p = float(p_dropout) if getattr(pol, "flg_drop", True) else 0.0
         G, B = self.model_learning.num_gp, pol.num_basis
-        world, rank = self._world()
         self._rollout_calls += 1
         if self.noise_mode == "reference":
-            # the reference's draw order: mask_0, then for t = 1..T-1: eps_t, mask_t   
-            masks = [torch.empty(M, 1, B, dtype=self.dtype).bernoulli_(1 - p).reshape(M, B)] if p > 0 else None
+            # the reference's draw order: mask_0, then for t = 1..T-1: eps_t, mask_t   (SURVEY 8c) -- drawn for the WHOLE swarm
+            # (every rank draws the same numbers from the same seed) and sliced to this rank's particles
+            Mt = self._m_total
+            masks = [torch.empty(Mt, 1, B, dtype=self.dtype).bernoulli_(1 - p).reshape(Mt, B)] if p > 0 else None
             eps = []
             for _ in range(1, T):
-                eps.append(torch.empty(M, G, dtype=self.dtype).normal_())
+                eps.append(torch.empty(Mt, G, dtype=self.dtype).normal_())
                 if p > 0:
-                    masks.append(torch.empty(M, 1, B, dtype=self.dtype).bernoulli_(1 - p).reshape(M, B))
-            eps = (torch.stack(eps) if eps else torch.zeros(0, M, G, dtype=self.dtype)).to(self.device).contiguous()
-            mk = None if masks is None else torch.stack(masks).to(torch.uint8).to(self.device).contiguous()
+                    masks.append(torch.empty(Mt, 1, B, dtype=self.dtype).bernoulli_(1 - p).reshape(Mt, B))
+            eps = self._shard_slice(torch.stack(eps) if eps else torch.zeros(0, Mt, G, dtype=self.dtype), 1).to(self.device).contiguous()
+            mk = None if masks is None else self._shard_slice(torch.stack(masks).to(torch.uint8), 1).to(self.device).contiguous()
             return ops.NoiseSpec(eps=eps, masks=mk), p
         return ops.NoiseSpec(seed=self.seed, call=self._rollout_calls, particle_offset=self._shard[0]), p
 
@@ -130,12 +144,13 @@ class MC_PILCO(torch.nn.Module):
         self._m_total = int(num_particles)
         M = self._shard[1]
         T = int(T_control)
-        x0 = self.sample_initial_particles(particles_initial_state_mean, particles_initial_state_var, flg_particles_init_uniform,
-                                           particles_init_up_bound, particles_init_low_bound, flg_particles_init_multi_gauss, M)
+        x0 = self._shard_slice(self.sample_initial_particles(particles_initial_state_mean, particles_initial_state_var, flg_particles_init_uniform,
+                                                             particles_init_up_bound, particles_init_low_bound, flg_particles_init_multi_gauss,
+                                                             self._m_total), 0)
         pol, ml = self.control_policy, self.model_learning
         if isinstance(pol, _Policy.Sum_of_gaussians) and hasattr(ml, "vel_indeces"):
             noise, p = self._rollout_noise(M, T, p_dropout)
-            states, inputs, status = ops.rollout(ml.packed(), pol.packed(), noise, x0, T, p)
+            states, inputs, status = ops.rollout(ml.packed(), pol.packed(), noise, x0, T, p, gp_sharding=self.gp_sharding)
             self.last_status = status
             return states, inputs
         # generic (unfused) path: any model / policy object with the reference's step interface
@@ -148,37 +163,69 @@ class MC_PILCO(torch.nn.Module):
         return torch.stack(xs), torch.stack(us)
 
     def _cost(self, states, inputs, trial_index):
-        if self.dist_group is not None:
-            world, _ = self._world()
-            m_total = sum(sharding.shard_counts(self._m_total, world))
-            try:
-                return self.cost_function(states, inputs, trial_index, group=self.dist_group, counts=sharding.shard_counts(m_total, world))
-            except TypeError:  # a user-supplied Expected_cost without the counts keyword (equal shards assumed)
-                return self.cost_function(states, inputs, trial_index, group=self.dist_group)
-        return self.cost_function(states, inputs, trial_index)
+        """(cost, std) of the whole swarm WITHOUT running backward (warm-up of the cost monitors, user calls).  Sharded: one
+        all-reduce of the summable cost moments."""
+        if self.dist_group is None:
+            return self.cost_function(states, inputs, trial_index)
+        with torch.no_grad():
+            cost, std, _ = self._cost_backward(states, inputs, trial_index, backward=False)
+        return cost, std
 
-    def _allreduce_grads(self):
-        if self.dist_group is not None:
-            sharding.allreduce_gradients(self.control_policy.parameters(), self.dist_group)
+    def _step_flags(self, cost):
+        """Device vector [cost is NaN, a GP-sharded launch timed out (MCP_STATUS_SYNC)] of the last fused rollout."""
+        from mc_pilco_amd import hipabi
+
+        st = self.last_status
+        sync = torch.zeros((), dtype=torch.bool, device=cost.device) if st is None or st.device != cost.device else \
+            (st.reshape(-1)[0] & hipabi.STATUS_SYNC) != 0
+        return torch.stack([torch.isnan(cost.detach()).reshape(()), sync.reshape(())]).to(self.dtype)
+
+    def _cost_backward(self, states, inputs, trial_index, backward=True):
+        """Expected cost of the rollout and (``backward``) its gradient in the policy parameters' ``.grad``.
+        Returns (cost, std, flags): flags is a device vector, > 0 where [the cost is NaN, a hand-off timed out] -- on EVERY rank
+        alike, so all ranks take the same retry decision.
+
+        Single process: the reference's two lines, ``cost_function(...)`` and ``cost.backward()`` (MC_PILCO.py:496,522).
+        Sharded: each rank forms its share sum_t sum_m c / M_total, runs its own backward sweep (the gradient of the pooled mean
+        needs nothing from the other ranks), and then ONE all-reduce sums [gradients | cost sums | flags]."""
+        if self.dist_group is None:
+            cost, std = self.cost_function(states, inputs, trial_index)
+            if backward:
+                # queued before the host looks at the cost (the NaN test is a sync point); gradients of a NaN rollout are discarded
+                cost.backward(retain_graph=False)
+            return cost, std, self._step_flags(cost)
+        T = states.shape[0]
+        if self._cost_shift is None or self._cost_shift.numel() != T:
+            self._cost_shift = torch.zeros(T, dtype=self.dtype, device=states.device)
+        cf = self.cost_function
+        share, sums = cf.local_moments(states, inputs, trial_index, self._m_total, self._cost_shift)
+        params = list(self.control_policy.parameters())
+        if backward:
+            share.backward(retain_graph=False)
+            for q in params:  # a parameter the cost does not reach still takes part in the message (every rank sends the same layout)
+                if q.requires_grad and q.grad is None:
+                    q.grad = torch.zeros_like(q)
+        sums_all, flags = self._reducer.reduce(params if backward else [], sums, self._step_flags(share))
+        new_shift = torch.empty_like(self._cost_shift)
+        cost, std = cf.from_sums(sums_all, self._m_total, self._cost_shift, new_shift)
+        self._cost_shift = new_shift
+        return cost, std, flags
 
     # ------------------------------------------------------------------------------------------------------------
     # policy optimisation
     # ------------------------------------------------------------------------------------------------------------
-    def _rollout_failed(self, cost):
-        """True when the cost is NaN (data, not an error: MC_PILCO.py:497).  The same device->host transfer carries the
-        hand-off bit of the last fused rollout's status word: a GP-sharded launch whose partner workgroups never met is a
-        hard error, never a silently wrong trajectory."""
-        from mc_pilco_amd import hipabi
-
-        flag = torch.isnan(cost.detach())
-        st = self.last_status
-        if st is not None and st.device == flag.device:
-            flag = flag | ((st.reshape(-1)[0] & hipabi.STATUS_SYNC) != 0)
-        if not bool(flag):
-            return False
-        if st is not None and (int(st.reshape(-1)[0]) & hipabi.STATUS_SYNC):
-            raise RuntimeError("mcp_rollout_fwd: GP-sharded launch timed out waiting for a partner workgroup (MCP_STATUS_SYNC)")
-        return True
+    def _rollout_failed(self, flags):
+        """Reads the step's flags (ONE device->host transfer).  True when the cost is NaN (data, not an error: MC_PILCO.py:497)
+        or when a GP-sharded launch timed out waiting for a partner workgroup; in the second case the GP-sharded launch forms
+        are switched off for this object (the device was not giving the grid co-residency -- another process, CU masking),
+        so the repeated step runs on the unsharded kernels: never a silently wrong trajectory, never a rank-local raise."""
+        nan, sync = (float(v) for v in flags.tolist())
+        if sync > 0:
+            if self.gp_sharding:
+                print("\nGP-sharded rollout: a partner workgroup never arrived (MCP_STATUS_SYNC) -- continuing on the unsharded kernels")
+            self.gp_sharding = False
+            return True
+        return nan > 0
 
     def reinforce_policy(self, T_control, num_particles, trial_index, particles_initial_state_mean, particles_initial_state_var,
                          flg_particles_init_uniform, particles_init_up_bound, particles_init_low_bound, flg_particles_init_multi_gauss,
@@ -209,9 +256,12 @@ class MC_PILCO(torch.nn.Module):
         with torch.no_grad():
             for _ in range(10):
                 st0, in0 = self.apply_policy(p_dropout=p_drop0, **sim)
-                cost0, _ = self._cost(st0, in0, trial_index)
-                if not self._rollout_failed(cost0):
+                cost0, _, fl0 = self._cost_backward(st0, in0, trial_index, backward=False)
+                sharded_before = self.gp_sharding
+                if not self._rollout_failed(fl0):
                     break
+                if sharded_before and not self.gp_sharding:
+                    continue  # a hand-off time-out, not a NaN: same policy, unsharded kernels
                 print("\nSE filter initialization: Cost is NaN - reinit the policy")
                 self.control_policy.reinit(**policy_reinit_dict)
         s = fresh_state()
@@ -226,11 +276,9 @@ class MC_PILCO(torch.nn.Module):
             nan = True
             for _ in range(10):
                 states, inputs = self.apply_policy(p_dropout=s["p_drop"], **sim)
-                cost, std = self._cost(states, inputs, trial_index)
-                # the adjoint sweep is queued before the host looks at the cost (the NaN test is a sync point: checking first would
-                # leave the GPU idle while the backward launches are prepared); gradients of a NaN rollout are simply discarded
-                cost.backward(retain_graph=False)
-                if self._rollout_failed(cost):
+                # cost + adjoint sweep (+ the one all-reduce of a sharded run) are queued before the host looks at the flags
+                cost, std, flags = self._cost_backward(states, inputs, trial_index)
+                if self._rollout_failed(flags):
                     print("\nCost is NaN: try sampling again")
                     opt.zero_grad()
                 else:
@@ -244,7 +292,6 @@ class MC_PILCO(torch.nn.Module):
                 es2 = alpha_diff_cost * (es2 + (1 - alpha_diff_cost) * (diff - s["es1"][step]) ** 2)
                 cost_prev = s["cost"][step]
                 s["ratio"][step + 1] = alpha_diff_cost * s["ratio"][step] + (1 - alpha_diff_cost) * (s["es1"][step + 1] / es2.sqrt())
-            self._allreduce_grads()
             opt.step()
             if step % num_step_print == 0:
                 now = float(cost.detach())
@@ -462,8 +509,9 @@ class MC_PILCO4PMS(MC_PILCO):
         pol, ml = self.control_policy, self.model_learning
         ref = self.noise_mode == "reference"  # draw on the CPU with the reference's calls, in its order
         ndev = torch.device("cpu") if ref else self.device
-        x = self.sample_initial_particles(particles_initial_state_mean, particles_initial_state_var, flg_particles_init_uniform,
-                                          particles_init_up_bound, particles_init_low_bound, flg_particles_init_multi_gauss, M)
+        x = self._shard_slice(self.sample_initial_particles(particles_initial_state_mean, particles_initial_state_var, flg_particles_init_uniform,
+                                                            particles_init_up_bound, particles_init_low_bound, flg_particles_init_multi_gauss,
+                                                            self._m_total), 0)
         b, a = signal.butter(1, self.filtering_dict["fc"])
         pos, vel = list(self.pos_indeces), list(self.vel_indeces)
         if self.fused and isinstance(pol, _Policy.Sum_of_gaussians) and hasattr(ml, "vel_indeces"):
@@ -471,23 +519,25 @@ class MC_PILCO4PMS(MC_PILCO):
             p = float(p_dropout) if getattr(pol, "flg_drop", True) else 0.0
             G, B = ml.num_gp, pol.num_basis
             self._rollout_calls += 1
-            if ref:  # the reference's draw order: mask_0; per step: eps_t, position noise, mask_t
-                masks = [torch.empty(M, 1, B, dtype=self.dtype).bernoulli_(1 - p).reshape(M, B)] if p > 0 else None
+            if ref:  # the reference's draw order: mask_0; per step: eps_t, position noise, mask_t (whole swarm, then this rank's slice)
+                Mt = self._m_total
+                masks = [torch.empty(Mt, 1, B, dtype=self.dtype).bernoulli_(1 - p).reshape(Mt, B)] if p > 0 else None
                 eps, pn = [], []
                 for _ in range(1, T):
-                    eps.append(torch.empty(M, G, dtype=self.dtype).normal_())
-                    pn.append(torch.randn(M, len(pos), dtype=self.dtype))
+                    eps.append(torch.empty(Mt, G, dtype=self.dtype).normal_())
+                    pn.append(torch.randn(Mt, len(pos), dtype=self.dtype))
                     if p > 0:
-                        masks.append(torch.empty(M, 1, B, dtype=self.dtype).bernoulli_(1 - p).reshape(M, B))
-                stack = lambda l, w: (torch.stack(l) if l else torch.zeros(0, M, w, dtype=self.dtype)).to(self.device).contiguous()
-                noise = ops.NoiseSpec(eps=stack(eps, G), masks=None if masks is None else torch.stack(masks).to(torch.uint8).to(self.device).contiguous())
+                        masks.append(torch.empty(Mt, 1, B, dtype=self.dtype).bernoulli_(1 - p).reshape(Mt, B))
+                stack = lambda l, w: self._shard_slice(torch.stack(l) if l else torch.zeros(0, Mt, w, dtype=self.dtype), 1).to(self.device).contiguous()
+                noise = ops.NoiseSpec(eps=stack(eps, G), masks=None if masks is None else
+                                      self._shard_slice(torch.stack(masks).to(torch.uint8), 1).to(self.device).contiguous())
                 pos_noise = stack(pn, len(pos))
             else:
                 noise = ops.NoiseSpec(seed=self.seed, call=self._rollout_calls, particle_offset=self._shard[0])
                 pos_noise = None
             meas = ops.MeasSpec(pos=pos, vel=vel, std_pos=[float(v) for v in np.asarray(self.std_meas_noise_sim)[pos]], b=b, a=a,
                                 pos_noise=pos_noise)
-            states, inputs, status = ops.rollout(ml.packed(), pol.packed(), noise, x, T, p, meas=meas)
+            states, inputs, status = ops.rollout(ml.packed(), pol.packed(), noise, x, T, p, meas=meas, gp_sharding=self.gp_sharding)
             self.last_status = status
             return states, inputs
         std_pos = torch.tensor(np.asarray(self.std_meas_noise_sim)[pos], dtype=self.dtype, device=self.device)

@@ -2,12 +2,19 @@
 
 Particles are independent through the whole rollout and its adjoint; they meet only in the cost's mean over
 particles (Cost_function.py:33) and in the parameter-gradient sum.  So every rank simulates its own contiguous slice
-of the particles, and per optimizer step there are exactly two small exchanges (RCCL through torch.distributed;
-messages are a few KB, latency-bound):
+of the particles, and per optimizer step there is exactly ONE small exchange (latency-bound, 10-100 KB):
 
-  gather_moments      all-gather of the [T,2] per-time-step cost moments (mean, centred sum of squares)
-  allreduce_gradients all-reduce(sum) of the flattened policy gradient (each rank's gradient is already scaled
-                      by 1/M_total), after which every rank applies the identical optimizer update
+  StepReducer.reduce  all-reduce(sum) of the flat fp64 message
+                      [dJ/dlog_lengthscales | dJ/dcenters | dJ/dweight | sum_m (c_t - shift_t) (T) | sum_m (c_t - shift_t)^2 (T) | flags]
+                      (each rank's gradient is already scaled by 1/M_total; the rank runs its backward sweep BEFORE the
+                      exchange -- d(sum_t mean_m c)/dx_tm = (1/M_total) dc/dx needs nothing from the other ranks), after
+                      which every rank forms the pooled cost / std from the sums and applies the identical optimizer update.
+                      The flags carry the kernels' status bits (NaN, hand-off time-out), so every rank takes the same
+                      retry decision.  Transport: torch.distributed (backend "nccl" = RCCL on the GPUs, gloo in the CPU
+                      tests) or the C ABI's own RCCL communicator (mcp_comm_init / mcp_allreduce_grad).
+
+  gather_moments / allreduce_gradients   the two-exchange form of round 1 (all-gather of [T,2] moments, then the gradient
+                      all-reduce); kept for callers that want the cost before they run backward.
 
 Noise is counted by GLOBAL particle id (mcp_noise.particle_offset), so a sharded run draws what one GPU would.
 This module is host-side plumbing only (no arithmetic of the hot path); it works with any backend
@@ -65,3 +72,59 @@ def allreduce_gradients(params, group) -> None:
         n = p.numel()
         p.grad.copy_(flat[o:o + n].reshape(p.shape))
         o += n
+
+
+class StepReducer:
+    """The single collective of a sharded optimizer step.  ``transport``: "torch" (torch.distributed on ``group``) or "abi"
+    (libmcpilco_hip's RCCL communicator, created once per process; the unique id travels through torch.distributed's
+    object broadcast, any backend)."""
+
+    def __init__(self, group=None, transport="torch"):
+        import torch.distributed as dist
+
+        self.group = dist.group.WORLD if group is None else group
+        self.world = dist.get_world_size(self.group)
+        self.rank = dist.get_rank(self.group)
+        self.transport = transport
+        if transport == "abi":
+            import ctypes as C
+
+            from . import hipabi as abi
+
+            lib = abi.lib()
+            if lib.mcp_comm_world() == 0:
+                buf = C.create_string_buffer(abi.COMM_ID_BYTES)
+                if self.rank == 0:
+                    abi.check(lib.mcp_comm_unique_id(buf), "mcp_comm_unique_id")
+                box = [bytes(buf.raw)]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0), group=self.group)
+                abi.check(lib.mcp_comm_init(self.world, self.rank, box[0]), "mcp_comm_init")
+            elif lib.mcp_comm_world() != self.world:
+                raise RuntimeError("libmcpilco_hip already holds a communicator of another size")
+        elif transport != "torch":
+            raise ValueError(transport)
+
+    def allreduce_(self, flat: torch.Tensor) -> torch.Tensor:
+        if self.transport == "abi":
+            from . import hipabi as abi
+
+            abi.check(abi.lib().mcp_allreduce_grad(abi.ptr(flat), flat.numel(), abi.stream()), "mcp_allreduce_grad")
+        else:
+            import torch.distributed as dist
+
+            dist.all_reduce(flat, group=self.group)
+        return flat
+
+    def reduce(self, params, sums: torch.Tensor, flags: torch.Tensor):
+        """params: tensors whose ``.grad`` (this rank's share, None = no gradient wanted) are summed in place; sums [2T] and
+        flags [k] (non-negative doubles) are summed too and returned."""
+        ps = [p for p in params if p.grad is not None]
+        parts = [p.grad.reshape(-1) for p in ps] + [sums.reshape(-1), flags.reshape(-1).to(sums.dtype)]
+        flat = self.allreduce_(torch.cat(parts))
+        o = 0
+        for p in ps:
+            n = p.numel()
+            p.grad.copy_(flat[o:o + n].reshape(p.shape))
+            o += n
+        ns = sums.numel()
+        return flat[o:o + ns], flat[o + ns:]

@@ -475,3 +475,161 @@ def speed_model_io(states, inputs, angle, not_angle, vel):
     z = gp_features(x, u, angle, not_angle)[:-1, :]
     ys = [(x[1:, i] - x[:-1, i]).reshape(-1, 1) for i in vel]
     return z, ys
+
+
+# --------------------------------------------------------------------------------------
+# delta-state dynamics model (Model_learning / Model_learning_RBF_angle_state)
+# --------------------------------------------------------------------------------------
+@dataclass
+class DeltaModel:
+    """Model_learning_RBF_angle_state, Model_learning.py:528-580: GP i predicts x_{t+1}[i] - x_t[i] for EVERY state component
+    from z = [x_notangle, sin(x_angle), cos(x_angle), u] (angle = () gives the plain Model_learning_RBF, z = [x, u])."""
+
+    hyp: List[GPHyper]
+    cache: List[GPCache]
+    angle: Sequence[int] = ()
+    not_angle: Sequence[int] = ()
+
+
+def delta_model_io(states, inputs, angle, not_angle):
+    """Model_learning.py:450-469 with :564-579 -- GP inputs z[:-1] and per-state targets x[1:,i]-x[:-1,i]."""
+    x = torch.as_tensor(states, dtype=DT)
+    u = torch.as_tensor(inputs, dtype=DT)
+    z = (gp_features(x, u, angle, not_angle) if len(angle) else torch.cat([x, u], 1))[:-1, :]
+    return z, [(x[1:, i] - x[:-1, i]).reshape(-1, 1) for i in range(x.shape[1])]
+
+
+def delta_next_state(m: DeltaModel, x, u, eps: Optional[torch.Tensor], particle_pred: bool = True):
+    """Model_learning.py:210-229 and :471-493 -- x' = x + delta, delta = mu + sqrt(var) eps (Normal.rsample) or mu."""
+    z = gp_features(x, u, m.angle, m.not_angle) if len(m.angle) else torch.cat([x, u], 1)
+    mus, vrs = [], []
+    for h, c in zip(m.hyp, m.cache):
+        mu, var = gp_estimate_from_alpha(h, c.X, z, c.alpha, c.Kinv)
+        mus.append(mu)
+        vrs.append(var.reshape(-1, 1))
+    dmu, dvar = torch.cat(mus, 1), torch.cat(vrs, 1)
+    if particle_pred:
+        if eps is None:
+            eps = torch.empty(dmu.shape, dtype=DT).normal_()
+        return x + dmu + torch.sqrt(dvar) * eps, dmu, dvar
+    return x + dmu, dmu, dvar
+
+
+# --------------------------------------------------------------------------------------
+# simple costs
+# --------------------------------------------------------------------------------------
+def distance_cost(states, target_state, lengthscales, active_dims):
+    """Cost_function.py:53-63 (distance_from_target) -- sum_i ((x_i - x*_i)/l_i)^2 in the reference's expanded form
+    ||x/l||^2 + ||x*/l||^2 - 2 (x/l)(x*/l)^T, [T,M]."""
+    a = states[:, :, list(active_dims)] / lengthscales
+    b = (target_state / lengthscales).reshape(1, -1)
+    d = (a * a).sum(2, keepdim=True) + (b * b).sum(1, keepdim=True).t() - 2.0 * torch.matmul(a, b.t())
+    return d[:, :, 0]
+
+
+def saturated_distance_cost(states, target_state, lengthscales, active_dims):
+    """Cost_function.py:80-101 (saturated_distance_from_target) -- 1 - exp(-distance)."""
+    return 1 - torch.exp(-distance_cost(states, target_state, lengthscales, active_dims))
+
+
+# --------------------------------------------------------------------------------------
+# mean-only rollout of a recorded input sequence
+# --------------------------------------------------------------------------------------
+def mean_rollout(m: SpeedModel, x_rec, u_rec, T_rollout: Optional[int] = None):
+    """MC_PILCO.py:347-373 -- from the first recorded state, x_{t} = get_next_state(x_{t-1}, u_rec[t-1], particle_pred=False)."""
+    x_rec = torch.as_tensor(x_rec, dtype=DT)
+    u_rec = torch.as_tensor(u_rec, dtype=DT)
+    n = x_rec.shape[0] if T_rollout is None else T_rollout
+    traj = torch.zeros(n, x_rec.shape[1], dtype=DT)
+    traj[0:1] = x_rec[0:1]
+    for t in range(1, n):
+        traj[t : t + 1], _, _ = next_state(m, traj[t - 1 : t], u_rec[t - 1 : t], None, particle_pred=False)
+    return traj
+
+
+# --------------------------------------------------------------------------------------
+# the optimizer loop
+# --------------------------------------------------------------------------------------
+def reinforce_policy(
+    m: SpeedModel,
+    pp: PolicyPar,
+    x0_mean,
+    x0_var,
+    M: int,
+    T: int,
+    cost_fn,
+    num_opt_steps: int,
+    lr: float,
+    p_dropout: float = 0.0,
+    alpha_diff_cost: float = 0.99,
+    lr_reduction_ratio: float = 0.5,
+    lr_min: float = 0.001,
+    p_drop_reduction: float = 0.0,
+    min_diff_cost: float = 0.1,
+    num_min_diff_cost: int = 200,
+    min_step: float = float("inf"),
+    make_optimizer=None,
+):
+    """MC_PILCO.reinforce_policy, policy_learning/MC_PILCO.py:375-613, for a Gaussian initial distribution and a run without
+    NaN costs (the NaN retry / reinit branches :479-501, :573-607 are not restated): warm-up rollout that seeds the monitor
+    (:430-456, under no_grad), then per step: rollout (x0, mask_0, then eps_t, mask_t from the torch CPU generator, :615-674)
+    -> expected cost -> exponential statistics of the cost difference (:508-519) -> backward -> optimizer step (:522-525) ->
+    learning-rate halving / dropout reduction / early exit (:543-566; the window slice keeps Python's negative-index
+    behaviour).  The policy parameters in ``pp`` are updated in place.
+    Returns (cost_list, std_list, info) with info = dict(lr_reductions=[steps], exit_step, last_states, last_inputs)."""
+    prm = [pp.log_ls, pp.centers, pp.weight]
+    for q in prm:
+        q.requires_grad_(True)
+        q.grad = None
+    make_optimizer = make_optimizer or (lambda p, lr: torch.optim.Adam(p, lr))
+
+    def rollout(p_drop):
+        x0 = sample_x0(x0_mean, x0_var, M)
+        return apply_policy(m, pp, x0, T, p_drop)
+
+    p_applied = p_dropout
+    with torch.no_grad():
+        st, _ = rollout(p_applied)
+        cost_tm1, _ = expected_cost(cost_fn(st))
+    cost_list = torch.zeros(num_opt_steps, dtype=DT)
+    std_list = torch.zeros(num_opt_steps, dtype=DT)
+    es1 = torch.zeros(num_opt_steps + 1, dtype=DT)
+    es2 = 0.0
+    ratio = torch.zeros(num_opt_steps + 1, dtype=DT)
+    cur_min_diff, cur_min_step = min_diff_cost, min_step
+    opt = make_optimizer(prm, lr)
+    step = done = 0
+    info = {"lr_reductions": [], "exit_step": None}
+    st = inp = None
+    while step < num_opt_steps:
+        opt.zero_grad()
+        st, inp = rollout(p_applied)
+        cost, std = expected_cost(cost_fn(st))
+        cost_list[step] = cost.detach()
+        std_list[step] = std.detach()
+        with torch.no_grad():
+            es1[step + 1] = alpha_diff_cost * es1[step] + (1 - alpha_diff_cost) * (cost - cost_tm1)
+            es2 = alpha_diff_cost * (es2 + (1 - alpha_diff_cost) * ((cost - cost_tm1 - es1[step]) ** 2))
+            cost_tm1 = cost_list[step]
+            ratio[step + 1] = alpha_diff_cost * ratio[step] + (1 - alpha_diff_cost) * (es1[step + 1] / es2.sqrt())
+        cost.backward()
+        opt.step()
+        if step > cur_min_step:
+            if int(torch.sum(torch.abs(ratio[step + 1 - num_min_diff_cost : step + 1]) < cur_min_diff)) >= num_min_diff_cost:
+                if lr > lr_min:
+                    lr = max(lr * lr_reduction_ratio, lr_min)
+                    cur_min_diff = max(cur_min_diff / 2, 0.01)
+                    cur_min_step = step + num_min_diff_cost
+                    opt = make_optimizer(prm, lr)
+                    p_applied = max(p_applied - p_drop_reduction, 0.0)
+                    info["lr_reductions"].append(step)
+                else:
+                    info["exit_step"] = step
+                    step = num_opt_steps
+        step += 1
+        done += 1
+    for q in prm:
+        q.requires_grad_(False)
+        q.grad = None
+    info["last_states"], info["last_inputs"] = st.detach(), inp.detach()
+    return cost_list[:done].detach(), std_list[:done].detach(), info

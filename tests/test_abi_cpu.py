@@ -13,8 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "mcpilco_hip.h")
 
 
-def declared_symbols():
-    txt = open(HEADER).read()
+DEBUG_HEADER = os.path.join(ROOT, "include", "mcpilco_hip_debug.h")
+
+
+def declared_symbols(header=HEADER):
+    txt = open(header).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(mcp_[a-z0-9_]+)\s*\(", txt)))
 
@@ -28,7 +31,13 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libmcpilco_hip.so does not export %s" % n
     assert set(hipabi.EXPORTED) == set(names)
-    assert lib.mcp_abi_version() == 2
+    # the test / diagnostic hooks live in their own header, outside the boundary, and the binding knows exactly those
+    dbg = declared_symbols(DEBUG_HEADER)
+    assert dbg and all(n.startswith("mcp_debug_") for n in dbg)
+    for n in dbg:
+        assert hasattr(lib, n)
+    assert set(k for k in hipabi._SIGS if k.startswith("mcp_debug")) == set(dbg)
+    assert lib.mcp_abi_version() == 3
     assert b"gfx950" in lib.mcp_build_info()
 
 
@@ -67,6 +76,21 @@ def test_argument_validation_without_gpu():
     c = hipabi.Cost()
     c.kind, c.S = 7, 4
     assert lib.mcp_cost_fwd(C.byref(c), 3, 4, None, None, None, None, None) == -1
+
+
+def test_comm_wrapper_without_a_communicator():
+    """mcp_allreduce_grad is a thin RCCL wrapper with one communicator per process: before mcp_comm_init it must refuse
+    (MCP_ERR_COMM), never crash; RCCL itself is bound at run time (no link-time dependency)."""
+    from mc_pilco_amd import hipabi
+
+    lib = hipabi.lib()
+    assert lib.mcp_comm_world() == 0
+    assert lib.mcp_allreduce_grad(C.c_void_p(8), 4, None) == -5
+    assert lib.mcp_allreduce_grad(None, 4, None) == -1
+    assert lib.mcp_comm_init(0, 0, None) == -1
+    assert lib.mcp_comm_destroy() == 0
+    out = subprocess.check_output(["ldd", hipabi.LIB_PATH]).decode()
+    assert "rccl" not in out
 
 
 def test_product_refuses_cpu_tensors():

@@ -1,6 +1,7 @@
 """GPU, two ranks (both on cuda:0, gloo rendezvous): the sharded HIP path -- per-rank fused rollout with global
-particle ids, pooled expected cost (mcp_cost_finalize over all-gathered moments), all-reduced gradient --
-reproduces the single-process HIP result on the same particles, in both noise modes."""
+particle ids, this rank's cost share and adjoint sweep, then ONE all-reduce of [gradient | cost sums | flags]
+(sharding.StepReducer, mcp_cost_sums / mcp_cost_finalize_sums) -- reproduces the single-process HIP result on the
+same particles; the two-exchange form of round 1 (all-gathered moments + gradient all-reduce) is checked beside it."""
 import os
 import socket
 
@@ -22,7 +23,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, out_q):
+def _run(rank, world, port, out_q, fused=True):
     import torch.distributed as dist
 
     import mcp_boot  # noqa: F401
@@ -45,10 +46,18 @@ def _run(rank, world, port, out_q):
     for p in w.params:
         p.grad = None
     st, inp, status = ops.rollout(w.model, w.policy, nz, x0_all[off:off + cnt], Tn, w.p_drop)
-    cost, std = ops.expected_cost(w.cost, st, group, sharding.shard_counts(m_total, world) if world > 1 else None)
-    cost.backward()
-    if world > 1:
-        sharding.allreduce_gradients(w.params, group)
+    if world > 1 and fused:
+        shift = torch.full((Tn,), 0.4, dtype=torch.float64, device=dev)
+        share, sums = ops.local_cost(w.cost, st, m_total, shift)
+        share.backward()
+        sums_all, fl = sharding.StepReducer(group).reduce(w.params, sums, status.to(torch.float64))
+        cost, std = ops.cost_from_sums(sums_all, m_total, shift)
+        assert float(fl.sum()) == 0.0
+    else:
+        cost, std = ops.expected_cost(w.cost, st, group, sharding.shard_counts(m_total, world) if world > 1 else None)
+        cost.backward()
+        if world > 1:
+            sharding.allreduce_gradients(w.params, group)
     torch.cuda.synchronize()
     res = (float(cost), float(std), [p.grad.cpu().numpy().copy() for p in w.params], st.detach().cpu().numpy(), off, cnt)
     if rank == 0 or world == 1:
@@ -58,7 +67,8 @@ def _run(rank, world, port, out_q):
         dist.destroy_process_group()
 
 
-def test_two_rank_hip_sharding_matches_single_process():
+@pytest.mark.parametrize("fused", [True, False])
+def test_two_rank_hip_sharding_matches_single_process(fused):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p1 = ctx.Process(target=_run, args=(0, 1, 0, q))
@@ -66,7 +76,7 @@ def test_two_rank_hip_sharding_matches_single_process():
     c1, s1, g1, st1, _, _ = q.get(timeout=300)
     p1.join(timeout=60)
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_run, args=(r, 2, port, q, fused)) for r in range(2)]
     for p in procs:
         p.start()
     c2, s2, g2, st2, off, cnt = q.get(timeout=300)
@@ -75,6 +85,6 @@ def test_two_rank_hip_sharding_matches_single_process():
         assert p.exitcode == 0
     assert np.array_equal(st2, st1[:, off:off + cnt])  # same noise per GLOBAL particle: bit-identical trajectories
     assert abs(c2 - c1) < 1e-13 * abs(c1)
-    assert abs(s2 - s1) < 1e-11 * abs(s1)
+    assert abs(s2 - s1) < 1e-10 * abs(s1)
     for a, b in zip(g2, g1):
         assert np.max(np.abs(a - b)) < 1e-12 * max(1.0, np.max(np.abs(b)))

@@ -176,3 +176,89 @@ def test_pms_rollout_cost_gradient(golden):
     assert relerr(pp.log_ls.grad, fx["g_log_ls"]) < 1e-8
     assert relerr(pp.centers.grad, fx["g_centers"]) < 1e-8
     assert relerr(pp.weight.grad, fx["g_weight"]) < 1e-8
+
+
+# ---- round-2 fixtures (tests/golden/make_golden_r2.py) -------------------------------------------------------------------
+def _speed_model_from(fx, n_gp=2):
+    from mc_pilco_amd import synthetic as sy
+
+    c = sy.CARTPOLE
+    hyp = [hyper(c["lengthscales"], float(fx["sigma_n"])) for _ in range(n_gp)]
+    Z, Ys = orc.speed_model_io(fx["states_tr"], fx["inputs_tr"], c["angle"], c["not_angle"], c["vel"])
+    caches = [orc.pretrain_gp(hyp[g], Z, Ys[g]) for g in range(n_gp)]
+    return orc.SpeedModel(hyp, caches, c["Ts"], c["angle"], c["not_angle"], c["vel"], c["not_vel"]), c
+
+
+@pytest.mark.parametrize("tag", ["plain", "forced"])
+def test_reinforce_policy_trace(golden, tag):
+    """The optimizer loop itself (MC_PILCO.py:375-613): the reference's cost trace over 6 Adam steps, and a run in which the
+    monitors force two learning-rate halvings (with dropout reductions: the RNG stream changes) and the early exit."""
+    fx = golden("policy_opt_trace")
+    m, c = _speed_model_from(fx)
+    pp = orc.PolicyPar(torch.log(T(fx["pol_ls"])).reshape(1, -1), T(fx["pol_centers"]), T(fx["pol_weight"]), c["u_max"], "angles", angle=[2],
+                       non_angle=[0, 1, 3])
+    cost_fn = lambda st: orc.cart_pole_cost(st, T(c["cost_target"]), T(c["cost_ls"]), c["cost_angle_index"], c["cost_pos_index"])
+    kw = dict(num_opt_steps=6, lr=0.01, p_dropout=0.25) if tag == "plain" else dict(
+        num_opt_steps=12, lr=0.01, p_dropout=0.25, alpha_diff_cost=0.9, lr_reduction_ratio=0.5, lr_min=0.004, p_drop_reduction=0.125,
+        min_diff_cost=1e9, num_min_diff_cost=2, min_step=0)
+    torch.manual_seed(int(fx[tag + "_seed"]))
+    cl, sl, info = orc.reinforce_policy(m, pp, T(fx["x0_mean"]), T(fx["x0_var"]), int(fx["M"]), 10, cost_fn, **kw)
+    assert len(cl) == len(fx[tag + "_cost_list"])
+    assert relerr(cl, fx[tag + "_cost_list"]) < 1e-8
+    assert relerr(sl, fx[tag + "_std_list"]) < 1e-7
+    assert len(info["lr_reductions"]) == int(fx[tag + "_n_lr_reductions"])
+    assert (info["exit_step"] is not None) == bool(fx[tag + "_early_exit"])
+    if tag == "forced":
+        assert info["lr_reductions"] == [1, 4] and info["exit_step"] == 7
+    assert float((info["last_states"] - T(fx[tag + "_last_states"])).abs().max()) < 1e-7
+    assert relerr(pp.centers.detach(), fx[tag + "_final_centers"]) < 1e-8
+    assert relerr(pp.weight.detach(), fx[tag + "_final_weight"]) < 1e-8
+    assert relerr(pp.log_ls.detach(), fx[tag + "_final_log_ls"]) < 1e-8
+
+
+def test_delta_state_model_step(golden):
+    from mc_pilco_amd import synthetic as sy
+
+    fx = golden("delta_model_step")
+    c = sy.CARTPOLE
+    Z, Ys = orc.delta_model_io(fx["states_tr"], fx["inputs_tr"], c["angle"], c["not_angle"])
+    assert relerr(Z, fx["gp_inputs"]) < 1e-15
+    hyp = [hyper(c["lengthscales"], float(fx["sigma_n"])) for _ in range(4)]
+    caches = [orc.pretrain_gp(hyp[g], Z, Ys[g]) for g in range(4)]
+    for g in range(4):
+        assert relerr(Ys[g], fx["gp_output%d" % g]) < 1e-15
+        assert relerr(caches[g].alpha, fx["alpha%d" % g]) < 1e-8
+    m = orc.DeltaModel(hyp, caches, c["angle"], c["not_angle"])
+    nxt, mu, var = orc.delta_next_state(m, T(fx["x"]), T(fx["u"]), T(fx["eps"]))
+    assert float((mu - T(fx["mu"])).abs().max()) < 1e-9
+    assert float((var - T(fx["var"])).abs().max()) < 1e-9
+    assert float((nxt - T(fx["next"])).abs().max()) < 1e-9
+    nm, _, _ = orc.delta_next_state(m, T(fx["x"]), T(fx["u"]), None, particle_pred=False)
+    assert float((nm - T(fx["next_mean"])).abs().max()) < 1e-9
+
+
+def test_simple_costs(golden):
+    fx = golden("simple_costs")
+    for tag, fn in (("dist", orc.distance_cost), ("sat", orc.saturated_distance_cost)):
+        st = T(fx["states"]).requires_grad_(True)
+        c, s = orc.expected_cost(fn(st, T(fx["target"]), T(fx["lengthscales"]), [int(i) for i in fx["active_dims"]]))
+        c.backward()
+        assert abs(float(c) - float(fx[tag + "_cost"])) < 1e-12 * abs(float(fx[tag + "_cost"]))
+        assert abs(float(s) - float(fx[tag + "_std"])) < 1e-12 * abs(float(fx[tag + "_std"]))
+        assert relerr(st.grad, fx[tag + "_grad"]) < 1e-12
+
+
+def test_mean_rollout(golden):
+    fx = golden("mean_rollout")
+    m, _ = _speed_model_from(fx)
+    assert float((orc.mean_rollout(m, fx["x_rec"], fx["u_rec"]) - T(fx["traj"])).abs().max()) < 1e-8
+    assert float((orc.mean_rollout(m, fx["x_rec"], fx["u_rec"], 12) - T(fx["traj12"])).abs().max()) < 1e-9
+
+
+def test_sod_with_seeded_permutation(golden):
+    fx = golden("sod_permutation")
+    h = hyper(fx["lengthscales"], float(fx["sigma_n"]))
+    torch.manual_seed(int(fx["seed"]))
+    perm = torch.arange(1, fx["X"].shape[0])[torch.randperm(fx["X"].shape[0] - 1)]
+    assert [int(i) for i in perm] == [int(i) for i in fx["perm"]]
+    assert orc.gp_get_sod(h, T(fx["X"]), T(fx["Y"]), float(fx["thr"]), perm) == [int(i) for i in fx["idx"]]

@@ -84,6 +84,76 @@ def test_two_rank_sharding_reproduces_single_process(m_total):
         assert np.max(np.abs(g - g1[k].numpy())) < 1e-12 * max(1.0, float(g1[k].abs().max()))
 
 
+def _worker_fused(rank, world, port, m_total, use_shift, out_q):
+    """The single-collective form (sharding.StepReducer): backward first, then ONE all-reduce of [grad | cost sums | flags]."""
+    import torch.distributed as dist
+
+    import mcp_boot  # noqa: F401
+    from mc_pilco_amd import sharding
+    from mc_pilco_amd.policy_learning.Cost_function import Expected_cost
+    from oracle import mcpilco_oracle as orc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fx = load_golden("rollout_se")
+    m = oracle_model(fx, "se")
+    pp = oracle_policy(fx, "se")
+    cost_fn = oracle_cost_fn(fx, "se")
+    off, cnt = sharding.shard_range(m_total, world, rank)
+    sl = slice(off, off + cnt)
+    Tn = fx["states"].shape[0]
+    prm = [pp.log_ls, pp.centers, pp.weight]
+    for p in prm:
+        p.requires_grad_(True)
+    st, _ = orc.apply_policy(m, pp, T(fx["states"][0][sl]), Tn, float(fx["p_drop"]), T(fx["eps"][:, sl]), T(fx["masks"][:, sl]))
+    ec = Expected_cost(lambda x, u, k: cost_fn(x))
+    shift = T(0.3 + 0.05 * np.arange(Tn)) if use_shift else None
+    share, sums = ec.local_moments(st, None, 0, m_total, shift)
+    share.backward()
+    red = sharding.StepReducer(dist.group.WORLD)
+    flags = torch.tensor([0.0, 1.0 if rank == world - 1 else 0.0], dtype=torch.float64)  # one rank raises a flag: every rank must see it
+    sums_all, fl = red.reduce(prm, sums, flags)
+    mean_out = torch.empty(Tn, dtype=torch.float64)
+    cost, std = Expected_cost.from_sums(sums_all, m_total, shift, mean_out)
+    out_q.put((rank, float(cost), float(std), [p.grad.numpy().copy() for p in prm], fl.tolist(), mean_out.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,m_total,use_shift", [(2, 24, False), (4, 23, True), (4, 22, False)])
+def test_single_allreduce_step_reproduces_single_process(world, m_total, use_shift):
+    """2 and 4 gloo ranks, even and uneven shards: gradient, cost, std and the flags agree on every rank and with one process."""
+    from oracle import mcpilco_oracle as orc
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fused, args=(r, world, port, m_total, use_shift, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fx = load_golden("rollout_se")
+    m, pp, cost_fn = oracle_model(fx, "se"), oracle_policy(fx, "se"), oracle_cost_fn(fx, "se")
+    sl = slice(0, m_total)
+    c1, s1, g1, st1, _ = orc.policy_grad_step(m, pp, T(fx["states"][0][sl]), fx["states"].shape[0], cost_fn, float(fx["p_drop"]), T(fx["eps"][:, sl]),
+                                              T(fx["masks"][:, sl]))
+    mean1 = cost_fn(st1).mean(1).detach().numpy()
+    for rank, cost, std, grads, fl, mean_t in res:
+        assert abs(cost - float(c1)) < 1e-12 * abs(float(c1))
+        assert abs(std - float(s1)) < 1e-9 * abs(float(s1))
+        assert np.max(np.abs(mean_t - mean1)) < 1e-13
+        assert fl[0] == 0.0 and fl[1] == 1.0
+        for g, k in zip(grads, ["log_ls", "centers", "weight"]):
+            assert np.max(np.abs(g - g1[k].numpy())) < 1e-12 * max(1.0, float(g1[k].abs().max()))
+        for g, g0 in zip(grads, res[0][3]):
+            assert np.array_equal(g, g0)  # identical on every rank: identical optimizer updates
+
+
 def test_shard_ranges_partition_the_particles():
     from mc_pilco_amd import sharding
 
