@@ -28,6 +28,14 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (= vector) peak, datasheet; see DESIGN.md
 
 
+def note(msg):
+    """Progress line on stderr (stdout carries the one JSON line)."""
+    print("[bench %.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -258,9 +266,13 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
         reducer = sharding.StepReducer(dist.group.WORLD, args.transport)
 
+    if rank == 0:
+        note("building workload %s" % args.workload)
     main_run = Runner(args, args.workload, dev, rank, world, reducer, M=args.particles or None, T=args.horizon or None)
     M, T, w = main_run.M, main_run.T, main_run.w
     el, fwd_ms, last_cost = main_run.run(args.steps, args.warmup)
+    if rank == 0:
+        note("%s: %d steps in %.3f s" % (args.workload, args.steps, el))
     ms_per_step = 1e3 * el / args.steps
     value = world * M * T / (el / args.steps)
 
@@ -299,9 +311,11 @@ def main():
             # D=24, N=400, M=2000, T=300) -- same step definition, fewer steps
             extra = []
             for name in ("c3", "c5"):
+                note("extra workload %s" % name)
                 r = Runner(args, name, dev, rank, world, reducer)
                 k = 5 if name == "c3" else 3
                 e2, f2, c2 = r.run(k, 2)
+                note("%s: %d steps in %.3f s" % (name, k, e2))
                 rf = r.roofline(f2)
                 rf.pop("achieved_basis")
                 rf["traffic"] = traffic.get(name)
@@ -312,9 +326,13 @@ def main():
                 torch.cuda.empty_cache()
             out["extra_workloads"] = extra
         if world == 1 and not args.no_cpu:
-            ncores = os.cpu_count() or 1
+            # the cores this process may actually run on (the box gives one GPU's share of the host, not os.cpu_count())
+            ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            ncores = max(1, min(ncores, int(os.environ.get("MCP_BENCH_MAX_THREADS", "32"))))
+            note("cpu_baseline: 1 thread")
             out["cpu_baseline"] = cpu_baseline(w.problem, M, T, w.p_drop, 1)
             if ncores > 1:
+                note("cpu_baseline: %d threads" % ncores)
                 out["cpu_baseline_all_cores"] = cpu_baseline(w.problem, M, T, w.p_drop, ncores)
         print(json.dumps(out), flush=True)
     if world > 1:

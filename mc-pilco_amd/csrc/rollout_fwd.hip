@@ -1344,6 +1344,7 @@ extern "C" int mcp_posterior_fwd(const mcp_gp* gp, int M, const double* Z, doubl
   a.Jvar = Jvar;
   a.status = status;
   int P0 = g_force_ppw ? g_force_ppw : pick_particles_per_wg(M);
+  if (P0 == 16) P0 = 4;  // (the single-step operator has no 16-particle form: more than 1024 test points run 4 per workgroup)
   if (P0 != 1 && P0 != 2 && P0 != 4) return MCP_ERR_ARG;
   for (int P = P0; P >= 1; P >>= 1) {
     FwdLayout L = fwd_layout(P, 1, 1, gp->kern.D, 1, 1, 1, gp->Npad, 2, 1, a.NCmax, false);

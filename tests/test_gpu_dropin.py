@@ -326,3 +326,217 @@ def test_initial_particle_distributions_match_reference(golden):
     x0 = obj.sample_initial_particles(T(fx["means"][0]), T(fx["vars"][0]), False, None, None, False, 20000)
     assert x0.is_cuda and float((x0.mean(0).cpu() - torch.as_tensor(fx["means"][0])).abs().max()) < 0.01
     assert float((x0.var(0).cpu() / torch.as_tensor(fx["vars"][0]) - 1).abs().max()) < 0.05
+
+
+# ---- round 2: the optimizer loop, the "next" rows of SURVEY 8f rank 4, cache / pointer lifetime -------------------------------
+def _trace_setup(fx):
+    ml = build_cartpole(fx, 0, False)
+    obj = build_mcpilco(dict(pol_ls=fx["pol_ls"], pol_centers=fx["pol_centers"], pol_weight=fx["pol_weight"]), ml, fx["pol_centers"].shape[0])
+    obj.noise_mode = "reference"
+    return obj
+
+
+@pytest.mark.parametrize("tag", ["plain", "forced"])
+def test_reinforce_policy_trace_matches_reference(golden, tag):
+    """MC_PILCO.reinforce_policy (MC_PILCO.py:375-613) on the drop-in, reference noise mode, same seed: the reference's cost trace over
+    6 Adam steps to 1e-8, and the run whose monitors force two learning-rate halvings, two dropout reductions (the second one
+    stops the mask draws: the RNG stream shifts) and the early exit after 8 of 12 steps; final policy parameters included."""
+    fx = golden("policy_opt_trace")
+    obj = _trace_setup(fx)
+    kw = dict(opt_steps_list=[6], lr_list=[0.01], p_dropout_list=[0.25]) if tag == "plain" else dict(
+        opt_steps_list=[12], lr_list=[0.01], p_dropout_list=[0.25], alpha_diff_cost=0.9, lr_reduction_ratio=0.5, lr_min=0.004,
+        p_drop_reduction=0.125, min_diff_cost=1e9, num_min_diff_cost=2, min_step=0)
+    torch.manual_seed(int(fx[tag + "_seed"]))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        costs, stds, st, inp = obj.reinforce_policy(
+            T_control=float(fx["T_control"]), num_particles=int(fx["M"]), trial_index=0, particles_initial_state_mean=T(fx["x0_mean"]),
+            particles_initial_state_var=T(fx["x0_var"]), flg_particles_init_uniform=False, particles_init_up_bound=None,
+            particles_init_low_bound=None, flg_particles_init_multi_gauss=False, f_optimizer="lambda p, lr : torch.optim.Adam(p, lr)",
+            num_step_print=100, policy_reinit_dict=None, **kw)
+    assert costs.shape == fx[tag + "_cost_list"].shape
+    assert relerr(costs, fx[tag + "_cost_list"]) < 1e-8
+    assert relerr(stds, fx[tag + "_std_list"]) < 1e-7
+    assert buf.getvalue().count("REDUCING THE LEARNING RATE") == int(fx[tag + "_n_lr_reductions"])
+    assert ("EXIT FROM OPTIMIZATION" in buf.getvalue()) == bool(fx[tag + "_early_exit"])
+    assert float(np.abs(st - fx[tag + "_last_states"]).max()) < 1e-7 and float(np.abs(inp - fx[tag + "_last_inputs"]).max()) < 1e-7
+    pol = obj.control_policy
+    assert relerr(pol.centers, fx[tag + "_final_centers"]) < 1e-8
+    assert relerr(pol.f_linear.weight, fx[tag + "_final_weight"]) < 1e-8
+    assert relerr(pol.log_lengthscales, fx[tag + "_final_log_ls"]) < 1e-8
+
+
+def test_delta_state_model_matches_reference(golden):
+    """Model_learning_RBF_angle_state (Model_learning.py:471-493, 528-580): GP i predicts the change of state i; one step."""
+    from mc_pilco_amd.model_learning import Model_learning as ML
+
+    fx = golden("delta_model_step")
+    c = sy.CARTPOLE
+    with quiet():
+        ml = ML.Model_learning_RBF_angle_state(num_gp=4, init_dict_list=[rbf_dict(6, c["lengthscales"], float(fx["sigma_n"]))] * 4,
+                                               angle_indeces=c["angle"], not_angle_indeces=c["not_angle"], dtype=dtype, device=dev())
+        ml.add_data(fx["states_tr"], fx["inputs_tr"])
+        with torch.no_grad():
+            for g in range(4):
+                ml.pretrain_gp(g)
+        ml.set_eval_mode()
+    assert relerr(ml.gp_inputs, fx["gp_inputs"]) < 1e-14
+    for g in range(4):
+        assert relerr(ml.gp_output_list[g], fx["gp_output%d" % g]) < 1e-14
+        assert relerr(ml.alpha_list[g], fx["alpha%d" % g]) < 1e-8
+    with torch.no_grad():
+        nm, mu, var = ml.get_next_state(T(fx["x"]), T(fx["u"]), particle_pred=False)
+        torch.manual_seed(12)
+        eps = torch.empty(20, 4, dtype=dtype).normal_()
+    assert float((mu.cpu() - torch.as_tensor(fx["mu"])).abs().max()) < 1e-9
+    assert float((var.cpu() - torch.as_tensor(fx["var"])).abs().max()) < 1e-9
+    assert float((nm.cpu() - torch.as_tensor(fx["next_mean"])).abs().max()) < 1e-9
+    assert np.array_equal(eps.numpy(), fx["eps"])
+    nxt = T(fx["x"]) + mu + torch.sqrt(var) * eps.to(dev())
+    assert float((nxt.cpu() - torch.as_tensor(fx["next"])).abs().max()) < 1e-9
+
+
+def test_simple_costs_match_reference(golden):
+    """Expected_distance / Expected_saturated_distance (Cost_function.py:39-101)."""
+    from mc_pilco_amd.policy_learning import Cost_function
+
+    fx = golden("simple_costs")
+    act = [int(i) for i in fx["active_dims"]]
+    for tag, cls in (("dist", Cost_function.Expected_distance), ("sat", Cost_function.Expected_saturated_distance)):
+        st = T(fx["states"]).requires_grad_(True)
+        cf = cls(target_state=T(fx["target"]), lengthscales=T(fx["lengthscales"]), active_dims=act)
+        c, s = cf(st, None, 0)
+        c.backward()
+        assert abs(float(c) - float(fx[tag + "_cost"])) < 1e-12 * abs(float(fx[tag + "_cost"]))
+        assert abs(float(s) - float(fx[tag + "_std"])) < 1e-12 * abs(float(fx[tag + "_std"]))
+        assert relerr(st.grad, fx[tag + "_grad"]) < 1e-12
+
+
+def test_mean_rollout_matches_reference(golden):
+    """MC_PILCO.rollout (MC_PILCO.py:347-373): mean-only prediction of a recorded trajectory."""
+    fx = golden("mean_rollout")
+    ml = build_cartpole(fx, 0, False)
+    pi = sy.cartpole_policy_init(B=16, seed=8)
+    obj = build_mcpilco(dict(pol_ls=pi["lengthscales"], pol_centers=pi["centers"], pol_weight=pi["weight"]), ml, 16)
+    obj.state_samples_history = [fx["x_rec"]]
+    obj.input_samples_history = [fx["u_rec"]]
+    with torch.no_grad(), quiet():
+        traj = obj.rollout(data_collection_index=0)
+        traj12 = obj.rollout(data_collection_index=0, T_rollout=12)
+    assert traj.shape == fx["traj"].shape and float(np.abs(traj - fx["traj"]).max()) < 1e-8
+    assert traj12.shape == (12, 4) and float(np.abs(traj12 - fx["traj12"]).max()) < 1e-9
+
+
+def test_sod_with_seeded_permutation_matches_reference(golden):
+    """GP_prior.get_SOD(flg_permutation=True) (GP_prior.py:244-247): the permutation is torch.randperm on the CPU generator, as
+    in the reference, so the same seed visits the samples in the same order; indices exact."""
+    from mc_pilco_amd.gpr_lib.GP_prior import Stationary_GP
+
+    fx = golden("sod_permutation")
+    with quiet():
+        gp = Stationary_GP.RBF(**rbf_dict(6, fx["lengthscales"], float(fx["sigma_n"])))
+        torch.manual_seed(int(fx["seed"]))
+        idx = gp.get_SOD(T(fx["X"]), T(fx["Y"]), float(fx["thr"]), flg_permutation=True)
+    assert [int(i) for i in idx] == [int(i) for i in fx["idx"]]
+
+
+def test_load_model_from_reference_log(golden, tmp_path):
+    """MC_PILCO.load_model_from_log (MC_PILCO.py:711-751) on a log.pkl written from REFERENCE objects (tests/golden/ref_log.pkl: its
+    keys, its state_dict names, CPU tensors): data replayed, hyper-parameters restored, pretrain reproduces the reference's alpha.
+    Then the drop-in's own log round trip: what it writes, it reads back to the same model."""
+    import os
+    import pickle
+    import shutil
+
+    from conftest import GOLDEN
+    from mc_pilco_amd.model_learning import Model_learning as ML
+
+    ex = golden("ref_log_expect")
+    c = sy.CARTPOLE
+
+    def fresh():
+        par = dict(num_gp=2, T_sampling=c["Ts"], angle_indeces=c["angle"], not_angle_indeces=c["not_angle"], vel_indeces=c["vel"],
+                   not_vel_indeces=c["not_vel"], dtype=dtype, device=dev(), init_dict_list=[rbf_dict(6, np.ones(6), 1.0)] * 2)
+        with quiet():
+            ml = ML.Speed_Model_learning_RBF_angle_state(**par)
+        pi = sy.cartpole_policy_init(B=16, seed=1)
+        return build_mcpilco(dict(pol_ls=pi["lengthscales"], pol_centers=pi["centers"], pol_weight=pi["weight"]), ml, 16)
+
+    folder = str(tmp_path) + "/"
+    shutil.copy(os.path.join(GOLDEN, "ref_log.pkl"), folder + "log.pkl")
+    obj = fresh()
+    with quiet():
+        obj.load_model_from_log(num_trial=1, folder=folder)
+        obj.load_policy_from_log(num_trial=1, folder=folder)
+    ml = obj.model_learning
+    assert len(obj.state_samples_history) == 2 and ml.gp_inputs.shape == ex["gp_inputs"].shape
+    assert relerr(ml.gp_inputs, ex["gp_inputs"]) < 1e-14
+    for g in range(2):
+        assert relerr(torch.exp(ml.gp_list[g].log_lengthscales_par), ex["ls%d" % g]) < 1e-14
+        assert relerr(ml.alpha_list[g], ex["alpha%d" % g]) < 1e-8
+    assert relerr(obj.control_policy.centers, ex["pol_centers"]) < 1e-15
+    # the drop-in's own log: written with the reference's keys, read back by a fresh object
+    obj.log_path = str(tmp_path / "own")
+    os.makedirs(obj.log_path)
+    with quiet():
+        obj._save_log()
+    obj2 = fresh()
+    with quiet():
+        obj2.load_model_from_log(num_trial=1, folder=obj.log_path + "/")
+    for g in range(2):
+        assert relerr(obj2.model_learning.alpha_list[g], ml.alpha_list[g].detach().cpu().numpy()) < 1e-12
+    log = pickle.load(open(obj.log_path + "/log.pkl", "rb"))
+    assert sorted(log["parameters_gp_0"][0].keys()) == sorted(["sigma_n_log", "log_lengthscales_par", "log_lambda_par", "mean_par"])
+
+
+def test_descriptor_pointers_survive_operator_calls_between_rollouts(golden):
+    """Round-1 advisor finding: the packed model's descriptor points at device copies of the kernel hyper-parameters; calling the
+    single-step operators on the same GP objects between two fused rollouts must not free or move them.  packed() rollout ->
+    get_next_state / posterior / get_estimate_from_alpha (with allocator churn) -> second rollout: bit-identical under fixed noise."""
+    from mc_pilco_amd import ops
+
+    fx = golden("rollout_se")
+    ml = build_cartpole(fx, 0, False)
+    obj = build_mcpilco(fx, ml, fx["pol_centers"].shape[0])
+    pm, pp = ml.packed(), obj.control_policy.packed()
+    x0 = T(fx["states"][0])
+    nz = ops.NoiseSpec(eps=T(fx["eps"]), masks=torch.as_tensor(fx["masks"]).to(dev()).contiguous())
+    with torch.no_grad():
+        a = ops.rollout(pm, pp, nz, x0, fx["states"].shape[0], 0.25)[0].clone()
+        for _ in range(3):
+            ml.get_next_state(T(fx["states"][1]), T(fx["inputs"][1]), particle_pred=False)
+            junk = [torch.zeros(n, dtype=dtype, device=dev()) for n in (6, 7, 64, 1, 13)]  # small blocks the allocator would hand back
+            for g in range(2):
+                ml.gp_list[g].get_estimate_from_alpha(ml.gp_inputs_tr_list[g], ml.gp_inputs[:5], ml.alpha_list[g], ml.m_X_list[g],
+                                                      K_X_inv=ml.K_X_inv_list[g])
+            del junk
+        assert ml.packed() is pm
+        b = ops.rollout(pm, pp, nz, x0, fx["states"].shape[0], 0.25)[0]
+    assert torch.equal(a, b)
+    assert float((a.cpu() - torch.as_tensor(fx["states"])).abs().max()) < 1e-8
+
+
+def test_posterior_cache_follows_the_hyper_parameters(golden):
+    """Round-1 advisor finding: get_alpha() followed by get_estimate_from_alpha() must see hyper-parameters changed in place in
+    between (optimizer step, load_state_dict), even when the new tensors land on the old addresses."""
+    from mc_pilco_amd.gpr_lib.GP_prior import Stationary_GP
+
+    fx = golden("kern_se")
+    with quiet():
+        gp = Stationary_GP.RBF(**rbf_dict(6, fx["lengthscales"], float(fx["sigma_n"])))
+    X, Y, Xs = T(fx["X"]), T(fx["Y"]), T(fx["Xs"])
+    with torch.no_grad():
+        alpha, mX, Kinv = gp.get_alpha(X, Y)
+        mu0, var0 = gp.get_estimate_from_alpha(X, Xs, alpha, mX, K_X_inv=Kinv)
+        assert relerr(mu0, fx["mu"]) < 1e-9
+        gp.log_lengthscales_par.add_(0.3)  # in place, like an optimizer step
+        alpha2, mX2, Kinv2 = gp.get_alpha(X, Y)
+        mu1, var1 = gp.get_estimate_from_alpha(X, Xs, alpha2, mX2, K_X_inv=Kinv2)
+        # same (X, alpha2, Kinv2) tensors, parameters moved back: must repack again, not serve the cached operands
+        gp.log_lengthscales_par.sub_(0.3)
+        mu2, _ = gp.get_estimate_from_alpha(X, Xs, alpha2, mX2, K_X_inv=Kinv2)
+        from mc_pilco_amd import ops
+
+        ref = ops.posterior(ops.PackedGP(gp.kernel_spec(), X, alpha2, Kinv2), Xs)[0]
+    assert float((mu1 - mu0).abs().max()) > 1e-4
+    assert torch.equal(mu2, ref) and float((mu2 - mu1).abs().max()) > 1e-6

@@ -519,3 +519,17 @@ def test_two_launch_sharding_matches_the_unsharded_kernels():
     assert float((out[0][0] - out[1][0]).abs().max()) < 2e-8 and float((out[0][1] - out[1][1]).abs().max()) < 2e-8
     for ga, gb in zip(out[0][2], out[1][2]):
         assert float((ga - gb).abs().max()) <= 1e-7 * max(1e-30, float(gb.abs().max()))
+
+
+def test_posterior_operator_takes_more_than_1024_test_points(golden):
+    """GP_prior.get_estimate_from_alpha on a large batch of test inputs (round 2: the operator refused M > 1024)."""
+    from gpu_helpers import G
+    from mc_pilco_amd import ops
+
+    fx = golden("kern_se")
+    sp = _kernel_spec(fx)
+    gp = ops.PackedGP(sp, G(fx["X"]), G(fx["alpha"]), G(fx["Kinv"]))
+    Xs = G(np.tile(fx["Xs"], (40, 1)))  # 1280 points
+    mu, var = ops.posterior(gp, Xs)
+    assert relerr(mu[:32], fx["mu"]) < 1e-10 and relerr(mu[-32:], fx["mu"]) < 1e-10
+    assert abserr(var[-32:], fx["var"]) < 1e-10

@@ -1,0 +1,282 @@
+"""GPU parity at BASELINE.json's real training-set sizes, against an independent answer (the CPU oracle on the same seeded
+inputs and the same noise): N=300 SE, N=300 SE+poly(2), N=400 / D=24 / G=6 UR5-shaped -- on EVERY forward kernel variant
+(1 / 2 / 4 / 16 particles per workgroup, unsharded and GP-sharded) and every backward sweep width (1 / 2 / 4).  This is where
+the tail-chunk paths of phase V (Npad = 304: a 48-row tail chunk; Npad = 400: a 16-row one), the alpha padding at Npad != N and
+the tile kernel's uneven block split are exercised against something that is not another variant of the same code.
+Plus: BASELINE.json's configs[4] at its stated size (UR5, M=2000, T=300, N=400) through size-independent properties, and
+real statistics of the in-kernel Philox noise (the mode every benchmark number is produced in).
+
+Tolerances (fp64): the oracle factorises K itself (torch Cholesky) and the HIP path its own way, so trajectories agree to the
+conditioning of K: states / inputs abs 1e-7 over 8 steps, cost rel 1e-9, gradients rel 1e-6 (tests/test_gpu_parity.py:238-243).
+"""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mcpilco_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+Tt = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+
+REAL = {"se300": ("c1", 48, 8), "sep2_300": ("c3", 48, 8), "ur5_400": ("c5", 40, 6)}
+
+
+@functools.lru_cache(maxsize=None)
+def oracle_answer(key):
+    """(cost, std, grads, states, inputs, x0, eps, masks) of the CPU oracle at the real N, small M and T, its own pretrain."""
+    from mc_pilco_amd import workloads
+
+    name, M, Tn = REAL[key]
+    pb = workloads.numpy_problem(name)
+    c = pb["cfg"]
+    if pb["target_traj"] is not None:
+        from mc_pilco_amd import synthetic as sy
+
+        pb["target_traj"] = sy.ur5_target_traj(T=Tn, Ts=c["Ts"])
+    hyp = []
+    for g in range(c["G"]):
+        pw = None if pb["poly"] is None else [torch.log(Tt(w)) for w in pb["poly"][g]]
+        hyp.append(orc.GPHyper(torch.log(Tt(c["lengthscales"])), torch.log(Tt([c["lam"]])), torch.log(Tt([c["sigma_n"]])), poly_log_par=pw))
+    caches = [orc.pretrain_gp(hyp[g], Tt(pb["Z"]), Tt(pb["Ys"][g])) for g in range(c["G"])]
+    m = orc.SpeedModel(hyp, caches, c["Ts"], c["angle"], c["not_angle"], c["vel"], c["not_vel"])
+    pi = pb["policy"]
+    pp = orc.PolicyPar(torch.log(Tt(pi["lengthscales"])).reshape(1, -1), Tt(pi["centers"]), Tt(pi["weight"]), c["u_max"], pb["policy_kind"],
+                       target_traj=None if pb["target_traj"] is None else Tt(pb["target_traj"]), **pb["policy_extra"])
+    if pb["system"] == "cartpole":
+        cost_fn = lambda st: orc.cart_pole_cost(st, Tt(c["cost_target"]), Tt(c["cost_ls"]), c["cost_angle_index"], c["cost_pos_index"])
+    else:
+        tt, ls = Tt(pb["target_traj"]), Tt(c["cost_ls"])
+        cost_fn = lambda st: orc.traj_cost(st, tt, ls)
+    p = 0.25
+    torch.manual_seed(17)
+    e0, eps, masks = orc.draw_noise(M, c["S"], c["G"], c["B"], Tn, p)
+    x0 = orc.sample_x0(Tt(c["x0_mean"]), Tt(c["x0_var"]), M, e0)
+    oc, os_, og, ost, oin = orc.policy_grad_step(m, pp, x0, Tn, cost_fn, p, eps, masks)
+    return dict(cost=float(oc), std=float(os_), grads=og, states=ost, inputs=oin, x0=x0, eps=eps, masks=masks, p=p, N=pb["Z"].shape[0])
+
+
+@functools.lru_cache(maxsize=None)
+def hip_workload(key):
+    from gpu_helpers import dev
+    from mc_pilco_amd import workloads
+
+    name, M, Tn = REAL[key]
+    return workloads.build(name, device=dev(), M=M, T=Tn)  # pretrain (Gram -> Cholesky -> inverse -> alpha) on the device
+
+
+@pytest.mark.parametrize("pb", [1, 2, 4])
+@pytest.mark.parametrize("code", [1, 2, 4, 16, 101, 102, 104, 116])
+@pytest.mark.parametrize("key", list(REAL))
+def test_every_variant_against_the_oracle_at_real_training_set_sizes(key, code, pb):
+    from gpu_helpers import dev, forced_variant
+    from mc_pilco_amd import ops
+
+    o = oracle_answer(key)
+    w = hip_workload(key)
+    assert w.model.gps[0].N == o["N"] and o["N"] in (300, 400)
+    nz = ops.NoiseSpec(eps=o["eps"].to(dev()).contiguous(), masks=o["masks"].to(torch.uint8).to(dev()).contiguous())
+    for q in w.params:
+        q.grad = None
+    with forced_variant(code, bwd_particles=pb) as fv:
+        st, inp, status = ops.rollout(w.model, w.policy, nz, o["x0"].to(dev()), w.T, o["p"])
+        c, s = ops.expected_cost(w.cost, st)
+        c.backward()
+        fv.check(sharding_optional=(key == "ur5_400"))
+    assert int(status.item()) == 0
+    assert float((st.detach().cpu() - o["states"]).abs().max()) < 1e-7
+    assert float((inp.detach().cpu() - o["inputs"]).abs().max()) < 1e-7
+    assert abs(float(c) - o["cost"]) < 1e-9 * abs(o["cost"])
+    assert abs(float(s) - o["std"]) < 1e-7 * max(abs(o["std"]), 1e-3)
+    for q, k in zip(w.params, ["log_ls", "centers", "weight"]):
+        g = o["grads"][k]
+        assert float((q.grad.cpu().reshape(g.shape) - g).abs().max()) < 1e-6 * float(g.abs().max()), k
+
+
+# -------------------------------------------------------------------------------------------------------------------------
+# configs[4] at its stated size
+# -------------------------------------------------------------------------------------------------------------------------
+def test_c5_full_size_properties():
+    """UR5 shape, M=2000, T=300, N=400, 6 GPs, D=24 (BASELINE.json configs[4]) on the automatic dispatch: bitwise determinism,
+    shard invariance (two half swarms with their global particle offsets reproduce the whole), status clean over all 300 steps."""
+    from gpu_helpers import dev
+    from mc_pilco_amd import hipabi, ops, workloads
+
+    w = workloads.build("c5", device=dev())
+    assert (w.M, w.T, w.model.gps[0].N, w.model.G, w.model.D) == (2000, 300, 400, 6, 24)
+    torch.manual_seed(3)
+    x0 = w.sample_x0()
+    nz = lambda off=0: ops.NoiseSpec(seed=12, call=9, particle_offset=off)
+    with torch.no_grad():
+        a, ua, sa = ops.rollout(w.model, w.policy, nz(), x0, w.T, w.p_drop)
+        assert hipabi.lib().mcp_debug_last_particles_per_wg() == 16
+        b, ub, _ = ops.rollout(w.model, w.policy, nz(), x0, w.T, w.p_drop)
+        assert int(sa.item()) == 0
+        assert torch.equal(a, b) and torch.equal(ua, ub)
+        assert bool(torch.isfinite(a).all())
+        h = w.M // 2
+        lo = ops.rollout(w.model, w.policy, nz(0), x0[:h].contiguous(), w.T, w.p_drop)[0]
+        hi = ops.rollout(w.model, w.policy, nz(h), x0[h:].contiguous(), w.T, w.p_drop)[0]
+        # (1000 particles may run with another GP split per workgroup than 2000: every GP's sums are formed by the same code
+        #  in the same order whichever workgroup owns it, so the halves reproduce the whole bit for bit)
+        assert torch.equal(torch.cat([lo, hi], 1), a)
+        c, s = ops.expected_cost(w.cost, a)
+        assert np.isfinite(float(c)) and np.isfinite(float(s))
+
+
+def test_c5_adjoint_matches_finite_difference_at_full_width():
+    """M=2000, N=400 on a 40-step horizon, where a central difference is accurate: directional derivative of the expected cost."""
+    from gpu_helpers import dev
+    from mc_pilco_amd import ops, workloads
+
+    w = workloads.build("c5", device=dev(), T=40)
+    torch.manual_seed(21)
+    x0 = w.sample_x0()
+
+    def cost_of():
+        st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=77, call=5), x0, w.T, w.p_drop)
+        return ops.expected_cost(w.cost, st)[0]
+
+    for q in w.params:
+        q.grad = None
+    cost_of().backward()
+    g = [q.grad.detach().clone() for q in w.params]
+    gen = torch.Generator(device=dev())
+    gen.manual_seed(5)
+    dirs = [torch.randn(q.shape, dtype=q.dtype, device=q.device, generator=gen) for q in w.params]
+    gd = sum(float((a * b).sum()) for a, b in zip(g, dirs))
+    eps = 1e-6
+    with torch.no_grad():
+        for q, d in zip(w.params, dirs):
+            q.add_(eps * d)
+        cp = float(cost_of())
+        for q, d in zip(w.params, dirs):
+            q.sub_(2 * eps * d)
+        cm = float(cost_of())
+    fd = (cp - cm) / (2 * eps)
+    assert abs(fd - gd) < 1e-5 * max(abs(gd), 1e-3), (fd, gd)
+
+
+# -------------------------------------------------------------------------------------------------------------------------
+# the in-kernel Philox noise, statistically
+# -------------------------------------------------------------------------------------------------------------------------
+def _eps_of(model, pol, x0, seed, call, Tn=3):
+    """Standard normals the kernel drew, recovered from the trajectories: eps = (delta - mu) / sigma with mu, sigma from the
+    single-step posterior operator at each particle's own (x_t, u_t).  Returns [Tn-1, M, G]."""
+    from mc_pilco_amd import ops
+
+    with torch.no_grad():
+        st, inp, status = ops.rollout(model, pol, ops.NoiseSpec(seed=seed, call=call), x0, Tn, 0.0)
+        assert int(status.item()) == 0
+        out = []
+        for t in range(Tn - 1):
+            x, u = st[t], inp[t]
+            z = torch.cat([x[:, [0, 1, 3]], torch.sin(x[:, 2:3]), torch.cos(x[:, 2:3]), u], 1).contiguous()
+            es = []
+            for g, v in enumerate((1, 3)):
+                mu, var = ops.posterior(model.gps[g], z)
+                es.append(((st[t + 1][:, v] - x[:, v]) - mu.reshape(-1)) / torch.sqrt(var))
+            out.append(torch.stack(es, 1))
+    return torch.stack(out)
+
+
+def test_philox_normals_are_standard_normal_and_independent():
+    """>= 10^5 draws per stream: mean, variance, kurtosis and a Kolmogorov-Smirnov bound against N(0,1); no correlation across
+    the GP index, neighbouring particles, time steps, `call`s and seeds."""
+    from scipy import stats
+
+    from conftest import load_golden
+    from gpu_helpers import G, packed_model, packed_policy
+
+    fx = load_golden("rollout_se")
+    model = packed_model(fx, "se")
+    pol = packed_policy(fx, "se", requires_grad=False)
+    M = 65536
+    x0 = G(0.05 * np.random.RandomState(0).randn(M, 4))
+    e = _eps_of(model, pol, x0, seed=7, call=1).cpu().numpy()  # [2, M, 2]
+    n = e.size
+    assert n >= 2.5e5
+    flat = e.reshape(-1)
+    assert abs(flat.mean()) < 4.0 / np.sqrt(n)
+    assert abs(flat.var() - 1.0) < 4.0 * np.sqrt(2.0 / n)
+    assert abs(stats.kurtosis(flat, fisher=False) - 3.0) < 5.0 * np.sqrt(24.0 / n)
+    assert abs(stats.skew(flat)) < 5.0 * np.sqrt(6.0 / n)
+    assert stats.kstest(flat, "norm").statistic < 1.95 / np.sqrt(n)  # alpha = 0.001
+    assert np.abs(flat).max() < 6.5  # Box-Muller on 52-bit uniforms reaches the tails but not absurdly
+    for t in range(2):
+        for g in range(2):
+            col = e[t, :, g]
+            assert stats.kstest(col, "norm").statistic < 1.95 / np.sqrt(col.size)
+
+    def corr(a, b):
+        return abs(float(np.corrcoef(a.reshape(-1), b.reshape(-1))[0, 1]))
+
+    lim = 4.5 / np.sqrt(M)
+    assert corr(e[0, :, 0], e[0, :, 1]) < lim          # across GPs
+    assert corr(e[0, :-1, 0], e[0, 1:, 0]) < lim       # neighbouring particles
+    assert corr(e[0, :, 0], e[1, :, 0]) < lim          # across time steps
+    e2 = _eps_of(model, pol, x0, seed=7, call=2).cpu().numpy()
+    e3 = _eps_of(model, pol, x0, seed=8, call=1).cpu().numpy()
+    assert corr(e[0], e2[0]) < lim and corr(e[0], e3[0]) < lim  # across calls and seeds
+    assert not np.array_equal(e, e2)
+
+
+def _keep_bits(p, M, Tn, seed, call, forced=0):
+    """Dropout keep decisions of the in-kernel generator for every (t, particle, basis), read back EXACTLY: all RBF centres sit
+    far inside one huge lengthscale (phi == 1 to 1e-12), weights are powers of two (25 basis functions per input, 8 inputs = 200),
+    no squashing -> u_k (1 - p) is the integer sum_j 2^j keep_j.  Returns bool [Tn, M, 200]."""
+    from gpu_helpers import G, dev, forced_variant, spec_from
+    from mc_pilco_amd import ops
+
+    S, U, B = 4, 8, 200
+    Wm = np.zeros((U, B))
+    for b in range(B):
+        Wm[b // 25, b] = 2.0 ** (b % 25)
+    pol = ops.PackedPolicy("plain", S, torch.log(G(np.full((1, S), 1e7))), G(np.zeros((B, S))), G(Wm), 1.0, False)
+    D = S + U
+    sp = spec_from(np.full(D, 1e3), 0.1)
+    gp = ops.PackedGP(sp, G(np.zeros((16, D))), G(np.zeros(16)), G(1e-3 * np.eye(16)))
+    model = ops.PackedModel([gp, gp], S, U, 0.05, [], list(range(S)), [1, 3], [0, 2])
+    x0 = G(np.zeros((M, S)))
+    with forced_variant(forced), torch.no_grad():
+        st, inp, status = ops.rollout(model, pol, ops.NoiseSpec(seed=seed, call=call), x0, Tn, p)
+    assert int(status.item()) == 0
+    v = (inp * (1.0 - p)).cpu().numpy()
+    iv = np.rint(v).astype(np.int64)
+    assert np.abs(v - iv).max() < 1e-3 and iv.min() >= 0 and iv.max() < 2 ** 25
+    bits = ((iv[..., None] >> np.arange(25)) & 1).astype(bool)  # [Tn, M, U, 25]
+    return bits.reshape(Tn, M, B)
+
+
+@pytest.mark.parametrize("p", [0.25, 0.1])
+def test_philox_dropout_keep_rate_and_independence(p):
+    """keep-rate = 1 - p overall, per basis function, per time step and per word of the 4-basis Philox block; no correlation
+    between neighbouring basis functions (inside a block and across blocks), particles, steps and calls; and the 16-particle
+    tile kernel and the backward-compatible variants draw the very same bits."""
+    M, Tn = 4096, 4
+    k = _keep_bits(p, M, Tn, seed=3, call=1)
+    n = k.size
+    q = 1.0 - p
+    sd = np.sqrt(p * q)
+    assert abs(k.mean() - q) < 4.0 * sd / np.sqrt(n)
+    per_basis = k.reshape(-1, 200).mean(0)
+    assert np.abs(per_basis - q).max() < 5.0 * sd / np.sqrt(M * Tn)
+    per_step = k.reshape(Tn, -1).mean(1)
+    assert np.abs(per_step - q).max() < 4.5 * sd / np.sqrt(M * 200)
+    per_word = np.array([k[:, :, w::4].mean() for w in range(4)])
+    assert np.abs(per_word - q).max() < 4.5 * sd / np.sqrt(n / 4)
+
+    def corr(a, b):
+        return abs(float(np.corrcoef(a.reshape(-1).astype(float), b.reshape(-1).astype(float))[0, 1]))
+
+    lim = 4.5 / np.sqrt(M * Tn * 199)
+    assert corr(k[:, :, :-1], k[:, :, 1:]) < lim                      # neighbouring basis functions (3 of 4 pairs share a block)
+    assert corr(k[:, :, 3:-1:4], k[:, :, 4::4]) < 4.5 / np.sqrt(M * Tn * 49)  # across block boundaries only
+    assert corr(k[:, :-1], k[:, 1:]) < 4.5 / np.sqrt((M - 1) * Tn * 200)      # neighbouring particles
+    assert corr(k[:-1], k[1:]) < 4.5 / np.sqrt(M * (Tn - 1) * 200)            # consecutive steps
+    k2 = _keep_bits(p, M, Tn, seed=3, call=2)
+    assert corr(k, k2) < 4.5 / np.sqrt(n)
+    for code in (1, 4, 16):
+        assert np.array_equal(_keep_bits(p, 512, 2, seed=3, call=1, forced=code), k[:2, :512])
