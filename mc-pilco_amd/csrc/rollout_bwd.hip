@@ -43,11 +43,11 @@ struct BwdArgs {
   } while (0)
 
 struct BwdLayout {
-  int invl, rec, xn, xb, zb, db, ab, sf, sb, sn, cs, snm, csm, cmv, cnv, nvx, red, itab, total;
+  int invl, rec, xn, xb, zb, db, ab, sf, sb, sn, cs, snm, csm, cmv, cnv, nvx, red, gla, cen, itab, total;
   int pstride;  // doubles between the per-particle copies of xn..cs
 };
 __host__ __device__ inline int bwd_rec_len(int S, int U, int D, int G, bool pms = false) { return 2 * S + 2 * U + G * D + (pms ? S : 0); }
-__host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int PF, int NW, int PB, bool pms = false) {
+__host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int PF, int NW, int PB, bool pms = false, bool cen_lds = false) {
   BwdLayout L;
   int o = 0;
   auto take = [&](int n) {
@@ -76,6 +76,8 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
   L.pstride = o - o0;
   o = o0 + PB * L.pstride;
   L.red = take(PB * NW * PF);
+  L.gla = take(PB * PF);                      // the serial waves' share of dJ/dlog_lengthscales at the end of the sweep
+  L.cen = take(cen_lds ? PF * NW * 64 : 0);  // RBF centres, transposed [q][thread] (wide policy classes)
   L.itab = take((2 * MCP_MAX_GP + 2 * MCP_MAX_STATE + MCP_MAX_INPUT + 1) / 2 + 1);
   L.total = o;
   return L;
@@ -98,12 +100,14 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
-  const int tid = threadIdx.x, NT = blockDim.x, NW = NT >> 6, lane = tid & 63;
+  int tid = threadIdx.x, lane = tid & 63;  // (not const: laundered once per time step, see the sweep loop)
+  const int NT = blockDim.x, NW = NT >> 6;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
   const mcp_meas& ms = pl.meas;
   const bool pms = ms.n > 0;
-  const BwdLayout L = bwd_layout(S, U, D, G, PF, NW, PB, pms);
+  constexpr bool CENREG = PFM <= 8;  // narrow policies keep their centres in registers; wider ones in LDS (transposed: conflict-free)
+  const BwdLayout L = bwd_layout(S, U, D, G, PF, NW, PB, pms, !CENREG);
   const int NR = bwd_rec_len(S, U, D, G, pms);
   const int PS = L.pstride;
   const int sp = wv < PB ? wv : 0;  // the particle slot whose serial chain this wave runs
@@ -150,18 +154,22 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     for (int i = 0; i < pl.n_non_angle; ++i) t_pna[i] = pl.non_angle[i];
     for (int i = 0; i < pl.n_angle; ++i) t_pan[i] = pl.angle[i];
   }
-  // the widest policies (PFM > 24) re-read their centres every step (L1/L2 hits) instead of holding 64 more VGPRs
-  constexpr bool CENREG = PFM <= 24;
-  typedef const double __attribute__((address_space(1))) * gcptr_t;
-  gcptr_t cenrow = (gcptr_t)pl.centers + (size_t)imin(b, B - 1) * PF;
-  double cen[CENREG ? PFM : 1], gc[PFM], gl[PFM], wgt[UM], gw[UM];
+  // Per-thread state across the whole sweep: the thread's rows of dJ/dcentres and dJ/dweight (and, narrow class only, its
+  // centres).  dJ/dlog_lengthscales has NO per-thread accumulator: with rr = (s_q - c_bq)/l_q and t2 = 2 dd rr,
+  //   dJ/dlog l_q = sum_b -t2 rr = sum_b (dJ/dc_bq contribution) (s_q - c_bq) = - s_q sb_q - sum_b c_bq (dJ/dc_bq contribution),
+  // where sb_q = sum_b t2/l_q is the feature adjoint the serial wave forms anyway: it accumulates -s_q sb_q per step, and the
+  // centre term is one product with the finished dJ/dcentres at the end.  (3 PFM -> 2 PFM [1 PFM] doubles of live state per
+  // thread: the UR5 class no longer updates spilled accumulators through scratch every step.)
+  double* cen_l = smem + L.cen;
+  double cen[CENREG ? PFM : 1], gc[PFM], wgt[UM], gw[UM];
 #pragma unroll
   for (int q = 0; q < PFM; ++q) {
     if (CENREG) cen[q] = (act && q < PF) ? pl.centers[(size_t)b * PF + q] : 0.0;
     gc[q] = 0.0;
-    gl[q] = 0.0;
   }
-#define BW_CEN(q) (CENREG ? cen[CENREG ? (q) : 0] : cenrow[q])
+  if (!CENREG)
+    for (int q = 0; q < PF; ++q) cen_l[q * NT + tid] = act ? pl.centers[(size_t)b * PF + q] : 0.0;
+#define BW_CEN(q) (CENREG ? cen[CENREG ? (q) : 0] : cen_l[(q) * NT + tid])
 #pragma unroll
   for (int k = 0; k < UM; ++k) {
     wgt[k] = (act && k < U) ? pl.weight[(size_t)k * B + b] : 0.0;
@@ -206,7 +214,8 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   // the record traffic (address arithmetic for BW_RPT elements, ~1.3 k cycles per step) is kept off the serial waves when the
   // workgroup has others: measured on wave 0's critical path before
   const bool pf_split = NW > PB;
-  const int pf_tid = pf_split ? tid - 64 * PB : tid, pf_nt = pf_split ? NT - 64 * PB : NT;
+  int pf_tid = pf_split ? tid - 64 * PB : tid;  // (recomputed from the laundered id every step)
+  const int pf_nt = pf_split ? NT - 64 * PB : NT;
   auto prefetch = [&](double (&pre)[BW_RPT], int t, int mbase) {
 #pragma unroll
     for (int k = 0; k < BW_RPT; ++k) {
@@ -263,6 +272,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     return sx;
   };
 
+  double glacc = 0.0;  // serial waves, lane q < PF: - sum over this wave's particle-steps of s_q sb_q
   unsigned long long last_stamp = clock64();
   for (int mbase = blockIdx.x * PB; mbase < M; mbase += gridDim.x * PB) {
     const int msp = imin(mbase + sp, M - 1);  // particle of this wave's serial chain
@@ -277,6 +287,12 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     park(pre, cur);
     lds_barrier();
     for (int t = T - 1; t >= 0; --t) {
+      // thread / lane ids are laundered per step: what the unrolled feature loops derive from them (LDS addresses, predicates) is
+      // recomputed where it is used instead of being hoisted out of the sweep, kept live next to the accumulators and spilled
+      asm volatile("" : "+v"(tid));
+      lane = tid & 63;
+      pf_tid = pf_split ? tid - 64 * PB : tid;
+      const int b = tid;
       BW_STAMP(11);
       if (t > 0) prefetch(pre, t - 1, mbase);
       // ---- serial section: wave p for particle slot p -----------------------------------------------
@@ -292,6 +308,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
             double s = 0.0;
             for (int w = 0; w < NW; ++w) s += redp[w * PF + lane];
             sb[lane] = s;
+            glacc = fma(-sf[lane], s, glacc);  // sf still holds the features of step t+1
           }
           __builtin_amdgcn_wave_barrier();
           if (lane < S) {
@@ -446,7 +463,6 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
                 double rr = (sfp[q] - BW_CEN(q)) * invl[q];
                 double t2 = 2.0 * dd * rr;
                 gc[q] = fma(-t2, invl[q], gc[q]);
-                gl[q] = fma(-t2, rr, gl[q]);
                 v = t2 * invl[q];
               }
               t2v[i] = v;
@@ -472,6 +488,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += redp[w * PF + lane];
         sb[lane] = s;
+        glacc = fma(-sf[lane], s, glacc);
       }
       __builtin_amdgcn_wave_barrier();
       if (lane < S) {
@@ -503,17 +520,20 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       if (k < U) out[PF + (size_t)B * PF + (size_t)k * B + b] = gw[k];
   }
   lds_barrier();
+  double* gla = smem + L.gla;
 #pragma unroll
   for (int q = 0; q < PFM; ++q) {
     if (q < PF) {
-      double sm = wave_sum(gl[q]);
+      double sm = wave_sum(act ? -BW_CEN(q) * gc[q] : 0.0);  // - sum_b c_bq dJ/dc_bq
       if (lane == 0) red[wv * PF + q] = sm;
     }
   }
+  if (serial && lane < PF) gla[sp * PF + lane] = glacc;
   lds_barrier();
   for (int it = tid; it < PF; it += NT) {
     double sm = 0.0;
     for (int w = 0; w < NW; ++w) sm += red[w * PF + it];
+    for (int p = 0; p < PB; ++p) sm += gla[p * PF + it];
     out[it] = sm;
   }
 }
@@ -566,8 +586,10 @@ static int launch_bwd(const BwdArgs& a, int NT, hipStream_t st) {
   const bool pms = a.pol.meas.n > 0;
   if (PB * bwd_rec_len(md.S, md.U, md.D, md.G, pms) > BW_RPT * (NT / 64 > PB ? NT - 64 * PB : NT)) return MCP_ERR_LIMIT;
   const int grid = imin((a.M + PB - 1) / PB, 1024);
-  BwdLayout L = bwd_layout(md.S, md.U, md.D, md.G, a.pol.P, NT / 64, PB, pms);
+  BwdLayout L = bwd_layout(md.S, md.U, md.D, md.G, a.pol.P, NT / 64, PB, pms, PFM > 8);
   const size_t lds = sizeof(double) * (size_t)L.total;
+  if (lds > MCP_LDS_LIMIT) return MCP_ERR_LIMIT;
+  MCP_ENSURE_MAX_LDS(rollout_bwd_kernel<PFM, UM, MAXNT, WPE, PB>);
   hipLaunchKernelGGL((rollout_bwd_kernel<PFM, UM, MAXNT, WPE, PB>), dim3(grid), dim3(NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return grid;

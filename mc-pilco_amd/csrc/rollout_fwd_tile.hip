@@ -723,8 +723,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+  const int wv0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
   constexpr int P = TL_PT;
   const TileLayout L = tile_layout(S, U, D, G, PF, a.NpadMax, a.maxdeg);
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   }
   const bool writer = !GSH || gbeg == 0;  // states / inputs are identical in the workgroups of a cluster: one of them stores
   int* abortw = reinterpret_cast<int*>(dl + P * G);
-  if (GSH && tid == 0) *abortw = 0;
+  if (GSH && tid0 == 0) *abortw = 0;
   const int m0 = cluster * P;
   uint32_t bad = 0;
   const bool drop = pl.p_drop > 0.0;
@@ -764,12 +764,12 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   const int RT = CLS == 0 ? 1 : ((D + 1 + 15) >> 4);  // row tiles of [X^T;1]: a compile-time 1 for the small class
 
   // ---- one-time staging ------------------------------------------------------------------
-  for (int it = tid; it < PF; it += RF_NT) invl[it] = exp(-pl.log_ls[it]);
-  stage_gp_tables(md.gp, md.var_scale, G, D, gpl, kpar, tid);
+  for (int it = tid0; it < PF; it += RF_NT) invl[it] = exp(-pl.log_ls[it]);
+  stage_gp_tables(md.gp, md.var_scale, G, D, gpl, kpar, tid0);
   lds_barrier();
   // launch constants of the degree-2 polynomial term: sum_j alpha_j X_jc X_je (for d mu/dz)
   if (MAXDEG >= 2 && a.maxdeg >= 2) {  // (qa has no storage when maxdeg < 2)
-    for (int it = tid; it < G * D * D; it += RF_NT) {
+    for (int it = tid0; it < G * D * D; it += RF_NT) {
       const int g = it / (D * D), r = it - g * D * D, c = r / D, e = r - c * D;
       const GpL& gp = gpl[g];
       double s = 0.0;
@@ -782,8 +782,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   gptr_t wgt = (gptr_t)pl.weight;
 
   // thread (p, s) owns state component s of particle p; threads 256.. draw the process noise of the step
-  const bool own = tid < P * S;
-  const int op = own ? tid / S : 0, os = own ? tid - op * S : 0;
+  const bool own = tid0 < P * S;
+  const int op = own ? tid0 / S : 0, os = own ? tid0 - op * S : 0;
   const int om = imin(m0 + op, M - 1);
   const bool ovalid = own && (m0 + op < M);
   double xn = own ? a.x0[(size_t)om * S + os] : 0.0;
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     }
   }
   // the last P*G threads draw the process noise of step t+1 while phase F of the first GP keeps only a few waves busy
-  const int et = tid - (RF_NT - P * G);
+  const int et = tid0 - (RF_NT - P * G);
   const bool edraw = et >= 0;
   const int ep = edraw ? et / G : 0, eg = edraw ? et - ep * G : 0;
   auto draw_eps = [&](int tt) {
@@ -845,6 +845,15 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   lds_barrier();
 
   for (int t = 0; t < T; ++t) {
+    // Lane and wave ids are laundered once per time step: everything the phases derive from them (operand addresses, feature
+    // and particle indices, predicates -- hundreds of values over the unrolled operand groups of the wide classes) is then
+    // recomputed where it is used instead of being hoisted out of the time loop, kept live across every phase and spilled to
+    // scratch (UR5 class: 158 -> see tools/kernel_resources.py).  A handful of integer instructions per phase against
+    // scratch reloads with global-memory latency inside the loop.
+    int lane = lane0, wv = wv0, tid = tid0;
+    asm volatile("" : "+v"(lane));
+    asm volatile("" : "+v"(tid));
+    asm volatile("" : "+s"(wv));
     // ---- phase S: publish x_t, the GP / policy features of each state component ------------------
     double xm = xn;  // what the policy sees of this component
     if (own) {
@@ -937,6 +946,9 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     if (t == T - 1) break;
 
     for (int g = gbeg; g < gend; ++g) {
+      asm volatile("" : "+v"(lane));  // (again per GP: nothing derived from the ids stays live across the GP loop)
+      asm volatile("" : "+v"(tid));
+      asm volatile("" : "+s"(wv));
       const GpL& gp = gpl[g];
       const double* kp = kpar + g * KP_STRIDE(D);
       const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
