@@ -26,6 +26,23 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_variant(tag, defines, verbose=True):
+    """Experiment helper: a second library libmcpilco_hip_<tag>.so with extra -D defines (select it with MCPILCO_HIP_LIB)."""
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".%s.o" % tag))
+        if _stale(o, [s] + HEADERS):
+            cmd = [HIPCC] + FLAGS + ["-D" + d for d in defines] + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        objs.append(o)
+    lib = os.path.join(HERE, "libmcpilco_hip_%s.so" % tag)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", lib])
+    return lib
+
+
 def build(force=False, verbose=True):
     objs = []
     for src in SOURCES:
@@ -46,4 +63,8 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:  # python build.py --variant TAG DEF1 DEF2 ...
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        build(force="--force" in sys.argv)

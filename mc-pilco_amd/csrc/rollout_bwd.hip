@@ -83,6 +83,9 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
   return L;
 }
 
+#ifndef BW_LAUNDER
+#define BW_LAUNDER(PFM, PB) ((PFM) > 8 || (PB) > 1)  // (narrow class, one particle per workgroup -- the latency-bound small-swarm sweep: measured 7 % slower with it)
+#endif
 #ifndef BW_WPE_A
 #define BW_WPE_A 2
 #endif
@@ -273,6 +276,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   };
 
   double glacc = 0.0;  // serial waves, lane q < PF: - sum over this wave's particle-steps of s_q sb_q
+  double fprev = 0.0;  // the policy feature this lane formed in the previous iteration of the sweep (= of step t+1)
   unsigned long long last_stamp = clock64();
   for (int mbase = blockIdx.x * PB; mbase < M; mbase += gridDim.x * PB) {
     const int msp = imin(mbase + sp, M - 1);  // particle of this wave's serial chain
@@ -289,9 +293,11 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     for (int t = T - 1; t >= 0; --t) {
       // thread / lane ids are laundered per step: what the unrolled feature loops derive from them (LDS addresses, predicates) is
       // recomputed where it is used instead of being hoisted out of the sweep, kept live next to the accumulators and spilled
-      asm volatile("" : "+v"(tid));
-      lane = tid & 63;
-      pf_tid = pf_split ? tid - 64 * PB : tid;
+      if (BW_LAUNDER(PFM, PB)) {
+        asm volatile("" : "+v"(tid));
+        lane = tid & 63;
+        pf_tid = pf_split ? tid - 64 * PB : tid;
+      }
       const int b = tid;
       BW_STAMP(11);
       if (t > 0) prefetch(pre, t - 1, mbase);
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
             double s = 0.0;
             for (int w = 0; w < NW; ++w) s += redp[w * PF + lane];
             sb[lane] = s;
-            glacc = fma(-sf[lane], s, glacc);  // sf still holds the features of step t+1
+            glacc = fma(-fprev, s, glacc);  // fprev: this lane's policy feature of step t+1
           }
           __builtin_amdgcn_wave_barrier();
           if (lane < S) {
@@ -374,6 +380,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
             f = r[oM + lane];
           }
           sf[lane] = f;
+          fprev = f;
         }
         __builtin_amdgcn_wave_barrier();
         // through the GP feature map z=[x_na, sin, cos, u]; adjoint of the pre-squash activation
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += redp[w * PF + lane];
         sb[lane] = s;
-        glacc = fma(-sf[lane], s, glacc);
+        glacc = fma(-fprev, s, glacc);
       }
       __builtin_amdgcn_wave_barrier();
       if (lane < S) {

@@ -34,6 +34,9 @@ using namespace mcp;
 #define RF_MAX_NA 7  // accumulators per Jacobian item: 2 (SE), 3 (SE+P1), 7 (SE+P2)
 #define RF_MAX_CHUNKS (MCP_MAX_GP * (MCP_MAX_TRAIN / 128))
 #define RF_GS 8  // rows of Kinv per register buffer (two buffers in flight per wave)
+#ifndef RF_NRES
+#define RF_NRES 1  // register groups of Kinv a wave keeps resident for the whole rollout (GP-sharded 4-particle launch)
+#endif
 
 struct FwdLayout {
   int mk;  // dropout keep bits of the step, one int per (particle, 4 basis functions): drawn in phase S by idle waves
@@ -301,20 +304,37 @@ __device__ __forceinline__ void load_rows(v2d (&A)[RF_GS], gptr_t p, size_t rstr
 }
 
 // units [ua, ub) of one chunk; `base` already points at this lane's two columns of its first row,
-// `kk` at its k row; consecutive units are rstride / kstride apart
-template <int P>
+// `kk` at its k row; consecutive units are rstride / kstride apart.
+// RESIDENT GROUPS (NRES > 0): the unit stream of a launch is static, so a wave reads the same rows of Kinv every time step.
+// The first `nres` (<= NRES) register groups of the wave's first segment are loaded ONCE, before the time loop, and stay in
+// VGPRs for the whole rollout (res[][]): every step they cost FMAs only, and the L2 -> CU stream -- the bound of this phase at
+// 16-21 cycles per wave-load whatever else the CU does -- carries that much less.  They are consumed after the first streamed
+// buffer has been issued (their FMAs hide its latency) and in the same order as before: results are bit-identical.
+template <int P, int NRES>
 __device__ __forceinline__ void matvec_rows(gptr_t base, size_t rstride, const double* __restrict__ kk, int kstride,
-                                            int ua, int ub, int lane, double (&acc)[2][P]) {
-  gptr_t p = base + (size_t)ua * rstride;
+                                            int ua, int ub, int lane, double (&acc)[2][P], const v2d (&res)[NRES > 0 ? NRES : 1][RF_GS],
+                                            int nres) {
   const size_t gstep = (size_t)RF_GS * rstride;
-  int u0 = ua;
-  const int nfull = (ub - ua) / RF_GS;
+  int u0 = ua + nres * RF_GS;  // first streamed unit
+  gptr_t p = base + (size_t)u0 * rstride;
+  const int nfull = (ub - u0) / RF_GS;
   v2d A[RF_GS], Bf[RF_GS];
   KBlock<P> kA, kB;  // the k block of a register buffer is read when the buffer's loads are issued
   if (nfull > 0) {
     load_rows(A, p, rstride);
     kA = read_k_block<P>(kk + u0 * kstride, kstride, RF_GS, lane);
     p += gstep;
+  }
+  if (NRES > 0) {
+#pragma unroll
+    for (int r = 0; r < NRES; ++r) {
+      if (r < nres) {  // wave-uniform
+        const KBlock<P> kR = read_k_block<P>(kk + (ua + r * RF_GS) * kstride, kstride, RF_GS, lane);
+        consume_rows<P>(res[NRES > 0 ? r : 0], kR, RF_GS, acc);
+      }
+    }
+  }
+  if (nfull > 0) {
     for (int g = 0; g < nfull; g += 2) {
       const bool hasB = g + 1 < nfull;
       if (hasB) {
@@ -345,31 +365,65 @@ __device__ __forceinline__ void matvec_rows(gptr_t base, size_t rstride, const d
   }
 }
 
-template <int P>
+// the first segment of wave wv's share of the unit stream: chunk, unit range and this lane's base pointer
+struct VSeg {
+  int c, ua, ub, gl, rb, R, Npad, sub, li;
+  gptr_t base;
+};
+__device__ __forceinline__ VSeg v_segment(const GpL* gpl, int g0, const int* tab, int c, int u, int u1, int lane) {
+  VSeg q;
+  q.c = c;
+  const int cs = tab[TAB_CSTART + c], ce = tab[TAB_CSTART + c + 1];
+  q.gl = tab[TAB_CG + c];
+  q.rb = tab[TAB_CBASE + c];
+  q.R = tab[TAB_CR + c];
+  q.Npad = __builtin_amdgcn_readfirstlane(gpl[g0 + q.gl].Npad);
+  q.ua = u - cs;
+  q.ub = imin(ce, u1) - cs;
+  q.sub = (q.R == 2) ? (lane >> 5) : 0;   // which of the unit's R rows this lane reads
+  q.li = (q.R == 2) ? (lane & 31) : lane;  // lane's column pair inside the chunk
+  const int i = q.rb + 2 * q.li;
+  q.base = (gptr_t)gpl[g0 + q.gl].Kinv + (size_t)q.sub * q.Npad + (i < q.Npad ? i : q.rb);
+  return q;
+}
+
+// loads the resident groups of this wave (once per launch); returns how many there are
+template <int NRES>
+__device__ __forceinline__ int load_resident(const GpL* gpl, int g0, const int* tab, int NC, int wv, int lane, v2d (&res)[NRES > 0 ? NRES : 1][RF_GS]) {
+  if (NRES == 0) return 0;
+  const int total = tab[TAB_CSTART + NC];
+  const int L = (total + RF_NW - 1) / RF_NW;
+  const int u = wv * L, u1 = imin(total, u + L);
+  int nres = 0;
+  if (u < u1) {
+    const VSeg q = v_segment(gpl, g0, tab, tab[TAB_WC0 + wv], u, u1, lane);
+    nres = imin(NRES, (q.ub - q.ua) / RF_GS);
+    const size_t rstride = (size_t)q.R * q.Npad;
+#pragma unroll
+    for (int r = 0; r < NRES; ++r)
+      if (r < nres) load_rows(res[NRES > 0 ? r : 0], q.base + (size_t)(q.ua + r * RF_GS) * rstride, rstride);
+  }
+  return nres;
+}
+
+template <int P, int NRES = 0>
 __device__ __forceinline__ void phase_v(const GpL* gpl, int g0, const int* tab, int NC, int NpadMax, const double* kb, double* part,
-                                        int wv, int lane) {
+                                        int wv, int lane, const v2d (&res)[NRES > 0 ? NRES : 1][RF_GS], int nres) {
   const int total = tab[TAB_CSTART + NC];
   const int L = (total + RF_NW - 1) / RF_NW;
   int u = wv * L;
   const int u1 = imin(total, u + L);
   if (u >= u1) return;
   int c = tab[TAB_WC0 + wv];
+  bool first = true;
   while (u < u1) {
-    const int cs = tab[TAB_CSTART + c], ce = tab[TAB_CSTART + c + 1];
-    const int gl = tab[TAB_CG + c], rb = tab[TAB_CBASE + c], R = tab[TAB_CR + c];
-    const int Npad = __builtin_amdgcn_readfirstlane(gpl[g0 + gl].Npad);
-    const double* Kinv = gpl[g0 + gl].Kinv;
-    const int ua = u - cs, ub = imin(ce, u1) - cs;
-    const int sub = (R == 2) ? (lane >> 5) : 0;   // which of the unit's R rows this lane reads
-    const int li = (R == 2) ? (lane & 31) : lane;  // lane's column pair inside the chunk
-    const int i = rb + 2 * li;
-    const bool ok = i < Npad;
+    const VSeg q = v_segment(gpl, g0, tab, c, u, u1, lane);
     double acc[2][P];
 #pragma unroll
     for (int p = 0; p < P; ++p) acc[0][p] = acc[1][p] = 0.0;
-    gptr_t base = (gptr_t)Kinv + (size_t)sub * Npad + (ok ? i : rb);
-    matvec_rows<P>(base, (size_t)R * Npad, kb + (gl * NpadMax + sub) * P, R * P, ua, ub, lane, acc);
-    if (R == 2) {
+    matvec_rows<P, NRES>(q.base, (size_t)q.R * q.Npad, kb + (q.gl * NpadMax + q.sub) * P, q.R * P, q.ua, q.ub, lane, acc, res, first ? nres : 0);
+    first = false;
+    if (q.R == 2) {
       // fold rows j+1 (lanes 32..63) into rows j (lanes 0..31)
 #pragma unroll
       for (int p = 0; p < P; ++p) {
@@ -378,14 +432,14 @@ __device__ __forceinline__ void phase_v(const GpL* gpl, int g0, const int* tab, 
       }
     }
     double* slot = part + (c + wv) * 128 * P;  // slot id = chunk + wave: unique, contiguous per chunk
-    if (lane == li) {
+    if (lane == q.li) {
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        slot[(2 * li) * P + p] = acc[0][p];
-        slot[(2 * li + 1) * P + p] = acc[1][p];
+        slot[(2 * q.li) * P + p] = acc[0][p];
+        slot[(2 * q.li + 1) * P + p] = acc[1][p];
       }
     }
-    u += ub - ua;
+    u += q.ub - q.ua;
     ++c;
   }
 }
@@ -658,8 +712,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
   const mcp_gp* gps = md.gp;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+  const int wv0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
   const int NpadMax = a.NpadMax, GB = a.GB;
   const FwdLayout L = fwd_layout(P, S, U, D, G, PF, B, NpadMax, a.maxdeg, GB, a.NCmax, XLDS, GSH ? 1 : G);
@@ -695,7 +749,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   const int gcluster = GSH ? a.m_off / P + cluster : cluster;  // cluster index in the whole swarm (hand-off slots)
   const bool writer = !GSH || myg == 0;  // states / inputs are identical in the workgroups of a cluster: one of them stores
   int* abortw = reinterpret_cast<int*>(dl + 2 * P * G);
-  if (GSH && tid == 0) *abortw = 0;
+  if (GSH && tid0 == 0) *abortw = 0;
   const int m0 = (GSH ? a.m_off : 0) + cluster * P;
   const int Mend = GSH ? a.m_off + a.m_cnt : M;  // one past the last particle of this launch (M itself: strides of the [T][M][.] arrays)
   uint32_t bad = 0;
@@ -705,37 +759,37 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   const int nna = md.n_not_angle, na = md.n_angle;
 
   // ---- one-time staging ------------------------------------------------------------------
-  for (int it = tid; it < PF; it += RF_NT) invl[it] = exp(-pl.log_ls[it]);
+  for (int it = tid0; it < PF; it += RF_NT) invl[it] = exp(-pl.log_ls[it]);
   double* umax_l = invl + PF;
-  if (tid < U) umax_l[tid] = pl.u_max[tid];
+  if (tid0 < U) umax_l[tid0] = pl.u_max[tid0];
   // the GPs this workgroup evaluates: all of them, or (GSH) its own one, which then lives in slot 0 of every LDS table
   const int GL = GSH ? 1 : G;
   const mcp_gp* gps_l = gps + myg;
-  stage_gp_tables(gps_l, md.var_scale + myg, GL, D, gpl, kpar, tid);
+  stage_gp_tables(gps_l, md.var_scale + myg, GL, D, gpl, kpar, tid0);
   if (XLDS) {
     for (int g = 0; g < GL; ++g) {
       const mcp_gp& gp = gps_l[g];
-      for (int it = tid; it < D * gp.Npad; it += RF_NT) {
+      for (int it = tid0; it < D * gp.Npad; it += RF_NT) {
         int d = it / gp.Npad, j = it - d * gp.Npad;
         xt_l[(g * D + d) * NpadMax + j] = gp.Xt[it];
       }
-      for (int it = tid; it < gp.Npad; it += RF_NT) al_l[g * NpadMax + it] = gp.alpha[it];
+      for (int it = tid0; it < gp.Npad; it += RF_NT) al_l[g * NpadMax + it] = gp.alpha[it];
     }
-    for (int it = tid; it < B * PF; it += RF_NT) cen_l[it] = pl.centers[it];
-    for (int it = tid; it < U * B; it += RF_NT) wgt_l[it] = pl.weight[it];
+    for (int it = tid0; it < B * PF; it += RF_NT) cen_l[it] = pl.centers[it];
+    for (int it = tid0; it < U * B; it += RF_NT) wgt_l[it] = pl.weight[it];
   }
   const double* cen = XLDS ? cen_l : pl.centers;
   const double* wgt = XLDS ? wgt_l : pl.weight;
   lds_barrier();
   int NC = 0;
   if (GSH)
-    NC = build_chunk_table(gpl, 0, 1, tab, tid);
+    NC = build_chunk_table(gpl, 0, 1, tab, tid0);
   else if (GB >= G)
-    NC = build_chunk_table(gpl, 0, G, tab, tid);
+    NC = build_chunk_table(gpl, 0, G, tab, tid0);
 
   // thread (p, s) owns state component s of particle p
-  const bool own = tid < P * S;
-  const int op = own ? tid / S : 0, os = own ? tid - op * S : 0;
+  const bool own = tid0 < P * S;
+  const int op = own ? tid0 / S : 0, os = own ? tid0 - op * S : 0;
   const int om = imin(m0 + op, Mend - 1);
   const bool ovalid = own && (m0 + op < Mend);
   double xn = own ? a.x0[(size_t)om * S + os] : 0.0;
@@ -764,8 +818,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   // carries the previous noisy position, noisy velocity and filtered velocity.
   const mcp_meas& ms = pl.meas;
   const bool pms = ms.n > 0;
-  int pm_pos = -1, pm_vel = -1, pm_pairlane = lane;
-  double pm_std = 0.0;  // (looked up here with a uniform index: per-lane indexing of the by-value argument would spill it)
+  int pm_pos = -1, pm_vel = -1, pm_pairlane = lane0;
+  double pm_std = 0.0;  // (looked up here with a uniform index: per-lane0 indexing of the by-value argument would spill it)
   if (pms && own) {
     for (int i = 0; i < ms.n; ++i) {
       if (ms.pos[i] == os) {
@@ -784,9 +838,18 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   for (int g = 0; g < G; ++g)
     if (own && md.not_vel[g] == os) vel_of_pos = md.vel[g];
   const double Ts = md.Ts;
+  // resident groups of phase V (see matvec_rows): the GP-sharded launch of the headline shape keeps RF_NRES register groups of
+  // its wave's share of Kinv for the whole rollout
+  constexpr int NRES = (GSH && MAXDEG == 0 && P == 4) ? RF_NRES : 0;
+  v2d vres[NRES > 0 ? NRES : 1][RF_GS];
+  if (NRES > 0) lds_barrier();  // the chunk table (written by thread 0) is read by every wave
+  const int nres = load_resident<NRES>(gpl, 0, tab, NC, wv0, lane0, vres);
   unsigned long long last_stamp = clock64();
 
   for (int t = 0; t < T; ++t) {
+    // (Laundering the ids per step, as the 16-particle kernel and the backward sweep do to stay out of scratch, was measured
+    //  here and dropped: 219 -> 189 VGPRs, but phases K / S / PHI pay for the recomputed decodes: +0.95 k cycles per step.)
+    const int tid = tid0, wv = wv0, lane = lane0;
     // ---- phase S: publish x_t and everything derived from a single state component --------------
     double xm = xn;  // what the policy sees of this component
     if (pms && wv == 0) {
@@ -925,7 +988,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       phase_k<P, XLDS, MAXDEG>(gpl, kpar, g0, gn, D, NpadMax, z, xt_l, kb, ks, pa, pb, tid);
       lds_barrier();
       RF_STAMP(3);
-      phase_v<P>(gpl, g0, tab, NC, NpadMax, kb, part, wv, lane);
+      phase_v<P, NRES>(gpl, g0, tab, NC, NpadMax, kb, part, wv, lane, vres, nres);
       lds_barrier();
       RF_STAMP(4);
       RF_STAMP(5);
@@ -1066,7 +1129,10 @@ __global__ __launch_bounds__(RF_NT) void posterior_fwd_kernel(PostArgs a) {
   __syncthreads();
   phase_k<P, false, 2>(gpl, kpar, 0, 1, D, NpadMax, z, nullptr, kb, ks, pa, pb, tid);
   __syncthreads();
-  phase_v<P>(gpl, 0, tab, NC, NpadMax, kb, part, wv, lane);
+  {
+    v2d nores[1][RF_GS];
+    phase_v<P, 0>(gpl, 0, tab, NC, NpadMax, kb, part, wv, lane, nores, 0);
+  }
   __syncthreads();
   phase_j<P, false, 2>(gpl, 0, 1, D, NpadMax, nullptr, nullptr, kb, ks, pa, pb, vb, tab, part, red, wv, lane);
   __syncthreads();

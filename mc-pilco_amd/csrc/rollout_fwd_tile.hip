@@ -41,7 +41,7 @@ struct TileLayout {
   int invl, xs, us, z, sf, dl, eps, ks, kv, qa, mup, gpl, kpar, scr, total;
   int ptile, upart;  // policy phase: per-wave phi tiles (alias the k / v panels, idle then, when those are large enough) and partial sums  // offsets in doubles
   int nslot;   // phase-J partial-tile slots in scr
-  int vslots;  // phase-V partial (32x16) slots in scr
+  int vslots;  // phase-V partial (32x16) slots in scr (7 let all 8 waves share the remainder blocks)
 };
 
 __host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, int PF, int NpadMax, int maxdeg) {
@@ -433,6 +433,30 @@ __device__ __forceinline__ int tile_j_reduce(v4d (&acc)[2][CT], int RT, double* 
   }
   if (wv < active) tile_j_store<CT>(acc, RT, scr + wv * slot, lane);
   return active;  // partials left in the slots
+}
+
+// Brings the 8 waves' partial tiles of phase J together: result (fixed summation order) in slot 0 of `scr`, where phase F reads
+// R.  With room for 8 slots in `scr` every wave simply parks its tiles there.  The wide classes have room for 1-2 slots only
+// (UR5: 12 KB per slot beside 115 KB of k / v panels): their waves park the tiles in the k / v panels instead -- dead once
+// every wave has left phase J, one barrier -- which replaces the pairwise hand-down through the few slots (three rounds of
+// store / barrier / add / barrier).
+template <int CT>
+__device__ __forceinline__ void tile_j_finish(v4d (&acc)[2][CT], int RT, double* scr, int nslot, double* panels, int panel_doubles, int wv,
+                                              int lane, int tid) {
+  const int slot = RT * CT * 256;
+  const bool in_panels = nslot < RF_NW && RF_NW * slot <= panel_doubles;
+  double* base = in_panels ? panels : scr;
+  if (in_panels) lds_barrier();  // every wave is done reading k and v
+  const int nfin = tile_j_reduce<CT>(acc, RT, base, in_panels ? RF_NW : nslot, wv, lane);
+  lds_barrier();
+  if (nfin > 1 || in_panels) {  // add the partials with all threads (fixed order), result in slot 0 of scr
+    for (int e = tid; e < slot; e += RF_NT) {
+      double sacc = base[e];
+      for (int w = 1; w < nfin; ++w) sacc += base[w * slot + e];
+      scr[e] = sacc;
+    }
+    lds_barrier();
+  }
 }
 
 // R[c][kind][p] = sum of the nfin partials; tile (c>>4, kind), element (row c&15, col p) in the accumulator layout
@@ -957,54 +981,75 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       lds_barrier();
       TL_STAMP(3);
       // ---- phase V ---------------------------------------------------------------------------
+      // Work = 32-row blocks of v x 16-row batches of the summation index.  Wave w takes blocks w, w + 8, ... in full; the
+      // last (nblk mod 8) blocks are dealt as ONE contiguous run of batches cut into 8 equal shares, so a share is at most two
+      // pieces (the tail of one block, the head of the next) and every wave carries the same load whatever nblk mod 8 is
+      // (Npad = 400: 41 batches per wave instead of 50 for five of them and 25 for the rest).  The piece that starts a block
+      // collects the partial tiles of the others through the scratch slots, in wave order (fixed summation order).
       {
-        const VSched q = tile_v_sched(Npad, L.vslots);
-        v4d acc[MAXTASK][2];
-        int blk[MAXTASK];
+        constexpr int NACC = MAXTASK + 1;
+        const int nblk = (Npad + 31) >> 5, nb = Npad >> 4;  // blocks; 16-row batches per block
+        const int nfull = nblk >> 3, rem = nblk & 7;
+        const int nshare = imin(RF_NW, L.vslots + 1);  // waves that share the remainder run (one scratch slot per non-collecting piece)
+        // batches per share; with too few scratch slots for equal shares, whole blocks (one per wave, no partial tiles at all)
+        const int tot = rem * nb, per = imin(nb, (tot + nshare - 1) / nshare);
+        const int s0 = imin(wv * per, tot), s1 = imin(tot, s0 + per);
+        v4d acc[NACC][2];
+        int blk[NACC];     // block of accumulator r (-1: unused)
+        bool coll[NACC];   // this accumulator's piece starts its block: it collects and stores
 #pragma unroll
-        for (int r = 0; r < MAXTASK; ++r) {
+        for (int r = 0; r < NACC; ++r) {
           acc[r][0] = (v4d){0.0, 0.0, 0.0, 0.0};
           acc[r][1] = (v4d){0.0, 0.0, 0.0, 0.0};
           blk[r] = -1;
+          coll[r] = false;
         }
-        const bool in_rem = q.rem > 0 && wv < q.rem * q.s;
-        const int part = in_rem ? wv % q.s : 0;
+        const int ba = rem ? s0 / nb : 0;                    // remainder block of piece A (index among the remainder blocks)
+        const int a0 = s0 - ba * nb, a1 = imin(nb, s1 - ba * nb);  // its batches [a0, a1)
+        const int b1 = s1 - (ba + 1) * nb;                    // piece B: batches [0, b1) of remainder block ba + 1 (if b1 > 0)
 #pragma unroll
-        for (int r = 0; r < MAXTASK; ++r) {
-          if (r < q.nfull) {
+        for (int r = 0; r < NACC; ++r) {
+          if (r < nfull) {
             blk[r] = r * RF_NW + wv;
+            coll[r] = true;
             tile_v_block(gp.Kinv, Npad, blk[r] * 32, 0, Npad, kv, lane, acc[r][0], acc[r][1]);
-          } else if (r == q.nfull && in_rem) {
-            blk[r] = q.nfull * RF_NW + wv / q.s;
-            const int js = part * q.Jp, je = imin(Npad, js + q.Jp);
-            if (js < je) tile_v_block(gp.Kinv, Npad, blk[r] * 32, js, je, kv, lane, acc[r][0], acc[r][1]);
+          } else if (r == nfull && s0 < s1) {
+            blk[r] = nfull * RF_NW + ba;
+            coll[r] = a0 == 0;
+            tile_v_block(gp.Kinv, Npad, blk[r] * 32, 16 * a0, 16 * a1, kv, lane, acc[r][0], acc[r][1]);
+          } else if (r == nfull + 1 && s0 < s1 && b1 > 0) {
+            blk[r] = nfull * RF_NW + ba + 1;
+            coll[r] = true;
+            tile_v_block(gp.Kinv, Npad, blk[r] * 32, 0, 16 * b1, kv, lane, acc[r][0], acc[r][1]);
           }
         }
-        // partial tiles of the split blocks -> scratch (slot = block-in-remainder * (s-1) + part-1)
+        // a piece that does not start its block (only piece A can; never wave 0) -> scratch slot wv - 1
 #pragma unroll
-        for (int r = 0; r < MAXTASK; ++r) {
-          if (r == q.nfull && in_rem && part > 0) {
-            double* s = scr + ((wv / q.s) * (q.s - 1) + part - 1) * 512;
+        for (int r = 0; r < NACC; ++r) {
+          if (r == nfull && blk[r] >= 0 && !coll[r]) {
+            double* sl = scr + (wv - 1) * 512;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              s[i * 64 + lane] = acc[r][0][i];
-              s[256 + i * 64 + lane] = acc[r][1][i];
+              sl[i * 64 + lane] = acc[r][0][i];
+              sl[256 + i * 64 + lane] = acc[r][1][i];
             }
           }
         }
         lds_barrier();  // every wave is done reading k: v may overwrite it
         TL_STAMP(4);
 #pragma unroll
-        for (int r = 0; r < MAXTASK; ++r) {
-          if (blk[r] < 0) continue;
-          if (r == q.nfull && in_rem) {
-            if (part > 0) continue;
-            for (int o = 1; o < q.s; ++o) {
-              const double* s = scr + ((wv / q.s) * (q.s - 1) + o - 1) * 512;
+        for (int r = 0; r < NACC; ++r) {
+          if (blk[r] < 0 || !coll[r]) continue;
+          if (r >= nfull) {
+            // the other pieces of this block: the waves after mine whose share starts strictly inside it, in wave order
+            const int beta = blk[r] - nfull * RF_NW;
+            const int lim = imin((beta + 1) * nb, tot);
+            for (int w2 = wv + 1; w2 < RF_NW && w2 * per < lim; ++w2) {
+              const double* sl = scr + (w2 - 1) * 512;
 #pragma unroll
               for (int i = 0; i < 4; ++i) {
-                acc[r][0][i] += s[i * 64 + lane];
-                acc[r][1][i] += s[256 + i * 64 + lane];
+                acc[r][0][i] += sl[i * 64 + lane];
+                acc[r][1][i] += sl[256 + i * 64 + lane];
               }
             }
           }
@@ -1022,32 +1067,23 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       lds_barrier();
       TL_STAMP(5);
       // ---- phase J -----------------------------------------------------------------------------
-      int CTg, nfin;
+      int CTg;
+      const int panel_doubles = 2 * a.NpadMax * TL_KR;  // ks and kv are adjacent in the layout
       if (MAXDEG == 0 || deg == 0) {
         v4d acc[2][TL_NCOL(0)];
         tile_phase_j<0, 1>(gp, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
-        nfin = tile_j_reduce<TL_NCOL(0)>(acc, RT, scr, L.nslot, wv, lane);
+        tile_j_finish<TL_NCOL(0)>(acc, RT, scr, L.nslot, ks, panel_doubles, wv, lane, tid);
         CTg = TL_NCOL(0);
       } else if (deg == 1) {
         v4d acc[2][TL_NCOL(1)];
         tile_phase_j<1, 1>(gp, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
-        nfin = tile_j_reduce<TL_NCOL(1)>(acc, RT, scr, L.nslot, wv, lane);
+        tile_j_finish<TL_NCOL(1)>(acc, RT, scr, L.nslot, ks, panel_doubles, wv, lane, tid);
         CTg = TL_NCOL(1);
       } else {
         v4d acc[2][TL_NCOL(2)];
         tile_phase_j<2, NG>(gp, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
-        nfin = tile_j_reduce<TL_NCOL(2)>(acc, RT, scr, L.nslot, wv, lane);
+        tile_j_finish<TL_NCOL(2)>(acc, RT, scr, L.nslot, ks, panel_doubles, wv, lane, tid);
         CTg = TL_NCOL(2);
-      }
-      lds_barrier();
-      if (nfin > 1) {  // add the partials with all threads (fixed order), result in slot 0
-        const int slot = RT * CTg * 256;
-        for (int e = tid; e < slot; e += RF_NT) {
-          double sacc = scr[e];
-          for (int w = 1; w < nfin; ++w) sacc += scr[w * slot + e];
-          scr[e] = sacc;
-        }
-        lds_barrier();
       }
       TL_STAMP(6);
       // ---- phase F: moments, sample, d delta/dz -------------------------------------------------

@@ -11,7 +11,7 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmcpilco_hip.so")
+LIB_PATH = os.environ.get("MCPILCO_HIP_LIB") or os.path.join(HERE, "libmcpilco_hip.so")  # (the override is for kernel experiments)
 
 MAX_GP, MAX_STATE, MAX_INPUT, MAX_GPDIM, MAX_PFEAT, MAX_BASIS, MAX_TRAIN = 8, 16, 8, 32, 32, 1024, 1024
 OK = 0
