@@ -108,6 +108,39 @@ __device__ __forceinline__ void wave_sum_first(double (&v)[N], int n) {
   }
 }
 
+// Eight wave sums at once by pair-halving: at every stage two values are folded into one register -- a lane keeps the value its
+// own lane-index bit selects and receives the partner lane's copy of the same value -- so the live values halve (8 -> 4 -> 2 -> 1)
+// while the lanes that hold a given value's partial sums spread over the wave: 7 exchanges + 3 single-value all-reduce stages
+// instead of 8 x 6 (wave_sum_multi).  On return lane l holds the wave total of value (l & 7), in every lane.
+// Exchanges: lane ^ 1, ^ 2 by quad_perm; ^ 4 by row_shl:4 / row_shr:4 under bank masks (which also pick, per bank, WHICH of the
+// two values is fetched: no select on the receive side); ^ 8 by row_ror:8; ^ 16, ^ 32 through the LDS crossbar (ds_bpermute).
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_merge(double old, double v) {
+  int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, BANK, false);
+  int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, BANK, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_pack8(const double (&v)[8], int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+  double w[4], x[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // lane ^ 1: quad_perm [1,0,3,2]
+    const double keep = b0 ? v[2 * i + 1] : v[2 * i], send = b0 ? v[2 * i] : v[2 * i + 1];
+    w[i] = keep + dpp_take<0xB1, 0xf>(send);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {  // lane ^ 2: quad_perm [2,3,0,1]
+    const double keep = b1 ? w[2 * i + 1] : w[2 * i], send = b1 ? w[2 * i] : w[2 * i + 1];
+    x[i] = keep + dpp_take<0x4E, 0xf>(send);
+  }
+  // lane ^ 4: banks 0, 2 (bit 2 clear) keep x[0] and fetch x[0] of lane + 4; banks 1, 3 keep x[1] and fetch x[1] of lane - 4
+  double y = (b2 ? x[1] : x[0]) + dpp_merge<0x114, 0xA>(dpp_merge<0x104, 0x5>(0.0, x[0]), x[1]);
+  y += dpp_take<0x128, 0xf>(y);  // lane ^ 8: row_ror:8
+  y += __shfl_xor(y, 16);
+  y += __shfl_xor(y, 32);
+  return y;
+}
+
 // ---------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011), counter-based: draws depend only on
 // (seed, call, global particle, time step, stream, index) -- never on launch geometry.

@@ -114,25 +114,33 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   const int NR = bwd_rec_len(S, U, D, G, pms);
   const int PS = L.pstride;
   const int sp = wv < PB ? wv : 0;  // the particle slot whose serial chain this wave runs
-  double* invl = smem + L.invl;
-  volatile double* rec = smem + L.rec;  // [2][PB][NR]
-  volatile double* xn = smem + L.xn + sp * PS;  // adjoint of x_{t+1}
-  volatile double* xb = smem + L.xb + sp * PS;  // adjoint of x_t without the policy path
-  volatile double* zb = smem + L.zb + sp * PS;
-  volatile double* db = smem + L.db + sp * PS;
-  volatile double* ab = smem + L.ab + sp * PS;
-  volatile double* sf = smem + L.sf + sp * PS;
-  volatile double* sb = smem + L.sb + sp * PS;
-  volatile double* sn = smem + L.sn + sp * PS;
-  volatile double* cs = smem + L.cs + sp * PS;
-  volatile double* snm = pms ? smem + L.snm + sp * PS : sn;  // measured angles' trig (== sn/cs without a measurement model)
-  volatile double* csm = pms ? smem + L.csm + sp * PS : cs;
-  volatile double* cmv = smem + L.cmv + sp * PS;
-  volatile double* cnv = smem + L.cnv + sp * PS;
-  volatile double* nvx = smem + L.nvx + sp * PS;
-  const volatile double* sf_all = smem + L.sf;  // particle p at + p * PS
-  const volatile double* ab_all = smem + L.ab;
-  volatile double* red = smem + L.red;  // [PB][NW][PF]
+  // Every LDS array is addressed through an explicit address-space-3 pointer.  Through generic pointers the serial section's
+  // volatile accesses compile to FLAT loads / stores (57 + 46 in the cart-pole instantiation): slower than ds_read / ds_write on
+  // the one dependent chain that bounds the sweep, each one waited for with vmcnt(0) AND lgkmcnt(0); and hipcc 7.2 hoists the
+  // LDS -> flat address casts out of the sweep and then fails its own machine verifier on some of them.
+  typedef volatile double __attribute__((address_space(3))) * vlds_t;
+  typedef const double __attribute__((address_space(3))) * clds_t;
+  typedef double __attribute__((address_space(3))) * lds_t;
+  lds_t invl_w = (lds_t)(smem + L.invl);
+  clds_t invl = (clds_t)(smem + L.invl);
+  vlds_t rec = (vlds_t)(smem + L.rec);  // [2][PB][NR]
+  vlds_t xn = (vlds_t)(smem + L.xn + sp * PS);  // adjoint of x_{t+1}
+  vlds_t xb = (vlds_t)(smem + L.xb + sp * PS);  // adjoint of x_t without the policy path
+  vlds_t zb = (vlds_t)(smem + L.zb + sp * PS);
+  vlds_t db = (vlds_t)(smem + L.db + sp * PS);
+  vlds_t ab = (vlds_t)(smem + L.ab + sp * PS);
+  vlds_t sf = (vlds_t)(smem + L.sf + sp * PS);
+  vlds_t sb = (vlds_t)(smem + L.sb + sp * PS);
+  vlds_t sn = (vlds_t)(smem + L.sn + sp * PS);
+  vlds_t cs = (vlds_t)(smem + L.cs + sp * PS);
+  vlds_t snm = pms ? (vlds_t)(smem + L.snm + sp * PS) : sn;  // measured angles' trig (== sn/cs without a measurement model)
+  vlds_t csm = pms ? (vlds_t)(smem + L.csm + sp * PS) : cs;
+  vlds_t cmv = (vlds_t)(smem + L.cmv + sp * PS);
+  vlds_t cnv = (vlds_t)(smem + L.cnv + sp * PS);
+  vlds_t nvx = (vlds_t)(smem + L.nvx + sp * PS);
+  clds_t sf_all = (clds_t)(smem + L.sf);  // particle p at + p * PS
+  clds_t ab_all = (clds_t)(smem + L.ab);
+  vlds_t red = (vlds_t)(smem + L.red);  // [PB][NW][PF]
   // integer / per-input tables in LDS: indexing the by-value kernel argument with a per-lane index would
   // make the compiler spill it to scratch
   int* t_vel = reinterpret_cast<int*>(smem + L.itab);
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   const int oX = 0, oU = S, oGX = S + U, oGU = 2 * S + U, oJ = 2 * S + 2 * U;
   const int oM = pms ? oJ + G * D : oX;  // measured state (what the policy was evaluated on)
 
-  for (int it = tid; it < PF; it += NT) invl[it] = exp(-pl.log_ls[it]);
+  for (int it = tid; it < PF; it += NT) invl_w[it] = exp(-pl.log_ls[it]);
   if (tid == 0) {
     for (int g = 0; g < G; ++g) {
       t_vel[g] = md.vel[g];
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   // where sb_q = sum_b t2/l_q is the feature adjoint the serial wave forms anyway: it accumulates -s_q sb_q per step, and the
   // centre term is one product with the finished dJ/dcentres at the end.  (3 PFM -> 2 PFM [1 PFM] doubles of live state per
   // thread: the UR5 class no longer updates spilled accumulators through scratch every step.)
-  double* cen_l = smem + L.cen;
+  lds_t cen_l = (lds_t)(smem + L.cen);
   double cen[CENREG ? PFM : 1], gc[PFM], wgt[UM], gw[UM];
 #pragma unroll
   for (int q = 0; q < PFM; ++q) {
@@ -305,8 +313,8 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       if (serial) {
         // the record of this step was parked before the last workgroup barrier and is not written again until the next one:
         // plain loads (the compiler may batch them), unlike the section's own scratch arrays, which need program order
-        const double* r = const_cast<const double*>(rec) + cur * NRP + sp * NR;
-        const volatile double* redp = red + sp * NW * PF;
+        clds_t r = (clds_t)(smem + L.rec) + cur * NRP + sp * NR;
+        const vlds_t redp = red + sp * NW * PF;
         const bool last = (t == T - 1);
         if (!last) {
           // finish step t+1: adjoint of the policy features -> adjoint of x_{t+1}
@@ -427,8 +435,8 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       for (int p = 0; p < PB; ++p) {
         // (plain reads: the serial waves' writes are ordered by the workgroup barrier above, and volatile would force a
         // separate LDS round trip for every use)
-        const double* sfp = const_cast<const double*>(sf_all) + p * PS;
-        const double* abp = const_cast<const double*>(ab_all) + p * PS;
+        clds_t sfp = sf_all + p * PS;
+        clds_t abp = ab_all + p * PS;
         const bool pv = mbase + p < M;
         double dd = 0.0;  // adjoint of dist_b (0 for idle threads and empty slots, so they add nothing below)
         if (act && pv) {
@@ -474,12 +482,8 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
               }
               t2v[i] = v;
             }
-            wave_sum_first<8>(t2v, PF - q0);
-            if (lane == 0) {
-#pragma unroll
-              for (int i = 0; i < 8; ++i)
-                if (q0 + i < PF) red[(p * NW + wv) * PF + q0 + i] = t2v[i];
-            }
+            const double tot = wave_sum_pack8(t2v, lane);  // lane l: the wave's sum of feature q0 + (l & 7)
+            if (lane < 8 && q0 + lane < PF) red[(p * NW + wv) * PF + q0 + lane] = tot;
           }
         }
       }
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     }
     // finish step 0: adjoint of x_0
     if (serial) {
-      const volatile double* redp = red + sp * NW * PF;
+      const vlds_t redp = red + sp * NW * PF;
       if (lane < PF) {
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += redp[w * PF + lane];
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       if (k < U) out[PF + (size_t)B * PF + (size_t)k * B + b] = gw[k];
   }
   lds_barrier();
-  double* gla = smem + L.gla;
+  lds_t gla = (lds_t)(smem + L.gla);
 #pragma unroll
   for (int q = 0; q < PFM; ++q) {
     if (q < PF) {
@@ -640,7 +644,8 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   // (two 256-thread workgroups per CU are resident: one particle per workgroup while M of them fit in one round, then 2, then 4;
   //  measured, tools/sweep_bwd_particles.py: M=800 1.74 / 1.34 / 1.92 ms, M=2000 3.24 / 2.51 / 2.07 ms for 1 / 2 / 4)
   int PB = g_force_bwd_pb ? g_force_bwd_pb : (M > 1024 ? 4 : (M > 512 ? 2 : 1));
-  if (!g_force_bwd_pb && (PF > 16 || U > 4)) PB = 1;  // the wide-policy instantiations are register bound already
+  if (!g_force_bwd_pb && (PF > 16 || U > 4)) PB = M > 1024 ? 2 : 1;  // wide policies: two particles per sweep on large swarms
+                                                                      // (tools/time_bwd.py, UR5 shape, M = 2000, T = 300: 27.7 -> 24.2 ms)
   if (PB != 1 && PB != 2 && PB != 4) return MCP_ERR_ARG;
   int NT = imax(bwd_threads(policy->B), 64 * PB);
   int rc = MCP_ERR_LIMIT;
