@@ -770,8 +770,18 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   if (GSH) {  // blocks b and b + 8 share an XCD: the members of a cluster sit 8 apart (speed only)
     const int CS = a.gsh_cs;
     const int b = blockIdx.x, grp = b / (8 * CS), r = b - grp * 8 * CS;
-    cluster = grp * 8 + (r & 7);
-    const int myc = r >> 3;
+    int myc;
+    if (8 % CS == 0) {
+      // Member c of every cluster goes to the XCDs [c * 8/CS, (c+1) * 8/CS) (blocks are dealt round-robin over the 8 XCDs), so
+      // an XCD's L2 only ever holds the Kinv of ONE GP range: the UR5 shape needs 3.8 MB per range against 4 MB of L2 -- with both
+      // members of a cluster on one XCD (round 1) its six Kinv thrashed the L2 (FETCH_SIZE 10.8 GB per launch, profiles/r02_c5_*).
+      const int W = 8 / CS, x = r & 7;  // x: the block's XCD under round-robin placement
+      myc = x / W;
+      cluster = grp * 8 + (r >> 3) * W + (x % W);
+    } else {
+      cluster = grp * 8 + (r & 7);
+      myc = r >> 3;
+    }
     if (cluster >= a.nclusters) return;
     gbeg = (myc * G) / CS;
     gend = ((myc + 1) * G) / CS;
@@ -1007,20 +1017,37 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         const int ba = rem ? s0 / nb : 0;                    // remainder block of piece A (index among the remainder blocks)
         const int a0 = s0 - ba * nb, a1 = imin(nb, s1 - ba * nb);  // its batches [a0, a1)
         const int b1 = s1 - (ba + 1) * nb;                    // piece B: batches [0, b1) of remainder block ba + 1 (if b1 > 0)
-#pragma unroll
+        // ONE inlined copy of the block routine: the pieces run through a loop and park their tile in the accumulator set of their
+        // index (uniform branches).  (Measured and dropped: letting waves 4-7 do their share with DPP-broadcast vector FMAs so
+        // that each SIMD's matrix AND vector pipe work on phase V.  fp64 MFMA and fp64 vector FMA do not run side by side on
+        // gfx950 -- tools/mfma_valu_coexec.hip, profiles/r02_mfma_valu_coexec.txt: a SIMD delivers 32 flop/tick whichever pipe or
+        // mix of pipes its two waves use -- so the split only added the vector path's overheads: V 148 k -> 176 k cycles at C5.)
         for (int r = 0; r < NACC; ++r) {
+          int pb = -1, pjs = 0, pje = 0;
+          bool pc = true;
           if (r < nfull) {
-            blk[r] = r * RF_NW + wv;
-            coll[r] = true;
-            tile_v_block(gp.Kinv, Npad, blk[r] * 32, 0, Npad, kv, lane, acc[r][0], acc[r][1]);
+            pb = r * RF_NW + wv;
+            pje = Npad;
           } else if (r == nfull && s0 < s1) {
-            blk[r] = nfull * RF_NW + ba;
-            coll[r] = a0 == 0;
-            tile_v_block(gp.Kinv, Npad, blk[r] * 32, 16 * a0, 16 * a1, kv, lane, acc[r][0], acc[r][1]);
+            pb = nfull * RF_NW + ba;
+            pc = a0 == 0;
+            pjs = 16 * a0;
+            pje = 16 * a1;
           } else if (r == nfull + 1 && s0 < s1 && b1 > 0) {
-            blk[r] = nfull * RF_NW + ba + 1;
-            coll[r] = true;
-            tile_v_block(gp.Kinv, Npad, blk[r] * 32, 0, 16 * b1, kv, lane, acc[r][0], acc[r][1]);
+            pb = nfull * RF_NW + ba + 1;
+            pje = 16 * b1;
+          }
+          if (pb < 0) continue;
+          v4d te = (v4d){0.0, 0.0, 0.0, 0.0}, to = (v4d){0.0, 0.0, 0.0, 0.0};
+          tile_v_block(gp.Kinv, Npad, pb * 32, pjs, pje, kv, lane, te, to);
+#pragma unroll
+          for (int q = 0; q < NACC; ++q) {
+            if (q == r) {
+              acc[q][0] = te;
+              acc[q][1] = to;
+              blk[q] = pb;
+              coll[q] = pc;
+            }
           }
         }
         // a piece that does not start its block (only piece A can; never wave 0) -> scratch slot wv - 1
