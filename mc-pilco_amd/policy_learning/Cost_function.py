@@ -103,18 +103,36 @@ class Cart_pole_cost(_HipExpectedCost):
 
 
 class Expected_saturated_distance_from_trajectory(_HipExpectedCost):
-    """1 - exp(-sum_i ((x_i - x*_{t,i}) / l_i)^2) over ``used_indeces``; target_traj must have one row per time step."""
+    """1 - exp(-sum_i ((x_i - x*_{t,i}) / l_i)^2) over ``used_indeces``; target_traj must have one row per time step.
+    ``flg_var_lengthscales``: ``lengthscales[trial_index]`` is the lengthscale vector of that trial (Cost_function.py:136-141)."""
 
     def __init__(self, target_traj, lengthscales, flg_var_lengthscales=False, used_indeces=None):
         super().__init__()
-        if flg_var_lengthscales:
-            raise NotImplementedError("flg_var_lengthscales=True is not implemented on the HIP path (unused by the launch scripts)")
-        self.target_traj, self.lengthscales = _np(target_traj), _np(lengthscales).reshape(-1)
+        self.flg_var_lengthscales = bool(flg_var_lengthscales)
+        self.target_traj = _np(target_traj)
+        self.lengthscales = [_np(l).reshape(-1) for l in lengthscales] if self.flg_var_lengthscales else _np(lengthscales).reshape(-1)
         self.used_indeces = None if used_indeces is None else [int(i) for i in used_indeces]
+        self._packed_by_trial = {}
 
-    def _pack(self, states):
-        return ops.PackedCost("traj", states.shape[2], states.device, target_traj=self.target_traj, lengthscales=self.lengthscales,
-                              used=self.used_indeces)
+    def _pack(self, states, trial_index=None):
+        ls = self.lengthscales[trial_index] if self.flg_var_lengthscales else self.lengthscales
+        return ops.PackedCost("traj", states.shape[2], states.device, target_traj=self.target_traj, lengthscales=ls, used=self.used_indeces)
+
+    def _select(self, states, trial_index):
+        """Per-trial lengthscales: one packed descriptor per trial index, chosen before the base class evaluates."""
+        if self.flg_var_lengthscales:
+            key = (int(trial_index), str(states.device))
+            if key not in self._packed_by_trial:
+                self._packed_by_trial[key] = self._pack(states, int(trial_index))
+            self._packed = self._packed_by_trial[key]
+
+    def forward(self, states_sequence, inputs_sequence=None, trial_index=None, group=None, counts=None):
+        self._select(states_sequence, trial_index)
+        return super().forward(states_sequence, inputs_sequence, trial_index, group, counts)
+
+    def local_moments(self, states_sequence, inputs_sequence, trial_index, m_total, shift=None):
+        self._select(states_sequence, trial_index)
+        return super().local_moments(states_sequence, inputs_sequence, trial_index, m_total, shift)
 
 
 # ---- simple torch-level variants (Cost_function.py:39-101) -------------------------------------------------------------

@@ -9,7 +9,8 @@ differentiable with respect to ``log_lengthscales``, ``centers`` and ``f_linear.
 reference, so ``state_dict``s interoperate).  ``packed()`` exposes the live parameters to the fused rollout.
 Dropout noise: ``noise_mode = "philox"`` (in-kernel counter-based generator, default) or ``"torch_cpu"`` (mask
 drawn exactly like ``torch.nn.functional.dropout`` draws it on the CPU -- parity with the reference).
-Not supported: ``flg_bias`` and a non-unit ``scale_factor`` (unused by every launch script).
+``scale_factor`` (plain ``Sum_of_gaussians`` only, as in the reference) is folded into the operands handed to the kernels.
+Not supported: ``flg_bias`` (unused by every launch script).
 Exploration policies (Random_exploration) run on the host once per trial and are plain numpy.
 """
 import numpy as np
@@ -70,8 +71,6 @@ class Sum_of_gaussians(Policy):
         super().__init__(state_dim=state_dim, input_dim=input_dim, flg_squash=flg_squash, u_max=u_max, dtype=dtype, device=device)
         if flg_bias:
             raise NotImplementedError("flg_bias=True is not implemented on the HIP path")
-        if scale_factor is not None and not np.allclose(np.asarray(scale_factor), 1.0):
-            raise NotImplementedError("scale_factor != 1 is not implemented on the HIP path")
         self.num_basis = num_basis
         if lengthscales_init is None:
             lengthscales_init = np.ones(state_dim)
@@ -83,7 +82,11 @@ class Sum_of_gaussians(Policy):
         self.f_linear = torch.nn.Linear(in_features=num_basis, out_features=input_dim, bias=False)
         w = np.ones([input_dim, num_basis]) if weight_init is None else np.asarray(weight_init)
         self.f_linear.weight = torch.nn.Parameter(torch.tensor(w, dtype=dtype, device=self.device).contiguous(), requires_grad=flg_train_weight)
-        self.scale_factor = torch.ones(1, state_dim, dtype=dtype, device=self.device)
+        # states / scale_factor before the RBF layer (Policy.py:220-222, 252): folded into the operands the kernels see --
+        # ((s/f - c)/l)^2 = ((s - c f)/(l f))^2, i.e. centres c*f and log-lengthscales log l + log f (see packed())
+        sf = np.ones(state_dim) if scale_factor is None else np.asarray(scale_factor, dtype=float).reshape(-1)
+        self.scale_factor = torch.tensor(sf, dtype=dtype, device=self.device).reshape([1, -1])
+        self._unit_scale = bool(np.all(sf == 1.0))
         self.flg_drop = flg_drop
         self.noise_mode = "philox"
         self.seed = 0
@@ -99,6 +102,12 @@ class Sum_of_gaussians(Policy):
 
     def packed(self) -> ops.PackedPolicy:
         """mcp_policy over the LIVE parameter tensors (optimizer updates are seen; rebuilt if a tensor was replaced)."""
+        if not self._unit_scale:
+            # derived operands, rebuilt per call (the parameters move every optimizer step); autograd carries the chain rule
+            # back to log_lengthscales / centers through the two elementwise ops
+            return ops.PackedPolicy(self._kind, self._system_state_dim(), self.log_lengthscales + torch.log(self.scale_factor),
+                                    (self.centers * self.scale_factor).contiguous(), self.f_linear.weight, self.u_max, self.flg_squash,
+                                    **self._pack_extra())
         key = (self.log_lengthscales.data_ptr(), self.centers.data_ptr(), self.f_linear.weight.data_ptr())
         if self._packed is None or self._packed[0] != key:
             pk = ops.PackedPolicy(self._kind, self._system_state_dim(), self.log_lengthscales, self.centers, self.f_linear.weight, self.u_max,

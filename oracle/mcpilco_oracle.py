@@ -283,6 +283,7 @@ class PolicyPar:
     non_angle: Sequence[int] = ()
     target_traj: Optional[torch.Tensor] = None  # [T,S]
     squash: bool = True
+    scale_factor: Optional[torch.Tensor] = None  # [P]; states / scale_factor before the RBF layer (plain class only, Policy.py:220-222, 252)
 
 
 def policy_features(pp: PolicyPar, x: torch.Tensor, t: Optional[int]) -> torch.Tensor:
@@ -304,6 +305,8 @@ def policy_forward(pp: PolicyPar, x, t=None, mask: Optional[torch.Tensor] = None
     exactly like F.dropout does on CPU (``empty_like(phi).bernoulli_(1-p)``).
     """
     s = policy_features(pp, x, t)
+    if pp.scale_factor is not None:
+        s = s / pp.scale_factor.reshape(1, -1)
     ls = torch.exp(pp.log_ls)
     a = s / ls
     c = pp.centers / ls

@@ -287,4 +287,36 @@ def ref_log():
 
 
 ref_log()
+
+
+# ---------------------------------------------------------------------------------------
+# options no launch script uses: policy scale_factor (Policy.py:220-222, 252), per-trial cost lengthscales (Cost_function.py:136-141)
+# ---------------------------------------------------------------------------------------
+def options():
+    rs = np.random.RandomState(41)
+    M, B = 12, 24
+    sf = np.array([2.0, 0.5, 3.0, 1.5])
+    with quiet:
+        pol = RP.Sum_of_gaussians(state_dim=4, input_dim=2, num_basis=B, lengthscales_init=0.8 + rs.rand(4), centers_init=rs.randn(B, 4),
+                                  weight_init=rs.randn(2, B), flg_squash=True, u_max=[3.0, 1.5], scale_factor=sf, flg_drop=True, dtype=dtype,
+                                  device=dev)
+    x = T(2.0 * rs.randn(M, 4))
+    wsum = T(rs.randn(M, 2))
+    u = pol(x, t=0, p_dropout=0.0)
+    (u * wsum).sum().backward()
+    out = dict(sf_x=N(x), sf_scale=sf, sf_ls=N(torch.exp(pol.log_lengthscales)), sf_centers=N(pol.centers), sf_weight=N(pol.f_linear.weight),
+               sf_umax=np.array([3.0, 1.5]), sf_u=N(u), sf_wsum=N(wsum), sf_g_log_ls=N(pol.log_lengthscales.grad), sf_g_centers=N(pol.centers.grad),
+               sf_g_weight=N(pol.f_linear.weight.grad))
+    Tn = 6
+    tt = sy.ur5_target_traj(T=Tn)
+    st = T(tt.reshape(Tn, 1, 12) + 0.4 * rs.randn(Tn, 10, 12)).requires_grad_(True)
+    ls_all = T(np.stack([np.array(sy.UR5["cost_ls"]), 0.5 + rs.rand(12)]))
+    cf = RC.Expected_saturated_distance_from_trajectory(target_traj=T(tt), lengthscales=ls_all, flg_var_lengthscales=True, used_indeces=list(range(12)))
+    cst, sd = cf(st, None, 1)
+    cst.backward()
+    out.update(vl_states=N(st), vl_target=tt, vl_ls_all=N(ls_all), vl_trial=1, vl_cost=N(cst), vl_std=N(sd), vl_grad=N(st.grad))
+    save("options", **out)
+
+
+options()
 print("done")

@@ -540,3 +540,31 @@ def test_posterior_cache_follows_the_hyper_parameters(golden):
         ref = ops.posterior(ops.PackedGP(gp.kernel_spec(), X, alpha2, Kinv2), Xs)[0]
     assert float((mu1 - mu0).abs().max()) > 1e-4
     assert torch.equal(mu2, ref) and float((mu2 - mu1).abs().max()) > 1e-6
+
+
+def test_policy_scale_factor_and_per_trial_cost_lengthscales(golden):
+    """Sum_of_gaussians(scale_factor=...) (Policy.py:220-222, 252: folded into the operands the kernels see, gradients through the
+    fold) and Expected_saturated_distance_from_trajectory(flg_var_lengthscales=True) (Cost_function.py:136-141) against the reference."""
+    from mc_pilco_amd.policy_learning import Cost_function, Policy
+
+    fx = golden("options")
+    with quiet():
+        pol = Policy.Sum_of_gaussians(state_dim=4, input_dim=2, num_basis=fx["sf_centers"].shape[0], lengthscales_init=fx["sf_ls"].reshape(-1),
+                                      centers_init=fx["sf_centers"], weight_init=fx["sf_weight"], flg_squash=True, u_max=[3.0, 1.5],
+                                      scale_factor=fx["sf_scale"], flg_drop=True, dtype=dtype, device=dev())
+    u = pol(T(fx["sf_x"]), t=0, p_dropout=0.0)
+    (u * T(fx["sf_wsum"])).sum().backward()
+    assert relerr(u, fx["sf_u"]) < 1e-12
+    assert relerr(pol.log_lengthscales.grad, fx["sf_g_log_ls"]) < 1e-10
+    assert relerr(pol.centers.grad, fx["sf_g_centers"]) < 1e-10
+    assert relerr(pol.f_linear.weight.grad, fx["sf_g_weight"]) < 1e-10
+    st = T(fx["vl_states"]).requires_grad_(True)
+    cf = Cost_function.Expected_saturated_distance_from_trajectory(target_traj=T(fx["vl_target"]), lengthscales=T(fx["vl_ls_all"]),
+                                                                   flg_var_lengthscales=True, used_indeces=list(range(12)))
+    c, s = cf(st, None, int(fx["vl_trial"]))
+    c.backward()
+    assert abs(float(c.detach()) - float(fx["vl_cost"])) < 1e-12 * abs(float(fx["vl_cost"]))
+    assert abs(float(s) - float(fx["vl_std"])) < 1e-12 * abs(float(fx["vl_std"]))
+    assert relerr(st.grad, fx["vl_grad"]) < 1e-12
+    c0, _ = cf(T(fx["vl_states"]), None, 0)  # the other trial's lengthscales give another cost
+    assert abs(float(c0) - float(c.detach())) > 1e-3

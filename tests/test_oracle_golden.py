@@ -262,3 +262,24 @@ def test_sod_with_seeded_permutation(golden):
     perm = torch.arange(1, fx["X"].shape[0])[torch.randperm(fx["X"].shape[0] - 1)]
     assert [int(i) for i in perm] == [int(i) for i in fx["perm"]]
     assert orc.gp_get_sod(h, T(fx["X"]), T(fx["Y"]), float(fx["thr"]), perm) == [int(i) for i in fx["idx"]]
+
+
+def test_policy_scale_factor_and_per_trial_cost_lengthscales(golden):
+    """Options no launch script uses: Sum_of_gaussians(scale_factor=...) (Policy.py:220-222, 252) and
+    Expected_saturated_distance_from_trajectory(flg_var_lengthscales=True) (Cost_function.py:136-141)."""
+    fx = golden("options")
+    prm = [torch.log(T(fx["sf_ls"])).reshape(1, -1), T(fx["sf_centers"]), T(fx["sf_weight"])]
+    for q in prm:
+        q.requires_grad_(True)
+    pp = orc.PolicyPar(prm[0], prm[1], prm[2], [float(v) for v in fx["sf_umax"]], "plain", scale_factor=T(fx["sf_scale"]))
+    u = orc.policy_forward(pp, T(fx["sf_x"]), 0)
+    (u * T(fx["sf_wsum"])).sum().backward()
+    assert relerr(u.detach(), fx["sf_u"]) < 1e-12
+    for q, k in zip(prm, ["sf_g_log_ls", "sf_g_centers", "sf_g_weight"]):
+        assert relerr(q.grad, fx[k]) < 1e-11
+    st = T(fx["vl_states"]).requires_grad_(True)
+    c, s = orc.expected_cost(orc.traj_cost(st, T(fx["vl_target"]), T(fx["vl_ls_all"])[int(fx["vl_trial"])]))
+    c.backward()
+    assert abs(float(c.detach()) - float(fx["vl_cost"])) < 1e-12 * abs(float(fx["vl_cost"]))
+    assert abs(float(s) - float(fx["vl_std"])) < 1e-12 * abs(float(fx["vl_std"]))
+    assert relerr(st.grad, fx["vl_grad"]) < 1e-12
