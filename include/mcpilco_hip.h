@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCP_ABI_VERSION 3
+#define MCP_ABI_VERSION 4
 
 #define MCP_OK 0
 #define MCP_ERR_ARG (-1)       /* null pointer / non-positive size                       */
@@ -134,6 +134,8 @@ typedef struct mcp_policy {
   const double* weight;   /* [U][B]  f_linear.weight (no bias)                         */
   const double* u_max;    /* [U]                                                       */
   const double* target_traj; /* [traj_len][S] or NULL                                  */
+  const double* bias;     /* [U]     f_linear.bias (flg_bias, Policy.py:203-212) or NULL: u = squash(W phi + bias); not dropped out */
+  double* g_bias;         /* [U]     OUT of mcp_rollout_bwd when bias != NULL: dJ/dbias (this rank's particles); may be NULL */
   mcp_meas meas;          /* what the policy is evaluated on (n == 0: the true state)  */
 } mcp_policy;
 
@@ -214,7 +216,7 @@ int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy, const mcp_
                     size_t workspace_bytes, void* stream);
 /* Reverse-time adjoint of the rollout: given dJ/dstates, dJ/dinputs (either may be NULL) returns
  * dJ/d{log_lengthscales [P], centers [B][P], f_linear.weight [U][B]} (overwritten, this rank's
- * particles only) and optionally dJ/dx0 [M][S].  Replaces autograd's backward through
+ * particles only; with policy->bias also dJ/dbias into policy->g_bias) and optionally dJ/dx0 [M][S].  Replaces autograd's backward through
  * MC_PILCO.py:522. */
 int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T,
                     const double* states, const double* inputs, const double* jac, const double* g_states,

@@ -76,7 +76,7 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
   L.pstride = o - o0;
   o = o0 + PB * L.pstride;
   L.red = take(PB * NW * PF);
-  L.gla = take(PB * PF);                      // the serial waves' share of dJ/dlog_lengthscales at the end of the sweep
+  L.gla = take(PB * (PF + MCP_MAX_INPUT));    // the serial waves' shares of dJ/dlog_lengthscales and dJ/dbias at the end of the sweep
   L.cen = take(cen_lds ? PF * NW * 64 : 0);  // RBF centres, transposed [q][thread] (wide policy classes)
   L.itab = take((2 * MCP_MAX_GP + 2 * MCP_MAX_STATE + MCP_MAX_INPUT + 1) / 2 + 1);
   L.total = o;
@@ -284,6 +284,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   };
 
   double glacc = 0.0;  // serial waves, lane q < PF: - sum over this wave's particle-steps of s_q sb_q
+  double gbacc = 0.0;  // serial waves, lane k < U: dJ/dbias_k = sum over this wave's particle-steps of the pre-squash adjoint
   double fprev = 0.0;  // the policy feature this lane formed in the previous iteration of the sweep (= of step t+1)
   unsigned long long last_stamp = clock64();
   for (int mbase = blockIdx.x * PB; mbase < M; mbase += gridDim.x * PB) {
@@ -400,7 +401,9 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         if (lane < U) {
           double ubar = r[oGU + lane] + zb[nna_g + 2 * na_g + lane];
           double th = r[oU + lane] / umax_lane;  // = tanh(a/u_max)
-          ab[lane] = pl.squash ? ubar * (1.0 - th * th) : ubar;
+          const double abv = pl.squash ? ubar * (1.0 - th * th) : ubar;
+          ab[lane] = abv;
+          if (spvalid) gbacc += abv;
         }
       }
       BW_STAMP(8);
@@ -520,8 +523,8 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   }
 
   // ---- write this workgroup's partial parameter gradients ------------------------------------
-  const int nparam = PF + B * PF + U * B;
-  double* out = a.slab + (size_t)blockIdx.x * nparam;
+  const int nparam = PF + B * PF + U * B;  // (+ U when the policy has a bias: the slab stride)
+  double* out = a.slab + (size_t)blockIdx.x * (nparam + (pl.bias ? U : 0));
   if (act) {
 #pragma unroll
     for (int q = 0; q < PFM; ++q)
@@ -540,6 +543,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     }
   }
   if (serial && lane < PF) gla[sp * PF + lane] = glacc;
+  if (serial && lane < U) gla[PB * PF + sp * U + lane] = gbacc;
   lds_barrier();
   for (int it = tid; it < PF; it += NT) {
     double sm = 0.0;
@@ -547,11 +551,16 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     for (int p = 0; p < PB; ++p) sm += gla[p * PF + it];
     out[it] = sm;
   }
+  if (pl.bias && tid < U) {  // dJ/dbias: behind the three gradients in the slab
+    double sm = 0.0;
+    for (int p = 0; p < PB; ++p) sm += gla[PB * PF + p * U + tid];
+    out[nparam + tid] = sm;
+  }
 }
 
 // sum the per-workgroup slabs in a fixed order (deterministic, no atomics)
-__global__ void grad_reduce_kernel(int nblk, int nparam, int PF, int BPF, const double* __restrict__ slab, double* __restrict__ g_log_ls,
-                                   double* __restrict__ g_centers, double* __restrict__ g_weight) {
+__global__ void grad_reduce_kernel(int nblk, int nparam, int PF, int BPF, int UB, const double* __restrict__ slab, double* __restrict__ g_log_ls,
+                                   double* __restrict__ g_centers, double* __restrict__ g_weight, double* __restrict__ g_bias) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nparam) return;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -568,8 +577,10 @@ __global__ void grad_reduce_kernel(int nblk, int nparam, int PF, int BPF, const 
     g_log_ls[i] = s;
   else if (i < PF + BPF)
     g_centers[i - PF] = s;
-  else
+  else if (i < PF + BPF + UB)
     g_weight[i - PF - BPF] = s;
+  else if (g_bias)
+    g_bias[i - PF - BPF - UB] = s;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -584,7 +595,7 @@ static int bwd_blocks(int M) { return imin(M, 1024); }
 
 extern "C" size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_policy* policy, int M, int T) {
   if (!policy || M <= 0 || T <= 0) return 0;
-  size_t nparam = (size_t)policy->P + (size_t)policy->B * policy->P + (size_t)policy->U * policy->B;
+  size_t nparam = (size_t)policy->P + (size_t)policy->B * policy->P + (size_t)policy->U * policy->B + (size_t)policy->U;  // (+ U: dJ/dbias)
   const size_t bwd = sizeof(double) * nparam * (size_t)bwd_blocks(M);   // mcp_rollout_bwd: per-workgroup gradient slabs
   const size_t fwd = model ? rollout_xch_bytes(M, model->G) : 0;         // mcp_rollout_fwd: hand-off granules (GP-sharded launch)
   return bwd > fwd ? bwd : fwd;
@@ -679,9 +690,9 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   }
   if (rc < 0) return rc;
   const int grid = rc;
-  const int nparam = PF + policy->B * PF + U * policy->B;
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3((nparam + 255) / 256), dim3(256), 0, st, grid, nparam, PF, policy->B * PF, a.slab, g_log_ls,
-                     g_centers, g_weight);
+  const int nparam = PF + policy->B * PF + U * policy->B + (policy->bias ? U : 0);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((nparam + 255) / 256), dim3(256), 0, st, grid, nparam, PF, policy->B * PF, U * policy->B, a.slab,
+                     g_log_ls, g_centers, g_weight, policy->bias ? policy->g_bias : nullptr);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }

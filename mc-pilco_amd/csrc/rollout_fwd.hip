@@ -66,7 +66,7 @@ __host__ __device__ inline FwdLayout fwd_layout(int P, int S, int U, int D, int 
     o += (n + 1) & ~1;  // keep 16-byte alignment
     return r;
   };
-  L.invl = take(PF + MCP_MAX_INPUT);  // policy inverse lengthscales | u_max (staged once: a global load on phase U's critical path otherwise)
+  L.invl = take(PF + 2 * MCP_MAX_INPUT);  // policy inverse lengthscales | u_max | bias (staged once: a global load on phase U's critical path otherwise)
   L.xs = take(2 * P * S);
   L.us = take(P * U);
   L.z = take(P * D);
@@ -761,7 +761,11 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   // ---- one-time staging ------------------------------------------------------------------
   for (int it = tid0; it < PF; it += RF_NT) invl[it] = exp(-pl.log_ls[it]);
   double* umax_l = invl + PF;
-  if (tid0 < U) umax_l[tid0] = pl.u_max[tid0];
+  double* bias_l = umax_l + MCP_MAX_INPUT;  // f_linear.bias (0 without flg_bias)
+  if (tid0 < U) {
+    umax_l[tid0] = pl.u_max[tid0];
+    bias_l[tid0] = pl.bias ? pl.bias[tid0] : 0.0;
+  }
   // the GPs this workgroup evaluates: all of them, or (GSH) its own one, which then lives in slot 0 of every LDS table
   const int GL = GSH ? 1 : G;
   const mcp_gp* gps_l = gps + myg;
@@ -964,6 +968,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       for (int b = lane; b < B; b += 64) s = fma(wk[b], ph[p * B + b], s);
       s = wave_sum(s);
       if (lane == 0) {
+        s += bias_l[k];
         double um = umax_l[k];
         double u = pl.squash ? um * tanh(s / um) : s;
         us[p * U + k] = u;

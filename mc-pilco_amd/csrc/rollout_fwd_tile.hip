@@ -966,6 +966,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       double sacc = 0.0;
 #pragma unroll
       for (int w = 0; w < RF_NW; ++w) sacc += up[(w * P + p) * U + k];
+      if (pl.bias) sacc += pl.bias[k];
       const double um = pl.u_max[k];
       const double u = pl.squash ? um * tanh(sacc / um) : sacc;
       us[p * U + k] = u;

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MCPILCO_HIP_LIB") or os.path.join(HERE, "libmcpilco_h
 MAX_GP, MAX_STATE, MAX_INPUT, MAX_GPDIM, MAX_PFEAT, MAX_BASIS, MAX_TRAIN = 8, 16, 8, 32, 32, 1024, 1024
 OK = 0
 ERRORS = {-1: "MCP_ERR_ARG", -2: "MCP_ERR_LIMIT", -3: "MCP_ERR_WORKSPACE", -4: "MCP_ERR_LAUNCH", -5: "MCP_ERR_COMM"}
-ABI_VERSION = 3
+ABI_VERSION = 4
 COMM_ID_BYTES = 128
 STATUS_NAN, STATUS_NONPOS_VAR, STATUS_NOT_SPD, STATUS_SYNC = 1, 2, 4, 8
 POLICY_PLAIN, POLICY_ANGLES, POLICY_TRAJ = 0, 1, 2
@@ -51,7 +51,7 @@ class Policy(C.Structure):
     _fields_ = [("kind", C.c_int32), ("S", C.c_int32), ("P", C.c_int32), ("B", C.c_int32), ("U", C.c_int32), ("squash", C.c_int32),
                 ("n_angle", C.c_int32), ("n_non_angle", C.c_int32), ("angle", C.c_int32 * MAX_STATE),
                 ("non_angle", C.c_int32 * MAX_STATE), ("traj_len", C.c_int32), ("p_drop", C.c_double), ("log_ls", dptr),
-                ("centers", dptr), ("weight", dptr), ("u_max", dptr), ("target_traj", dptr), ("meas", Meas)]
+                ("centers", dptr), ("weight", dptr), ("u_max", dptr), ("target_traj", dptr), ("bias", dptr), ("g_bias", dptr), ("meas", Meas)]
 
 
 class Noise(C.Structure):

@@ -229,9 +229,10 @@ class PackedModel:
 class PackedPolicy:
     """mcp_policy over the live parameter tensors (no copies: the optimizer's updates are seen)."""
 
-    def __init__(self, kind, S, log_ls, centers, weight, u_max, squash=True, angle=(), non_angle=(), target_traj=None):
+    def __init__(self, kind, S, log_ls, centers, weight, u_max, squash=True, angle=(), non_angle=(), target_traj=None, bias=None):
         dev = _dev(centers.device)
         self.log_ls, self.centers, self.weight = log_ls, centers, weight
+        self.bias = bias  # [U] f_linear.bias (flg_bias) or None
         B, P = centers.shape
         U = weight.shape[0]
         um = np.full(U, float(u_max)) if np.isscalar(u_max) else np.asarray(u_max, dtype=np.float64).reshape(-1)
@@ -254,9 +255,13 @@ class PackedPolicy:
 
     def bind(self, p_drop):
         """Refreshes parameter pointers (they must be contiguous fp64 GPU tensors) and p_drop."""
-        for t in (self.log_ls, self.centers, self.weight):
+        for t in (self.log_ls, self.centers, self.weight) + (() if self.bias is None else (self.bias,)):
             if t.dtype != DT or not t.is_cuda or not t.is_contiguous():
                 raise RuntimeError("policy parameters must be contiguous float64 GPU tensors")
+        if self.bias is not None and self.bias.numel() != self.U:
+            raise RuntimeError("policy bias must have one entry per input")
+        self.c.bias = None if self.bias is None else self.bias.data_ptr()
+        self.c.g_bias = None
         self.c.log_ls = self.log_ls.data_ptr()
         self.c.centers = self.centers.data_ptr()
         self.c.weight = self.weight.data_ptr()
@@ -383,6 +388,8 @@ def rollout_backward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseS
     g_c = torch.empty(policy.B, policy.P, dtype=DT, device=dev)
     g_w = torch.empty(policy.U, policy.B, dtype=DT, device=dev)
     g_x0 = torch.empty(M, policy.S, dtype=DT, device=dev) if want_gx0 else None
+    g_b = torch.empty(policy.U, dtype=DT, device=dev) if policy.bias is not None else None
+    pc.g_bias = None if g_b is None else g_b.data_ptr()
     gs = None if g_states is None else g_states.to(dtype=DT).contiguous()
     gi = None if g_inputs is None else g_inputs.to(dtype=DT).contiguous()
     _set_meas(policy, meas, T, M, meas_buf)
@@ -392,7 +399,8 @@ def rollout_backward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseS
                                             nbytes, abi.stream()), "mcp_rollout_bwd")
     finally:
         _set_meas(policy, None, T, M, None)
-    return g_ls, g_c, g_w, g_x0
+        pc.g_bias = None
+    return g_ls, g_c, g_w, g_x0, g_b
 
 
 class RolloutFunction(torch.autograd.Function):
@@ -401,8 +409,8 @@ class RolloutFunction(torch.autograd.Function):
     parameters (and x0); the GP model is frozen, as after ``Model_learning.set_eval_mode``."""
 
     @staticmethod
-    def forward(ctx, x0, log_ls, centers, weight, model, policy, noise, T, p_drop, particle_pred, meas=None, gp_sharding=True):
-        need = any(ctx.needs_input_grad[:4])
+    def forward(ctx, x0, log_ls, centers, weight, bias, model, policy, noise, T, p_drop, particle_pred, meas=None, gp_sharding=True):
+        need = any(ctx.needs_input_grad[:5])
         out = rollout_forward_raw(model, policy, noise, x0, T, p_drop, particle_pred, need_jac=need, meas=meas, gp_sharding=gp_sharding)
         states, inputs, jac, status = out[:4]
         ctx.model, ctx.policy, ctx.noise, ctx.p_drop = model, policy, noise, p_drop
@@ -417,16 +425,18 @@ class RolloutFunction(torch.autograd.Function):
         states, inputs, jac = ctx.saved_tensors
         if not ctx.has_jac:
             jac = None
-        g_ls, g_c, g_w, g_x0 = rollout_backward_raw(ctx.model, ctx.policy, ctx.noise, states, inputs, jac, g_states, g_inputs, ctx.p_drop,
-                                                    want_gx0=ctx.needs_input_grad[0], meas=ctx.meas, meas_buf=ctx.meas_buf)
-        return g_x0, g_ls.reshape(ctx.policy.log_ls.shape), g_c, g_w, None, None, None, None, None, None, None, None
+        g_ls, g_c, g_w, g_x0, g_b = rollout_backward_raw(ctx.model, ctx.policy, ctx.noise, states, inputs, jac, g_states, g_inputs, ctx.p_drop,
+                                                         want_gx0=ctx.needs_input_grad[0], meas=ctx.meas, meas_buf=ctx.meas_buf)
+        if g_b is not None:
+            g_b = g_b.reshape(ctx.policy.bias.shape)
+        return g_x0, g_ls.reshape(ctx.policy.log_ls.shape), g_c, g_w, g_b, None, None, None, None, None, None, None, None
 
 
 def rollout(model, policy, noise, x0, T, p_drop=0.0, particle_pred=True, meas: Optional[MeasSpec] = None, gp_sharding=True):
     """Differentiable fused rollout.  Returns (states, inputs, status).  ``meas``: measurement model between the particles and
     the policy (partially measurable systems); None = the policy sees the true state.  ``gp_sharding`` False forbids the
     GP-sharded launch forms (used to repeat a step whose hand-off reported MCP_STATUS_SYNC)."""
-    return RolloutFunction.apply(x0, policy.log_ls, policy.centers, policy.weight, model, policy, noise, int(T), float(p_drop),
+    return RolloutFunction.apply(x0, policy.log_ls, policy.centers, policy.weight, policy.bias, model, policy, noise, int(T), float(p_drop),
                                  bool(particle_pred), meas, bool(gp_sharding))
 
 

@@ -10,7 +10,7 @@ reference, so ``state_dict``s interoperate).  ``packed()`` exposes the live para
 Dropout noise: ``noise_mode = "philox"`` (in-kernel counter-based generator, default) or ``"torch_cpu"`` (mask
 drawn exactly like ``torch.nn.functional.dropout`` draws it on the CPU -- parity with the reference).
 ``scale_factor`` (plain ``Sum_of_gaussians`` only, as in the reference) is folded into the operands handed to the kernels.
-Not supported: ``flg_bias`` (unused by every launch script).
+``flg_bias`` adds ``f_linear.bias`` (not dropped out) to the linear layer inside the kernels; its gradient comes out of the adjoint sweep.
 Exploration policies (Random_exploration) run on the host once per trial and are plain numpy.
 """
 import numpy as np
@@ -69,8 +69,6 @@ class Sum_of_gaussians(Policy):
                  bias_init=None, flg_train_bias=False, flg_squash=False, u_max=1, scale_factor=None, flg_drop=True, dtype=torch.float64,
                  device=torch.device("cuda")):
         super().__init__(state_dim=state_dim, input_dim=input_dim, flg_squash=flg_squash, u_max=u_max, dtype=dtype, device=device)
-        if flg_bias:
-            raise NotImplementedError("flg_bias=True is not implemented on the HIP path")
         self.num_basis = num_basis
         if lengthscales_init is None:
             lengthscales_init = np.ones(state_dim)
@@ -79,9 +77,12 @@ class Sum_of_gaussians(Policy):
         if centers_init is None:
             centers_init = centers_init_min + (centers_init_max - centers_init_min) * np.random.rand(num_basis, state_dim)
         self.centers = torch.nn.Parameter(torch.tensor(np.asarray(centers_init), dtype=dtype, device=self.device), requires_grad=flg_train_centers)
-        self.f_linear = torch.nn.Linear(in_features=num_basis, out_features=input_dim, bias=False)
+        self.f_linear = torch.nn.Linear(in_features=num_basis, out_features=input_dim, bias=bool(flg_bias))
         w = np.ones([input_dim, num_basis]) if weight_init is None else np.asarray(weight_init)
         self.f_linear.weight = torch.nn.Parameter(torch.tensor(w, dtype=dtype, device=self.device).contiguous(), requires_grad=flg_train_weight)
+        if flg_bias:  # Policy.py:203-212: torch.nn.Linear's own initial bias unless bias_init is given; trained only with flg_train_bias
+            b0 = self.f_linear.bias.detach().to(torch.float64).cpu().numpy() if bias_init is None else np.asarray(bias_init, dtype=float).reshape(-1)
+            self.f_linear.bias = torch.nn.Parameter(torch.tensor(b0, dtype=dtype, device=self.device).contiguous(), requires_grad=flg_train_bias)
         # states / scale_factor before the RBF layer (Policy.py:220-222, 252): folded into the operands the kernels see --
         # ((s/f - c)/l)^2 = ((s - c f)/(l f))^2, i.e. centres c*f and log-lengthscales log l + log f (see packed())
         sf = np.ones(state_dim) if scale_factor is None else np.asarray(scale_factor, dtype=float).reshape(-1)
@@ -107,11 +108,12 @@ class Sum_of_gaussians(Policy):
             # back to log_lengthscales / centers through the two elementwise ops
             return ops.PackedPolicy(self._kind, self._system_state_dim(), self.log_lengthscales + torch.log(self.scale_factor),
                                     (self.centers * self.scale_factor).contiguous(), self.f_linear.weight, self.u_max, self.flg_squash,
-                                    **self._pack_extra())
-        key = (self.log_lengthscales.data_ptr(), self.centers.data_ptr(), self.f_linear.weight.data_ptr())
+                                    bias=self.f_linear.bias, **self._pack_extra())
+        key = (self.log_lengthscales.data_ptr(), self.centers.data_ptr(), self.f_linear.weight.data_ptr(),
+               None if self.f_linear.bias is None else self.f_linear.bias.data_ptr())
         if self._packed is None or self._packed[0] != key:
             pk = ops.PackedPolicy(self._kind, self._system_state_dim(), self.log_lengthscales, self.centers, self.f_linear.weight, self.u_max,
-                                  self.flg_squash, **self._pack_extra())
+                                  self.flg_squash, bias=self.f_linear.bias, **self._pack_extra())
             self._packed = (key, pk)
         return self._packed[1]
 
@@ -190,4 +192,4 @@ class Sum_of_gaussians_with_target_trajectory(Sum_of_gaussians):
     def _packed_at(self, t):
         """Descriptor whose target row 0 is x*_t (single-step evaluation at time t)."""
         return ops.PackedPolicy("traj", self._system_state_dim(), self.log_lengthscales, self.centers, self.f_linear.weight, self.u_max,
-                                self.flg_squash, target_traj=self.target_traj[t:t + 1])
+                                self.flg_squash, target_traj=self.target_traj[t:t + 1], bias=self.f_linear.bias)

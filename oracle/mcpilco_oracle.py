@@ -283,6 +283,7 @@ class PolicyPar:
     non_angle: Sequence[int] = ()
     target_traj: Optional[torch.Tensor] = None  # [T,S]
     squash: bool = True
+    bias: Optional[torch.Tensor] = None  # [U] f_linear.bias (flg_bias, Policy.py:203-212)
     scale_factor: Optional[torch.Tensor] = None  # [P]; states / scale_factor before the RBF layer (plain class only, Policy.py:220-222, 252)
 
 
@@ -317,6 +318,8 @@ def policy_forward(pp: PolicyPar, x, t=None, mask: Optional[torch.Tensor] = None
             mask = torch.empty(phi.shape[0], 1, phi.shape[1], dtype=DT).bernoulli_(1 - p_drop).reshape(phi.shape)
         phi = phi * (mask / (1.0 - p_drop))
     lin = phi @ pp.weight.t()
+    if pp.bias is not None:
+        lin = lin + pp.bias.reshape(1, -1)
     if not pp.squash:
         return lin
     um = pp.u_max if isinstance(pp.u_max, (int, float)) else torch.tensor(pp.u_max, dtype=DT)

@@ -9,6 +9,7 @@ running its own classes.  Only arrays / plain pickled data are stored -- no refe
   simple_costs          Expected_distance / Expected_saturated_distance (policy_learning/Cost_function.py:39-101)
   mean_rollout          MC_PILCO.rollout (MC_PILCO.py:347-373): mean-only prediction of a recorded trajectory
   sod_permutation       GP_prior.get_SOD(flg_permutation=True) (gpr_lib/GP_prior/GP_prior.py:244-247), seeded
+  options               policy scale_factor, per-trial cost lengthscales;  rollout_bias: policy with flg_bias, full rollout + gradient
   ref_log.pkl (+ ref_log_expect.npz)   a log.pkl with the reference's keys and state_dicts, written from reference objects, for
                         MC_PILCO.load_model_from_log (MC_PILCO.py:711-751) of the drop-in
 """
@@ -319,4 +320,46 @@ def options():
 
 
 options()
+
+
+# ---------------------------------------------------------------------------------------
+# policy with an output bias (flg_bias, Policy.py:203-212): full apply_policy + cost + backward, noise recovered by replay
+# ---------------------------------------------------------------------------------------
+def rollout_bias(M=16, Tn=8, p=0.25, seed=108, B=32):
+    ml, xtr, utr, sig = speed_model(100)
+    pi = sy.cartpole_policy_init(B=B, seed=9)
+    ppar = dict(state_dim=4, input_dim=1, num_basis=B, angle_indices=np.array([2]), non_angle_indices=np.array([0, 1, 3]),
+                lengthscales_init=pi["lengthscales"], centers_init=pi["centers"], weight_init=pi["weight"], flg_squash=True, u_max=c["u_max"],
+                flg_bias=True, bias_init=np.array([1.7]), flg_train_bias=True, flg_drop=True, dtype=dtype, device=dev)
+    with quiet:
+        obj = RMC.MC_PILCO(T_sampling=c["Ts"], state_dim=4, input_dim=1, f_sim=lambda y, t, u: None, f_model_learning=lambda **kw: ml,
+                           model_learning_par={}, f_rand_exploration_policy=RP.Random_exploration,
+                           rand_exploration_policy_par=dict(state_dim=4, input_dim=1, u_max=1.0, dtype=dtype, device=dev),
+                           f_control_policy=RP.Sum_of_gaussians_with_angles, control_policy_par=ppar, f_cost_function=RC.Cart_pole_cost,
+                           cost_function_par=dict(target_state=T(c["cost_target"]), lengthscales=T(c["cost_ls"]), angle_index=2, pos_index=0),
+                           log_path=None, dtype=dtype, device=dev)
+    pol = obj.control_policy
+    x0m, x0v = T(c["x0_mean"]), T(np.array([1e-2, 1e-2, 4e-2, 1e-2]))
+    torch.manual_seed(seed)
+    st, inp = obj.apply_policy(particles_initial_state_mean=x0m, particles_initial_state_var=x0v, flg_particles_init_uniform=False,
+                               particles_init_up_bound=None, particles_init_low_bound=None, flg_particles_init_multi_gauss=False,
+                               num_particles=M, T_control=Tn, p_dropout=p)
+    cost, std = obj.cost_function(st, inp, 0)
+    cost.backward()
+    torch.manual_seed(seed)
+    eps0 = torch.empty(M, 4, dtype=dtype).normal_()
+    masks = [torch.empty(M, 1, B, dtype=dtype).bernoulli_(1 - p).reshape(M, B)]
+    eps = []
+    for _ in range(1, Tn):
+        eps.append(torch.empty(M, 2, dtype=dtype).normal_())
+        masks.append(torch.empty(M, 1, B, dtype=dtype).bernoulli_(1 - p).reshape(M, B))
+    x0 = x0m.reshape(1, -1) + torch.sqrt(x0v).reshape(1, -1) * eps0
+    assert torch.equal(x0, st[0].detach()), "noise replay does not reproduce the reference's x0"
+    save("rollout_bias", states_tr=xtr, inputs_tr=utr, sigma_n=sig, x0_mean=N(x0m), x0_var=N(x0v), eps=N(torch.stack(eps)),
+         masks=N(torch.stack(masks)).astype(np.uint8), p_drop=p, seed=seed, states=N(st), inputs=N(inp), cost=N(cost), std=N(std),
+         pol_ls=N(torch.exp(pol.log_lengthscales)), pol_centers=N(pol.centers), pol_weight=N(pol.f_linear.weight), pol_bias=N(pol.f_linear.bias),
+         g_log_ls=N(pol.log_lengthscales.grad), g_centers=N(pol.centers.grad), g_weight=N(pol.f_linear.weight.grad), g_bias=N(pol.f_linear.bias.grad))
+
+
+rollout_bias()
 print("done")

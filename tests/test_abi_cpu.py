@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     for n in dbg:
         assert hasattr(lib, n)
     assert set(k for k in hipabi._SIGS if k.startswith("mcp_debug")) == set(dbg)
-    assert lib.mcp_abi_version() == 3
+    assert lib.mcp_abi_version() == 4
     assert b"gfx950" in lib.mcp_build_info()
 
 
@@ -71,7 +71,7 @@ def test_argument_validation_without_gpu():
     assert lib.mcp_rollout_fwd(C.byref(m), C.byref(p), C.byref(n), 4, 3, 1, None, None, None, None, None, None, 0, None) == -1
     assert lib.mcp_rollout_workspace_bytes(C.byref(m), C.byref(p), 0, 0) == 0
     p.P, p.B, p.U = 5, 200, 1
-    assert lib.mcp_rollout_workspace_bytes(C.byref(m), C.byref(p), 400, 150) == 8 * (5 + 200 * 5 + 200) * 400
+    assert lib.mcp_rollout_workspace_bytes(C.byref(m), C.byref(p), 400, 150) == 8 * (5 + 200 * 5 + 200 + 1) * 400  # (+ U: dJ/dbias)
     assert lib.mcp_sod_workspace_bytes(300) == 8 * 300 * 300
     c = hipabi.Cost()
     c.kind, c.S = 7, 4

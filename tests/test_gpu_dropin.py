@@ -568,3 +568,38 @@ def test_policy_scale_factor_and_per_trial_cost_lengthscales(golden):
     assert relerr(st.grad, fx["vl_grad"]) < 1e-12
     c0, _ = cf(T(fx["vl_states"]), None, 0)  # the other trial's lengthscales give another cost
     assert abs(float(c0) - float(c.detach())) > 1e-3
+
+
+def test_policy_bias_seed_for_seed_parity_with_reference(golden):
+    """Sum_of_gaussians_with_angles(flg_bias=True, flg_train_bias=True) through the drop-in MC_PILCO class, reference noise mode."""
+    from mc_pilco_amd.policy_learning import MC_PILCO, Cost_function, Policy
+
+    fx = golden("rollout_bias")
+    ml = build_cartpole(fx, 0, False)
+    c = sy.CARTPOLE
+    B = fx["pol_centers"].shape[0]
+    ppar = dict(state_dim=4, input_dim=1, num_basis=B, angle_indices=np.array([2]), non_angle_indices=np.array([0, 1, 3]),
+                lengthscales_init=fx["pol_ls"].reshape(-1), centers_init=fx["pol_centers"], weight_init=fx["pol_weight"], flg_squash=True,
+                u_max=c["u_max"], flg_bias=True, bias_init=fx["pol_bias"], flg_train_bias=True, flg_drop=True, dtype=dtype, device=dev())
+    with quiet():
+        obj = MC_PILCO.MC_PILCO(T_sampling=c["Ts"], state_dim=4, input_dim=1, f_sim=lambda y, t, u: None, f_model_learning=lambda **kw: ml,
+                                model_learning_par={}, f_rand_exploration_policy=Policy.Random_exploration,
+                                rand_exploration_policy_par=dict(state_dim=4, input_dim=1, u_max=1.0, dtype=dtype),
+                                f_control_policy=Policy.Sum_of_gaussians_with_angles, control_policy_par=ppar,
+                                f_cost_function=Cost_function.Cart_pole_cost,
+                                cost_function_par=dict(target_state=T(c["cost_target"]), lengthscales=T(c["cost_ls"]), angle_index=2, pos_index=0),
+                                log_path=None, dtype=dtype, device=dev())
+    obj.noise_mode = "reference"
+    assert sorted(obj.control_policy.state_dict().keys()) == ["centers", "f_linear.bias", "f_linear.weight", "log_lengthscales"]
+    M, Tn, p = fx["states"].shape[1], fx["states"].shape[0], float(fx["p_drop"])
+    torch.manual_seed(int(fx["seed"]))
+    st, inp = obj.apply_policy(particles_initial_state_mean=T(fx["x0_mean"]), particles_initial_state_var=T(fx["x0_var"]),
+                               flg_particles_init_uniform=False, particles_init_up_bound=None, particles_init_low_bound=None,
+                               flg_particles_init_multi_gauss=False, num_particles=M, T_control=Tn, p_dropout=p)
+    cost, std = obj.cost_function(st, inp, 0)
+    cost.backward()
+    assert float((st.detach().cpu() - torch.as_tensor(fx["states"])).abs().max()) < 1e-8
+    assert abs(float(cost.detach()) - float(fx["cost"])) < 1e-10 * abs(float(fx["cost"]))
+    pol = obj.control_policy
+    assert relerr(pol.f_linear.bias.grad, fx["g_bias"]) < 1e-7
+    assert relerr(pol.centers.grad, fx["g_centers"]) < 1e-7 and relerr(pol.f_linear.weight.grad, fx["g_weight"]) < 1e-7

@@ -533,3 +533,48 @@ def test_posterior_operator_takes_more_than_1024_test_points(golden):
     mu, var = ops.posterior(gp, Xs)
     assert relerr(mu[:32], fx["mu"]) < 1e-10 and relerr(mu[-32:], fx["mu"]) < 1e-10
     assert abserr(var[-32:], fx["var"]) < 1e-10
+
+
+@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16, 101, 102, 104, 116])
+def test_rollout_with_policy_bias_vs_reference(golden, ppw):
+    """flg_bias (Policy.py:203-212) through the C ABI: mcp_policy.bias enters the linear layer in every forward variant, the adjoint
+    sweep returns dJ/dbias (mcp_policy.g_bias) next to the three other gradients."""
+    from gpu_helpers import G, dev, forced_variant, noise_from, packed_cost, packed_model
+    from mc_pilco_amd import ops
+    from mc_pilco_amd import synthetic as sy
+
+    fx = golden("rollout_bias")
+    model, cost = packed_model_from_training(fx), packed_cost(fx, "se")
+    c = sy.CARTPOLE
+    prm = [torch.log(G(fx["pol_ls"])).reshape(1, -1).requires_grad_(True), G(fx["pol_centers"]).requires_grad_(True),
+           G(fx["pol_weight"]).requires_grad_(True), G(fx["pol_bias"]).requires_grad_(True)]
+    pol = ops.PackedPolicy("angles", c["S"], prm[0], prm[1], prm[2], c["u_max"], True, angle=[2], non_angle=[0, 1, 3], bias=prm[3])
+    with forced_variant(ppw) as fv:
+        st, inp, status = ops.rollout(model, pol, noise_from(fx), G(fx["states"][0]), fx["states"].shape[0], float(fx["p_drop"]))
+        cc, ss = ops.expected_cost(cost, st)
+        cc.backward()
+        fv.check()
+    assert int(status.item()) == 0
+    assert abserr(st, fx["states"]) < 1e-8 and abserr(inp, fx["inputs"]) < 1e-8
+    assert abs(float(cc) - float(fx["cost"])) < 1e-10 * abs(float(fx["cost"]))
+    for q, k in zip(prm, ["g_log_ls", "g_centers", "g_weight", "g_bias"]):
+        assert relerr(q.grad.reshape(fx[k].shape), fx[k]) < 1e-7, k
+
+
+def packed_model_from_training(fx):
+    """HIP pretrain (Gram -> Cholesky -> inverse -> alpha) on a fixture's training data, cart-pole speed model."""
+    from gpu_helpers import G, spec_from
+    from mc_pilco_amd import ops
+    from mc_pilco_amd import synthetic as sy
+
+    c = sy.CARTPOLE
+    Z, Ys = orc.speed_model_io(fx["states_tr"], fx["inputs_tr"], c["angle"], c["not_angle"], c["vel"])
+    gps = []
+    for g in range(2):
+        sp = spec_from(c["lengthscales"], float(fx["sigma_n"]))
+        K = ops.cov_build(sp, G(Z.numpy()), None, noise=True)
+        U, _, stt = ops.chol_factor(K)
+        assert int(stt.item()) == 0
+        _, Kinv = ops.chol_inverse(U)
+        gps.append(ops.PackedGP(sp, G(Z.numpy()), ops.gp_alpha(Kinv, G(Ys[g].numpy()), 0.0), Kinv))
+    return ops.PackedModel(gps, 4, 1, c["Ts"], c["angle"], c["not_angle"], c["vel"], c["not_vel"])

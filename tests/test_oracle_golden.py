@@ -283,3 +283,20 @@ def test_policy_scale_factor_and_per_trial_cost_lengthscales(golden):
     assert abs(float(c.detach()) - float(fx["vl_cost"])) < 1e-12 * abs(float(fx["vl_cost"]))
     assert abs(float(s) - float(fx["vl_std"])) < 1e-12 * abs(float(fx["vl_std"]))
     assert relerr(st.grad, fx["vl_grad"]) < 1e-12
+
+
+def test_rollout_with_policy_bias(golden):
+    """flg_bias (Policy.py:203-212): u = squash(W (phi o mask) + b); full rollout, cost and the four gradients."""
+    fx = golden("rollout_bias")
+    m, c = _speed_model_from(fx)
+    prm = [torch.log(T(fx["pol_ls"])).reshape(1, -1), T(fx["pol_centers"]), T(fx["pol_weight"]), T(fx["pol_bias"])]
+    for q in prm:
+        q.requires_grad_(True)
+    pp = orc.PolicyPar(prm[0], prm[1], prm[2], c["u_max"], "angles", angle=[2], non_angle=[0, 1, 3], bias=prm[3])
+    st, inp = orc.apply_policy(m, pp, T(fx["states"][0]), fx["states"].shape[0], float(fx["p_drop"]), T(fx["eps"]), T(fx["masks"]))
+    cost, std = orc.expected_cost(orc.cart_pole_cost(st, T(c["cost_target"]), T(c["cost_ls"]), c["cost_angle_index"], c["cost_pos_index"]))
+    cost.backward()
+    assert float((st.detach() - T(fx["states"])).abs().max()) < 1e-9 and float((inp.detach() - T(fx["inputs"])).abs().max()) < 1e-9
+    assert abs(float(cost.detach()) - float(fx["cost"])) < 1e-11 * abs(float(fx["cost"]))
+    for q, k in zip(prm, ["g_log_ls", "g_centers", "g_weight", "g_bias"]):
+        assert relerr(q.grad, fx[k]) < 1e-8, k
