@@ -147,7 +147,8 @@ class Runner:
 
             bb, aa = signal.butter(1, 0.5)  # test_mcpilco4pms_cartpole.py:155-157: pos [0,2], vel [1,3], fc 0.5
             self.meas = ops.MeasSpec(pos=[0, 2], vel=[1, 3], std_pos=[0.01, 0.01], b=bb, a=aa)
-        self.opt = torch.optim.Adam(self.w.params, lr=0.01)
+        # (fused=True: one kernel for the three parameter tensors -- the same update as the reference's "torch.optim.Adam(p, lr)")
+        self.opt = torch.optim.Adam(self.w.params, lr=0.01, fused=True)
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(1234 + rank)
         self.status_or = torch.zeros(1, dtype=torch.int32, device=dev)

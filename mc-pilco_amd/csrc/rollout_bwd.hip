@@ -558,21 +558,31 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   }
 }
 
-// sum the per-workgroup slabs in a fixed order (deterministic, no atomics)
-__global__ void grad_reduce_kernel(int nblk, int nparam, int PF, int BPF, int UB, const double* __restrict__ slab, double* __restrict__ g_log_ls,
-                                   double* __restrict__ g_centers, double* __restrict__ g_weight, double* __restrict__ g_bias) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nparam) return;
+// sum the per-workgroup slabs in a fixed order (deterministic, no atomics): 64 parameters per workgroup, its 4 waves take a
+// quarter of the slabs each (4 independent partial sums per thread keep loads in flight), partials meet in LDS.  (One thread per
+// parameter walking all slabs left 5 workgroups on the device: 34 us for 3.9 MB at the headline shape.)
+__global__ __launch_bounds__(256) void grad_reduce_kernel(int nblk, int nparam, int PF, int BPF, int UB, const double* __restrict__ slab,
+                                                          double* __restrict__ g_log_ls, double* __restrict__ g_centers,
+                                                          double* __restrict__ g_weight, double* __restrict__ g_bias) {
+  __shared__ double part[4][64];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const int per = (nblk + 3) / 4, k0 = q * per, k1 = imin(nblk, k0 + per);
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-  int k = 0;
-  for (; k + 3 < nblk; k += 4) {
-    s0 += slab[(size_t)k * nparam + i];
-    s1 += slab[(size_t)(k + 1) * nparam + i];
-    s2 += slab[(size_t)(k + 2) * nparam + i];
-    s3 += slab[(size_t)(k + 3) * nparam + i];
+  if (i < nparam) {
+    int k = k0;
+    for (; k + 3 < k1; k += 4) {
+      s0 += slab[(size_t)k * nparam + i];
+      s1 += slab[(size_t)(k + 1) * nparam + i];
+      s2 += slab[(size_t)(k + 2) * nparam + i];
+      s3 += slab[(size_t)(k + 3) * nparam + i];
+    }
+    for (; k < k1; ++k) s0 += slab[(size_t)k * nparam + i];
   }
-  for (; k < nblk; ++k) s0 += slab[(size_t)k * nparam + i];
-  double s = (s0 + s1) + (s2 + s3);
+  part[q][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q != 0 || i >= nparam) return;
+  const double s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
   if (i < PF)
     g_log_ls[i] = s;
   else if (i < PF + BPF)
@@ -691,7 +701,7 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   if (rc < 0) return rc;
   const int grid = rc;
   const int nparam = PF + policy->B * PF + U * policy->B + (policy->bias ? U : 0);
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3((nparam + 255) / 256), dim3(256), 0, st, grid, nparam, PF, policy->B * PF, U * policy->B, a.slab,
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((nparam + 63) / 64), dim3(256), 0, st, grid, nparam, PF, policy->B * PF, U * policy->B, a.slab,
                      g_log_ls, g_centers, g_weight, policy->bias ? policy->g_bias : nullptr);
   MCP_LAUNCH_CHECK();
   return MCP_OK;

@@ -88,3 +88,35 @@ def test_two_rank_hip_sharding_matches_single_process(fused):
     assert abs(s2 - s1) < 1e-10 * abs(s1)
     for a, b in zip(g2, g1):
         assert np.max(np.abs(a - b)) < 1e-12 * max(1.0, np.max(np.abs(b)))
+
+
+def _abi_comm_single_rank(out_q):
+    """mcp_comm_* / mcp_allreduce_grad on a one-rank communicator (all a one-GPU box can host): RCCL loads at run time, the
+    communicator is created once, an all-reduce over one rank is the identity, a second init with the same geometry is a no-op."""
+    import ctypes as C
+
+    import mcp_boot  # noqa: F401
+    from mc_pilco_amd import hipabi
+
+    torch.cuda.set_device(0)
+    lib = hipabi.lib()
+    uid = C.create_string_buffer(hipabi.COMM_ID_BYTES)
+    rc = [lib.mcp_comm_unique_id(uid), lib.mcp_comm_init(1, 0, uid.raw), lib.mcp_comm_world(), lib.mcp_comm_init(1, 0, uid.raw)]
+    x = torch.arange(1506, dtype=torch.float64, device="cuda") * 0.5
+    y = x.clone()
+    rc.append(lib.mcp_allreduce_grad(hipabi.ptr(y), y.numel(), hipabi.stream()))
+    torch.cuda.synchronize()
+    same = bool(torch.equal(x, y))
+    rc += [lib.mcp_comm_init(2, 0, uid.raw), lib.mcp_comm_destroy(), lib.mcp_comm_world()]
+    out_q.put((rc, same))
+
+
+def test_abi_collective_on_a_single_rank_communicator():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_abi_comm_single_rank, args=(q,))
+    p.start()
+    rc, same = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert rc == [0, 0, 1, 0, 0, -1, 0, 0] and same  # (a second init with another geometry is refused: one communicator per process)
