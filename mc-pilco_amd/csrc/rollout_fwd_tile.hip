@@ -38,13 +38,14 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define TL_NCOL(deg) ((deg) == 0 ? 2 : ((deg) == 1 ? 3 : 5))
 
 struct TileLayout {
-  int invl, xs, us, z, sf, dl, eps, ks, kv, qa, mup, gpl, kpar, scr, total;
+  int invl, xs, us, z, sf, dl, eps, ks, kv, qa, mup, gpl, kpar, scr, xt, al, total;
+  int xl;      // training inputs X^T and alpha of every GP staged in LDS (xt, al; row pitch NpadMax)
   int ptile, upart;  // policy phase: per-wave phi tiles (alias the k / v panels, idle then, when those are large enough) and partial sums  // offsets in doubles
   int nslot;   // phase-J partial-tile slots in scr
   int vslots;  // phase-V partial (32x16) slots in scr (7 let all 8 waves share the remainder blocks)
 };
 
-__host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, int PF, int NpadMax, int maxdeg) {
+__host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, int PF, int NpadMax, int maxdeg, bool want_xl = false) {
   TileLayout L;
   int o = 0;
   auto take = [&](int n) {
@@ -67,20 +68,31 @@ __host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, in
   L.gpl = take(G * GPL_DOUBLES);
   L.kpar = take(G * KP_STRIDE(D));
   const int slot = RT * CT * 256;
-  const int avail = MCP_LDS_LIMIT / 8 - o;
-  int nslot = 8;
-  while (nslot > 1 && nslot * slot > avail) nslot >>= 1;
-  int scr = nslot * slot;
-  if (scr < 7 * 512 && 7 * 512 <= avail) scr = 7 * 512;
+  const int xneed = G * (D + 1) * NpadMax + 4;  // X^T [G][D][NpadMax] | alpha [G][NpadMax]
+  const bool panels_ok = RF_NW * slot <= 2 * NpadMax * TL_KR;  // phase J can park its 8 partial tiles in the dead k / v panels
   const int ptiles = RF_NW * 16 * 17;
   const bool pt_in_scr = 2 * NpadMax * TL_KR < ptiles;
   const int polneed = RF_NW * 16 + (pt_in_scr ? ptiles : 0) + RF_NW * TL_PT * U;  // exchange slots, [phi tiles,] partial sums
-  if (scr < polneed) scr = polneed;  // per-wave exchange slots + policy partial sums
+  auto scr_size = [&](int nslot, int avail) {
+    int scr = nslot * slot;
+    if (scr < 7 * 512 && 7 * 512 <= avail) scr = 7 * 512;
+    if (scr < polneed) scr = polneed;  // per-wave exchange slots + policy partial sums
+    return scr;
+  };
+  // with the panels as parking space ONE phase-J slot (the result) is enough: the LDS that frees takes the small operands of phases K and J
+  const bool xl = want_xl && panels_ok && o + scr_size(1, MCP_LDS_LIMIT / 8 - o - xneed) + xneed <= MCP_LDS_LIMIT / 8;
+  const int avail = MCP_LDS_LIMIT / 8 - o - (xl ? xneed : 0);
+  int nslot = xl ? 1 : 8;
+  while (nslot > 1 && nslot * slot > avail) nslot >>= 1;
+  const int scr = scr_size(nslot, avail);
   L.nslot = nslot;
   L.vslots = scr / 512;
   L.scr = take(scr);
   L.ptile = pt_in_scr ? L.scr + RF_NW * 16 : L.ks;
   L.upart = L.scr + RF_NW * 16 + (pt_in_scr ? ptiles : 0);
+  L.xl = xl ? 1 : 0;
+  L.xt = xl ? take(G * D * NpadMax) : 0;
+  L.al = xl ? take(G * NpadMax) : 0;
   L.total = o;
   return L;
 }
@@ -101,8 +113,8 @@ __host__ __device__ inline TileLayout tile_layout(int S, int U, int D, int G, in
 // |z_p|^2 and |X_j|^2 are partial sums over the lane's own features, folded across the 4 feature lanes by two
 // lane exchanges.  Tiles of 16 training points are dealt round-robin to the 8 waves, the B operands of the next tile
 // are loaded (unconditionally) before the current tile is consumed.
-template <int NDQ>
-__device__ __forceinline__ void tile_k_load(double (&bx)[NDQ], double& alj, gptr_t Xt, gptr_t al, int Npad, int D, int tile, int kk, int n) {
+template <int NDQ, typename PT>
+__device__ __forceinline__ void tile_k_load(double (&bx)[NDQ], double& alj, PT Xt, PT al, int Npad, int D, int tile, int kk, int n) {
 #pragma unroll
   for (int i = 0; i < NDQ; ++i) bx[i] = Xt[(size_t)imin(4 * i + kk, D - 1) * Npad + 16 * tile + n];
   alj = al[16 * tile + n];  // zero on the padding rows (unused, and optimised away, for SE-only models)
@@ -152,13 +164,13 @@ __device__ __forceinline__ void tile_k_consume(const double (&bx)[NDQ], double a
     kv[o] = kt;
   }
 }
-template <int MAXDEG, int NDQ>
-__device__ __forceinline__ void tile_phase_k(const GpL& gp, const double* kp, int D, const double* z, double* ks, double* kv, double* wslot,
-                                             double* mup, int wv, int lane, unsigned long long* dbg = nullptr) {
+// PT: where X^T and alpha come from -- global memory (gptr_t; row pitch = the GP's Npad) or their LDS copies (const double*; pitch NpadMax)
+template <int MAXDEG, int NDQ, typename PT>
+__device__ __forceinline__ void tile_phase_k(const GpL& gp, PT Xt, PT al, int xpitch, const double* kp, int D, const double* z, double* ks, double* kv,
+                                             double* wslot, double* mup, int wv, int lane, unsigned long long* dbg = nullptr) {
   unsigned long long tq0 = dbg ? clock64() : 0;
   const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
   const int kk = lane >> 4, n = lane & 15;
-  gptr_t Xt = (gptr_t)gp.Xt;
   TileKConst<MAXDEG, NDQ> c;
   c.N = __builtin_amdgcn_readfirstlane(gp.N);
   c.deg = MAXDEG == 0 ? 0 : __builtin_amdgcn_readfirstlane(gp.deg);
@@ -192,14 +204,13 @@ __device__ __forceinline__ void tile_phase_k(const GpL& gp, const double* kp, in
   if (dbg && lane == 0) { unsigned long long now = clock64(); dbg[12] += now - tq0; tq0 = now; }
   double macc[4] = {0.0, 0.0, 0.0, 0.0};
   if (wv < ntile) {
-    gptr_t al = (gptr_t)gp.alpha;
     const int nt = (ntile - wv + RF_NW - 1) / RF_NW;
     double b0[NDQ], b1[NDQ], al0, al1;
-    tile_k_load<NDQ>(b0, al0, Xt, al, Npad, D, wv, kk, n);
+    tile_k_load<NDQ>(b0, al0, Xt, al, xpitch, D, wv, kk, n);
     for (int sI = 0; sI + 1 < nt; sI += 2) {
-      tile_k_load<NDQ>(b1, al1, Xt, al, Npad, D, wv + RF_NW * (sI + 1), kk, n);
+      tile_k_load<NDQ>(b1, al1, Xt, al, xpitch, D, wv + RF_NW * (sI + 1), kk, n);
       tile_k_consume<MAXDEG, NDQ>(b0, al0, c, wv + RF_NW * sI, kk, n, ks, kv, macc);
-      tile_k_load<NDQ>(b0, al0, Xt, al, Npad, D, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
+      tile_k_load<NDQ>(b0, al0, Xt, al, xpitch, D, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
       tile_k_consume<MAXDEG, NDQ>(b1, al1, c, wv + RF_NW * (sI + 1), kk, n, ks, kv, macc);
     }
     if (nt & 1) tile_k_consume<MAXDEG, NDQ>(b0, al0, c, wv + RF_NW * (nt - 1), kk, n, ks, kv, macc);
@@ -297,20 +308,20 @@ template <int DEG, int NDQ>
 struct TileJBatch {
   double a0[4], a1[4], al[4], xq[DEG >= 2 ? NDQ : 1];
 };
-template <int DEG, int NDQ>
-__device__ __forceinline__ void tile_j_load(TileJBatch<DEG, NDQ>& b, gptr_t Xt, gptr_t al, int Npad, int D, int RT, int cc0, int cc1, int jb, int kk,
-                                            int n) {
+template <int DEG, int NDQ, typename PT>
+__device__ __forceinline__ void tile_j_load(TileJBatch<DEG, NDQ>& b, PT Xt, PT al, int xpitch, int Npad, int D, int RT, int cc0, int cc1, int jb,
+                                            int kk, int n) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int j = imin(jb + 4 * u + kk, Npad - 1);
-    b.a0[u] = Xt[(size_t)cc0 * Npad + j];
-    b.a1[u] = RT > 1 ? Xt[(size_t)cc1 * Npad + j] : 0.0;
+    b.a0[u] = Xt[(size_t)cc0 * xpitch + j];
+    b.a1[u] = RT > 1 ? Xt[(size_t)cc1 * xpitch + j] : 0.0;
     b.al[u] = al[j];
   }
   if (DEG >= 2) {
     const int jr = imin(jb + n, Npad - 1);
 #pragma unroll
-    for (int i = 0; i < NDQ; ++i) b.xq[i] = Xt[(size_t)imin(4 * i + kk, D - 1) * Npad + jr];
+    for (int i = 0; i < NDQ; ++i) b.xq[i] = Xt[(size_t)imin(4 * i + kk, D - 1) * xpitch + jr];
   }
 }
 template <int DEG, int NDQ>
@@ -354,17 +365,16 @@ __device__ __forceinline__ void tile_j_consume(const TileJBatch<DEG, NDQ>& b, co
     }
   }
 }
-template <int DEG, int NDQ>
-__device__ __forceinline__ void tile_phase_j(const GpL& gp, const double* kp, int D, const double* z, const double* ks, const double* kv,
-                                             v4d (&acc)[2][TL_NCOL(DEG)], int RT, int wv, int lane, unsigned long long* dbg = nullptr) {
+template <int DEG, int NDQ, typename PT>
+__device__ __forceinline__ void tile_phase_j(const GpL& gp, PT Xt, PT al, int xpitch, const double* kp, int D, const double* z, const double* ks,
+                                             const double* kv, v4d (&acc)[2][TL_NCOL(DEG)], int RT, int wv, int lane,
+                                             unsigned long long* dbg = nullptr) {
   constexpr int CT = TL_NCOL(DEG);
   unsigned long long tq0 = dbg ? clock64() : 0;
   const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
   const int per = ((Npad + RF_NW * 4 - 1) / (RF_NW * 4)) * 4;
   const int j0 = imin(wv * per, Npad), j1 = imin(Npad, j0 + per);
   const int kk = lane >> 4, n = lane & 15;
-  gptr_t Xt = (gptr_t)gp.Xt;
-  gptr_t al = (gptr_t)gp.alpha;
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -382,12 +392,12 @@ __device__ __forceinline__ void tile_phase_j(const GpL& gp, const double* kp, in
   const int nbat = (j1 - j0 + 15) >> 4;
   if (dbg && lane == 0) { unsigned long long now = clock64(); dbg[14] += now - tq0; tq0 = now; }
   TileJBatch<DEG, NDQ> b0, b1;
-  tile_j_load<DEG, NDQ>(b0, Xt, al, Npad, D, RT, cc0, cc1, j0, kk, n);
+  tile_j_load<DEG, NDQ>(b0, Xt, al, xpitch, Npad, D, RT, cc0, cc1, j0, kk, n);
   for (int b = 0; b + 1 < nbat; b += 2) {
     const int ja = j0 + 16 * b;
-    tile_j_load<DEG, NDQ>(b1, Xt, al, Npad, D, RT, cc0, cc1, ja + 16, kk, n);
+    tile_j_load<DEG, NDQ>(b1, Xt, al, xpitch, Npad, D, RT, cc0, cc1, ja + 16, kk, n);
     tile_j_consume<DEG, NDQ>(b0, zwa, zwb, D, RT, Npad, ja, j1, kk, n, ks, kv, acc);
-    tile_j_load<DEG, NDQ>(b0, Xt, al, Npad, D, RT, cc0, cc1, j0 + 16 * imin(b + 2, nbat - 1), kk, n);
+    tile_j_load<DEG, NDQ>(b0, Xt, al, xpitch, Npad, D, RT, cc0, cc1, j0 + 16 * imin(b + 2, nbat - 1), kk, n);
     tile_j_consume<DEG, NDQ>(b1, zwa, zwb, D, RT, Npad, ja + 16, j1, kk, n, ks, kv, acc);
   }
   if (nbat & 1) tile_j_consume<DEG, NDQ>(b0, zwa, zwb, D, RT, Npad, j0 + 16 * (nbat - 1), j1, kk, n, ks, kv, acc);
@@ -740,7 +750,9 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
 // PMS: the policy is evaluated on a simulated measurement (mcp_meas, MC_PILCO4PMS.apply_policy) instead of the true state
 // GSH: a.gsh_cs workgroups per 16-particle tile, each evaluates G / gsh_cs consecutive GPs (and, redundantly, the policy); they hand
 // each other the sampled increments once per step exactly as the small-tile kernel's GP-sharded launch does (rollout_fwd.hip).
-template <int MAXDEG, int CLS, bool PMS, bool GSH = false>
+// XL: X^T and alpha of every GP are staged in LDS once per launch (cart-pole class, when the layout has the room): phases K and J
+// then take their small operands with LDS latency instead of an L2 round trip per tile / batch
+template <int MAXDEG, int CLS, bool PMS, bool GSH = false, bool XL = false>
 __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   constexpr int NG = CLS == 0 ? 2 : (CLS == 1 ? 6 : 8);              // feature groups of 4 (GP inputs, policy features)
   constexpr int MAXTASK = CLS == 2 ? TL_MAXTASK : 2;                  // 32-row blocks of Kinv per wave
@@ -751,7 +763,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   const int wv0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
   constexpr int P = TL_PT;
-  const TileLayout L = tile_layout(S, U, D, G, PF, a.NpadMax, a.maxdeg);
+  const TileLayout L = tile_layout(S, U, D, G, PF, a.NpadMax, a.maxdeg, XL);
   double* invl = smem + L.invl;
   double* xs = smem + L.xs;
   double* us = smem + L.us;
@@ -800,6 +812,18 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   // ---- one-time staging ------------------------------------------------------------------
   for (int it = tid0; it < PF; it += RF_NT) invl[it] = exp(-pl.log_ls[it]);
   stage_gp_tables(md.gp, md.var_scale, G, D, gpl, kpar, tid0);
+  if (XL) {
+    double* xt_w = smem + L.xt;
+    double* al_w = smem + L.al;
+    for (int g = 0; g < G; ++g) {
+      const mcp_gp& gq = md.gp[g];
+      for (int it = tid0; it < D * a.NpadMax; it += RF_NT) {
+        const int d = it / a.NpadMax, j = it - d * a.NpadMax;
+        xt_w[(g * D + d) * a.NpadMax + j] = j < gq.Npad ? gq.Xt[(size_t)d * gq.Npad + j] : 0.0;
+      }
+      for (int it = tid0; it < a.NpadMax; it += RF_NT) al_w[g * a.NpadMax + it] = it < gq.Npad ? gq.alpha[it] : 0.0;
+    }
+  }
   lds_barrier();
   // launch constants of the degree-2 polynomial term: sum_j alpha_j X_jc X_je (for d mu/dz)
   if (MAXDEG >= 2 && a.maxdeg >= 2) {  // (qa has no storage when maxdeg < 2)
@@ -988,7 +1012,14 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       const double* kp = kpar + g * KP_STRIDE(D);
       const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
       const int deg = MAXDEG == 0 ? 0 : __builtin_amdgcn_readfirstlane(gp.deg);
-      tile_phase_k<MAXDEG, NG>(gp, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+      const double* xt_g = smem + L.xt + g * D * a.NpadMax;  // (XL only)
+      const double* al_g = smem + L.al + g * a.NpadMax;
+      if (XL)
+        tile_phase_k<MAXDEG, NG>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane,
+                                 (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+      else
+        tile_phase_k<MAXDEG, NG>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane,
+                                 (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
       lds_barrier();
       TL_STAMP(3);
       // ---- phase V ---------------------------------------------------------------------------
@@ -1099,17 +1130,29 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       const int panel_doubles = 2 * a.NpadMax * TL_KR;  // ks and kv are adjacent in the layout
       if (MAXDEG == 0 || deg == 0) {
         v4d acc[2][TL_NCOL(0)];
-        tile_phase_j<0, 1>(gp, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+        if (XL)
+          tile_phase_j<0, 1>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+        else
+          tile_phase_j<0, 1>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
+                               (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
         tile_j_finish<TL_NCOL(0)>(acc, RT, scr, L.nslot, ks, panel_doubles, wv, lane, tid);
         CTg = TL_NCOL(0);
       } else if (deg == 1) {
         v4d acc[2][TL_NCOL(1)];
-        tile_phase_j<1, 1>(gp, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+        if (XL)
+          tile_phase_j<1, 1>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+        else
+          tile_phase_j<1, 1>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
+                               (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
         tile_j_finish<TL_NCOL(1)>(acc, RT, scr, L.nslot, ks, panel_doubles, wv, lane, tid);
         CTg = TL_NCOL(1);
       } else {
         v4d acc[2][TL_NCOL(2)];
-        tile_phase_j<2, NG>(gp, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+        if (XL)
+          tile_phase_j<2, NG>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+        else
+          tile_phase_j<2, NG>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
+                               (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
         tile_j_finish<TL_NCOL(2)>(acc, RT, scr, L.nslot, ks, panel_doubles, wv, lane, tid);
         CTg = TL_NCOL(2);
       }
@@ -1271,50 +1314,57 @@ bool fwd_tile_fits(const mcp_model* model, const mcp_policy* policy) {
   return sizeof(double) * (size_t)L.total <= MCP_LDS_LIMIT;
 }
 
-template <int MAXDEG, int CLS, bool PMS>
+template <int MAXDEG, int CLS, bool PMS, bool XL>
 static int launch_tile_pms(const FwdArgs& a, size_t lds, hipStream_t st) {
-  MCP_ENSURE_MAX_LDS(rollout_fwd_tile_kernel<MAXDEG, CLS, PMS>);
+  MCP_ENSURE_MAX_LDS(rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, false, XL>);
   const int grid = (a.M + TL_PT - 1) / TL_PT;
-  hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, CLS, PMS>), dim3(grid), dim3(RF_NT), lds, st, a);
+  hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, false, XL>), dim3(grid), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }
 
-template <int MAXDEG, int CLS, bool PMS>
+template <int MAXDEG, int CLS, bool PMS, bool XL>
 static int launch_tile_gsh(const FwdArgs& a, size_t lds, hipStream_t st) {
-  MCP_ENSURE_MAX_LDS(rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true>);
+  MCP_ENSURE_MAX_LDS(rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true, XL>);
   const int grid = ((a.nclusters + 7) / 8) * 8 * a.gsh_cs;
-  hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true>), dim3(grid), dim3(RF_NT), lds, st, a);
+  hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true, XL>), dim3(grid), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }
+// the cart-pole class stages X^T / alpha in LDS when the layout has the room for it (tile_layout decides; the wider classes never have)
 template <int MAXDEG, int CLS>
-static int launch_tile_gsh_deg(const FwdArgs& a, size_t lds, hipStream_t st) {
-  return a.pol.meas.n > 0 ? launch_tile_gsh<MAXDEG, CLS, true>(a, lds, st) : launch_tile_gsh<MAXDEG, CLS, false>(a, lds, st);
+static int launch_tile_gsh_deg(const FwdArgs& a, hipStream_t st) {
+  const TileLayout L = tile_layout(a.model.S, a.model.U, a.model.D, a.model.G, a.pol.P, a.NpadMax, a.maxdeg, CLS == 0);
+  const size_t lds = sizeof(double) * (size_t)L.total;
+  const bool pms = a.pol.meas.n > 0;
+  if (CLS == 0 && L.xl) return pms ? launch_tile_gsh<MAXDEG, CLS, true, CLS == 0>(a, lds, st) : launch_tile_gsh<MAXDEG, CLS, false, CLS == 0>(a, lds, st);
+  return pms ? launch_tile_gsh<MAXDEG, CLS, true, false>(a, lds, st) : launch_tile_gsh<MAXDEG, CLS, false, false>(a, lds, st);
 }
 
 template <int MAXDEG, int CLS>
-static int launch_tile_deg(const FwdArgs& a, size_t lds, hipStream_t st) {
-  return a.pol.meas.n > 0 ? launch_tile_pms<MAXDEG, CLS, true>(a, lds, st) : launch_tile_pms<MAXDEG, CLS, false>(a, lds, st);
+static int launch_tile_deg(const FwdArgs& a, hipStream_t st) {
+  const TileLayout L = tile_layout(a.model.S, a.model.U, a.model.D, a.model.G, a.pol.P, a.NpadMax, a.maxdeg, CLS == 0);
+  const size_t lds = sizeof(double) * (size_t)L.total;
+  const bool pms = a.pol.meas.n > 0;
+  if (CLS == 0 && L.xl) return pms ? launch_tile_pms<MAXDEG, CLS, true, CLS == 0>(a, lds, st) : launch_tile_pms<MAXDEG, CLS, false, CLS == 0>(a, lds, st);
+  return pms ? launch_tile_pms<MAXDEG, CLS, true, false>(a, lds, st) : launch_tile_pms<MAXDEG, CLS, false, false>(a, lds, st);
 }
 
 int launch_fwd_tile(const FwdArgs& a, hipStream_t st) {
   if (!fwd_tile_fits(&a.model, &a.pol)) return MCP_ERR_LIMIT;
-  TileLayout L = tile_layout(a.model.S, a.model.U, a.model.D, a.model.G, a.pol.P, a.NpadMax, a.maxdeg);
-  const size_t lds = sizeof(double) * (size_t)L.total;
   const int D = a.model.D, PF = a.pol.P, U = a.model.U;
   const int cls = a.NpadMax > 512 ? 2 : ((D <= 8 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2));
   // one instantiation per (highest polynomial degree, class): no code or registers for kernel terms the model does not have
   switch (cls * 3 + a.maxdeg) {
-    case 0: return launch_tile_deg<0, 0>(a, lds, st);
-    case 1: return launch_tile_deg<1, 0>(a, lds, st);
-    case 2: return launch_tile_deg<2, 0>(a, lds, st);
-    case 3: return launch_tile_deg<0, 1>(a, lds, st);
-    case 4: return launch_tile_deg<1, 1>(a, lds, st);
-    case 5: return launch_tile_deg<2, 1>(a, lds, st);
-    case 6: return launch_tile_deg<0, 2>(a, lds, st);
-    case 7: return launch_tile_deg<1, 2>(a, lds, st);
-    default: return launch_tile_deg<2, 2>(a, lds, st);
+    case 0: return launch_tile_deg<0, 0>(a, st);
+    case 1: return launch_tile_deg<1, 0>(a, st);
+    case 2: return launch_tile_deg<2, 0>(a, st);
+    case 3: return launch_tile_deg<0, 1>(a, st);
+    case 4: return launch_tile_deg<1, 1>(a, st);
+    case 5: return launch_tile_deg<2, 1>(a, st);
+    case 6: return launch_tile_deg<0, 2>(a, st);
+    case 7: return launch_tile_deg<1, 2>(a, st);
+    default: return launch_tile_deg<2, 2>(a, st);
   }
 }
 
@@ -1326,15 +1376,13 @@ int launch_fwd_tile_sharded(const FwdArgs& a, hipStream_t st) {
   if (a.NpadMax > 512) return MCP_ERR_LIMIT;
   const int cls = (D <= 8 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2);
   if (cls == 2) return MCP_ERR_LIMIT;
-  TileLayout L = tile_layout(a.model.S, a.model.U, a.model.D, a.model.G, a.pol.P, a.NpadMax, a.maxdeg);
-  const size_t lds = sizeof(double) * (size_t)L.total;
   switch (cls * 3 + a.maxdeg) {
-    case 0: return launch_tile_gsh_deg<0, 0>(a, lds, st);
-    case 1: return launch_tile_gsh_deg<1, 0>(a, lds, st);
-    case 2: return launch_tile_gsh_deg<2, 0>(a, lds, st);
-    case 3: return launch_tile_gsh_deg<0, 1>(a, lds, st);
-    case 4: return launch_tile_gsh_deg<1, 1>(a, lds, st);
-    default: return launch_tile_gsh_deg<2, 1>(a, lds, st);
+    case 0: return launch_tile_gsh_deg<0, 0>(a, st);
+    case 1: return launch_tile_gsh_deg<1, 0>(a, st);
+    case 2: return launch_tile_gsh_deg<2, 0>(a, st);
+    case 3: return launch_tile_gsh_deg<0, 1>(a, st);
+    case 4: return launch_tile_gsh_deg<1, 1>(a, st);
+    default: return launch_tile_gsh_deg<2, 1>(a, st);
   }
 }
 
