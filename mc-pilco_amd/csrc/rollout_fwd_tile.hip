@@ -355,6 +355,7 @@ __device__ __forceinline__ void tile_j_consume(const TileJBatch<DEG, NDQ>& b, co
   const int c0 = n, c1 = 16 + n;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
+    if (jb + 4 * u >= j1) continue;  // (wave-uniform) rows past this wave's share carry zero weights: their MFMAs are not issued at all
     const double av0 = c0 < D ? b.a0[u] : (c0 == D ? 1.0 : 0.0);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv[u][ct], acc[0][ct], 0, 0, 0);
