@@ -579,3 +579,21 @@ def packed_model_from_training(fx):
         _, Kinv = ops.chol_inverse(U)
         gps.append(ops.PackedGP(sp, G(Z.numpy()), ops.gp_alpha(Kinv, G(Ys[g].numpy()), 0.0), Kinv))
     return ops.PackedModel(gps, 4, 1, c["Ts"], c["angle"], c["not_angle"], c["vel"], c["not_vel"])
+
+
+def test_recovery_path_runs_unsharded():
+    """The step that follows an MCP_STATUS_SYNC is repeated with gp_sharding=False (no hand-off workspace is passed): the library
+    must then launch unsharded, and give the same trajectories (to rounding) as the GP-sharded launch the dispatch would pick."""
+    from gpu_helpers import dev
+    from mc_pilco_amd import hipabi, ops, workloads
+
+    w = workloads.build("c1", device=dev(), M=400, T=12)
+    torch.manual_seed(2)
+    x0 = w.sample_x0()
+    with torch.no_grad():
+        a, ua, sa = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=6, call=1), x0, w.T, w.p_drop)
+        assert hipabi.lib().mcp_debug_last_gp_sharded() >= 1
+        b, ub, sb = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=6, call=1), x0, w.T, w.p_drop, gp_sharding=False)
+        assert hipabi.lib().mcp_debug_last_gp_sharded() == 0
+    assert int(sa.item()) == 0 and int(sb.item()) == 0
+    assert float((a - b).abs().max()) < 1e-8 and float((ua - ub).abs().max()) < 1e-8
