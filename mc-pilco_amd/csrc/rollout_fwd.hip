@@ -970,7 +970,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       if (lane == 0) {
         s += bias_l[k];
         double um = umax_l[k];
-        double u = pl.squash ? um * tanh(s / um) : s;
+        double u = pl.squash ? um * fast_tanh(s / um) : s;
         us[p * U + k] = u;
         z[p * D + nna + 2 * na + k] = u;
         if (m0 + p < Mend) {

@@ -993,7 +993,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       for (int w = 0; w < RF_NW; ++w) sacc += up[(w * P + p) * U + k];
       if (pl.bias) sacc += pl.bias[k];
       const double um = pl.u_max[k];
-      const double u = pl.squash ? um * tanh(sacc / um) : sacc;
+      const double u = pl.squash ? um * fast_tanh(sacc / um) : sacc;
       us[p * U + k] = u;
       z[p * D + nna + 2 * na + k] = u;
       if (m0 + p < M) {
