@@ -408,18 +408,24 @@ __device__ __forceinline__ void tile_phase_j(const GpL& gp, PT Xt, PT al, int xp
 // The 8 waves' partial tiles meet in `nslot` (1, 2, 4 or 8, whatever fits the LDS) slots: while more waves than slots hold a
 // partial, the upper half hands its tiles to the lower half through the slots (fixed pairing, fixed order); the
 // remaining min(8, nslot) partials stay in the slots and phase F adds them as it reads.  With 8 slots: no exchange at all.
+// Only the accumulator registers that hold rows c <= D are parked and added (row = (lane >> 4) + 4 r: with D + 1 = 7 rows of
+// [X^T; 1] registers 2 and 3 of every tile are never read); the slot layout itself is unchanged.
+__device__ __forceinline__ int tile_j_rmax(int D, int rt) { return (imin(D - 16 * rt, 15)) >> 2; }
 template <int CT>
-__device__ __forceinline__ void tile_j_store(const v4d (&acc)[2][CT], int RT, double* s, int lane) {
+__device__ __forceinline__ void tile_j_store(const v4d (&acc)[2][CT], int RT, int D, double* s, int lane) {
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
-    if (rt < RT)
+    if (rt < RT) {
+      const int rmax = tile_j_rmax(D, rt);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[(rt * CT + ct) * 256 + r * 64 + lane] = acc[rt][ct][r];
+        for (int r = 0; r < 4; ++r)
+          if (r <= rmax) s[(rt * CT + ct) * 256 + r * 64 + lane] = acc[rt][ct][r];
+    }
 }
 template <int CT>
-__device__ __forceinline__ int tile_j_reduce(v4d (&acc)[2][CT], int RT, double* scr, int nslot, int wv, int lane) {
+__device__ __forceinline__ int tile_j_reduce(v4d (&acc)[2][CT], int RT, int D, double* scr, int nslot, int wv, int lane) {
   const int slot = RT * CT * 256;
   int active = RF_NW;
   for (; active > nslot; active >>= 1) {
@@ -427,22 +433,25 @@ __device__ __forceinline__ int tile_j_reduce(v4d (&acc)[2][CT], int RT, double* 
     for (int base = 0; base < half; base += nslot) {
       // writers: waves half+base .. half+base+nslot-1 ; readers: waves base .. base+nslot-1
       const int wi = wv - half - base, ri = wv - base;
-      if (wi >= 0 && wi < nslot && wv < active) tile_j_store<CT>(acc, RT, scr + wi * slot, lane);
+      if (wi >= 0 && wi < nslot && wv < active) tile_j_store<CT>(acc, RT, D, scr + wi * slot, lane);
       lds_barrier();
       if (ri >= 0 && ri < nslot && ri + base < half) {
         const double* s = scr + ri * slot;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
-          if (rt < RT)
+          if (rt < RT) {
+            const int rmax = tile_j_rmax(D, rt);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) acc[rt][ct][r] += s[(rt * CT + ct) * 256 + r * 64 + lane];
+              for (int r = 0; r < 4; ++r)
+                if (r <= rmax) acc[rt][ct][r] += s[(rt * CT + ct) * 256 + r * 64 + lane];
+          }
       }
       lds_barrier();
     }
   }
-  if (wv < active) tile_j_store<CT>(acc, RT, scr + wv * slot, lane);
+  if (wv < active) tile_j_store<CT>(acc, RT, D, scr + wv * slot, lane);
   return active;  // partials left in the slots
 }
 
@@ -450,24 +459,45 @@ __device__ __forceinline__ int tile_j_reduce(v4d (&acc)[2][CT], int RT, double* 
 // R.  With room for 8 slots in `scr` every wave simply parks its tiles there.  The wide classes have room for 1-2 slots only
 // (UR5: 12 KB per slot beside 115 KB of k / v panels): their waves park the tiles in the k / v panels instead -- dead once
 // every wave has left phase J, one barrier -- which replaces the pairwise hand-down through the few slots (three rounds of
-// store / barrier / add / barrier).
+// store / barrier / add / barrier).  The final add walks the live (tile, register) pairs only and issues all partial reads of an
+// element before the first add (a loop over a run-time count made it one LDS round trip per partial).
 template <int CT>
-__device__ __forceinline__ void tile_j_finish(v4d (&acc)[2][CT], int RT, double* scr, int nslot, double* panels, int panel_doubles, int wv,
-                                              int lane, int tid) {
+__device__ __forceinline__ void tile_j_finish(v4d (&acc)[2][CT], int RT, int D, double* scr, int nslot, double* panels, int panel_doubles, int wv,
+                                              int lane, int tid, unsigned long long* dbg = nullptr) {
   const int slot = RT * CT * 256;
   const bool in_panels = nslot < RF_NW && RF_NW * slot <= panel_doubles;
   double* base = in_panels ? panels : scr;
+  unsigned long long tq0 = dbg ? clock64() : 0;
   if (in_panels) lds_barrier();  // every wave is done reading k and v
-  const int nfin = tile_j_reduce<CT>(acc, RT, base, in_panels ? RF_NW : nslot, wv, lane);
+  if (dbg && lane == 0) { unsigned long long now = clock64(); dbg[9] += now - tq0; tq0 = now; }
+  const int nfin = tile_j_reduce<CT>(acc, RT, D, base, in_panels ? RF_NW : nslot, wv, lane);
   lds_barrier();
+  if (dbg && lane == 0) { unsigned long long now = clock64(); dbg[10] += now - tq0; tq0 = now; }
   if (nfin > 1 || in_panels) {  // add the partials with all threads (fixed order), result in slot 0 of scr
-    for (int e = tid; e < slot; e += RF_NT) {
-      double sacc = base[e];
-      for (int w = 1; w < nfin; ++w) sacc += base[w * slot + e];
+    const int n0 = tile_j_rmax(D, 0) + 1, n1 = RT > 1 ? tile_j_rmax(D, 1) + 1 : 0;  // live registers per tile, row tile 0 / 1
+    const int nlive = CT * (n0 + n1);
+    for (int q = wv; q < nlive; q += RF_NW) {  // one (tile, register) pair = 64 elements per wave and pass
+      const int q1 = q - CT * n0;
+      const int n1s = imax(n1, 1);
+      const int tt = q1 < 0 ? q / n0 : CT + q1 / n1s, r = q1 < 0 ? q - (q / n0) * n0 : q1 - (q1 / n1s) * n1s;
+      const int e = tt * 256 + r * 64 + lane;
+      double sacc;
+      if (nfin == RF_NW) {
+        double x[RF_NW];
+#pragma unroll
+        for (int w = 0; w < RF_NW; ++w) x[w] = base[w * slot + e];
+        sacc = x[0];
+#pragma unroll
+        for (int w = 1; w < RF_NW; ++w) sacc += x[w];
+      } else {
+        sacc = base[e];
+        for (int w = 1; w < nfin; ++w) sacc += base[w * slot + e];
+      }
       scr[e] = sacc;
     }
     lds_barrier();
   }
+  if (dbg && lane == 0) dbg[11] += clock64() - tq0;
 }
 
 // R[c][kind][p] = sum of the nfin partials; tile (c>>4, kind), element (row c&15, col p) in the accumulator layout
@@ -1136,16 +1166,16 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         else
           tile_phase_j<0, 1>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
                                (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
-        tile_j_finish<TL_NCOL(0)>(acc, RT, scr, L.nslot, ks, panel_doubles, wv, lane, tid);
+        tile_j_finish<TL_NCOL(0)>(acc, RT, D, scr, L.nslot, ks, panel_doubles, wv, lane, tid, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
         CTg = TL_NCOL(0);
-      } else if (deg == 1) {
+      } else if (MAXDEG == 1 || deg == 1) {
         v4d acc[2][TL_NCOL(1)];
         if (XL)
           tile_phase_j<1, 1>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
         else
           tile_phase_j<1, 1>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
                                (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
-        tile_j_finish<TL_NCOL(1)>(acc, RT, scr, L.nslot, ks, panel_doubles, wv, lane, tid);
+        tile_j_finish<TL_NCOL(1)>(acc, RT, D, scr, L.nslot, ks, panel_doubles, wv, lane, tid, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
         CTg = TL_NCOL(1);
       } else {
         v4d acc[2][TL_NCOL(2)];
@@ -1154,7 +1184,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         else
           tile_phase_j<2, NG>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
                                (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
-        tile_j_finish<TL_NCOL(2)>(acc, RT, scr, L.nslot, ks, panel_doubles, wv, lane, tid);
+        tile_j_finish<TL_NCOL(2)>(acc, RT, D, scr, L.nslot, ks, panel_doubles, wv, lane, tid, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
         CTg = TL_NCOL(2);
       }
       TL_STAMP(6);
@@ -1178,7 +1208,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           }
           kzz += p1;
           ktv += pv;
-          if (deg >= 2) {
+          if (MAXDEG >= 2 && deg >= 2) {
             double qv = 0.0;
             for (int d = 0; d < D; ++d) {
               const double zz = zp[d] * zp[d];
@@ -1228,7 +1258,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
             const double w1c = kp[KP_W1(D) + c];
             Jmu = fma(w1c, kp[KP_AX(D) + c], Jmu);
             Jvar += 2.0 * w1c * (zp[c] - tile_r(Rr, c, 2, p));
-            if (deg >= 2) {
+            if (MAXDEG >= 2 && deg >= 2) {
               const double* Q = qa + g * D * D;
               const double a_ = kp[KP_W20(D) + c], b_ = kp[KP_W21(D) + c];
               double qa_ = 0.0, qb_ = 0.0;  // sum_e w21_e z_e Q[c][e],  sum_e w20_e z_e Q[c][e]

@@ -40,5 +40,6 @@ v2 = buf2.cpu().tolist()
 print("bwd per step cycles: serial(wave0) %.0f | barrier1 %.0f | RBF stage %.0f | park+barrier2 %.0f" % tuple(x / w.T for x in (v2[8], v2[9], v2[10], v2[11])))
 print("workload", name, "T", w.T, "M", w.M, "ppw forced", ppw, "launched", hipabi.lib().mcp_debug_last_particles_per_wg(), "gp-sharded", hipabi.lib().mcp_debug_last_gp_sharded(), "total cycles", tot, "-> per step", tot / (w.T - 1))
 print("tile kernel detail (wave 0, per step, all GPs): K setup %.0f, K tiles %.0f | J setup %.0f, J batches %.0f cyc" % tuple(v[i] / (w.T - 1) for i in (12, 13, 14, 15)))
+print("J finish (wave 0, per step, all GPs): wait for the other waves %.0f, park + barrier %.0f, add + barrier %.0f cyc" % tuple(v[i] / (w.T - 1) for i in (9, 10, 11)))
 for n, c in zip(names, v):
     print("%-14s %12d  %5.1f%%  %8.0f cyc/step" % (n, c, 100.0 * c / tot, c / (w.T - 1)))
