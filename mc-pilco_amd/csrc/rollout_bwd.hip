@@ -665,8 +665,9 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   // (two 256-thread workgroups per CU are resident: one particle per workgroup while M of them fit in one round, then 2, then 4;
   //  measured, tools/sweep_bwd_particles.py: M=800 1.74 / 1.34 / 1.92 ms, M=2000 3.24 / 2.51 / 2.07 ms for 1 / 2 / 4)
   int PB = g_force_bwd_pb ? g_force_bwd_pb : (M > 1024 ? 4 : (M > 512 ? 2 : 1));
-  if (!g_force_bwd_pb && (PF > 16 || U > 4)) PB = M > 1024 ? 2 : 1;  // wide policies: two particles per sweep on large swarms
-                                                                      // (tools/time_bwd.py, UR5 shape, M = 2000, T = 300: 27.7 -> 24.2 ms)
+  if (!g_force_bwd_pb && (PF > 16 || U > 4)) PB = M > 1024 ? 4 : 1;  // wide policies: four particles per sweep on large swarms where the
+                                                                      // instantiation exists (> 256 basis functions), else two
+                                                                      // (tools/time_bwd.py, UR5 shape, M = 2000, T = 300: 18.1 / 15.5 / 14.5 ms for 1 / 2 / 4)
   if (PB != 1 && PB != 2 && PB != 4) return MCP_ERR_ARG;
   int NT = imax(bwd_threads(policy->B), 64 * PB);
   int rc = MCP_ERR_LIMIT;
@@ -687,7 +688,7 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
       if (NT <= 256)
         rc = PB == 2 ? launch_bwd<24, 6, 256, BW_WPE_A, 2>(a, NT, st) : PB == 1 ? launch_bwd<24, 6, 256, BW_WPE_A, 1>(a, NT, st) : MCP_ERR_LIMIT;
       else
-        rc = PB == 2 ? launch_bwd<24, 6, 512, 2, 2>(a, NT, st) : PB == 1 ? launch_bwd<24, 6, 512, 2, 1>(a, NT, st) : MCP_ERR_LIMIT;
+        rc = PB == 4 ? launch_bwd<24, 6, 512, 2, 4>(a, NT, st) : PB == 2 ? launch_bwd<24, 6, 512, 2, 2>(a, NT, st) : PB == 1 ? launch_bwd<24, 6, 512, 2, 1>(a, NT, st) : MCP_ERR_LIMIT;
     } else {
       if (NT <= 256)
         rc = PB == 2 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 256, BW_WPE_A, 2>(a, NT, st)
