@@ -24,8 +24,10 @@ int mcp_debug_last_gp_sharded(void);
 void mcp_debug_set_fwd_mode(int xlds, int gb);
 /* backward sweep: particles per workgroup 1 / 2 / 4; 0 = automatic */
 void mcp_debug_set_bwd_particles(int pb);
-/* device buffers of 16 uint64 per-phase cycle totals of workgroup 0 (NULL = off) */
+/* device buffers of 16 uint64 per-phase cycle totals of one workgroup (NULL = off); the forward kernels stamp workgroup
+   `block` (0 by default; the partner of workgroup 0 in a 2-way GP-sharded launch of the small-tile kernel is workgroup 8) */
 void mcp_debug_set_stamp_buffer(void* device_u64x16);
+void mcp_debug_set_stamp_block(int block);
 void mcp_debug_set_bwd_stamp_buffer(void* device_u64x16);
 
 #ifdef __cplusplus

@@ -998,7 +998,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       RF_STAMP(4);
       RF_STAMP(5);
       phase_j<P, XLDS, MAXDEG>(gpl, g0, gn, D, NpadMax, xt_l, al_l, kb, ks, pa, pb, vb, tab, part, red, wv, lane,
-                               (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+                               (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
       lds_barrier();
       RF_STAMP(6);
       // ---- phase F: sample delta_g and fold the sampling into d delta/dz ------------------------
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
     }
     if (GSH && wv == 0) {
       // collect the other GPs' increments: lane -> (other GP, particle, half); every pass re-reads every granule
-      const unsigned long long tx0_ = (a.stamps && blockIdx.x == 0) ? clock64() : 0;
+      const unsigned long long tx0_ = (a.stamps && blockIdx.x == a.stamp_block) ? clock64() : 0;
       const int ngr = (G - 1) * P * 2;
       const bool act = lane < ngr;
       const int go = act ? lane / (2 * P) : 0, r = act ? lane - go * 2 * P : 0;
@@ -1067,7 +1067,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       }
       if (act) reinterpret_cast<unsigned*>(dl)[2 * ((r >> 1) * G + gq) + (r & 1)] = val;
       if (!done && lane == 0) *abortw = 1;
-      if (a.stamps && blockIdx.x == 0 && lane == 0) a.stamps[8] += clock64() - tx0_;
+      if (a.stamps && blockIdx.x == a.stamp_block && lane == 0) a.stamps[8] += clock64() - tx0_;
     }
     lds_barrier();
     if (GSH && *abortw) {  // uniform (the barrier's memory clobber forces the re-read): a partner never arrived
@@ -1194,6 +1194,8 @@ extern "C" void mcp_debug_set_fwd_mode(int xlds, int gb) {
 }
 static unsigned long long* g_stamps = nullptr;  // diagnostic hook: device buffer of 16 u64 phase-cycle totals
 extern "C" void mcp_debug_set_stamp_buffer(void* p) { g_stamps = (unsigned long long*)p; }
+static unsigned g_stamp_block = 0;
+extern "C" void mcp_debug_set_stamp_block(int b) { g_stamp_block = b > 0 ? (unsigned)b : 0u; }
 
 // ---- GP-sharded launch: G workgroups per particle cluster ----------------------------------------------------------
 static int g_gp_sharding = -1;  // test hook: -1 automatic, 0 never, 1 whenever the grid fits the device
@@ -1288,6 +1290,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   a.jac = jac;
   a.status = status;
   a.stamps = g_stamps;
+  a.stamp_block = g_stamp_block;
   a.xch = nullptr;
   a.nclusters = 0;
   a.m_off = 0;

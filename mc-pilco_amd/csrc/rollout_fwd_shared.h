@@ -44,7 +44,8 @@ struct FwdArgs {
   double* inputs;
   double* jac;
   uint32_t* status;
-  unsigned long long* stamps;  // diagnostic only (mcp_debug_set_stamp_buffer): per-phase cycle totals of workgroup 0
+  unsigned long long* stamps;  // diagnostic only (mcp_debug_set_stamp_buffer): per-phase cycle totals of workgroup `stamp_block`
+  unsigned stamp_block;        // (mcp_debug_set_stamp_block; 0 by default)
   // GP-sharded launch (rollout_fwd.hip, GSH): the G workgroups of a particle cluster hand each other their GP's sampled
   // increment once per step through 8-byte {tag, value} granules  xch[cluster][t & 1][g][p][half]  (zeroed per launch)
   unsigned long long* xch;
@@ -56,7 +57,7 @@ struct FwdArgs {
 
 #define RF_STAMP(k)                                 \
   do {                                              \
-    if (a.stamps && tid == 0 && blockIdx.x == 0) {  \
+    if (a.stamps && tid == 0 && blockIdx.x == a.stamp_block) {  \
       unsigned long long now_ = clock64();          \
       a.stamps[k] += now_ - last_stamp;             \
       last_stamp = now_;                            \

@@ -1047,10 +1047,10 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       const double* al_g = smem + L.al + g * a.NpadMax;
       if (XL)
         tile_phase_k<MAXDEG, NG>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane,
-                                 (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+                                 (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
       else
         tile_phase_k<MAXDEG, NG>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane,
-                                 (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+                                 (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
       lds_barrier();
       TL_STAMP(3);
       // ---- phase V ---------------------------------------------------------------------------
@@ -1162,29 +1162,29 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       if (MAXDEG == 0 || deg == 0) {
         v4d acc[2][TL_NCOL(0)];
         if (XL)
-          tile_phase_j<0, 1>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+          tile_phase_j<0, 1>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         else
           tile_phase_j<0, 1>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
-                               (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
-        tile_j_finish<TL_NCOL(0)>(acc, RT, D, scr, L.nslot, ks, panel_doubles, wv, lane, tid, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+                               (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
+        tile_j_finish<TL_NCOL(0)>(acc, RT, D, scr, L.nslot, ks, panel_doubles, wv, lane, tid, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         CTg = TL_NCOL(0);
       } else if (MAXDEG == 1 || deg == 1) {
         v4d acc[2][TL_NCOL(1)];
         if (XL)
-          tile_phase_j<1, 1>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+          tile_phase_j<1, 1>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         else
           tile_phase_j<1, 1>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
-                               (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
-        tile_j_finish<TL_NCOL(1)>(acc, RT, D, scr, L.nslot, ks, panel_doubles, wv, lane, tid, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+                               (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
+        tile_j_finish<TL_NCOL(1)>(acc, RT, D, scr, L.nslot, ks, panel_doubles, wv, lane, tid, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         CTg = TL_NCOL(1);
       } else {
         v4d acc[2][TL_NCOL(2)];
         if (XL)
-          tile_phase_j<2, NG>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+          tile_phase_j<2, NG>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         else
           tile_phase_j<2, NG>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
-                               (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
-        tile_j_finish<TL_NCOL(2)>(acc, RT, D, scr, L.nslot, ks, panel_doubles, wv, lane, tid, (a.stamps && blockIdx.x == 0 && wv == 0) ? a.stamps : nullptr);
+                               (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
+        tile_j_finish<TL_NCOL(2)>(acc, RT, D, scr, L.nslot, ks, panel_doubles, wv, lane, tid, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         CTg = TL_NCOL(2);
       }
       TL_STAMP(6);

@@ -98,6 +98,7 @@ _SIGS = {
     "mcp_debug_last_particles_per_wg": (C.c_int, []),
     "mcp_debug_set_bwd_particles": (None, [C.c_int]),
     "mcp_debug_set_stamp_buffer": (None, [dptr]),
+    "mcp_debug_set_stamp_block": (None, [C.c_int]),
     "mcp_debug_set_fwd_mode": (None, [C.c_int, C.c_int]),
     "mcp_debug_set_bwd_stamp_buffer": (None, [dptr]),
     "mcp_debug_set_gp_sharding": (None, [C.c_int]),

@@ -20,6 +20,7 @@ elif ppw:
     hipabi.lib().mcp_debug_set_gp_sharding(0)
 for i in range(2):
     ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=i), x0, w.T, w.p_drop)
+hipabi.lib().mcp_debug_set_stamp_block(int(os.environ.get("MCP_STAMP_BLOCK", "0")))  # which workgroup is stamped
 hipabi.lib().mcp_debug_set_stamp_buffer(buf.data_ptr())
 ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=9), x0, w.T, w.p_drop)
 torch.cuda.synchronize()
