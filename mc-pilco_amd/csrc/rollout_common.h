@@ -33,6 +33,16 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // hand-off buffer of the GP-sharded forward launch (rollout_fwd.hip): [clusters][2][G][P][2] granules of 8 bytes, clusters * P < M + 16 (a launch per chunk, each rounded up to whole clusters)
 static inline size_t rollout_xch_bytes(int M, int G) { return ((size_t)(M + 16) * 2 * G * 2 * sizeof(unsigned long long) + 15) & ~(size_t)15; }
 
+// Packed phase-J operands of the 16-particle kernel's wide classes (D + 1 > 16; rollout_fwd_tile.hip, tile_xj_pack_kernel): per GP two
+// variants ([X^T; 1] and its columns scaled by alpha_j) x two row tiles x (NpadMax / 8) x 64 lanes x 2 doubles, placed behind the hand-off
+// granules in the caller's workspace.  0 for narrow models.
+static inline size_t rollout_xj_bytes(const mcp_model* m) {
+  if (!m || m->D + 1 <= 16 || m->D + 1 > 32) return 0;
+  int npad = 0;
+  for (int g = 0; g < m->G; ++g) npad = m->gp[g].Npad > npad ? m->gp[g].Npad : npad;
+  return (size_t)m->G * 2 * 2 * (size_t)((npad + 7) / 8) * 64 * 2 * sizeof(double);
+}
+
 static inline bool model_ok(const mcp_model* m) {
   if (!m) return false;
   if (m->S <= 0 || m->S > MCP_MAX_STATE || m->U <= 0 || m->U > MCP_MAX_INPUT || m->G <= 0 || m->G > MCP_MAX_GP) return false;

@@ -1292,6 +1292,15 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   a.stamps = g_stamps;
   a.stamp_block = g_stamp_block;
   a.xch = nullptr;
+  a.xj = nullptr;
+  a.xj_stride = 0;
+  {
+    const size_t xoff = rollout_xch_bytes(M, model->G), xb = rollout_xj_bytes(model);
+    if (xb && workspace && workspace_bytes >= xoff + xb) {
+      a.xj = (double*)((char*)workspace + xoff);
+      a.xj_stride = (int)(xb / sizeof(double) / (size_t)model->G);
+    }
+  }
   a.nclusters = 0;
   a.m_off = 0;
   a.m_cnt = M;

@@ -46,6 +46,8 @@ struct FwdArgs {
   uint32_t* status;
   unsigned long long* stamps;  // diagnostic only (mcp_debug_set_stamp_buffer): per-phase cycle totals of workgroup `stamp_block`
   unsigned stamp_block;        // (mcp_debug_set_stamp_block; 0 by default)
+  double* xj;                  // packed phase-J operand of the wide 16-particle classes (workspace; null: not available), see rollout_xj_bytes
+  int xj_stride;               // doubles per GP
   // GP-sharded launch (rollout_fwd.hip, GSH): the G workgroups of a particle cluster hand each other their GP's sampled
   // increment once per step through 8-byte {tag, value} granules  xch[cluster][t & 1][g][p][half]  (zeroed per launch)
   unsigned long long* xch;

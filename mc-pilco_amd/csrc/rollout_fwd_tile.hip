@@ -35,6 +35,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define TL_MAXTASK 4   // 32-row blocks of Kinv per wave (N <= 1024)
 #define TL_VU 4        // 4-row steps per register batch in phase V (two batches in flight)
 #define TL_JU 4        // 4-row steps per operand batch in phase J
+#ifndef TL_JNB
+#define TL_JNB 4       // 16-row operand batches in flight in the per-tile form of phase J (wide classes)
+#endif
 #define TL_NCOL(deg) ((deg) == 0 ? 2 : ((deg) == 1 ? 3 : 5))
 
 struct TileLayout {
@@ -403,6 +406,115 @@ __device__ __forceinline__ void tile_phase_j(const GpL& gp, PT Xt, PT al, int xp
   }
   if (nbat & 1) tile_j_consume<DEG, NDQ>(b0, zwa, zwb, D, RT, Npad, j0 + 16 * (nbat - 1), j1, kk, n, ks, kv, acc);
   if (dbg && lane == 0) dbg[15] += clock64() - tq0;
+}
+
+// Wide classes (D + 1 > 16: two row tiles), degree <= 1: ONE output tile (row tile, weight column) per wave over ALL of j, so there are no
+// partial tiles to bring together -- no parking, no add, no second barrier -- and the only operands a wave streams are its own 16 rows of
+// [X^T; 1] (global, four 16-row batches in flight) and the panel values of its weight kind.  RT x CT = 4 or 6 tiles keep 4 or 6 of the 8 waves
+// busy for Npad / 4 MFMAs each (two accumulators, even / odd steps); at the UR5 shape the split-j form spent 17 k cycles per GP in its
+// batch loop (58 % of its MFMA time) plus 5.5 k in the finish, this one ~13 k in all.
+// (the weight kind KIND is a template parameter of the loop: as a run-time switch per operand it became a tree of scalar branches whose
+//  joins made every counter wait conservative -- 188 s_waitcnt in the loop, a memory round trip per step)
+// The A operand comes from a packed copy of [X^T; 1] that the launch function builds in the caller's workspace (tile_xj_pack_kernel):
+// per GP and row tile, for every PAIR of 4-row steps the 64 lanes' two operand values side by side, so one dwordx4 per lane = 1 KB
+// contiguous per wave feeds two MFMAs.  Read from X^T (16 pieces of 32 B per step) or from row-major X (4 runs of 128 B) the loop was
+// bound by the number of cache lines its loads touch (23 k cycles per GP either way, deeper prefetch made it worse).
+template <int KIND>
+__device__ __forceinline__ v4d tile_j_bytile_run(gptr2_t xa0, int bfirst, int nbat, unsigned okv, int lane, const double* ks0, const double* kv0) {
+  constexpr int NB = TL_JNB;
+  const gptr2_t xa = xa0 + (size_t)bfirst * 128;  // batches [bfirst, bfirst + nbat) of the GP
+  const double* ks = ks0 + bfirst * 16 * TL_KR;
+  const double* kv = kv0 + bfirst * 16 * TL_KR;
+  v2d A[NB][2];
+#pragma unroll
+  for (int s = 0; s < NB; ++s) {
+    const int b = imin(s, nbat - 1);
+    A[s][0] = xa[(2 * b) * 64 + lane];
+    A[s][1] = xa[(2 * b + 1) * 64 + lane];
+  }
+  v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = (v4d){0.0, 0.0, 0.0, 0.0};
+  auto consume = [&](const v2d (&Au)[2], int b) {
+    const double* kb_ = ks + b * 16 * TL_KR;
+    const double* vb_ = kv + b * 16 * TL_KR;
+    double w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (KIND == 0) w[u] = kb_[okv + 4 * u * TL_KR];  // (alpha_j sits in the operand copy this kind reads)
+      if (KIND == 1) w[u] = kb_[okv + 4 * u * TL_KR] * vb_[okv + 4 * u * TL_KR];
+      if (KIND == 2) w[u] = vb_[okv + 4 * u * TL_KR];
+    }
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Au[0].x, w[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Au[0].y, w[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Au[1].x, w[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Au[1].y, w[3], acc1, 0, 0, 0);
+  };
+  // whole groups of NB batches without a branch inside; the last nbat mod NB batches afterwards
+  const int nfull = nbat / NB;
+  for (int g4 = 0; g4 < nfull; ++g4) {
+#pragma unroll
+    for (int s = 0; s < NB; ++s) {
+      const int b = g4 * NB + s;
+      consume(A[s], b);
+      const int bn = imin(b + NB, nbat - 1);
+      A[s][0] = xa[(2 * bn) * 64 + lane];
+      A[s][1] = xa[(2 * bn + 1) * 64 + lane];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NB; ++s)
+    if (nfull * NB + s < nbat) consume(A[s], nfull * NB + s);
+  return acc0 + acc1;
+}
+template <int DEG>
+__device__ __forceinline__ void tile_phase_j_bytile(const GpL& gp, const double* xj_g, int npb, const double* ks, const double* kv, double* scr, int RT,
+                                                    int nh, int wv, int lane, unsigned long long* dbg = nullptr) {
+  static_assert(DEG <= 1, "degree 2 keeps the split-j form (its mini-product would be repeated per weight kind)");
+  constexpr int CT = TL_NCOL(DEG);
+  unsigned long long tq0 = dbg ? clock64() : 0;
+  const int Npad = __builtin_amdgcn_readfirstlane(gp.Npad);
+  const int kk = lane >> 4, n = lane & 15;
+  const int nbat = Npad >> 4;  // (Npad is a multiple of 16; padded rows carry alpha = v = 0)
+  const unsigned okv = (unsigned)(kk * TL_KR + n);
+  // work items = (tile, j-half): RT x CT = 6 tiles are 12 items, wave w takes items w and w + 8, so that every SIMD (waves s, s + 4) gets three
+  // half tiles; the two partial tiles of a tile go to scratch slots 0 / 1 and phase F adds them as it reads (nh = 1: whole tiles, one slot)
+  const int ntile = RT * CT, slot = ntile * 256;
+  const int bh = (nbat + nh - 1) / nh;
+  for (int item = wv; item < nh * ntile; item += RF_NW) {
+    const int hh = item / ntile, tile = item - hh * ntile;
+    const int rt = tile / CT, ct = tile - rt * CT;  // wave-uniform
+    const int bfirst = hh * bh, nb = imin(nbat, bfirst + bh) - bfirst;
+    // variant 0: [X^T; 1]   variant 1: its columns scaled by alpha_j (the weight kind kse alpha then needs no alpha of its own)
+    const gptr2_t xa = (gptr2_t)((gptr_t)xj_g + (size_t)((ct == 0 ? 2 : 0) + rt) * npb * 128);
+    v4d r = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (nb <= 0) {
+    } else if (ct == 0)
+      r = tile_j_bytile_run<0>(xa, bfirst, nb, okv, lane, ks, kv);
+    else if (ct == 1)
+      r = tile_j_bytile_run<1>(xa, bfirst, nb, okv, lane, ks, kv);
+    else
+      r = tile_j_bytile_run<2>(xa, bfirst, nb, okv, lane, ks, kv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) scr[hh * slot + tile * 256 + i * 64 + lane] = r[i];
+  }
+  if (dbg && lane == 0) dbg[15] += clock64() - tq0;
+}
+// [X^T; 1] of every GP in the operand order of tile_j_bytile_run: element ((var * 2 + rt) * npb + q) * 128 + lane * 2 + h  holds row
+// c = 16 rt + (lane & 15) of step 2 q + h, i.e. training point j = 4 (2 q + h) + (lane >> 4):  X[j][c] for c < D, 1 for c == D, 0 beyond (and
+// for j >= Npad); variant 1 holds the same times alpha_j.
+__global__ __launch_bounds__(256) void tile_xj_pack_kernel(mcp_model model, double* xj, int xj_stride, int npb) {
+  const int g = blockIdx.y, rt = blockIdx.z & 1, var = blockIdx.z >> 1;
+  const mcp_gp& gp = model.gp[g];
+  const int D = model.D;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < npb * 128; e += gridDim.x * 256) {
+    const int h = e & 1, lane = (e >> 1) & 63, q = e >> 7;
+    const int c = 16 * rt + (lane & 15), j = 4 * (2 * q + h) + (lane >> 4);
+    double v = 0.0;
+    if (j < gp.Npad) {
+      v = c < D ? gp.X[(size_t)j * D + c] : (c == D ? 1.0 : 0.0);
+      if (var) v *= gp.alpha[j];
+    }
+    xj[(size_t)g * xj_stride + (size_t)(var * 2 + rt) * npb * 128 + e] = v;
+  }
 }
 
 // The 8 waves' partial tiles meet in `nslot` (1, 2, 4 or 8, whatever fits the LDS) slots: while more waves than slots hold a
@@ -1158,8 +1270,17 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       TL_STAMP(5);
       // ---- phase J -----------------------------------------------------------------------------
       int CTg;
+      const int jnh = (CLS >= 1 && a.xj && L.nslot >= 2 && (MAXDEG <= 1 || deg <= 1)) ? 2 : 1;  // partial tiles per tile left by the per-tile form of phase J
       const int panel_doubles = 2 * a.NpadMax * TL_KR;  // ks and kv are adjacent in the layout
-      if (MAXDEG == 0 || deg == 0) {
+      if (CLS >= 1 && a.xj && (MAXDEG == 0 || deg == 0)) {
+        tile_phase_j_bytile<0>(gp, a.xj + (size_t)g * a.xj_stride, a.xj_stride / 512, ks, kv, scr, RT, jnh, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
+        lds_barrier();
+        CTg = TL_NCOL(0);
+      } else if (CLS >= 1 && a.xj && (MAXDEG == 1 || deg == 1)) {
+        tile_phase_j_bytile<1>(gp, a.xj + (size_t)g * a.xj_stride, a.xj_stride / 512, ks, kv, scr, RT, jnh, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
+        lds_barrier();
+        CTg = TL_NCOL(1);
+      } else if (MAXDEG == 0 || deg == 0) {
         v4d acc[2][TL_NCOL(0)];
         if (XL)
           tile_phase_j<0, 1>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
@@ -1189,7 +1310,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       }
       TL_STAMP(6);
       // ---- phase F: moments, sample, d delta/dz -------------------------------------------------
-      const TileR Rr = {scr, CTg, 1, RT * CTg * 256};
+      const TileR Rr = {scr, CTg, jnh, RT * CTg * 256};
       for (int it = tid; it < P * (D + 1); it += RF_NT) {
         const int p = it / (D + 1), c = it - p * (D + 1);
         const double* zp = z + p * D;
@@ -1381,8 +1502,17 @@ static int launch_tile_deg(const FwdArgs& a, hipStream_t st) {
   return pms ? launch_tile_pms<MAXDEG, CLS, true, false>(a, lds, st) : launch_tile_pms<MAXDEG, CLS, false, false>(a, lds, st);
 }
 
+// builds the packed phase-J operand in the caller's workspace (wide classes with a workspace; a few microseconds per rollout)
+static int tile_xj_pack(const FwdArgs& a, hipStream_t st) {
+  if (!a.xj) return MCP_OK;
+  const int npb = a.xj_stride / 512;
+  hipLaunchKernelGGL(tile_xj_pack_kernel, dim3((npb * 128 + 255) / 256, a.model.G, 4), dim3(256), 0, st, a.model, a.xj, a.xj_stride, npb);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
 int launch_fwd_tile(const FwdArgs& a, hipStream_t st) {
   if (!fwd_tile_fits(&a.model, &a.pol)) return MCP_ERR_LIMIT;
+  if (tile_xj_pack(a, st) != MCP_OK) return MCP_ERR_LAUNCH;
   const int D = a.model.D, PF = a.pol.P, U = a.model.U;
   const int cls = a.NpadMax > 512 ? 2 : ((D <= 8 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2));
   // one instantiation per (highest polynomial degree, class): no code or registers for kernel terms the model does not have
@@ -1407,6 +1537,7 @@ int launch_fwd_tile_sharded(const FwdArgs& a, hipStream_t st) {
   if (a.NpadMax > 512) return MCP_ERR_LIMIT;
   const int cls = (D <= 8 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2);
   if (cls == 2) return MCP_ERR_LIMIT;
+  if (tile_xj_pack(a, st) != MCP_OK) return MCP_ERR_LAUNCH;
   switch (cls * 3 + a.maxdeg) {
     case 0: return launch_tile_gsh_deg<0, 0>(a, st);
     case 1: return launch_tile_gsh_deg<1, 0>(a, st);

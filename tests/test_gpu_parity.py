@@ -597,3 +597,31 @@ def test_recovery_path_runs_unsharded():
         assert hipabi.lib().mcp_debug_last_gp_sharded() == 0
     assert int(sa.item()) == 0 and int(sb.item()) == 0
     assert float((a - b).abs().max()) < 1e-8 and float((ua - ub).abs().max()) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M", [(40, 48), (100, 64)])
+def test_wide_class_phase_j_forms_agree(N, M):
+    """UR5-shaped models (two row tiles of [X^T; 1]) run phase J one output tile per wave from the packed operand copy in the workspace;
+    without a workspace (gp_sharding=False) the library keeps the split-j form.  Same trajectories, Jacobian-fed gradients and status."""
+    from gpu_helpers import dev, forced_variant
+    from mc_pilco_amd import ops, workloads
+
+    w = workloads.build("tiny_ur5", device=dev(), N=N, M=M, T=6)
+    torch.manual_seed(5)
+    x0 = w.sample_x0()
+    outs = []
+    for sharding in (True, False):
+        for p in w.params:
+            p.grad = None
+        with forced_variant(16) as fv:
+            st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=9, call=2), x0, w.T, w.p_drop, gp_sharding=sharding)
+            fv.check()
+            c, _ = ops.expected_cost(w.cost, st)
+            c.backward()
+        assert int(status.item()) == 0
+        outs.append((st.detach().clone(), inp.detach().clone(), [p.grad.detach().clone() for p in w.params]))
+    (sa, ua, ga), (sb, ub, gb) = outs
+    assert float((sa - sb).abs().max()) < 1e-9 and float((ua - ub).abs().max()) < 1e-9
+    for x, y in zip(ga, gb):
+        assert float((x - y).abs().max()) <= 1e-8 * (1.0 + float(y.abs().max()))
