@@ -129,9 +129,13 @@ struct TileKConst {
   double zz4[4], lam, w1D;
   int deg, N;
 };
-template <int MAXDEG, int NDQ>
+// EXACT: the GP's polynomial degree IS MAXDEG (the usual case: one kernel family for all GPs of a model), so the degree tests below are
+// compile-time; with the run-time tests every operand step and every result row had a scalar branch, and the joins of those branches
+// made the loop's counter waits conservative (the next tile's loads were waited for before the current tile's MFMAs).
+template <int MAXDEG, int NDQ, bool EXACT>
 __device__ __forceinline__ void tile_k_consume(const double (&bx)[NDQ], double alj, const TileKConst<MAXDEG, NDQ>& c, int tile, int kk, int n,
                                                double* ks, double* kv, double (&macc)[4]) {
+  const int deg = EXACT ? MAXDEG : c.deg;
   double sxx = 0.0;
 #pragma unroll
   for (int i = 0; i < NDQ; ++i) {
@@ -143,8 +147,8 @@ __device__ __forceinline__ void tile_k_consume(const double (&bx)[NDQ], double a
 #pragma unroll
   for (int i = 0; i < NDQ; ++i) {
     Cse = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a_se[i], bx[i], Cse, 0, 0, 0);
-    if (MAXDEG >= 1 && c.deg >= 1) Cp1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a_p1[i], bx[i], Cp1, 0, 0, 0);
-    if (MAXDEG >= 2 && c.deg >= 2) {
+    if (MAXDEG >= 1 && deg >= 1) Cp1 = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a_p1[i], bx[i], Cp1, 0, 0, 0);
+    if (MAXDEG >= 2 && deg >= 2) {
       CA = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a_A[i], bx[i], CA, 0, 0, 0);
       CB = __builtin_amdgcn_mfma_f64_16x16x4f64(c.a_B[i], bx[i], CB, 0, 0, 0);
     }
@@ -156,9 +160,9 @@ __device__ __forceinline__ void tile_k_consume(const double (&bx)[NDQ], double a
     const double dist = (c.zz4[r] + xx) + Cse[r];
     double kse = c.lam * exp(-dist);
     double kt = kse;
-    if (MAXDEG >= 1 && c.deg >= 1) {
+    if (MAXDEG >= 1 && deg >= 1) {
       kt += Cp1[r] + c.w1D;
-      if (MAXDEG >= 2 && c.deg >= 2) kt = fma(CA[r], CB[r], kt);
+      if (MAXDEG >= 2 && deg >= 2) kt = fma(CA[r], CB[r], kt);
     }
     if (!live) kse = kt = 0.0;
     if (MAXDEG >= 1) macc[r] = fma(alj, kt, macc[r]);  // posterior mean  sum_j alpha_j k_j  (GP_prior.py:145), all kernel terms at once
@@ -168,7 +172,7 @@ __device__ __forceinline__ void tile_k_consume(const double (&bx)[NDQ], double a
   }
 }
 // PT: where X^T and alpha come from -- global memory (gptr_t; row pitch = the GP's Npad) or their LDS copies (const double*; pitch NpadMax)
-template <int MAXDEG, int NDQ, typename PT>
+template <int MAXDEG, int NDQ, typename PT, bool EXACT = false>
 __device__ __forceinline__ void tile_phase_k(const GpL& gp, PT Xt, PT al, int xpitch, const double* kp, int D, const double* z, double* ks, double* kv,
                                              double* wslot, double* mup, int wv, int lane, unsigned long long* dbg = nullptr) {
   unsigned long long tq0 = dbg ? clock64() : 0;
@@ -212,11 +216,11 @@ __device__ __forceinline__ void tile_phase_k(const GpL& gp, PT Xt, PT al, int xp
     tile_k_load<NDQ>(b0, al0, Xt, al, xpitch, D, wv, kk, n);
     for (int sI = 0; sI + 1 < nt; sI += 2) {
       tile_k_load<NDQ>(b1, al1, Xt, al, xpitch, D, wv + RF_NW * (sI + 1), kk, n);
-      tile_k_consume<MAXDEG, NDQ>(b0, al0, c, wv + RF_NW * sI, kk, n, ks, kv, macc);
+      tile_k_consume<MAXDEG, NDQ, EXACT>(b0, al0, c, wv + RF_NW * sI, kk, n, ks, kv, macc);
       tile_k_load<NDQ>(b0, al0, Xt, al, xpitch, D, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
-      tile_k_consume<MAXDEG, NDQ>(b1, al1, c, wv + RF_NW * (sI + 1), kk, n, ks, kv, macc);
+      tile_k_consume<MAXDEG, NDQ, EXACT>(b1, al1, c, wv + RF_NW * (sI + 1), kk, n, ks, kv, macc);
     }
-    if (nt & 1) tile_k_consume<MAXDEG, NDQ>(b0, al0, c, wv + RF_NW * (nt - 1), kk, n, ks, kv, macc);
+    if (nt & 1) tile_k_consume<MAXDEG, NDQ, EXACT>(b0, al0, c, wv + RF_NW * (nt - 1), kk, n, ks, kv, macc);
   }
   // this wave's share of the mean: sum over its 16 training-point lanes, one partial per particle.  (SE-only models read the
   // mean off the ones-row of phase J's product instead, which costs nothing there.)
@@ -1157,12 +1161,21 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       const int deg = MAXDEG == 0 ? 0 : __builtin_amdgcn_readfirstlane(gp.deg);
       const double* xt_g = smem + L.xt + g * D * a.NpadMax;  // (XL only)
       const double* al_g = smem + L.al + g * a.NpadMax;
-      if (XL)
-        tile_phase_k<MAXDEG, NG>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane,
-                                 (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
-      else
-        tile_phase_k<MAXDEG, NG>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane,
-                                 (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
+      {
+        unsigned long long* kdbg = (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr;
+        const bool exact = MAXDEG >= 1 && deg == MAXDEG;  // (MAXDEG == 0 has no degree tests to remove)
+        if (XL) {
+          if (exact)
+            tile_phase_k<MAXDEG, NG, const double*, MAXDEG >= 1>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane, kdbg);
+          else
+            tile_phase_k<MAXDEG, NG, const double*, false>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane, kdbg);
+        } else {
+          if (exact)
+            tile_phase_k<MAXDEG, NG, gptr_t, MAXDEG >= 1>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane, kdbg);
+          else
+            tile_phase_k<MAXDEG, NG, gptr_t, false>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane, kdbg);
+        }
+      }
       lds_barrier();
       TL_STAMP(3);
       // ---- phase V ---------------------------------------------------------------------------
