@@ -210,7 +210,9 @@ size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_policy* pol
  * workgroups of a particle cluster each evaluate one GP and hand each other the sampled increments
  * once per step through this buffer (zeroed by the call, on `stream`); results agree with the
  * unsharded launch to rounding.  MCP_STATUS_SYNC in `status` reports a hand-off that timed out
- * (the trajectories are then invalid).  Without a workspace the launch is never sharded. */
+ * (the trajectories are then invalid).  Without a workspace the launch is never sharded.  For models with more
+ * than 15 GP-input dimensions the workspace also takes the packed operand copies of the 16-particle kernel's
+ * moment / Jacobian contraction (rebuilt by every call, on `stream`); without it that phase keeps its slower form. */
 int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
                     const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
                     size_t workspace_bytes, void* stream);
