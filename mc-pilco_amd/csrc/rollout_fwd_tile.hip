@@ -654,7 +654,9 @@ template <int NQ>
 struct TilePolRConst {
   double a_s[NQ], ilq[NQ], ss4[4];
 };
-template <int NQ, int UM>
+// DM: dropout mode -- 0 none, 1 Philox keep bits, 2 the caller's mask buffer (a template parameter: as run-time tests inside the tile
+// loop the modes were scalar branches between the loads and the MFMAs, with conservative counter waits at their joins)
+template <int NQ, int UM, int DM>
 __device__ __forceinline__ void tile_polr_consume(const double (&cb)[NQ], const double (&wk)[UM], const TilePolRConst<NQ>& c, const FwdArgs& a,
                                                  int B, int U, int t, int m0, int tile, int kk, int n, int lane, bool drop, double keep_scale,
                                                  uint32_t drop_thr, double (&uacc)[4][UM]) {
@@ -672,8 +674,8 @@ __device__ __forceinline__ void tile_polr_consume(const double (&cb)[NQ], const 
   const bool bvalid = b < B;
   const int bc = imin(b, B - 1);
   bool keep[4] = {true, true, true, true};
-  if (drop) {
-    if (a.nz.masks) {
+  if (DM != 0) {
+    if (DM == 2) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int mm = imin(m0 + kk + 4 * r, a.M - 1);
@@ -703,14 +705,14 @@ __device__ __forceinline__ void tile_polr_consume(const double (&cb)[NQ], const 
   for (int r = 0; r < 4; ++r) {
     const double dist = (c.ss4[r] + cc) + C[r];
     double phi = exp(-dist);
-    if (drop) phi = keep[r] ? phi * keep_scale : 0.0;
+    if (DM != 0) phi = keep[r] ? phi * keep_scale : 0.0;
     if (!bvalid) phi = 0.0;
 #pragma unroll
     for (int k = 0; k < UM; ++k)
       if (k < U) uacc[r][k] = fma(wk[k], phi, uacc[r][k]);
   }
 }
-template <int NQ, int UM>
+template <int NQ, int UM, int DM>
 __device__ __forceinline__ void tile_policy_reg(const FwdArgs& a, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* upart,
                                             int B, int PF, int U, int t, int m0, int wv, int lane, bool drop, double keep_scale, uint32_t drop_thr) {
   const int kk = lane >> 4, n = lane & 15;
@@ -744,11 +746,11 @@ __device__ __forceinline__ void tile_policy_reg(const FwdArgs& a, const double* 
     tile_polr_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, wv, kk, n);
     for (int sI = 0; sI + 1 < nt; sI += 2) {
       tile_polr_load<NQ, UM>(c1, w1, cen, wgt, B, PF, U, wv + RF_NW * (sI + 1), kk, n);
-      tile_polr_consume<NQ, UM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, uacc);
+      tile_polr_consume<NQ, UM, DM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, uacc);
       tile_polr_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
-      tile_polr_consume<NQ, UM>(c1, w1, c, a, B, U, t, m0, wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
+      tile_polr_consume<NQ, UM, DM>(c1, w1, c, a, B, U, t, m0, wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
     }
-    if (nt & 1) tile_polr_consume<NQ, UM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
+    if (nt & 1) tile_polr_consume<NQ, UM, DM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
   }
   // sum over the 16 basis lanes of each row; lane 15 of row kq holds the partial of particles kq + 4 r
 #pragma unroll
@@ -782,7 +784,7 @@ template <int NQ>
 struct TilePolConst {
   double a_s[NQ], ilq[NQ], ss4[4];
 };
-template <int NQ>
+template <int NQ, int DM>
 __device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const double (&wb)[4], const TilePolConst<NQ>& c, const FwdArgs& a, int B,
                                                  int U, int t, int m0, int tile, int kk, int n, int lane, bool drop, double keep_scale,
                                                  uint32_t drop_thr, double* ptile, v4d& uacc) {
@@ -800,8 +802,8 @@ __device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const d
   const bool bvalid = b < B;
   const int bc = imin(b, B - 1);
   bool keep[4] = {true, true, true, true};
-  if (drop) {
-    if (a.nz.masks) {
+  if (DM != 0) {
+    if (DM == 2) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int mm = imin(m0 + kk + 4 * r, a.M - 1);
@@ -832,7 +834,7 @@ __device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const d
   for (int r = 0; r < 4; ++r) {
     const double dist = (c.ss4[r] + cc) + C[r];
     double phi = exp(-dist);
-    if (drop) phi = keep[r] ? phi * keep_scale : 0.0;
+    if (DM != 0) phi = keep[r] ? phi * keep_scale : 0.0;
     if (!bvalid) phi = 0.0;
     ptile[(kk + 4 * r) * TL_PHP + n] = phi;
   }
@@ -844,7 +846,7 @@ __device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const d
     uacc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bw, uacc, 0, 0, 0);
   }
 }
-template <int NQ>
+template <int NQ, int DM>
 __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* ptile,
                                             double* upart, int B, int PF, int U, int t, int m0, int wv, int lane, bool drop, double keep_scale,
                                             uint32_t drop_thr) {
@@ -875,11 +877,11 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
     tile_pol_load<NQ>(c0, w0, cen, wgt, B, PF, U, wv, kk, n);
     for (int sI = 0; sI + 1 < nt; sI += 2) {
       tile_pol_load<NQ>(c1, w1, cen, wgt, B, PF, U, wv + RF_NW * (sI + 1), kk, n);
-      tile_pol_consume<NQ>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
+      tile_pol_consume<NQ, DM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
       tile_pol_load<NQ>(c0, w0, cen, wgt, B, PF, U, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
-      tile_pol_consume<NQ>(c1, w1, c, a, B, U, t, m0, wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
+      tile_pol_consume<NQ, DM>(c1, w1, c, a, B, U, t, m0, wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
     }
-    if (nt & 1) tile_pol_consume<NQ>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
+    if (nt & 1) tile_pol_consume<NQ, DM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
   }
   if (n < U) {
 #pragma unroll
@@ -1123,11 +1125,25 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     lds_barrier();
     TL_STAMP(0);
     // ---- policy: phi and W phi on the matrix cores, partial sums per wave -> LDS ----------------------
-    if (CLS == 0)
-      tile_policy_reg<NG, 2>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
-    else
-      tile_policy<NG>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.ptile + wv * 16 * TL_PHP, smem + L.upart, B, PF, U, t, m0, wv, lane, drop,
-                      keep_scale, drop_thr);
+    {
+      const int dm = !drop ? 0 : (a.nz.masks ? 2 : 1);  // wave-uniform
+      double* pt_w = smem + L.ptile + wv * 16 * TL_PHP;
+      if (CLS == 0) {
+        if (dm == 1)
+          tile_policy_reg<NG, 2, 1>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+        else if (dm == 2)
+          tile_policy_reg<NG, 2, 2>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+        else
+          tile_policy_reg<NG, 2, 0>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+      } else {
+        if (dm == 1)
+          tile_policy<NG, 1>(a, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+        else if (dm == 2)
+          tile_policy<NG, 2>(a, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+        else
+          tile_policy<NG, 0>(a, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+      }
+    }
     lds_barrier();
     TL_STAMP(1);
     // ---- squash, publish u ----------------------------------------------------------------------------
