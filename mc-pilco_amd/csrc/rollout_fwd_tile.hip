@@ -315,14 +315,16 @@ template <int DEG, int NDQ>
 struct TileJBatch {
   double a0[4], a1[4], al[4], xq[DEG >= 2 ? NDQ : 1];
 };
-template <int DEG, int NDQ, typename PT>
+// ONE_RT: the class has a single row tile of [X^T; 1] (D + 1 <= 16, the cart-pole class), so the second tile's loads and MFMAs are not
+// compiled at all (as a run-time test they were a scalar branch per 4-row step).
+template <int DEG, int NDQ, typename PT, bool ONE_RT>
 __device__ __forceinline__ void tile_j_load(TileJBatch<DEG, NDQ>& b, PT Xt, PT al, int xpitch, int Npad, int D, int RT, int cc0, int cc1, int jb,
                                             int kk, int n) {
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int j = imin(jb + 4 * u + kk, Npad - 1);
     b.a0[u] = Xt[(size_t)cc0 * xpitch + j];
-    b.a1[u] = RT > 1 ? Xt[(size_t)cc1 * xpitch + j] : 0.0;
+    b.a1[u] = (!ONE_RT && RT > 1) ? Xt[(size_t)cc1 * xpitch + j] : 0.0;
     b.al[u] = al[j];
   }
   if (DEG >= 2) {
@@ -331,7 +333,7 @@ __device__ __forceinline__ void tile_j_load(TileJBatch<DEG, NDQ>& b, PT Xt, PT a
     for (int i = 0; i < NDQ; ++i) b.xq[i] = Xt[(size_t)imin(4 * i + kk, D - 1) * xpitch + jr];
   }
 }
-template <int DEG, int NDQ>
+template <int DEG, int NDQ, bool ONE_RT>
 __device__ __forceinline__ void tile_j_consume(const TileJBatch<DEG, NDQ>& b, const double (&zwa)[NDQ], const double (&zwb)[NDQ], int D, int RT, int Npad,
                                                int jb, int j1, int kk, int n, const double* ks, const double* kv, v4d (&acc)[2][TL_NCOL(DEG)]) {
   constexpr int CT = TL_NCOL(DEG);
@@ -366,14 +368,14 @@ __device__ __forceinline__ void tile_j_consume(const TileJBatch<DEG, NDQ>& b, co
     const double av0 = c0 < D ? b.a0[u] : (c0 == D ? 1.0 : 0.0);
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[0][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, bv[u][ct], acc[0][ct], 0, 0, 0);
-    if (RT > 1) {
+    if (!ONE_RT && RT > 1) {
       const double av1 = c1 < D ? b.a1[u] : (c1 == D ? 1.0 : 0.0);
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) acc[1][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, bv[u][ct], acc[1][ct], 0, 0, 0);
     }
   }
 }
-template <int DEG, int NDQ, typename PT>
+template <int DEG, int NDQ, typename PT, bool ONE_RT = false>
 __device__ __forceinline__ void tile_phase_j(const GpL& gp, PT Xt, PT al, int xpitch, const double* kp, int D, const double* z, const double* ks,
                                              const double* kv, v4d (&acc)[2][TL_NCOL(DEG)], int RT, int wv, int lane,
                                              unsigned long long* dbg = nullptr) {
@@ -400,15 +402,15 @@ __device__ __forceinline__ void tile_phase_j(const GpL& gp, PT Xt, PT al, int xp
   const int nbat = (j1 - j0 + 15) >> 4;
   if (dbg && lane == 0) { unsigned long long now = clock64(); dbg[14] += now - tq0; tq0 = now; }
   TileJBatch<DEG, NDQ> b0, b1;
-  tile_j_load<DEG, NDQ>(b0, Xt, al, xpitch, Npad, D, RT, cc0, cc1, j0, kk, n);
+  tile_j_load<DEG, NDQ, PT, ONE_RT>(b0, Xt, al, xpitch, Npad, D, RT, cc0, cc1, j0, kk, n);
   for (int b = 0; b + 1 < nbat; b += 2) {
     const int ja = j0 + 16 * b;
-    tile_j_load<DEG, NDQ>(b1, Xt, al, xpitch, Npad, D, RT, cc0, cc1, ja + 16, kk, n);
-    tile_j_consume<DEG, NDQ>(b0, zwa, zwb, D, RT, Npad, ja, j1, kk, n, ks, kv, acc);
-    tile_j_load<DEG, NDQ>(b0, Xt, al, xpitch, Npad, D, RT, cc0, cc1, j0 + 16 * imin(b + 2, nbat - 1), kk, n);
-    tile_j_consume<DEG, NDQ>(b1, zwa, zwb, D, RT, Npad, ja + 16, j1, kk, n, ks, kv, acc);
+    tile_j_load<DEG, NDQ, PT, ONE_RT>(b1, Xt, al, xpitch, Npad, D, RT, cc0, cc1, ja + 16, kk, n);
+    tile_j_consume<DEG, NDQ, ONE_RT>(b0, zwa, zwb, D, RT, Npad, ja, j1, kk, n, ks, kv, acc);
+    tile_j_load<DEG, NDQ, PT, ONE_RT>(b0, Xt, al, xpitch, Npad, D, RT, cc0, cc1, j0 + 16 * imin(b + 2, nbat - 1), kk, n);
+    tile_j_consume<DEG, NDQ, ONE_RT>(b1, zwa, zwb, D, RT, Npad, ja + 16, j1, kk, n, ks, kv, acc);
   }
-  if (nbat & 1) tile_j_consume<DEG, NDQ>(b0, zwa, zwb, D, RT, Npad, j0 + 16 * (nbat - 1), j1, kk, n, ks, kv, acc);
+  if (nbat & 1) tile_j_consume<DEG, NDQ, ONE_RT>(b0, zwa, zwb, D, RT, Npad, j0 + 16 * (nbat - 1), j1, kk, n, ks, kv, acc);
   if (dbg && lane == 0) dbg[15] += clock64() - tq0;
 }
 
@@ -1312,27 +1314,27 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       } else if (MAXDEG == 0 || deg == 0) {
         v4d acc[2][TL_NCOL(0)];
         if (XL)
-          tile_phase_j<0, 1>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
+          tile_phase_j<0, 1, const double*, CLS == 0>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         else
-          tile_phase_j<0, 1>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
+          tile_phase_j<0, 1, gptr_t, CLS == 0>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
                                (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         tile_j_finish<TL_NCOL(0)>(acc, RT, D, scr, L.nslot, ks, panel_doubles, wv, lane, tid, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         CTg = TL_NCOL(0);
       } else if (MAXDEG == 1 || deg == 1) {
         v4d acc[2][TL_NCOL(1)];
         if (XL)
-          tile_phase_j<1, 1>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
+          tile_phase_j<1, 1, const double*, CLS == 0>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         else
-          tile_phase_j<1, 1>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
+          tile_phase_j<1, 1, gptr_t, CLS == 0>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
                                (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         tile_j_finish<TL_NCOL(1)>(acc, RT, D, scr, L.nslot, ks, panel_doubles, wv, lane, tid, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         CTg = TL_NCOL(1);
       } else {
         v4d acc[2][TL_NCOL(2)];
         if (XL)
-          tile_phase_j<2, NG>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
+          tile_phase_j<2, NG, const double*, CLS == 0>(gp, xt_g, al_g, a.NpadMax, kp, D, z, ks, kv, acc, RT, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         else
-          tile_phase_j<2, NG>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
+          tile_phase_j<2, NG, gptr_t, CLS == 0>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, acc, RT, wv, lane,
                                (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         tile_j_finish<TL_NCOL(2)>(acc, RT, D, scr, L.nslot, ks, panel_doubles, wv, lane, tid, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
         CTg = TL_NCOL(2);
