@@ -86,6 +86,9 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
 #ifndef BW_LAUNDER
 #define BW_LAUNDER(PFM, PB) ((PFM) > 8 || (PB) > 1)  // (narrow class, one particle per workgroup -- the latency-bound small-swarm sweep: measured 7 % slower with it)
 #endif
+#ifndef BW_MASK_FROM
+#define BW_MASK_FROM 8  // classes with PFM beyond this run the RBF stage with chunk-level tests and masked values
+#endif
 #ifndef BW_WPE_A
 #define BW_WPE_A 2
 #endif
@@ -444,11 +447,36 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         double dd = 0.0;  // adjoint of dist_b (0 for idle threads and empty slots, so they add nothing below)
         if (act && pv) {
           double dist = 0.0;
+          if constexpr (PFM > BW_MASK_FROM) {
+            // wide classes: one uniform test per 8 features, reads at clamped indices and masked values inside (a test per feature put
+            // every LDS read into its own basic block: 616 s_waitcnt for 600 ds_read in the 24 / 6 instantiation, a round trip per operand;
+            // masked terms add exact zeros, so the sums are unchanged)
 #pragma unroll
-          for (int q = 0; q < PFM; ++q) {
-            if (q < PF) {
-              double rr = (sfp[q] - BW_CEN(q)) * invl[q];
-              dist = fma(rr, rr, dist);
+            for (int q0 = 0; q0 < PFM; q0 += 8) {
+              if (q0 < PF) {
+                double sv[8], cv[8], iv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                  const int q = imin(q0 + i, PF - 1);
+                  sv[i] = sfp[q];
+                  cv[i] = cen_l[q * NT + tid];
+                  iv[i] = invl[q];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                  double rr = (sv[i] - cv[i]) * iv[i];
+                  rr = q0 + i < PF ? rr : 0.0;
+                  dist = fma(rr, rr, dist);
+                }
+              }
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < PFM; ++q) {
+              if (q < PF) {
+                double rr = (sfp[q] - BW_CEN(q)) * invl[q];
+                dist = fma(rr, rr, dist);
+              }
             }
           }
           double phi = exp(-dist);
@@ -460,7 +488,11 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
           double phibar = 0.0;
 #pragma unroll
           for (int k = 0; k < UM; ++k) {
-            if (k < U) {
+            if constexpr (PFM > BW_MASK_FROM) {  // (wide classes: masked instead of tested, as above)
+              const double abk = k < U ? abp[imin(k, U - 1)] : 0.0;
+              gw[k] = fma(abk, phi * mk, gw[k]);
+              phibar = fma(k < U ? wgt[k] : 0.0, abk, phibar);
+            } else if (k < U) {
               double abk = abp[k];
               gw[k] = fma(abk, phi * mk, gw[k]);
               phibar = fma(wgt[k], abk, phibar);
@@ -477,7 +509,16 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
             for (int i = 0; i < 8; ++i) {
               const int q = q0 + i;
               double v = 0.0;
-              if (q < PFM && q < PF) {
+              if constexpr (PFM > BW_MASK_FROM) {
+                if (q < PFM) {
+                  const int qc = imin(q, PF - 1);
+                  const double il = invl[qc];
+                  const double rr = (sfp[qc] - cen_l[qc * NT + tid]) * il;
+                  const double t2 = q < PF ? 2.0 * dd * rr : 0.0;
+                  gc[q < PFM ? q : 0] = fma(-t2, il, gc[q < PFM ? q : 0]);
+                  v = t2 * il;
+                }
+              } else if (q < PFM && q < PF) {
                 double rr = (sfp[q] - BW_CEN(q)) * invl[q];
                 double t2 = 2.0 * dd * rr;
                 gc[q] = fma(-t2, invl[q], gc[q]);
