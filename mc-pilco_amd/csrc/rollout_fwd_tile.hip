@@ -626,9 +626,10 @@ struct TileR {
 };
 __device__ __forceinline__ double tile_r(const TileR& R, int c, int kind, int p) {
   const double* q = R.base + ((c >> 4) * R.CT + kind) * 256 + ((c & 15) >> 2) * 64 + ((c & 3) << 4) + p;
-  double s = q[0];
-  for (int w = 1; w < R.nfin; ++w) s += q[w * R.slot];
-  return s;
+  // nfin is 1 or 2: both reads always (the second at offset 0 again when there is one partial), a select instead of a loop -- phase F
+  // calls this dozens of times per thread and a run-time loop made each call a branch with its own LDS wait
+  const double s0 = q[0], s1 = q[R.nfin > 1 ? R.slot : 0];
+  return R.nfin > 1 ? s0 + s1 : s0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1353,6 +1354,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         if (MAXDEG >= 1 && deg >= 1) {
           double p1 = kp[KP_W1(D) + D];
           double pv = kp[KP_W1(D) + D] * tile_r(Rr, D, 2, p);
+#pragma unroll 4
           for (int d = 0; d < D; ++d) {
             const double wz = kp[KP_W1(D) + d] * zp[d];
             p1 = fma(wz, zp[d], p1);
@@ -1362,6 +1364,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           ktv += pv;
           if (MAXDEG >= 2 && deg >= 2) {
             double qv = 0.0;
+#pragma unroll 4
             for (int d = 0; d < D; ++d) {
               const double zz = zp[d] * zp[d];
               Sa = fma(kp[KP_W20(D) + d], zz, Sa);
@@ -1414,6 +1417,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
               const double* Q = qa + g * D * D;
               const double a_ = kp[KP_W20(D) + c], b_ = kp[KP_W21(D) + c];
               double qa_ = 0.0, qb_ = 0.0;  // sum_e w21_e z_e Q[c][e],  sum_e w20_e z_e Q[c][e]
+#pragma unroll 4
               for (int e = 0; e < D; ++e) {
                 qa_ = fma(kp[KP_W21(D) + e] * zp[e], Q[c * D + e], qa_);
                 qb_ = fma(kp[KP_W20(D) + e] * zp[e], Q[c * D + e], qb_);
