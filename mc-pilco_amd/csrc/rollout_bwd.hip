@@ -459,7 +459,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
                 for (int i = 0; i < 8; ++i) {
                   const int q = imin(q0 + i, PF - 1);
                   sv[i] = sfp[q];
-                  cv[i] = cen_l[q * NT + tid];
+                  cv[i] = CENREG ? cen[CENREG ? imin(q0 + i, PFM - 1) : 0] : cen_l[q * NT + tid];  // (register centres: 0 beyond PF)
                   iv[i] = invl[q];
                 }
 #pragma unroll
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
                 if (q < PFM) {
                   const int qc = imin(q, PF - 1);
                   const double il = invl[qc];
-                  const double rr = (sfp[qc] - cen_l[qc * NT + tid]) * il;
+                  const double rr = (sfp[qc] - (CENREG ? cen[CENREG ? q : 0] : cen_l[qc * NT + tid])) * il;
                   const double t2 = q < PF ? 2.0 * dd * rr : 0.0;
                   gc[q < PFM ? q : 0] = fma(-t2, il, gc[q < PFM ? q : 0]);
                   v = t2 * il;
