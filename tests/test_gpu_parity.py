@@ -625,3 +625,34 @@ def test_wide_class_phase_j_forms_agree(N, M):
     assert float((sa - sb).abs().max()) < 1e-9 and float((ua - ub).abs().max()) < 1e-9
     for x, y in zip(ga, gb):
         assert float((x - y).abs().max()) <= 1e-8 * (1.0 + float(y.abs().max()))
+
+
+@pytest.mark.gpu
+def test_wide_class_with_a_different_subset_size_per_gp():
+    """Subset-of-data pretraining keeps a different number of points per GP (Model_learning.py:176-199): the packed phase-J operands are
+    laid out on the largest Npad, every GP runs its own batch count.  All forward variants agree on such a model."""
+    from gpu_helpers import dev, forced_variant
+    from mc_pilco_amd import ops, workloads
+
+    w = workloads.build("tiny_ur5", device=dev(), N=80, M=32, T=5)
+    pb, c = w.problem, w.problem["cfg"]
+    sizes = [40, 56, 80, 72, 48, 64]
+    gps = []
+    for g in range(c["G"]):
+        spec = workloads.spec_for(c, c["sigma_n"], None if pb["poly"] is None else pb["poly"][g])
+        gps.append(workloads.pretrain_packed(spec, pb["Z"][: sizes[g]], pb["Ys"][g][: sizes[g]], dev()))
+    model = ops.PackedModel(gps, c["S"], c["U"], c["Ts"], c["angle"], c["not_angle"], c["vel"], c["not_vel"])
+    torch.manual_seed(8)
+    x0 = w.sample_x0()
+    outs = {}
+    with torch.no_grad():
+        for code, sharding in ((16, True), (16, False), (4, True), (1, True)):
+            with forced_variant(code) as fv:
+                st, inp, status = ops.rollout(model, w.policy, ops.NoiseSpec(seed=4, call=1), x0, w.T, w.p_drop, gp_sharding=sharding)
+                fv.check()
+            assert int(status.item()) == 0
+            outs[(code, sharding)] = (st.clone(), inp.clone())
+    ref = outs[(1, True)]
+    for key, (st, inp) in outs.items():
+        assert float((st - ref[0]).abs().max()) < 1e-9, key
+        assert float((inp - ref[1]).abs().max()) < 1e-9, key
