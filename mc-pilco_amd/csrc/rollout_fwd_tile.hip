@@ -631,6 +631,10 @@ __device__ __forceinline__ double tile_r(const TileR& R, int c, int kind, int p)
   const double s0 = q[0], s1 = q[R.nfin > 1 ? R.slot : 0];
   return R.nfin > 1 ? s0 + s1 : s0;
 }
+// the cart-pole class always leaves ONE finished tile set (split-j form of phase J)
+__device__ __forceinline__ double tile_r1(const TileR& R, int c, int kind, int p) {
+  return R.base[((c >> 4) * R.CT + kind) * 256 + ((c & 15) >> 2) * 64 + ((c & 3) << 4) + p];
+}
 
 // ---------------------------------------------------------------------------------------
 // policy phase: u = u_max tanh((W (phi o mask)) / u_max),  phi_b = exp(-|| (s - c_b)/l ||^2)   (Policy.py:242-265)
@@ -1343,22 +1347,23 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       TL_STAMP(6);
       // ---- phase F: moments, sample, d delta/dz -------------------------------------------------
       const TileR Rr = {scr, CTg, jnh, RT * CTg * 256};
+#define TL_R(c, k, p) (CLS == 0 ? tile_r1(Rr, c, k, p) : tile_r(Rr, c, k, p))
       for (int it = tid; it < P * (D + 1); it += RF_NT) {
         const int p = it / (D + 1), c = it - p * (D + 1);
         const double* zp = z + p * D;
         const double vscale = gp.var_scale;
         // k(z,z) and the v-weighted sum  k^T Kinv k
         double kzz = gp.lambda;
-        double ktv = tile_r(Rr, D, 1, p);
+        double ktv = TL_R(D, 1, p);
         double Sa = 0.0, Sb = 0.0;
         if (MAXDEG >= 1 && deg >= 1) {
           double p1 = kp[KP_W1(D) + D];
-          double pv = kp[KP_W1(D) + D] * tile_r(Rr, D, 2, p);
+          double pv = kp[KP_W1(D) + D] * TL_R(D, 2, p);
 #pragma unroll 4
           for (int d = 0; d < D; ++d) {
             const double wz = kp[KP_W1(D) + d] * zp[d];
             p1 = fma(wz, zp[d], p1);
-            pv = fma(wz, tile_r(Rr, d, 2, p), pv);
+            pv = fma(wz, TL_R(d, 2, p), pv);
           }
           kzz += p1;
           ktv += pv;
@@ -1369,7 +1374,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
               const double zz = zp[d] * zp[d];
               Sa = fma(kp[KP_W20(D) + d], zz, Sa);
               Sb = fma(kp[KP_W21(D) + d], zz, Sb);
-              qv = fma(kp[KP_W20(D) + d] * zp[d], tile_r(Rr, d, 3, p), qv);
+              qv = fma(kp[KP_W20(D) + d] * zp[d], TL_R(d, 3, p), qv);
             }
             kzz = fma(Sa, Sb, kzz);
             ktv += qv;
@@ -1388,7 +1393,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
 #pragma unroll
             for (int w = 0; w < RF_NW; ++w) mu += mup[w * P + p];
           } else {
-            mu += tile_r(Rr, D, 0, p);
+            mu += TL_R(D, 0, p);
           }
           const double dv = a.particle_pred ? fma(sd, eps, mu) : mu;
           dl[p * G + g] = dv;
@@ -1405,14 +1410,14 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         } else if (a.jac && m0 + p < M) {
           const double il = kp[KP_INVLS(D) + c];
           const double il2 = il * il;
-          const double r0 = fma(zp[c], tile_r(Rr, D, 0, p), -tile_r(Rr, c, 0, p));
-          const double r1 = fma(zp[c], tile_r(Rr, D, 1, p), -tile_r(Rr, c, 1, p));
+          const double r0 = fma(zp[c], TL_R(D, 0, p), -TL_R(c, 0, p));
+          const double r1 = fma(zp[c], TL_R(D, 1, p), -TL_R(c, 1, p));
           double Jmu = -2.0 * il2 * r0;
           double Jvar = 4.0 * il2 * r1;
           if (MAXDEG >= 1 && deg >= 1) {
             const double w1c = kp[KP_W1(D) + c];
             Jmu = fma(w1c, kp[KP_AX(D) + c], Jmu);
-            Jvar += 2.0 * w1c * (zp[c] - tile_r(Rr, c, 2, p));
+            Jvar += 2.0 * w1c * (zp[c] - TL_R(c, 2, p));
             if (MAXDEG >= 2 && deg >= 2) {
               const double* Q = qa + g * D * D;
               const double a_ = kp[KP_W20(D) + c], b_ = kp[KP_W21(D) + c];
@@ -1423,12 +1428,13 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
                 qb_ = fma(kp[KP_W20(D) + e] * zp[e], Q[c * D + e], qb_);
               }
               Jmu += a_ * qa_ + b_ * qb_;
-              Jvar += 2.0 * zp[c] * (a_ * Sb + b_ * Sa) - 2.0 * (a_ * tile_r(Rr, c, 3, p) + b_ * tile_r(Rr, c, 4, p));
+              Jvar += 2.0 * zp[c] * (a_ * Sb + b_ * Sa) - 2.0 * (a_ * TL_R(c, 3, p) + b_ * TL_R(c, 4, p));
             }
           }
           a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
         }
       }
+#undef TL_R
       if (g == gbeg && edraw && t + 1 < T - 1) draw_eps(t + 1);
       if (GSH && wv == 0 && g == gend - 1) {
         // collect the other workgroups' increments (rollout_fwd.hip): lane -> (other GP, particle, half), 64 granules per pass,
