@@ -73,6 +73,14 @@ def test_argument_validation_without_gpu():
     p.P, p.B, p.U = 5, 200, 1
     assert lib.mcp_rollout_workspace_bytes(C.byref(m), C.byref(p), 400, 150) == 8 * (5 + 200 * 5 + 200 + 1) * 400  # (+ U: dJ/dbias)
     assert lib.mcp_sod_workspace_bytes(300) == 8 * 300 * 300
+    # wide models (more than 15 GP-input dimensions): the forward part also holds the packed phase-J operands of the 16-particle kernel,
+    # per GP 2 variants x 2 row tiles x Npad/8 pair-steps x 64 lanes x 2 doubles behind the hand-off granules
+    m.G, m.D = 6, 24
+    for g in range(6):
+        m.gp[g].Npad = 400
+    p.P, p.B, p.U = 24, 8, 6  # (tiny policy: the backward slabs stay below the forward part)
+    xch = ((16 + 16) * 2 * 6 * 2 * 8 + 15) & ~15
+    assert lib.mcp_rollout_workspace_bytes(C.byref(m), C.byref(p), 16, 5) == max(xch + 6 * 2 * 2 * 50 * 64 * 2 * 8, 8 * (24 + 8 * 24 + 6 * 8 + 6) * 16)
     c = hipabi.Cost()
     c.kind, c.S = 7, 4
     assert lib.mcp_cost_fwd(C.byref(c), 3, 4, None, None, None, None, None) == -1
