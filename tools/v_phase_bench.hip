@@ -131,12 +131,12 @@ __global__ __launch_bounds__(512) void vbench(const double* Kinv, int Npad, int 
 //   B (one panel read per column quad q and parity): k[jb + 2 (4 k + blk) + par][4 q + e]       (conflict-free at pitch 18)
 //   acc[R][q]: partial sums over this block's j-quads of v[row0 + 4 R + i][4 q + j], lane 16 i + 4 blk + j; the 4 blocks are added once at the end.
 // A wave takes 16-row units w, w + 8, ...; batch = 32 rows of j: 4 Kinv loads + 8 panel reads feed 32 MFMAs with no vector instruction between.
-template <bool STREAM, bool LDSB = true>
-__global__ __launch_bounds__(512) void vbench_ks(const double* Kinv, int Npad, int steps, double* out, unsigned long long* cyc) {
+template <bool STREAM, bool LDSB = true, int NT = 512>
+__global__ __launch_bounds__(NT) void vbench_ks(const double* Kinv, int Npad, int steps, double* out, unsigned long long* cyc) {
   extern __shared__ double smem[];
   double* kv = smem;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  for (int e = tid; e < (Npad + 32) * KR; e += 512) kv[e] = 1e-3 * (e % 97);
+  for (int e = tid; e < (Npad + 32) * KR; e += NT) kv[e] = 1e-3 * (e % 97);
   __syncthreads();
   const int k = lane >> 4, blk = (lane >> 2) & 3, e = lane & 3;
   const int jp = 2 * (4 * k + blk);
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512) void vbench_ks(const double* Kinv, int Npad, i
   double sink = 0.0;
   unsigned long long t0 = clock64();
   for (int st = 0; st < steps; ++st) {
-    for (int un = wv; un < nunit; un += 8) {
+    for (int un = wv; un < nunit; un += NT / 64) {
       gptr2_t a0 = (gptr2_t)((const double __attribute__((address_space(1)))*)Kinv + (size_t)(un * 16 + e) * Npad + jp);
       const size_t rstep = (size_t)4 * Npad / 2;  // 4 rows in v2d units
       const double* b0 = kv + jp * KR + e;
@@ -209,14 +209,14 @@ __global__ __launch_bounds__(512) void vbench_ks(const double* Kinv, int Npad, i
     __syncthreads();
   }
   unsigned long long t1 = clock64();
-  out[(size_t)blockIdx.x * 512 + tid] = sink;
+  out[(size_t)blockIdx.x * NT + tid] = sink;
   if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
 }
-template <bool STREAM, bool LDSB = true>
+template <bool STREAM, bool LDSB = true, int NT = 512>
 static void run_ks(const double* Kinv, int Npad, int steps, double* out, unsigned long long* cyc, const char* name) {
   const size_t lds = (size_t)(Npad + 32) * KR * 8;
-  hipFuncSetAttribute((const void*)vbench_ks<STREAM, LDSB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((vbench_ks<STREAM, LDSB>), dim3(250), dim3(512), lds, 0, Kinv, Npad, steps, out, cyc);
+  hipFuncSetAttribute((const void*)vbench_ks<STREAM, LDSB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((vbench_ks<STREAM, LDSB, NT>), dim3(250), dim3(NT), lds, 0, Kinv, Npad, steps, out, cyc);
   hipDeviceSynchronize();
   unsigned long long h = 0;
   hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
@@ -242,7 +242,7 @@ int main(int argc, char** argv) {
   double *Kinv, *out;
   unsigned long long* cyc;
   const size_t n = (size_t)Npad * (Npad + 64) + 64;
-  hipMalloc(&Kinv, n * 8); hipMalloc(&out, 250 * 512 * 8); hipMalloc(&cyc, 8);
+  hipMalloc(&Kinv, n * 8); hipMalloc(&out, 250 * 1024 * 8); hipMalloc(&cyc, 8);
   double* h = (double*)malloc(n * 8);
   for (size_t i = 0; i < n; ++i) h[i] = 1e-3 * (double)(i % 1013);
   hipMemcpy(Kinv, h, n * 8, hipMemcpyHostToDevice);
@@ -257,5 +257,8 @@ int main(int argc, char** argv) {
   run_ks<true>(Kinv, Npad, steps, out, cyc, "4x4x4_4b k-split blocks (no rotations), Kinv streamed");
   run_ks<false>(Kinv, Npad, steps, out, cyc, "4x4x4_4b k-split blocks, A in registers");
   run_ks<false, false>(Kinv, Npad, steps, out, cyc, "4x4x4_4b k-split blocks, A and B in registers");
+  run_ks<false, false, 1024>(Kinv, Npad, steps, out, cyc, "4x4x4_4b k-split, A and B in registers, 16 waves per workgroup");
+  run_ks<false, true, 1024>(Kinv, Npad, steps, out, cyc, "4x4x4_4b k-split, A in registers, 16 waves per workgroup");
+  run_ks<true, true, 1024>(Kinv, Npad, steps, out, cyc, "4x4x4_4b k-split, Kinv streamed, 16 waves per workgroup");
   return 0;
 }
