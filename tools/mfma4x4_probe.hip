@@ -125,6 +125,27 @@ __global__ __launch_bounds__(512) void rate(int mode, int nit, double* out, unsi
     for (int R = 0; R < 4; ++R)
 #pragma unroll
       for (int q = 0; q < 4; ++q) s0 += acc[R][q];
+  } else if (mode == 7) {  // 8 accumulators, result written to a DIFFERENT register than the addend (two register sets, ping-pong)
+    double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0, d0, d1, d2, d3, d4, d5, d6, d7;
+#define MF(D, A, B, C) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %3" : "=v"(D) : "v"(A), "v"(B), "v"(C))
+    for (int it = 0; it < nit; ++it) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        MF(d0, x, y, c0); MF(d1, x1, y, c1); MF(d2, y, x, c2); MF(d3, y1, x, c3); MF(d4, x, y1, c4); MF(d5, x1, y1, c5); MF(d6, y, x1, c6); MF(d7, y1, x1, c7);
+        MF(c0, x, y, d0); MF(c1, x1, y, d1); MF(c2, y, x, d2); MF(c3, y1, x, d3); MF(c4, x, y1, d4); MF(c5, x1, y1, d5); MF(c6, y, x1, d6); MF(c7, y1, x1, d7);
+      }
+    }
+    s0 = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+  } else if (mode == 8) {  // as mode 0 (in place) through the same inline asm, for comparison
+    double c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0, c7 = 0;
+#define MFI(C, A, B) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(C) : "v"(A), "v"(B))
+    for (int it = 0; it < nit; ++it) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        MFI(c0, x, y); MFI(c1, x1, y); MFI(c2, y, x); MFI(c3, y1, x); MFI(c4, x, y1); MFI(c5, x1, y1); MFI(c6, y, x1); MFI(c7, y1, x1);
+      }
+    }
+    s0 = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
   } else {  // dependent chain of 4x4x4 on one accumulator
     for (int it = 0; it < nit; ++it) {
 #pragma unroll
@@ -163,9 +184,9 @@ int main() {
   double* out; unsigned long long* cyc;
   hipMalloc(&out, 512 * 512 * 8); hipMalloc(&cyc, 64);
   const int nit = 200;
-  const char* names[7] = {"4x4x4_4b, 8 independent accumulators", "16x16x4, 4 independent accumulators", "4x4x4_4b, one dependent chain",
-                          "4x4x4_4b, 8 acc + 6 v_mov_b32_dpp per 8", "4x4x4_4b, 8 acc + one LDS read per 8", "4x4x4_4b, 8 acc + one v_add_u32 per MFMA", "4x4x4_4b, 16 acc, 4 A x 4 B operands"};
-  for (int mode = 0; mode < 7; ++mode) {
+  const char* names[9] = {"4x4x4_4b, 8 independent accumulators", "16x16x4, 4 independent accumulators", "4x4x4_4b, one dependent chain",
+                          "4x4x4_4b, 8 acc + 6 v_mov_b32_dpp per 8", "4x4x4_4b, 8 acc + one LDS read per 8", "4x4x4_4b, 8 acc + one v_add_u32 per MFMA", "4x4x4_4b, 16 acc, 4 A x 4 B operands", "4x4x4_4b, 8 acc, result register != addend register", "4x4x4_4b, 8 acc in place (inline asm)"};
+  for (int mode = 0; mode < 9; ++mode) {
     hipLaunchKernelGGL(rate, dim3(256), dim3(512), 0, 0, mode, nit, out, cyc);
     hipLaunchKernelGGL(rate, dim3(256), dim3(512), 0, 0, mode, nit, out, cyc);
     hipDeviceSynchronize();

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512) void vbench(const double* Kinv, int Npad, int 
 //   B (one panel read per column quad q and parity): k[jb + 2 (4 k + blk) + par][4 q + e]       (conflict-free at pitch 18)
 //   acc[R][q]: partial sums over this block's j-quads of v[row0 + 4 R + i][4 q + j], lane 16 i + 4 blk + j; the 4 blocks are added once at the end.
 // A wave takes 16-row units w, w + 8, ...; batch = 32 rows of j: 4 Kinv loads + 8 panel reads feed 32 MFMAs with no vector instruction between.
-template <bool STREAM, bool LDSB = true, int NT = 512>
+template <bool STREAM, bool LDSB = true, int NT = 512, int DEPTH = 2>
 __global__ __launch_bounds__(NT) void vbench_ks(const double* Kinv, int Npad, int steps, double* out, unsigned long long* cyc) {
   extern __shared__ double smem[];
   double* kv = smem;
@@ -194,13 +194,32 @@ __global__ __launch_bounds__(NT) void vbench_ks(const double* Kinv, int Npad, in
         }
       }
       load(A0, B0, 0);
-      for (int b = 0; b + 1 < nb; b += 2) {
-        load(A1, B1, b + 1);
-        mma(A0, B0);
-        load(A0, B0, b + 2 < nb ? b + 2 : nb - 1);
-        mma(A1, B1);
+      const unsigned long long u0 = clock64();
+      if (DEPTH == 3) {  // loads two batches ahead of the MFMA run that uses them
+        v2d A2[4];
+        double B2[4][2];
+        load(A1, B1, nb > 1 ? 1 : 0);
+        int b = 0;
+        for (; b + 2 < nb; b += 3) {
+          load(A2, B2, b + 2);
+          mma(A0, B0);
+          load(A0, B0, b + 3 < nb ? b + 3 : nb - 1);
+          mma(A1, B1);
+          load(A1, B1, b + 4 < nb ? b + 4 : nb - 1);
+          mma(A2, B2);
+        }
+        if (b < nb) mma(A0, B0);
+        if (b + 1 < nb) mma(A1, B1);
+      } else {
+        for (int b = 0; b + 1 < nb; b += 2) {
+          load(A1, B1, b + 1);
+          mma(A0, B0);
+          load(A0, B0, b + 2 < nb ? b + 2 : nb - 1);
+          mma(A1, B1);
+        }
+        if (nb & 1) mma(A0, B0);
       }
-      if (nb & 1) mma(A0, B0);
+      if (blockIdx.x == 0 && tid == 0 && un == wv && st == steps - 1) cyc[1] = clock64() - u0;  // wave 0's first unit of the last repetition
 #pragma unroll
       for (int R = 0; R < 4; ++R)
 #pragma unroll
@@ -212,15 +231,17 @@ __global__ __launch_bounds__(NT) void vbench_ks(const double* Kinv, int Npad, in
   out[(size_t)blockIdx.x * NT + tid] = sink;
   if (blockIdx.x == 0 && tid == 0) cyc[0] = t1 - t0;
 }
-template <bool STREAM, bool LDSB = true, int NT = 512>
+template <bool STREAM, bool LDSB = true, int NT = 512, int DEPTH = 2>
 static void run_ks(const double* Kinv, int Npad, int steps, double* out, unsigned long long* cyc, const char* name) {
   const size_t lds = (size_t)(Npad + 32) * KR * 8;
-  hipFuncSetAttribute((const void*)vbench_ks<STREAM, LDSB, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((vbench_ks<STREAM, LDSB, NT>), dim3(250), dim3(NT), lds, 0, Kinv, Npad, steps, out, cyc);
+  hipFuncSetAttribute((const void*)vbench_ks<STREAM, LDSB, NT, DEPTH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((vbench_ks<STREAM, LDSB, NT, DEPTH>), dim3(250), dim3(NT), lds, 0, Kinv, Npad, steps, out, cyc);
   hipDeviceSynchronize();
-  unsigned long long h = 0;
+  unsigned long long h = 0, h1 = 0;
   hipMemcpy(&h, cyc, 8, hipMemcpyDeviceToHost);
+  hipMemcpy(&h1, cyc + 1, 8, hipMemcpyDeviceToHost);
   const double per = (double)h / steps;
+  printf("   (wave 0, one 16-row unit: %.1f ticks per MFMA)\n", (double)h1 / (((Npad + 31) / 32) * 32.0));
   const double flop = 2.0 * (double)Npad * (32.0 * ((Npad + 31) / 32)) * 16.0;
   printf("%-62s %9.0f ticks per repetition, %6.1f flop/tick/CU, Kinv stream %5.1f B/tick/CU\n", name, per, flop / per, STREAM ? 8.0 * Npad * (32.0 * ((Npad + 31) / 32)) / per : 0.0);
 }
@@ -242,7 +263,7 @@ int main(int argc, char** argv) {
   double *Kinv, *out;
   unsigned long long* cyc;
   const size_t n = (size_t)Npad * (Npad + 64) + 64;
-  hipMalloc(&Kinv, n * 8); hipMalloc(&out, 250 * 1024 * 8); hipMalloc(&cyc, 8);
+  hipMalloc(&Kinv, n * 8); hipMalloc(&out, 250 * 1024 * 8); hipMalloc(&cyc, 64);
   double* h = (double*)malloc(n * 8);
   for (size_t i = 0; i < n; ++i) h[i] = 1e-3 * (double)(i % 1013);
   hipMemcpy(Kinv, h, n * 8, hipMemcpyHostToDevice);
@@ -260,5 +281,8 @@ int main(int argc, char** argv) {
   run_ks<false, false, 1024>(Kinv, Npad, steps, out, cyc, "4x4x4_4b k-split, A and B in registers, 16 waves per workgroup");
   run_ks<false, true, 1024>(Kinv, Npad, steps, out, cyc, "4x4x4_4b k-split, A in registers, 16 waves per workgroup");
   run_ks<true, true, 1024>(Kinv, Npad, steps, out, cyc, "4x4x4_4b k-split, Kinv streamed, 16 waves per workgroup");
+  run_ks<false, true, 512, 3>(Kinv, Npad, steps, out, cyc, "4x4x4_4b k-split, A in registers, panel reads 2 batches ahead");
+  run_ks<true, true, 512, 3>(Kinv, Npad, steps, out, cyc, "4x4x4_4b k-split, Kinv streamed, loads 2 batches ahead");
+  run_ks<true, true, 1024, 3>(Kinv, Npad, steps, out, cyc, "4x4x4_4b k-split, Kinv streamed, 2 batches ahead, 16 waves");
   return 0;
 }
