@@ -20,13 +20,17 @@ int mcp_debug_last_particles_per_wg(void);
 void mcp_debug_set_gp_sharding(int mode);
 /* number of GP-sharded launches the last forward call made (0 = unsharded) */
 int mcp_debug_last_gp_sharded(void);
+/* the latency-lean GP-sharded kernel of narrow SE-only models (rollout_fwd_lat_kernel): -1 / 1 wherever it applies, 0 never */
+void mcp_debug_set_fwd_lean(int mode);
+/* 1 when the last mcp_rollout_fwd ran that kernel */
+int mcp_debug_last_fwd_lean(void);
 /* small-tile kernel: xlds -1 automatic / 0 never stage the small operands in LDS; gb = GPs per pass (0 = as many as fit) */
 void mcp_debug_set_fwd_mode(int xlds, int gb);
 /* backward sweep: particles per workgroup 1 / 2 / 4; 0 = automatic */
 void mcp_debug_set_bwd_particles(int pb);
 /* device buffers of 16 uint64 per-phase cycle totals of one workgroup (NULL = off); the forward kernels stamp workgroup
    `block` (0 by default; the partner of workgroup 0 in a 2-way GP-sharded launch of the small-tile kernel is workgroup 8) */
-void mcp_debug_set_stamp_buffer(void* device_u64x16);
+void mcp_debug_set_stamp_buffer(void* device_u64x16); /* (the lean small-swarm kernel writes 24 slots: pass 32) */
 void mcp_debug_set_stamp_block(int block);
 void mcp_debug_set_bwd_stamp_buffer(void* device_u64x16);
 

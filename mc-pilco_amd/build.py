@@ -26,11 +26,15 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_variant(tag, defines, verbose=True):
-    """Experiment helper: a second library libmcpilco_hip_<tag>.so with extra -D defines (select it with MCPILCO_HIP_LIB)."""
+def build_variant(tag, defines, verbose=True, only=None):
+    """Experiment helper: a second library libmcpilco_hip_<tag>.so with extra -D defines (select it with MCPILCO_HIP_LIB).
+    ``only``: the sources the defines concern (the others are linked from the main build's objects)."""
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
+        if only is not None and src not in only:
+            objs.append(os.path.join(CSRC, src.replace(".hip", ".o")))
+            continue
         o = os.path.join(CSRC, src.replace(".hip", ".%s.o" % tag))
         if _stale(o, [s] + HEADERS):
             cmd = [HIPCC] + FLAGS + ["-D" + d for d in defines] + ["-c", s, "-o", o]
@@ -66,5 +70,8 @@ if __name__ == "__main__":
     if "--variant" in sys.argv:  # python build.py --variant TAG DEF1 DEF2 ...
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    elif "--variant-fwd" in sys.argv:  # the same, recompiling rollout_fwd.hip only
+        i = sys.argv.index("--variant-fwd")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], only=["rollout_fwd.hip"]))
     else:
         build(force="--force" in sys.argv)

@@ -43,6 +43,20 @@ static inline size_t rollout_xj_bytes(const mcp_model* m) {
   return (size_t)m->G * 2 * 2 * (size_t)((npad + 7) / 8) * 64 * 2 * sizeof(double);
 }
 
+// Kinv as MFMA operand tiles for the lean small-swarm kernel (rollout_fwd.hip, kt_pack_kernel): G x NpadMax^2 doubles behind the
+// packed phase-J operands in the caller's workspace, rebuilt by every call.  0 for models that kernel does not take.
+#define RL_MAXD_ 8
+static inline size_t rollout_kt_bytes(const mcp_model* m) {
+  if (!m || m->D > RL_MAXD_ || m->G < 2) return 0;
+  int npad = 0;
+  for (int g = 0; g < m->G; ++g) {
+    if (m->gp[g].kern.poly_deg != 0) return 0;
+    npad = m->gp[g].Npad > npad ? m->gp[g].Npad : npad;
+  }
+  if (npad > 384) return 0;
+  return sizeof(double) * ((size_t)m->G * npad * npad + 6 * 128);  // (+ one register buffer of slack: the last stream may be read past its end)
+}
+
 static inline bool model_ok(const mcp_model* m) {
   if (!m) return false;
   if (m->S <= 0 || m->S > MCP_MAX_STATE || m->U <= 0 || m->U > MCP_MAX_INPUT || m->G <= 0 || m->G > MCP_MAX_GP) return false;

@@ -48,6 +48,8 @@ struct FwdArgs {
   unsigned stamp_block;        // (mcp_debug_set_stamp_block; 0 by default)
   double* xj;                  // packed phase-J operand of the wide 16-particle classes (workspace; null: not available), see rollout_xj_bytes
   int xj_stride;               // doubles per GP
+  const double* kt;            // Kinv as MFMA operand tiles (lean small-swarm kernel, rollout_fwd.hip; workspace; null: not available)
+  int kt_stride;               // doubles per GP
   // GP-sharded launch (rollout_fwd.hip, GSH): the G workgroups of a particle cluster hand each other their GP's sampled
   // increment once per step through 8-byte {tag, value} granules  xch[cluster][t & 1][g][p][half]  (zeroed per launch)
   unsigned long long* xch;

@@ -103,6 +103,8 @@ _SIGS = {
     "mcp_debug_set_bwd_stamp_buffer": (None, [dptr]),
     "mcp_debug_set_gp_sharding": (None, [C.c_int]),
     "mcp_debug_last_gp_sharded": (C.c_int, []),
+    "mcp_debug_set_fwd_lean": (None, [C.c_int]),
+    "mcp_debug_last_fwd_lean": (C.c_int, []),
 }
 EXPORTED = [k for k in _SIGS if not k.startswith("mcp_debug")]
 

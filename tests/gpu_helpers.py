@@ -63,13 +63,15 @@ def noise_from(fx):
 class forced_variant:
     """Context manager over the library's test hooks: ``code`` 0 = automatic dispatch; 1 / 2 / 4 = that many particles per
     workgroup, all GPs in the workgroup; 16 = the 16-particle matrix-core kernel; 101 / 102 / 104 / 116 = the GP-sharded launch
-    (G workgroups per cluster of 1 / 2 / 4 / 16 particles, met by a per-step hand-off).  ``check()`` asserts that the forced
-    variant is the one that ran."""
+    (G workgroups per cluster of 1 / 2 / 4 / 16 particles, met by a per-step hand-off) on the GENERAL kernels; 201 / 202 / 204 =
+    the GP-sharded launch on the latency-lean kernel of narrow SE-only models (``rollout_fwd_lat_kernel``; models it does not
+    cover run the general sharded kernel).  ``check()`` asserts that the forced variant is the one that ran."""
 
     def __init__(self, code, bwd_particles=None):
         self.code = code
         self.ppw = code % 100
         self.sharded = code >= 100
+        self.lean = code >= 200
         self.pb = bwd_particles if bwd_particles is not None else {0: 0, 1: 1, 2: 2, 4: 4, 16: 4}[self.ppw]
 
     def __enter__(self):
@@ -79,11 +81,13 @@ class forced_variant:
         L.mcp_debug_set_particles_per_wg(self.ppw)
         L.mcp_debug_set_bwd_particles(self.pb)
         L.mcp_debug_set_gp_sharding(1 if self.sharded else (-1 if self.code == 0 else 0))
+        L.mcp_debug_set_fwd_lean(-1 if (self.lean or self.code == 0) else 0)
         return self
 
-    def check(self, sharding_optional=False):
+    def check(self, sharding_optional=False, lean_expected=None):
         """``sharding_optional``: wide shapes whose operands do not fit the LDS beside the policy's cannot be GP-sharded; the
-        library then runs the unsharded kernel of the same tile size."""
+        library then runs the unsharded kernel of the same tile size.  ``lean_expected``: for codes 2xx, whether the model is
+        one the lean kernel covers (None: not checked)."""
         from mc_pilco_amd import hipabi
 
         L = hipabi.lib()
@@ -91,6 +95,10 @@ class forced_variant:
             assert L.mcp_debug_last_particles_per_wg() == self.ppw, "forced kernel variant was not the one launched"
             if not (sharding_optional and self.sharded):
                 assert bool(L.mcp_debug_last_gp_sharded()) == self.sharded, "GP sharding was not what the test forced"
+            if not self.lean:
+                assert L.mcp_debug_last_fwd_lean() == 0, "the general kernel was forced, the lean one ran"
+            elif lean_expected is not None:
+                assert bool(L.mcp_debug_last_fwd_lean()) == bool(lean_expected), "lean kernel: expected %s" % lean_expected
 
     def __exit__(self, *exc):
         from mc_pilco_amd import hipabi
@@ -99,7 +107,8 @@ class forced_variant:
         L.mcp_debug_set_particles_per_wg(0)
         L.mcp_debug_set_bwd_particles(0)
         L.mcp_debug_set_gp_sharding(-1)
+        L.mcp_debug_set_fwd_lean(-1)
         return False
 
 
-VARIANTS = [0, 1, 2, 4, 16, 101, 102, 104, 116]
+VARIANTS = [0, 1, 2, 4, 16, 101, 102, 104, 116, 201, 202, 204]

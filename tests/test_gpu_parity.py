@@ -163,7 +163,7 @@ def test_next_state_step(golden):
     assert abserr(torch.stack([var0, var1], 1), fx["var"]) < 1e-11
 
 
-@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16, 101, 102, 104, 116])
+@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16, 101, 102, 104, 116, 201, 202, 204])
 @pytest.mark.parametrize("name,kind", ROLLOUT_FIXTURES)
 def test_rollout_cost_gradient_vs_reference(golden, name, kind, ppw):
     """apply_policy + expected cost + backward on the reference's recorded noise, on every kernel variant (gpu_helpers.forced_variant)."""
@@ -171,7 +171,7 @@ def test_rollout_cost_gradient_vs_reference(golden, name, kind, ppw):
     from mc_pilco_amd import ops
 
     fx = golden(name)
-    if ppw and name == "rollout_se_long" and ppw not in (2, 104):
+    if ppw and name == "rollout_se_long" and ppw not in (2, 104, 204):
         pytest.skip("long rollout checked at one forced tile size per launch kind")
     model = packed_model(fx, kind)
     pol = packed_policy(fx, kind)
@@ -268,7 +268,7 @@ def test_philox_mode_properties():
     assert 0.5 < float(d.std() / a[1, :, 1].std()) < 1.5 and float(a[1, :, 1].std()) > 0
 
 
-@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16, 101, 102, 104, 116])
+@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16, 101, 102, 104, 116, 201, 202, 204])
 def test_pms_rollout_cost_gradient_vs_reference(golden, ppw):
     """MC_PILCO4PMS.apply_policy + cost + backward through the C ABI (mcp_meas): the measurement filter between particles and
     policy is carried inside the fused kernels; the reference's recorded eps / position noise / masks are injected."""
@@ -341,7 +341,7 @@ def test_kernel_variants_agree_on_odd_shapes(case):
     torch.manual_seed(11)
     x0 = w.sample_x0()
     ref = None
-    for code in [1, 2, 4, 16, 101, 102, 104, 116]:
+    for code in [1, 2, 4, 16, 101, 102, 104, 116, 201, 202, 204]:
         with forced_variant(code) as fv:
             for q in w.params:
                 q.grad = None
@@ -536,7 +536,7 @@ def test_posterior_operator_takes_more_than_1024_test_points(golden):
     assert abserr(var[-32:], fx["var"]) < 1e-10
 
 
-@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16, 101, 102, 104, 116])
+@pytest.mark.parametrize("ppw", [0, 1, 2, 4, 16, 101, 102, 104, 116, 201, 202, 204])
 def test_rollout_with_policy_bias_vs_reference(golden, ppw):
     """flg_bias (Policy.py:203-212) through the C ABI: mcp_policy.bias enters the linear layer in every forward variant, the adjoint
     sweep returns dJ/dbias (mcp_policy.g_bias) next to the three other gradients."""

@@ -68,7 +68,7 @@ def hip_workload(key):
 
 
 @pytest.mark.parametrize("pb", [1, 2, 4])
-@pytest.mark.parametrize("code", [1, 2, 4, 16, 101, 102, 104, 116])
+@pytest.mark.parametrize("code", [1, 2, 4, 16, 101, 102, 104, 116, 201, 202, 204])
 @pytest.mark.parametrize("key", list(REAL))
 def test_every_variant_against_the_oracle_at_real_training_set_sizes(key, code, pb):
     from gpu_helpers import dev, forced_variant

@@ -11,10 +11,11 @@ Mo = int(sys.argv[3]) if len(sys.argv) > 3 else None
 To = int(sys.argv[4]) if len(sys.argv) > 4 else None
 pd = float(sys.argv[5]) if len(sys.argv) > 5 else 0.25
 w = workloads.build(name, device=dev, M=Mo, T=To, p_drop=pd)
-buf = torch.zeros(16, dtype=torch.int64, device=dev)
+buf = torch.zeros(32, dtype=torch.int64, device=dev)
 x0 = w.sample_x0()
 hipabi.lib().mcp_debug_set_particles_per_wg(ppw % 100)
-if ppw >= 100:  # 101 / 102 / 104: force the GP-sharded launch with that cluster size
+hipabi.lib().mcp_debug_set_fwd_lean(0 if 100 <= ppw < 200 else -1)  # 1xx: the general sharded kernel; 2xx / automatic: the lean one where it applies
+if ppw >= 100:  # 101 / 102 / 104 (general kernel), 201 / 202 / 204 (lean kernel): force the GP-sharded launch with that cluster size
     hipabi.lib().mcp_debug_set_gp_sharding(1)
 elif ppw:
     hipabi.lib().mcp_debug_set_gp_sharding(0)
@@ -27,6 +28,8 @@ torch.cuda.synchronize()
 hipabi.lib().mcp_debug_set_stamp_buffer(None)
 v = buf.cpu().tolist()
 names = ["S(state/feat)", "PHI", "U", "K", "V(matvec)", "vsum", "J", "F+integrate", "(hand-off wait, inside F)"]
+if hipabi.lib().mcp_debug_last_fwd_lean():  # the lean kernel's five barrier intervals (the serial section of wave 0 is "F")
+    names = ["S (wave 0)", "policy+K(state)", "-", "u+K(exp)", "-", "-", "V + J (to the barrier)", "F+hand-off+integrate", "(hand-off wait, inside F)"]
 tot = sum(v[:8])
 # backward stamps
 w.params[0].grad = None
@@ -39,8 +42,12 @@ torch.cuda.synchronize()
 hipabi.lib().mcp_debug_set_bwd_stamp_buffer(None)
 v2 = buf2.cpu().tolist()
 print("bwd per step cycles: serial(wave0) %.0f | barrier1 %.0f | RBF stage %.0f | park+barrier2 %.0f" % tuple(x / w.T for x in (v2[8], v2[9], v2[10], v2[11])))
-print("workload", name, "T", w.T, "M", w.M, "ppw forced", ppw, "launched", hipabi.lib().mcp_debug_last_particles_per_wg(), "gp-sharded", hipabi.lib().mcp_debug_last_gp_sharded(), "total cycles", tot, "-> per step", tot / (w.T - 1))
+print("workload", name, "T", w.T, "M", w.M, "ppw forced", ppw, "launched", hipabi.lib().mcp_debug_last_particles_per_wg(), "gp-sharded", hipabi.lib().mcp_debug_last_gp_sharded(), "lean", hipabi.lib().mcp_debug_last_fwd_lean(), "total cycles", tot, "-> per step", tot / (w.T - 1))
 print("tile kernel detail (wave 0, per step, all GPs): K setup %.0f, K tiles %.0f | J setup %.0f, J batches %.0f cyc" % tuple(v[i] / (w.T - 1) for i in (12, 13, 14, 15)))
 print("J finish (wave 0, per step, all GPs): wait for the other waves %.0f, park + barrier %.0f, add + barrier %.0f cyc" % tuple(v[i] / (w.T - 1) for i in (9, 10, 11)))
+if hipabi.lib().mcp_debug_last_fwd_lean():
+    print("lean kernel, wave 0 per step: S compute (to the barrier) %.0f | F compute (delta, granules, Jacobian stores) %.0f | hand-off poll %.0f | J (own rows) %.0f cyc"
+          % tuple(v[i] / (w.T - 1) for i in (15, 9, 10, 12)))
+    print("lean kernel, phase V per wave (own time, before the barrier):", " ".join("%.0f" % (v[16 + i] / (w.T - 1)) for i in range(8)))
 for n, c in zip(names, v):
     print("%-14s %12d  %5.1f%%  %8.0f cyc/step" % (n, c, 100.0 * c / tot, c / (w.T - 1)))
