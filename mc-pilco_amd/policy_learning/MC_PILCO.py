@@ -154,6 +154,10 @@ class MC_PILCO(torch.nn.Module):
             self.last_status = status
             return states, inputs
         # generic (unfused) path: any model / policy object with the reference's step interface
+        if world > 1:
+            # its noise (torch draws inside get_next_state / the policy's dropout) is per LOCAL particle: identically seeded ranks
+            # would simulate correlated shards, not the particles one GPU would
+            raise NotImplementedError("particle sharding needs the fused rollout (Sum_of_gaussians policy + speed-integration model)")
         xs = [x0]
         us = [pol(x0, t=0, p_dropout=p_dropout)]
         for t in range(1, T):
@@ -205,10 +209,9 @@ class MC_PILCO(torch.nn.Module):
             for q in params:  # a parameter the cost does not reach still takes part in the message (every rank sends the same layout)
                 if q.requires_grad and q.grad is None:
                     q.grad = torch.zeros_like(q)
-        sums_all, flags = self._reducer.reduce(params if backward else [], sums, self._step_flags(share))
-        new_shift = torch.empty_like(self._cost_shift)
-        cost, std = cf.from_sums(sums_all, self._m_total, self._cost_shift, new_shift)
-        self._cost_shift = new_shift
+        # one all-reduce; pooled cost / std; a NaN rollout neither poisons the next steps' shift nor goes unnoticed on the other ranks
+        cost, std, flags, self._cost_shift = sharding.finish_step(cf, self._reducer, params if backward else [], sums, self._step_flags(share),
+                                                                  self._m_total, self._cost_shift)
         return cost, std, flags
 
     # ------------------------------------------------------------------------------------------------------------
@@ -540,6 +543,8 @@ class MC_PILCO4PMS(MC_PILCO):
             states, inputs, status = ops.rollout(ml.packed(), pol.packed(), noise, x, T, p, meas=meas, gp_sharding=self.gp_sharding)
             self.last_status = status
             return states, inputs
+        if world > 1:  # (per-LOCAL-particle torch draws: identically seeded ranks would simulate correlated shards)
+            raise NotImplementedError("particle sharding needs the fused rollout (fused=True, Sum_of_gaussians policy, speed-integration model)")
         std_pos = torch.tensor(np.asarray(self.std_meas_noise_sim)[pos], dtype=self.dtype, device=self.device)
         saved_mode = getattr(pol, "noise_mode", None)
         if ref and saved_mode is not None:

@@ -128,3 +128,22 @@ class StepReducer:
             o += n
         ns = sums.numel()
         return flat[o:o + ns], flat[o + ns:]
+
+
+def finish_step(cost_cls, reducer: "StepReducer", params, sums: torch.Tensor, flags: torch.Tensor, m_total: int, shift: torch.Tensor):
+    """What follows a rank's own backward sweep in a sharded optimizer step: the ONE all-reduce of [gradients | cost sums | flags],
+    the pooled (cost, std) from the reduced sums, and the shift of the next step's sums.
+
+    Returns (cost, std, flags, next_shift).  ``flags[0]`` additionally counts a non-finite POOLED cost -- computed from the reduced
+    sums, hence identical on every rank: all ranks take the same retry decision (MC_PILCO.py:497) even when the NaN sits in
+    another rank's particles.  The shift is only the numerical centre of the summable moments; a component that came out
+    non-finite (a NaN rollout) keeps its previous value, so the steps after a NaN rollout are not poisoned by it.
+    ``cost_cls`` provides ``from_sums(sums, n_total, shift, mean_out)`` (policy_learning.Cost_function.Expected_cost or its HIP
+    subclasses)."""
+    sums_all, fl = reducer.reduce(params, sums, flags)
+    new_shift = torch.empty_like(shift)
+    cost, std = cost_cls.from_sums(sums_all, m_total, shift, new_shift)
+    next_shift = torch.where(torch.isfinite(new_shift), new_shift, shift)
+    fl = fl.clone()
+    fl[0] = fl[0] + (~torch.isfinite(cost.detach())).to(fl.dtype)
+    return cost, std, fl, next_shift

@@ -164,3 +164,102 @@ def test_shard_ranges_partition_the_particles():
             for (o0, c0), (o1, _) in zip(rs, rs[1:]):
                 assert o0 + c0 == o1
             assert max(c for _, c in rs) - min(c for _, c in rs) <= 1
+
+
+def _worker_nan_step(rank, world, port, m_total, out_q):
+    """Three sharded steps on the same particles; in step 0 one particle of rank 1 has a NaN cost."""
+    import torch.distributed as dist
+
+    import mcp_boot  # noqa: F401
+    from mc_pilco_amd import sharding
+    from mc_pilco_amd.policy_learning.Cost_function import Expected_cost
+    from oracle import mcpilco_oracle as orc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fx = load_golden("rollout_se")
+    m, pp, cost_fn = oracle_model(fx, "se"), oracle_policy(fx, "se"), oracle_cost_fn(fx, "se")
+    off, cnt = sharding.shard_range(m_total, world, rank)
+    sl = slice(off, off + cnt)
+    Tn = fx["states"].shape[0]
+    prm = [pp.log_ls, pp.centers, pp.weight]
+    for p in prm:
+        p.requires_grad_(True)
+    red = sharding.StepReducer(dist.group.WORLD)
+    shift = torch.zeros(Tn, dtype=torch.float64)
+    out = []
+    for step in range(3):
+        for p in prm:
+            p.grad = None
+        st, _ = orc.apply_policy(m, pp, T(fx["states"][0][sl]), Tn, float(fx["p_drop"]), T(fx["eps"][:, sl]), T(fx["masks"][:, sl]))
+
+        def poisoned(x, u, k, step=step):
+            c = cost_fn(x)
+            if step == 0 and rank == 1:
+                c = c.clone()
+                c[3, 0] = float("nan")
+            return c
+
+        ec = Expected_cost(poisoned)
+        share, sums = ec.local_moments(st, None, 0, m_total, shift)
+        share.backward()
+        local_nan = torch.isnan(share.detach()).reshape(()).to(torch.float64)
+        cost, std, fl, shift = sharding.finish_step(Expected_cost, red, prm, sums, torch.stack([local_nan, torch.zeros((), dtype=torch.float64)]),
+                                                    m_total, shift)
+        out.append((float(cost), float(std), fl.tolist(), bool(torch.isfinite(shift).all())))
+    out_q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_nan_rollout_does_not_poison_the_following_sharded_steps():
+    """after a NaN rollout the pooled per-step means must not become the next step's shift, and the rank whose
+    particles are clean must still see the retry flag.  Step 0: NaN on rank 1 only -> cost NaN and flags[0] > 0 on BOTH ranks;
+    steps 1, 2: finite, equal to the single-process cost of the same particles."""
+    from oracle import mcpilco_oracle as orc
+
+    world, m_total = 2, 24
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_nan_step, args=(r, world, port, m_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    fx = load_golden("rollout_se")
+    m, pp, cost_fn = oracle_model(fx, "se"), oracle_policy(fx, "se"), oracle_cost_fn(fx, "se")
+    sl = slice(0, m_total)
+    c1, s1, _, _, _ = orc.policy_grad_step(m, pp, T(fx["states"][0][sl]), fx["states"].shape[0], cost_fn, float(fx["p_drop"]), T(fx["eps"][:, sl]),
+                                           T(fx["masks"][:, sl]))
+    for rank in range(world):
+        steps = res[rank]
+        assert np.isnan(steps[0][0]) and steps[0][2][0] > 0 and steps[0][3]  # NaN seen, flag raised on every rank, shift still finite
+        for cost, std, fl, ok in steps[1:]:
+            assert fl[0] == 0 and ok
+            assert abs(cost - float(c1)) < 1e-12 * abs(float(c1))
+            assert abs(std - float(s1)) < 1e-9 * abs(float(s1))
+
+
+def test_eight_rank_shard_arithmetic_of_the_c4_swarm():
+    """BASELINE.json configs[3]: M = 32 000 particles over 8 ranks -- counts, offsets, the 1/M_total scaling of the shares and the
+    pooled cost / std from the summed moments (plain arithmetic, no process group: what 8 ranks would send and receive)."""
+    from mc_pilco_amd import sharding
+    from mc_pilco_amd.policy_learning.Cost_function import Expected_cost
+
+    M, R, Tn = 32000, 8, 5
+    rs = [sharding.shard_range(M, R, r) for r in range(R)]
+    assert [c for _, c in rs] == [4000] * 8 and [o for o, _ in rs] == [4000 * r for r in range(R)]
+    g = torch.Generator().manual_seed(4)
+    costs = torch.rand(Tn, M, dtype=torch.float64, generator=g)
+    shift = costs.mean(1) + 0.01
+    ec = Expected_cost(lambda x, u, k: x)
+    shares, sums = zip(*[ec.local_moments(costs[:, o:o + c], None, 0, M, shift) for o, c in rs])
+    assert abs(float(sum(shares)) - float(costs.mean(1).sum())) < 1e-12
+    cost, std = Expected_cost.from_sums(sum(sums), M, shift)
+    assert abs(float(cost) - float(costs.mean(1).sum())) < 1e-12
+    assert abs(float(std) - float(costs.std(1).sum())) < 1e-10
