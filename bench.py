@@ -2,20 +2,31 @@
 """Benchmark of the MC-PILCO hot path on MI355X: one "step" = one policy-gradient step of
 MC_PILCO.reinforce_policy (policy_learning/MC_PILCO.py:484-525) -- fused particle rollout,
 expected cost, reverse-time adjoint, [one all-reduce of gradient + cost sums], Adam update -- on
-synthetic cart-pole-shaped data (BASELINE.json configs[1]: 4-D state, SE kernel, N=300, M=400
-particles per GPU, T=150).  Metric: particle-steps/s = M*T / step time, whole job.
+synthetic cart-pole-shaped data.  Metric: particle-steps/s = M*T / step time, whole job.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c3|c5] [--no-cpu] [--no-extra]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c1_script|c3|c4|c5] [--no-cpu] [--no-extra]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself as
-child processes -- before this process makes any GPU call -- and relays rank 0's JSON line.
+Workload.  One GPU: BASELINE.json configs[1] (c1: 4-D state, SE kernel, N=300, M=400 particles, T=150).  N > 1 GPUs:
+configs[3] (c4: SE + polynomial(2), 4000 particles PER GPU -- 32 000 over 8 -- T=150), weak scaling; the JSON line of an
+N > 1 run carries `scaling_reference` = the same per-GPU shard timed on one GPU without the collective (so that the
+efficiency of THIS workload can be read off one line) and the latency-bound c1 shard as an extra.
 
-Multi-GPU: particles are sharded (weak scaling: M per GPU fixed); the ranks meet in ONE all-reduce
-per step (RCCL): [gradient | per-time-step cost sums | status flags].  Prints ONE JSON line on rank 0.
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself as child processes -- before
+this process makes any GPU call -- relays rank 0's JSON line and WATCHES the children: a rank that dies, or 180 s
+without any rank finishing while rank 0 is silent, ends the run with a non-zero exit code instead of a hang.
+
+Multi-GPU: particles are sharded; the ranks meet in ONE all-reduce per step (RCCL): [gradient | per-time-step cost sums |
+status flags].  Before the workload is built every rank runs a PRE-FLIGHT (one 8-byte all-reduce under a time-out) whose
+failure names backend and transport.  Prints ONE JSON line on rank 0.
+
+The timed region: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize; blocks are
+repeated until >= 1 s has been measured and the MEDIAN block is reported (`blocks`, `block_ms` in the line).
 """
 import argparse
+import datetime
+import hashlib
 import json
 import os
 import subprocess
@@ -26,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix (= vector) peak, datasheet; see DESIGN.md
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E, MI355X_MICROARCH.md
 
 
 def note(msg):
@@ -41,25 +53,32 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c1")
+    ap.add_argument("--workload", default=None, help="c1 (default on one GPU), c1_script, c3, c4 (default on N > 1 GPUs), c5")
     ap.add_argument("--particles", type=int, default=0, help="particles per GPU (default: the workload's M)")
     ap.add_argument("--horizon", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads (c3, c5) of the default single-GPU run")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_workloads of the default runs")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="repeat the K-step block until this much has been measured")
     ap.add_argument("--noise", default="philox", choices=["philox", "buffers"])
     ap.add_argument("--pms", action="store_true", help="partially measurable system: the policy sees noisy positions and filtered "
                     "finite-difference velocities (MC_PILCO4PMS.apply_policy); cart-pole workloads")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
     ap.add_argument("--transport", default="torch", choices=["torch", "abi"],
                     help="who carries the step's all-reduce: torch.distributed, or the C ABI's RCCL communicator (mcp_allreduce_grad)")
+    ap.add_argument("--collective-smoke", action="store_true",
+                    help="N > 1: additionally time the step's message through the OTHER transport (the C ABI's communicator when the run "
+                         "uses torch.distributed and vice versa) and report both latencies")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--watchdog-seconds", type=float, default=180.0, help="spawned ranks: give up after this long without progress")
     return ap.parse_args()
 
 
 def spawn_ranks(args):
-    """`bench.py --gpus N` started bare: run the N ranks as children (one per GPU) and relay rank 0's output.  Nothing in this
-    process has touched the GPU (torch is not even imported yet), and the children are fresh interpreters -- no exec of a
-    process that holds the device."""
+    """`bench.py --gpus N` started bare: run the N ranks as children (one per GPU), relay rank 0's output and watch them.
+    Nothing in this process has touched the GPU (torch is not even imported yet), and the children are fresh interpreters --
+    no exec of a process that holds the device.  A child that exits non-zero, or `--watchdog-seconds` without any sign of
+    life (no child finishing, no new stderr/stdout byte from rank 0), terminates the rest: exit code != 0, never a hang."""
+    import selectors
     import socket
 
     s = socket.socket()
@@ -72,14 +91,64 @@ def spawn_ranks(args):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = rc or p.wait()
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=subprocess.PIPE if r == 0 else None))
+    sel = selectors.DefaultSelector()
+    for f in (procs[0].stdout, procs[0].stderr):
+        os.set_blocking(f.fileno(), False)
+        sel.register(f, selectors.EVENT_READ)
+    out = b""
+    last_life = time.monotonic()
+    open_streams = 2
+    rc = None
+    while rc is None:
+        for key, _ in sel.select(timeout=1.0):
+            data = key.fileobj.read()
+            if data:
+                last_life = time.monotonic()
+                if key.fileobj is procs[0].stdout:
+                    out += data
+                else:
+                    sys.stderr.buffer.write(data)
+                    sys.stderr.flush()
+            elif data == b"":
+                sel.unregister(key.fileobj)
+                open_streams -= 1
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            note("rank %d exited with code %d -- terminating the other ranks" % bad[0])
+            rc = bad[0][1] or 1
+        elif all(c == 0 for c in codes) and open_streams == 0:
+            rc = 0
+        elif time.monotonic() - last_life > args.watchdog_seconds:
+            note("watchdog: no progress for %.0f s -- terminating all ranks" % args.watchdog_seconds)
+            rc = 124
+    if rc != 0:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
     sys.stdout.write(out.decode())
     sys.stdout.flush()
     raise SystemExit(rc)
+
+
+def kernel_sources_sha16():
+    """Identity of the kernel sources a measurement belongs to (profiles/traffic.json is only quoted when it matches)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mc-pilco_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "mcpilco_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(problem, M, T, p_drop, threads, budget_s=12.0):
@@ -132,12 +201,14 @@ def cpu_baseline(problem, M, T, p_drop, threads, budget_s=12.0):
 class Runner:
     """One workload on this rank's GPU: builds it, and runs / times policy-gradient steps."""
 
+    STATUS_BITS = 4  # NaN, non-positive variance, not SPD, hand-off time-out (include/mcpilco_hip.h)
+
     def __init__(self, args, name, dev, rank, world, reducer, M=None, T=None):
         import torch
 
-        from mc_pilco_amd import ops, workloads
+        from mc_pilco_amd import ops, sharding, workloads
 
-        self.torch, self.ops = torch, ops
+        self.torch, self.ops, self.sharding = torch, ops, sharding
         self.args, self.name, self.dev, self.rank, self.world, self.reducer = args, name, dev, rank, world, reducer
         self.w = workloads.build(name, device=dev, M=M, T=T)
         self.M, self.T = self.w.M, self.w.T
@@ -152,12 +223,15 @@ class Runner:
         self.gen = torch.Generator(device=dev)
         self.gen.manual_seed(1234 + rank)
         self.status_or = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.flags_sum = torch.zeros(1 + self.STATUS_BITS, dtype=torch.float64, device=dev)  # reduced flags of every step, on every rank alike
         self.shift = torch.zeros(self.T, dtype=torch.float64, device=dev)
         self.flops = workloads.flops_per_particle_step(self.w)
+        self.bits = torch.tensor([1 << b for b in range(self.STATUS_BITS)], dtype=torch.int32, device=dev)
 
-    def step(self, i, ev):
+    def step(self, i, ev, sharded=None):
         torch, ops, w, args = self.torch, self.ops, self.w, self.args
         M, T = self.M, self.T
+        sharded = (self.world > 1) if sharded is None else sharded
         x0 = w.sample_x0(M, generator=self.gen)
         eps = masks = None
         if args.noise == "buffers":
@@ -172,14 +246,14 @@ class Runner:
         if ev is not None:
             ev[1].record()
         self.status_or |= status
-        if self.world > 1:
-            # this rank's share of the pooled cost -> its own adjoint sweep -> ONE all-reduce of [gradient | cost sums | flags]
+        if sharded:
+            # this rank's share of the pooled cost -> its own adjoint sweep -> ONE all-reduce of [gradient | cost sums | flags]; the
+            # flags are one 0/1 entry per status bit (summed doubles are counts, not an OR) + "local share is NaN"
             share, sums = ops.local_cost(w.cost, states, self.world * M, self.shift)
             share.backward()
-            sums_all, _flags = self.reducer.reduce(w.params, sums, status.to(torch.float64))
-            new_shift = torch.empty_like(self.shift)
-            cost = ops.cost_from_sums(sums_all, self.world * M, self.shift, new_shift)[0]
-            self.shift = new_shift
+            fl = torch.cat([torch.isnan(share.detach()).reshape(1).to(torch.float64), ((status & self.bits) != 0).to(torch.float64)])
+            cost, _std, fl_all, self.shift = self.sharding.finish_step(_SumsCost, self.reducer, w.params, sums, fl, self.world * M, self.shift)
+            self.flags_sum += fl_all
         else:
             cost, _std = ops.expected_cost(w.cost, states)
             cost.backward()
@@ -193,45 +267,121 @@ class Runner:
             dist.barrier()
         self.torch.cuda.synchronize()
 
-    def run(self, steps, warmup):
-        """warmup untimed steps, then exactly `steps` timed ones between barriers.  Returns (seconds [max over ranks],
-        mean forward-kernel ms from HIP events on the launch stream, last cost)."""
-        torch = self.torch
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        for i in range(warmup):
-            self.step(i, None)
-        self.barrier()
-        t0 = time.perf_counter()
-        cost = None
-        for i in range(steps):
-            cost = self.step(warmup + i, evs[i])
-        self.barrier()
-        el = time.perf_counter() - t0
-        fwd_ms = sum(a.elapsed_time(b) for (a, b) in evs) / len(evs)
+    def check_flags(self):
+        """After the timed blocks: any status bit raised on ANY rank invalidates the measurement -- decided alike on every rank
+        (the flags travelled with every step's all-reduce), so no rank is left waiting in a collective."""
+        bad = int(self.status_or.item()) != 0
         if self.world > 1:
-            import torch.distributed as dist
+            bad = bad or bool((self.flags_sum > 0).any().item())
+        if bad:
+            raise SystemExit("bench: kernel status flags were raised during the run (local %s, reduced counts %s) -- the measurement is invalid"
+                             % (self.ops.status_flags(self.status_or), self.flags_sum.tolist()))
 
-            tmax = torch.tensor([el], dtype=torch.float64, device=self.dev)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            el = float(tmax.item())
-        st = int(self.status_or.item())
-        if st != 0:
-            raise SystemExit("bench: kernel status flags %s were raised during the run -- the measurement is invalid" % self.ops.status_flags(self.status_or))
-        return el, fwd_ms, float(cost.detach())
+    def run(self, steps, warmup, min_seconds=0.0, sharded=None):
+        """warmup untimed steps, then blocks of exactly `steps` timed ones between barriers, repeated until `min_seconds` have been
+        measured (the number of blocks follows from the first block's time, maximum over ranks, so every rank runs the same).
+        Returns (median block seconds [max over ranks], mean forward-kernel ms from HIP events on the launch stream, last cost,
+        all block seconds)."""
+        torch = self.torch
+        sharded = (self.world > 1) if sharded is None else sharded
+        for i in range(warmup):
+            self.step(i, None, sharded)
+        blocks, fwd, cost, k, nblocks = [], [], None, warmup, 1
+        while len(blocks) < nblocks:
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            self.barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                cost = self.step(k + i, evs[i], sharded)
+            self.barrier()
+            el = time.perf_counter() - t0
+            k += steps
+            if self.world > 1 and sharded:
+                import torch.distributed as dist
+
+                tmax = torch.tensor([el], dtype=torch.float64, device=self.dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                el = float(tmax.item())
+            blocks.append(el)
+            fwd.append(sum(a.elapsed_time(b) for (a, b) in evs) / len(evs))
+            if len(blocks) == 1 and min_seconds > 0:
+                nblocks = max(1, min(50, int(min_seconds / max(el, 1e-6)) + 1))
+        self.check_flags()
+        order = sorted(range(len(blocks)), key=lambda j: blocks[j])
+        mid = order[len(order) // 2]
+        return blocks[mid], fwd[mid], float(cost.detach()), blocks
 
     def kernel_name(self):
         from mc_pilco_amd import hipabi
 
         L = hipabi.lib()
+        if L.mcp_debug_last_fwd_lean():
+            return "rollout_fwd_lat_kernel (GP-sharded)"
         name = "rollout_fwd_tile_kernel" if L.mcp_debug_last_particles_per_wg() == 16 else "rollout_fwd_kernel"
         return name + (" (GP-sharded)" if L.mcp_debug_last_gp_sharded() else "")
 
-    def roofline(self, fwd_ms):
+    def roofline(self, fwd_ms, step_s, traffic):
+        """`frac` prices the algorithmic flops of a whole step (fwd + bwd) against the FORWARD kernel's time -- the
+        contract's per-kernel figure (the forward kernel also forms the GP Jacobians the adjoint sweep consumes); `frac_step`
+        prices the same flops against the whole step (forward + cost + adjoint + Adam [+ all-reduce])."""
+        name = self.kernel_name()
+        small = not name.startswith("rollout_fwd_tile")
         ach = self.flops * self.M * self.T / (fwd_ms * 1e-3) / 1e12
-        return {"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "traffic": None,
-                "kernel": self.kernel_name(), "kernel_ms": fwd_ms, "alg_flops_per_particle_step": self.flops, "units_per_launch": self.M * self.T,
-                "achieved_basis": "algorithmic fwd+bwd flops per particle-step (SURVEY 8d) x M x T / the FORWARD kernel's mean launch time "
-                                  "(HIP events on the launch stream); the forward kernel also forms the GP Jacobians the adjoint sweep consumes"}
+        ach_step = self.flops * self.M * self.T / step_s / 1e12
+        r = {"bound": "l2-stream+latency" if small else "fp64 units (mfma)", "roof": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS,
+             "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "frac_step": ach_step / FP64_PEAK_TFLOPS, "traffic": traffic,
+             "kernel": name, "kernel_ms": fwd_ms, "alg_flops_per_particle_step": self.flops, "units_per_launch": self.M * self.T,
+             "achieved_basis": "algorithmic fwd+bwd flops per particle-step (SURVEY 8d) x M x T / the FORWARD kernel's mean launch time "
+                               "(HIP events on the launch stream); frac_step: the same flops / ms_per_step",
+             "regime": ("T-sequential chain of 4 barrier-separated phases per step + the per-CU L2->CU stream of one Kinv per workgroup and "
+                        "step; fp64 flop roof not reachable at M=400 (DESIGN.md 4.1)") if small else
+                       "fp64 matrix pipe (MFMA 16x16x4) beside VALU exp / Philox phases"}
+        if traffic:
+            gbps = traffic / (fwd_ms * 1e-3) / 1e9
+            r["hbm_gbps"], r["hbm_frac"] = gbps, gbps / HBM_PEAK_GBPS
+        return r
+
+
+class _SumsCost:
+    """`from_sums` of sharding.finish_step through the C ABI (mcp_cost_finalize_sums)."""
+
+    @staticmethod
+    def from_sums(sums, n_total, shift=None, mean_out=None):
+        from mc_pilco_amd import ops
+
+        out = ops.cost_from_sums(sums, n_total, shift, mean_out)
+        return out[0], out[1]
+
+
+def preflight(dist, torch, dev, args, rank, world):
+    """One 8-byte all-reduce before anything is built: a broken transport shows up here, with a message, inside the process
+    group's time-out -- not as a hang in step 0."""
+    t0 = time.perf_counter()
+    try:
+        x = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(x)
+        torch.cuda.synchronize()
+        if int(x.item()) != world:
+            raise RuntimeError("all-reduce of ones returned %s on rank %d, expected %d" % (x.item(), rank, world))
+    except Exception as e:  # noqa: BLE001
+        raise SystemExit("bench: pre-flight all-reduce failed on rank %d (backend %s, transport %s, world %d, device %s): %r"
+                         % (rank, args.backend, args.transport, world, dev, e))
+    return time.perf_counter() - t0
+
+
+def time_collective(torch, reducer, n, dev, calls=50):
+    """Mean latency of the step's message (n doubles) through `reducer`, HIP-event timed, after 5 warm-up calls."""
+    buf = torch.zeros(n, dtype=torch.float64, device=dev)
+    for _ in range(5):
+        reducer.allreduce_(buf)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(calls):
+        reducer.allreduce_(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    return 1e3 * e0.elapsed_time(e1) / calls
 
 
 def main():
@@ -241,8 +391,13 @@ def main():
         spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("MCP_BENCH_TEST_HANG") == str(rank):  # test hook of the watchdog (tests/test_bench_cpu.py): this rank never shows up
+        time.sleep(3600)
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    default_workload = args.workload is None
+    if default_workload:
+        args.workload = "c1" if world == 1 else "c4"
 
     import torch
 
@@ -255,77 +410,128 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     reducer = None
+    collective = None
     if world > 1:
         import torch.distributed as dist
 
         from mc_pilco_amd import sharding
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        tmo = datetime.timedelta(seconds=120)
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
+            else:
+                dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=tmo)
+        except Exception as e:  # noqa: BLE001
+            raise SystemExit("bench: init_process_group(%s) failed on rank %d of %d: %r" % (args.backend, rank, world, e))
+        pf = preflight(dist, torch, dev, args, rank, world)
+        if rank == 0:
+            note("pre-flight all-reduce over %d ranks (%s): %.2f s" % (world, args.backend, pf))
         reducer = sharding.StepReducer(dist.group.WORLD, args.transport)
 
     if rank == 0:
         note("building workload %s" % args.workload)
     main_run = Runner(args, args.workload, dev, rank, world, reducer, M=args.particles or None, T=args.horizon or None)
     M, T, w = main_run.M, main_run.T, main_run.w
-    el, fwd_ms, last_cost = main_run.run(args.steps, args.warmup)
-    if rank == 0:
-        note("%s: %d steps in %.3f s" % (args.workload, args.steps, el))
-    ms_per_step = 1e3 * el / args.steps
-    value = world * M * T / (el / args.steps)
+    nmsg = sum(p.numel() for p in w.params) + 2 * T + 1 + Runner.STATUS_BITS
+    if world > 1:
+        us = time_collective(torch, reducer, nmsg, dev)
+        collective = {"per_step": 1, "doubles": nmsg, "transport": args.transport, "backend": args.backend, "us_per_call": us}
+        if args.collective_smoke:
+            other = "abi" if args.transport == "torch" else "torch"
+            try:
+                from mc_pilco_amd import sharding
 
+                collective["us_per_call_" + other] = time_collective(torch, sharding.StepReducer(dist.group.WORLD, other), nmsg, dev)
+            except Exception as e:  # noqa: BLE001  (a smoke: reported, not fatal)
+                collective["error_" + other] = repr(e)
+    block_s, fwd_ms, last_cost, blocks = main_run.run(args.steps, args.warmup, args.min_seconds)
     if rank == 0:
-        regimes = {"rollout_fwd_kernel": "per-CU L2->L1 stream of Kinv (phase V) + T-sequential per-step latency; peak = fp64 MFMA/VALU rate",
-                   "rollout_fwd_tile_kernel": "fp64 matrix pipe (MFMA 16x16x4) beside VALU exp / Philox phases"}
-        roof = main_run.roofline(fwd_ms)
-        roof["regime"] = regimes.get(roof["kernel"].split(" ")[0], "")
+        note("%s: %d block(s) of %d steps, median %.3f s" % (args.workload, len(blocks), args.steps, block_s))
+    ms_per_step = 1e3 * block_s / args.steps
+    value = world * M * T / (block_s / args.steps)
+
+    traffic_all, sha = {}, kernel_sources_sha16()
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic_all = json.load(open(tf))
+        except Exception:  # noqa: BLE001
+            traffic_all = {}
+    traffic_ok = traffic_all.get("kernel_sources_sha16") == sha  # counters of OTHER kernel sources are not quoted
+    tkey = {"c4": "c3", "c1_script": None}.get(args.workload, args.workload)
+    traffic_of = lambda k: traffic_all.get(k) if (traffic_ok and k) else None
+
+    # every rank takes part in the extras that involve all ranks (none do: the extras below are single-rank work on rank 0's
+    # schedule, so the other ranks simply wait at the final barrier); only rank 0 prints
+    out = None
+    if rank == 0:
+        roof = main_run.roofline(fwd_ms, block_s / args.steps, traffic_of(tkey))
+        if not traffic_ok:
+            roof["traffic_note"] = "profiles/traffic.json was collected for other kernel sources (%s != %s): not quoted" % (
+                traffic_all.get("kernel_sources_sha16"), sha)
         out = {
             "metric": "particle-steps/s (M x T per policy-grad step), cart-pole GP",
             "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (RK4 cart-pole rollouts, N=%d training points/GP, fixed trained-like hyper-parameters, on-device %s noise)"
                     % (w.model.gps[0].N, "Philox" if args.noise == "philox" else "torch.randn buffers"),
-            "config": {"workload": "%s: %s, %d GPs, D=%d, N=%d, B=%d, M=%d particles/GPU, T=%d, p_dropout=%.2f; step = rollout fwd + cost + "
-                                   "adjoint bwd%s + Adam%s" % (args.workload, w.problem["system"], w.model.G, w.model.D, w.model.gps[0].N, w.policy.B, M, T,
-                                                            w.p_drop, " + 1 RCCL all-reduce [grad|cost sums|flags]" if world > 1 else "",
+            "config": {"workload": "%s: %s, %d GPs, D=%d, N=%d, B=%d, poly degree %d, M=%d particles/GPU, T=%d, p_dropout=%.2f; step = rollout fwd + cost + "
+                                   "adjoint bwd%s + Adam%s" % (args.workload, w.problem["system"], w.model.G, w.model.D, w.model.gps[0].N, w.policy.B,
+                                                            w.problem["deg"], M, T, w.p_drop,
+                                                            " + 1 RCCL all-reduce [grad|cost sums|flags]" if world > 1 else "",
                                                             "; policy on measured states (MC_PILCO4PMS)" if args.pms else ""),
-                       "particles_per_gpu": M, "horizon": T, "parallelism": "particle-dp%d" % world,
-                       "collective": None if world == 1 else {"per_step": 1, "doubles": sum(p.numel() for p in w.params) + 2 * T + 1,
-                                                              "transport": args.transport, "backend": args.backend}},
+                       "particles_per_gpu": M, "particles_total": world * M, "horizon": T, "parallelism": "particle-dp%d" % world,
+                       "collective": collective},
+            "blocks": len(blocks), "block_ms": [1e3 * b for b in blocks],
             "roofline": roof,
+            "kernel_sources_sha16": sha,
             "final_cost": last_cost,
         }
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        traffic = {}
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf))
-            except Exception:
-                traffic = {}
-        out["roofline"]["traffic"] = traffic.get(args.workload)
-        default_run = world == 1 and args.workload == "c1" and not args.particles and not args.horizon and not args.pms
+    if world > 1 and not args.no_extra:
+        # (a) the SAME per-GPU shard on one GPU, no collective: value x N would be perfect weak scaling of this workload;
+        # (b) the latency-bound c1 shard (M = 400 per GPU), sharded, for comparison with the single-GPU headline.
+        # Every rank runs both (lockstep: the sharded one contains collectives).
+        ref_s, _, _, _ = main_run.run(max(3, args.steps // 4), 1, 0.0, sharded=False)
+        k1 = max(3, args.steps // 4)
+        c1 = Runner(args, "c1", dev, rank, world, reducer)
+        c1_s, c1_f, _, _ = c1.run(args.steps, 2, 0.0)
+        if rank == 0:
+            out["scaling_reference"] = {"what": "the same %s shard (M=%d) on ONE GPU without the collective, %d steps" % (args.workload, M, k1),
+                                        "value_one_gpu": M * T / (ref_s / k1), "ms_per_step": 1e3 * ref_s / k1,
+                                        "efficiency_vs_it": value / (world * M * T / (ref_s / k1))}
+            out["extra_workloads"] = [{"workload": "c1 (M=%d per GPU, sharded over %d GPUs: latency bound)" % (c1.M, world), "value": world * c1.M * c1.T / (c1_s / args.steps),
+                                       "unit": "particle-steps/s", "ms_per_step": 1e3 * c1_s / args.steps, "kernel": c1.kernel_name(), "kernel_ms": c1_f}]
+        del c1
+    if rank == 0:
+        default_run = world == 1 and default_workload and not args.particles and not args.horizon and not args.pms
         if default_run and not args.no_extra:
-            # the other single-GPU configurations of BASELINE.json, measured in the same run: c3 (SE+poly(2), M=4000) and c5 (UR5, 6 GPs,
-            # D=24, N=400, M=2000, T=300) -- same step definition, fewer steps
+            # the other single-GPU configurations of BASELINE.json, measured in the same run: the launch script's own horizon (T=60,
+            # SURVEY 8d), c3 (SE+poly(2), M=4000) and c5 (UR5, 6 GPs, D=24, N=400, M=2000, T=300) -- same step definition, fewer steps
             extra = []
-            for name in ("c3", "c5"):
+            for name, k in (("c1_script", 20), ("c3", 5), ("c5", 3)):
                 note("extra workload %s" % name)
                 r = Runner(args, name, dev, rank, world, reducer)
-                k = 5 if name == "c3" else 3
-                e2, f2, c2 = r.run(k, 2)
+                e2, f2, c2, _ = r.run(k, 2)
                 note("%s: %d steps in %.3f s" % (name, k, e2))
-                rf = r.roofline(f2)
+                rf = r.roofline(f2, e2 / k, traffic_of(name if name != "c1_script" else None))
                 rf.pop("achieved_basis")
-                rf["traffic"] = traffic.get(name)
                 extra.append({"workload": name, "particles": r.M, "horizon": r.T, "N": r.w.model.gps[0].N, "gps": r.w.model.G,
                               "value": r.M * r.T / (e2 / k), "unit": "particle-steps/s", "ms_per_step": 1e3 * e2 / k, "steps": k, "warmup": 2,
                               "kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"], "frac": rf["frac"], "roofline": rf, "final_cost": c2})
                 del r
                 torch.cuda.empty_cache()
             out["extra_workloads"] = extra
+            # the drop-in class's own loop (monitors, NaN test, printing, Adam): MC_PILCO.reinforce_policy, 100 steps, same shape
+            note("MC_PILCO.reinforce_policy on the drop-in classes (100 steps)")
+            from mc_pilco_amd import workloads
+
+            s_loop, c_first, c_last = workloads.time_reinforce_policy(dev, 100)
+            out["loop_ms_per_step"] = 1e3 * s_loop
+            out["loop"] = {"what": "MC_PILCO.reinforce_policy of the drop-in package, 100 optimizer steps at the c1 shape (monitors, NaN check, "
+                                   "Adam, printing included)", "value": M * T / s_loop, "unit": "particle-steps/s", "cost_first": c_first,
+                           "cost_last": c_last}
         if world == 1 and not args.no_cpu:
             # the cores this process may actually run on (the box gives one GPU's share of the host, not os.cpu_count())
             ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -340,9 +546,9 @@ def main():
         import torch.distributed as dist
 
         dist.barrier()
-        if args.transport == "abi":
-            from mc_pilco_amd import hipabi
+        from mc_pilco_amd import hipabi
 
+        if hipabi.lib().mcp_comm_world() != 0:
             hipabi.lib().mcp_comm_destroy()
         dist.destroy_process_group()
 

@@ -41,11 +41,17 @@ Rccl g_rccl;
 
 bool rccl_load() {
   if (g_rccl.handle) return true;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  // first the copy the process has loaded already (PyTorch-ROCm ships its own librccl under torch/lib: binding a second RCCL
+  // from /opt/rocm into the same process would give two sets of communicators), then a fresh load
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
   void* h = nullptr;
   for (const char* n : names) {
-    h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
     if (h) break;
+  }
+  for (const char* n : names) {
+    if (h) break;
+    h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
   }
   if (!h) return false;
   g_rccl.get_unique_id = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");

@@ -19,6 +19,7 @@ CONFIGS = {
     "c1": ("cartpole", 0, 300, 400, 150),   # configs[0]/[1]: cart-pole SE kernel, M=400, T=150, N~300
     "c1_script": ("cartpole", 0, 300, 400, 60),  # the launch script's own horizon int(3.0/0.05)
     "c3": ("cartpole", 2, 300, 4000, 150),  # configs[2]: SE + polynomial(2), M=4000
+    "c4": ("cartpole", 2, 300, 4000, 150),  # configs[3]: the c3 model, M=32000 over 8 GPUs = 4000 particles per GPU (bench.py --gpus N)
     "c5": ("ur5", 1, 400, 2000, 300),       # configs[4]: UR5 12-D state, 6 GPs, SE + polynomial(1)
     "tiny": ("cartpole", 0, 48, 16, 6),
     "tiny_ur5": ("ur5", 1, 40, 8, 5),
@@ -155,3 +156,67 @@ def flops_per_particle_step(w: Workload):
         f += 2 * N * N + (3 * D + 8) * N + fpoly  # forward
         f += (6 * D + 6) * N + fpoly  # backward
     return f
+
+
+def dropin_c1(device, pms=False, num_particles=400, T_control=7.5):
+    """The headline workload (cart-pole SE, N=300, M=400, T=150, B=200) on the DROP-IN classes: an ``MC_PILCO`` object with a
+    pretrained model and the keyword arguments of ``reinforce_policy`` -- what bench.py's ``loop_ms_per_step`` and
+    tools/time_reinforce_policy.py time (the same work as one bench step plus the loop's monitors, NaN check and printing)."""
+    import contextlib
+    import io
+
+    from .model_learning import Model_learning as ML
+    from .policy_learning import MC_PILCO, Cost_function, Policy
+
+    dt = DT
+    c = sy.CARTPOLE
+    Tt = lambda a: torch.tensor(np.asarray(a), dtype=dt, device=device)
+    rbf = dict(active_dims=np.arange(6), lengthscales_init=np.asarray(c["lengthscales"], dtype=float), flg_train_lengthscales=True,
+               lambda_init=np.ones(1), flg_train_lambda=False, sigma_n_init=c["sigma_n"] * np.ones(1), sigma_n_num=None, flg_train_sigma_n=True,
+               dtype=dt, device=device)
+    mlp = dict(num_gp=2, T_sampling=c["Ts"], angle_indeces=c["angle"], not_angle_indeces=c["not_angle"], vel_indeces=c["vel"],
+               not_vel_indeces=c["not_vel"], dtype=dt, device=device, init_dict_list=[rbf] * 2)
+    pi = sy.cartpole_policy_init(B=200, seed=1)
+    ppar = dict(state_dim=4, input_dim=1, num_basis=200, angle_indices=np.array([2]), non_angle_indices=np.array([0, 1, 3]),
+                lengthscales_init=pi["lengthscales"], centers_init=pi["centers"], weight_init=pi["weight"], flg_squash=True, u_max=c["u_max"],
+                flg_drop=True, dtype=dt, device=device)
+    kw = dict(T_sampling=c["Ts"], state_dim=4, input_dim=1, f_sim=lambda y, t, u: None, f_model_learning=ML.Speed_Model_learning_RBF_angle_state,
+              model_learning_par=mlp, f_rand_exploration_policy=Policy.Random_exploration,
+              rand_exploration_policy_par=dict(state_dim=4, input_dim=1, u_max=10.0, dtype=dt), f_control_policy=Policy.Sum_of_gaussians_with_angles,
+              control_policy_par=ppar, f_cost_function=Cost_function.Cart_pole_cost,
+              cost_function_par=dict(target_state=Tt(c["cost_target"]), lengthscales=Tt(c["cost_ls"]), angle_index=2, pos_index=0), log_path=None,
+              dtype=dt, device=device)
+    with contextlib.redirect_stdout(io.StringIO()):
+        if pms:
+            obj = MC_PILCO.MC_PILCO4PMS(pos_indeces=[0, 2], vel_indeces=[1, 3], std_meas_noise=0.01 * np.ones(4), filtering_dict={"fc": 0.5}, **kw)
+        else:
+            obj = MC_PILCO.MC_PILCO(**kw)
+        for xs, us in sy.cartpole_rollouts(n_roll=5):
+            obj.model_learning.add_data(np.asarray(xs), np.asarray(us))
+        with torch.no_grad():
+            for g in range(2):
+                obj.model_learning.pretrain_gp(g)
+        obj.model_learning.set_eval_mode()
+    args = dict(T_control=T_control, num_particles=num_particles, trial_index=0, particles_initial_state_mean=Tt(c["x0_mean"]),
+                particles_initial_state_var=Tt(c["x0_var"]), flg_particles_init_uniform=False, particles_init_up_bound=None,
+                particles_init_low_bound=None, flg_particles_init_multi_gauss=False, lr_list=[0.01],
+                f_optimizer="lambda p, lr : torch.optim.Adam(p, lr)", num_step_print=50, p_dropout_list=[0.25],
+                policy_reinit_dict=dict(lenghtscales_par=np.ones(5), centers_par=np.array([np.pi, np.pi, np.pi, 1.0, 1.0]), weight_par=10.0))
+    return obj, args
+
+
+def time_reinforce_policy(device, steps=100, pms=False):
+    """(seconds per optimizer step of MC_PILCO.reinforce_policy on the drop-in classes, first cost, last cost)."""
+    import contextlib
+    import io
+    import time
+
+    obj, args = dropin_c1(device, pms=pms)
+    with contextlib.redirect_stdout(io.StringIO()):
+        obj.reinforce_policy(opt_steps_list=[10], **args)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = obj.reinforce_policy(opt_steps_list=[steps], **args)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    return el / steps, float(out[0][0]), float(out[0][-1])

@@ -10,7 +10,7 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf "$OUT" && mkdir -p "$OUT"
-B="python3 $R/bench.py --no-cpu --no-extra"
+B="python3 $R/bench.py --no-cpu --no-extra --min-seconds 0"
 run() { echo "[$(date +%T)] $1"; shift; "$@" || exit 1; }
 run "c1 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c1_stats" -o c1 -- $B --steps 20 --warmup 3 > "$OUT/c1_stats.log" 2>&1
 run "c3 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c3_stats" -o c3 -- $B --workload c3 --steps 5 --warmup 2 > "$OUT/c3_stats.log" 2>&1

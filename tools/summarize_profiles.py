@@ -52,6 +52,19 @@ for cfg, (M, T, balg) in SHAPES.items():
             out[cfg + "_mfma_pipe_busy"] = util
             print("tile kernel (%s): MFMA busy %.3e cycles per launch = %.3e v_mfma_f64_16x16x4 at 64 cycles, matrix-pipe utilisation %.1f %%"
                   % (cfg, busy[-1], busy[-1] / 64, 100 * util))
+# identity of what was measured: bench.py quotes these numbers only while the kernel sources are the ones profiled
+sys.path.insert(0, ROOT)
+import datetime
+import subprocess
+
+import bench
+
+out["kernel_sources_sha16"] = bench.kernel_sources_sha16()
+out["date"] = datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%dT%H:%MZ")
+try:
+    out["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:  # noqa: BLE001
+    out["commit"] = None
 json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 for cfg in SHAPES:
