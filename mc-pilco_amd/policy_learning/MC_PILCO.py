@@ -176,13 +176,17 @@ class MC_PILCO(torch.nn.Module):
         return cost, std
 
     def _step_flags(self, cost):
-        """Device vector [cost is NaN, a GP-sharded launch timed out (MCP_STATUS_SYNC)] of the last fused rollout."""
+        """Device vector [cost is NaN, a GP-sharded launch timed out (MCP_STATUS_SYNC), a predictive variance was <= 0
+        (MCP_STATUS_NONPOS_VAR)] of the last fused rollout."""
         from mc_pilco_amd import hipabi
 
         st = self.last_status
-        sync = torch.zeros((), dtype=torch.bool, device=cost.device) if st is None or st.device != cost.device else \
-            (st.reshape(-1)[0] & hipabi.STATUS_SYNC) != 0
-        return torch.stack([torch.isnan(cost.detach()).reshape(()), sync.reshape(())]).to(self.dtype)
+        if st is None or st.device != cost.device:
+            sync = nonpos = torch.zeros((), dtype=torch.bool, device=cost.device)
+        else:
+            sync = (st.reshape(-1)[0] & hipabi.STATUS_SYNC) != 0
+            nonpos = (st.reshape(-1)[0] & hipabi.STATUS_NONPOS_VAR) != 0
+        return torch.stack([torch.isnan(cost.detach()).reshape(()), sync.reshape(()), nonpos.reshape(())]).to(self.dtype)
 
     def _cost_backward(self, states, inputs, trial_index, backward=True):
         """Expected cost of the rollout and (``backward``) its gradient in the policy parameters' ``.grad``.
@@ -222,7 +226,13 @@ class MC_PILCO(torch.nn.Module):
         or when a GP-sharded launch timed out waiting for a partner workgroup; in the second case the GP-sharded launch forms
         are switched off for this object (the device was not giving the grid co-residency -- another process, CU masking),
         so the repeated step runs on the unsharded kernels: never a silently wrong trajectory, never a rank-local raise."""
-        nan, sync = (float(v) for v in flags.tolist())
+        nan, sync, nonpos = (float(v) for v in flags.tolist())
+        if nonpos > 0 and not nan > 0:
+            # The reference samples with Normal(mean, sqrt(var)).rsample() (Model_learning.py:704), whose argument validation raises
+            # ValueError on a scale that is not > 0 -- an exactly zero / negative predictive variance is a modelling error there, not a
+            # case of the NaN retry.  Same here (on every rank alike in a sharded run: the flag travels with the step's all-reduce).
+            raise ValueError("Expected parameter scale of the particles' sampling distribution to be > 0: a GP's predictive variance was <= 0 "
+                             "(MCP_STATUS_NONPOS_VAR)")
         if sync > 0:
             if self.gp_sharding:
                 print("\nGP-sharded rollout: a partner workgroup never arrived (MCP_STATUS_SYNC) -- continuing on the unsharded kernels")
@@ -249,6 +259,8 @@ class MC_PILCO(torch.nn.Module):
             print("\nDROPOUT ACTIVE:")
             print("p_dropout:", p_drop0)
         make_opt = eval(f_optimizer)  # the reference passes optimizers as strings, e.g. "lambda p, lr : torch.optim.Adam(p, lr)"
+        # re-initialisations draw where the rest of the noise is drawn: in "reference" mode on the CPU generator (the reference's stream)
+        self.control_policy.draw_device = torch.device("cpu") if self.noise_mode == "reference" else None
 
         def fresh_state():
             return dict(cost=torch.zeros(n_steps, device=dev, dtype=dt), std=torch.zeros(n_steps, device=dev, dtype=dt),
@@ -439,6 +451,21 @@ class MC_PILCO(torch.nn.Module):
             traj[t:t + 1, :], _, _ = self.model_learning.get_next_state(current_state=traj[t - 1:t, :], current_input=us[t - 1:t, :],
                                                                          particle_pred=particle_pred)
         return traj.detach().cpu().numpy()
+
+    def get_model_learning_performance(self, data_collection_index, flg_pretrain=False):
+        """One-step GP predictions on the data of one interaction with the system (MC_PILCO.py:260-306): prints the MSE per GP,
+        returns (gp_inputs, targets [numpy per GP], means [numpy per GP], variances [tensors, scaled by norm_list^2])."""
+        ml = self.model_learning
+        t_dev = lambda a: torch.tensor(a, dtype=self.dtype, device=self.device)
+        gp_inputs, targets, means, variances = ml.get_gp_estimate_from_data(states=t_dev(self.state_samples_history[data_collection_index]),
+                                                                           inputs=t_dev(self.input_samples_history[data_collection_index]),
+                                                                           flg_pretrain=flg_pretrain)
+        variances = [variances[i] * ml.norm_list[i] ** 2 for i in range(ml.num_gp)]
+        targets = [targets[i].detach().cpu().numpy() for i in range(ml.num_gp)]
+        means = [means[i].detach().cpu().numpy() for i in range(ml.num_gp)]
+        for i in range(ml.num_gp):
+            print("MSE gp" + str(i) + ": ", ((targets[i] - means[i]) ** 2).mean())
+        return gp_inputs, targets, means, variances
 
     def get_rollout_prediction_performance(self, data_collection_index, T_rollout=None, add_name=""):
         pred = self.rollout(data_collection_index, T_rollout=T_rollout)

@@ -41,6 +41,13 @@ class Policy(torch.nn.Module):
         super().to(device)
         self.device = torch.device(device)
 
+    def squashing(self, u, u_max):
+        """u_max tanh(u / u_max), u_max a scalar or one bound per input (Policy.py:52-60).  The fused kernels apply the same
+        squashing inside the rollout; this method is the reference's public helper for user code."""
+        if not np.isscalar(u_max):
+            u_max = torch.tensor(u_max, dtype=self.dtype, device=self.device)
+        return u_max * torch.tanh(u / u_max)
+
     def get_np_policy(self):
         return lambda state, t: self.forward_np(state, t)
 
@@ -118,10 +125,14 @@ class Sum_of_gaussians(Policy):
         return self._packed[1]
 
     def reinit(self, lenghtscales_par, centers_par, weight_par):
+        """Policy.py:229-240: lengthscales reset, centres uniform in +-centers_par, weights uniform in +-weight_par / 2 (two
+        ``torch.rand`` draws, in this order).  ``draw_device`` (set by MC_PILCO in "reference" noise mode) = where the draws are made:
+        on the CPU generator they are the reference's own numbers for the same seed."""
         dev, dt = self.device, self.dtype
+        ddev = getattr(self, "draw_device", None) or dev
         self.log_lengthscales.data = torch.tensor(np.log(lenghtscales_par), dtype=dt, device=dev).reshape([1, -1])
-        self.centers.data = torch.tensor(centers_par, dtype=dt, device=dev) * 2 * (torch.rand(self.num_basis, self.state_dim, dtype=dt, device=dev) - 0.5)
-        self.f_linear.weight.data = weight_par * (torch.rand(self.input_dim, self.num_basis, dtype=dt, device=dev) - 0.5)
+        self.centers.data = torch.tensor(centers_par, dtype=dt, device=dev) * 2 * (torch.rand(self.num_basis, self.state_dim, dtype=dt, device=ddev).to(dev) - 0.5)
+        self.f_linear.weight.data = weight_par * (torch.rand(self.input_dim, self.num_basis, dtype=dt, device=ddev).to(dev) - 0.5)
         self._packed = None
 
     # ---- evaluation -------------------------------------------------------------------------------------------------

@@ -556,6 +556,16 @@ def mean_rollout(m: SpeedModel, x_rec, u_rec, T_rollout: Optional[int] = None):
 # --------------------------------------------------------------------------------------
 # the optimizer loop
 # --------------------------------------------------------------------------------------
+def policy_reinit(pp: PolicyPar, lenghtscales_par, centers_par, weight_par):
+    """Sum_of_gaussians.reinit, policy_learning/Policy.py:229-240: lengthscales reset, centres uniform in +-centers_par, weights
+    uniform in +-weight_par/2 -- two ``torch.rand`` draws, in this order."""
+    B, P = pp.centers.shape
+    U = pp.weight.shape[0]
+    pp.log_ls.data = torch.log(torch.as_tensor(lenghtscales_par, dtype=DT)).reshape(1, -1)
+    pp.centers.data = torch.as_tensor(centers_par, dtype=DT) * 2 * (torch.rand(B, P, dtype=DT) - 0.5)
+    pp.weight.data = weight_par * (torch.rand(U, B, dtype=DT) - 0.5)
+
+
 def reinforce_policy(
     m: SpeedModel,
     pp: PolicyPar,
@@ -575,28 +585,57 @@ def reinforce_policy(
     num_min_diff_cost: int = 200,
     min_step: float = float("inf"),
     make_optimizer=None,
+    nan_calls=(),
+    policy_reinit_dict=None,
 ):
-    """MC_PILCO.reinforce_policy, policy_learning/MC_PILCO.py:375-613, for a Gaussian initial distribution and a run without
-    NaN costs (the NaN retry / reinit branches :479-501, :573-607 are not restated): warm-up rollout that seeds the monitor
-    (:430-456, under no_grad), then per step: rollout (x0, mask_0, then eps_t, mask_t from the torch CPU generator, :615-674)
-    -> expected cost -> exponential statistics of the cost difference (:508-519) -> backward -> optimizer step (:522-525) ->
-    learning-rate halving / dropout reduction / early exit (:543-566; the window slice keeps Python's negative-index
-    behaviour).  The policy parameters in ``pp`` are updated in place.
-    Returns (cost_list, std_list, info) with info = dict(lr_reductions=[steps], exit_step, last_states, last_inputs)."""
+    """MC_PILCO.reinforce_policy, policy_learning/MC_PILCO.py:375-613, for a Gaussian initial distribution: warm-up rollout that
+    seeds the monitor (:430-456, under no_grad; a NaN cost there re-initialises the policy, up to 10 times), then per step: up to
+    ten rollouts until the cost is not NaN (:479-501; x0, mask_0, then eps_t, mask_t from the torch CPU generator, :615-674) ->
+    expected cost -> exponential statistics of the cost difference (:508-519) -> backward -> optimizer step (:522-525, taken on the
+    NaN cost too when all ten attempts failed) -> learning-rate halving / dropout reduction / early exit (:543-566; the window
+    slice keeps Python's negative-index behaviour) -> after ten NaN attempts: policy re-initialised, step counters, cost lists,
+    the first-order statistics, optimizer, learning rate's ``min_diff`` / ``min_step`` and dropout reset (:573-607; like the
+    reference NOT the second-moment statistic nor the previous cost, which stay NaN -- monitors only).
+    ``nan_calls``: indices of expected-cost evaluations (counted from the warm-up one) whose cost is forced to NaN -- how the
+    fixtures drive these branches (tests/golden/make_golden_r3.py).  The policy parameters in ``pp`` are updated in place.
+    Returns (cost_list, std_list, info) with info = dict(lr_reductions=[steps], exit_step, last_states, last_inputs, n_retry,
+    n_reinit, n_init_reinit, after_reinit)."""
     prm = [pp.log_ls, pp.centers, pp.weight]
     for q in prm:
         q.requires_grad_(True)
         q.grad = None
     make_optimizer = make_optimizer or (lambda p, lr: torch.optim.Adam(p, lr))
+    nan_calls = set(int(i) for i in nan_calls)
+    calls = [0]
+    info = {"lr_reductions": [], "exit_step": None, "n_retry": 0, "n_reinit": 0, "n_init_reinit": 0, "after_reinit": None}
 
     def rollout(p_drop):
         x0 = sample_x0(x0_mean, x0_var, M)
         return apply_policy(m, pp, x0, T, p_drop)
 
+    def ecost(st):
+        c, s = expected_cost(cost_fn(st))
+        k = calls[0]
+        calls[0] += 1
+        return (c * float("nan") if k in nan_calls else c), s
+
+    def reinit():
+        policy_reinit(pp, **policy_reinit_dict)
+        info["after_reinit"] = [q.detach().clone() for q in prm]
+
+    lr0 = lr
     p_applied = p_dropout
     with torch.no_grad():
-        st, _ = rollout(p_applied)
-        cost_tm1, _ = expected_cost(cost_fn(st))
+        attempts, flg_nan = 0, True
+        while attempts < 10 and flg_nan:
+            st, _ = rollout(p_applied)
+            cost_tm1, _ = ecost(st)
+            if torch.isnan(cost_tm1):
+                attempts += 1
+                info["n_init_reinit"] += 1
+                reinit()
+            else:
+                flg_nan = False
     cost_list = torch.zeros(num_opt_steps, dtype=DT)
     std_list = torch.zeros(num_opt_steps, dtype=DT)
     es1 = torch.zeros(num_opt_steps + 1, dtype=DT)
@@ -605,12 +644,18 @@ def reinforce_policy(
     cur_min_diff, cur_min_step = min_diff_cost, min_step
     opt = make_optimizer(prm, lr)
     step = done = 0
-    info = {"lr_reductions": [], "exit_step": None}
     st = inp = None
     while step < num_opt_steps:
         opt.zero_grad()
-        st, inp = rollout(p_applied)
-        cost, std = expected_cost(cost_fn(st))
+        attempts, flg_nan = 0, True
+        while attempts < 10 and flg_nan:
+            st, inp = rollout(p_applied)
+            cost, std = ecost(st)
+            if torch.isnan(cost):
+                attempts += 1
+                info["n_retry"] += 1
+            else:
+                flg_nan = False
         cost_list[step] = cost.detach()
         std_list[step] = std.detach()
         with torch.no_grad():
@@ -634,8 +679,55 @@ def reinforce_policy(
                     step = num_opt_steps
         step += 1
         done += 1
+        if flg_nan:  # ten NaN rollouts in a row (:573-607)
+            info["n_reinit"] += 1
+            reinit()
+            step = done = 0
+            cur_min_step, cur_min_diff = min_step, min_diff_cost
+            cost_list = torch.zeros(num_opt_steps, dtype=DT)
+            std_list = torch.zeros(num_opt_steps, dtype=DT)
+            es1 = torch.zeros(num_opt_steps + 1, dtype=DT)
+            ratio = torch.zeros(num_opt_steps + 1, dtype=DT)
+            lr = lr0
+            opt = make_optimizer(prm, lr)
+            p_applied = p_dropout
     for q in prm:
         q.requires_grad_(False)
         q.grad = None
     info["last_states"], info["last_inputs"] = st.detach(), inp.detach()
+    info["cost_calls"] = calls[0]
     return cost_list[:done].detach(), std_list[:done].detach(), info
+
+
+# --------------------------------------------------------------------------------------
+# GP hyper-parameter training
+# --------------------------------------------------------------------------------------
+def marginal_nll(h: GPHyper, X, Y):
+    """Marginal_log_likelihood, gpr_lib/Likelihood/Gaussian_likelihood.py:15-24, on GP_prior.forward's outputs
+    (GP_prior.py:91-115):  1/2 ((Y - m)^T K^-1 (Y - m) + logdet K)."""
+    mX, K, Kinv, logdet = gp_forward(h, X)
+    r = Y - mX
+    return 0.5 * (r.t() @ Kinv @ r + logdet).reshape(())
+
+
+def fit_model(h: GPHyper, X, Y, n_epoch: int, lr: float, make_optimizer=None):
+    """GP_prior.fit_model (GP_prior.py:179-230) as Model_learning.train_gp_likelihood drives it (Model_learning.py:398-421): ONE
+    full batch per epoch, Adam on the trainable log-parameters.  ``h``'s tensors are updated in place.  Returns (losses [n_epoch],
+    trajectory: list over epochs 0..n_epoch of the parameter tensors in the order [log_sigma_n, log_ls, log_lambda, *poly])."""
+    prm = [h.log_sigma_n, h.log_ls, h.log_lambda] + list(h.poly_log_par or [])
+    for q in prm:
+        q.requires_grad_(True)
+        q.grad = None
+    opt = (make_optimizer or (lambda p: torch.optim.Adam(p, lr=lr)))(prm)
+    losses, traj = [], [[q.detach().clone() for q in prm]]
+    for _ in range(n_epoch):
+        opt.zero_grad()
+        loss = marginal_nll(h, X, Y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+        traj.append([q.detach().clone() for q in prm])
+    for q in prm:
+        q.requires_grad_(False)
+        q.grad = None
+    return torch.tensor(losses, dtype=DT), traj

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 Tt = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
 
-REAL = {"se300": ("c1", 48, 8), "sep2_300": ("c3", 48, 8), "ur5_400": ("c5", 40, 6)}
+REAL = {"se300": ("c1", 48, 8), "sep2_300": ("c3", 48, 8), "ur5_400": ("c5", 40, 6), "se300_long": ("c1", 32, 150)}
 
 
 @functools.lru_cache(maxsize=None)
@@ -55,7 +55,8 @@ def oracle_answer(key):
     e0, eps, masks = orc.draw_noise(M, c["S"], c["G"], c["B"], Tn, p)
     x0 = orc.sample_x0(Tt(c["x0_mean"]), Tt(c["x0_var"]), M, e0)
     oc, os_, og, ost, oin = orc.policy_grad_step(m, pp, x0, Tn, cost_fn, p, eps, masks)
-    return dict(cost=float(oc), std=float(os_), grads=og, states=ost, inputs=oin, x0=x0, eps=eps, masks=masks, p=p, N=pb["Z"].shape[0])
+    return dict(cost=float(oc), std=float(os_), grads=og, states=ost, inputs=oin, x0=x0, eps=eps, masks=masks, p=p, N=pb["Z"].shape[0],
+                caches=caches, problem=pb)
 
 
 @functools.lru_cache(maxsize=None)
@@ -67,9 +68,123 @@ def hip_workload(key):
     return workloads.build(name, device=dev(), M=M, T=Tn)  # pretrain (Gram -> Cholesky -> inverse -> alpha) on the device
 
 
+@functools.lru_cache(maxsize=None)
+def hip_workload_on_oracle_operands(key):
+    """The HIP descriptors packed from the ORACLE's own pretrain (its Kinv and alpha, torch Cholesky): both sides then evaluate the
+    same posterior operands and only the rollout / adjoint kernels differ."""
+    from gpu_helpers import G, dev
+    from mc_pilco_amd import ops, workloads
+
+    name, M, Tn = REAL[key]
+    o = oracle_answer(key)
+    w = workloads.build(name, device=dev(), M=M, T=Tn)
+    pb, c = o["problem"], o["problem"]["cfg"]
+    gps = []
+    for g in range(c["G"]):
+        spec = workloads.spec_for(c, c["sigma_n"], None if pb["poly"] is None else pb["poly"][g])
+        cache = o["caches"][g]
+        gps.append(ops.PackedGP(spec, G(cache.X.numpy()), G(cache.alpha.numpy()), G(cache.Kinv.numpy())))
+    w.model = ops.PackedModel(gps, c["S"], c["U"], c["Ts"], c["angle"], c["not_angle"], c["vel"], c["not_vel"])
+    return w
+
+
+ACHIEVED = {}
+
+
 @pytest.mark.parametrize("pb", [1, 2, 4])
 @pytest.mark.parametrize("code", [1, 2, 4, 16, 101, 102, 104, 116, 201, 202, 204])
-@pytest.mark.parametrize("key", list(REAL))
+@pytest.mark.parametrize("key", ["se300", "sep2_300", "ur5_400"])
+def test_rollout_kernels_alone_against_the_oracle_at_real_sizes(key, code, pb):
+    """with each side factorising K itself, the real-size comparison could only hold 1e-7 (the conditioning of K).
+    Here the HIP rollout runs on the oracle's OWN Kinv / alpha (N = 300, 300 + poly(2), 400 / D = 24): what differs is the rollout and
+    adjoint kernels alone -- states abs 1e-9, inputs abs 2e-9 (|u| <= u_max = 10: 2e-10 relative), cost rel 1e-11, gradients rel
+    1e-9, on every forward variant x backward width.  The maxima reached are printed (pytest -s) and kept in ACHIEVED; round 3, all
+    variants alike: states 4e-11 .. 9e-10, inputs 3e-11 .. 1.4e-9, cost rel <= 8e-13, gradients rel <= 4e-11 -- the summation order
+    of the N = 300 contractions against a Kinv of condition 5e5, not a property of any one kernel."""
+    from gpu_helpers import dev, forced_variant
+    from mc_pilco_amd import ops
+
+    o = oracle_answer(key)
+    w = hip_workload_on_oracle_operands(key)
+    nz = ops.NoiseSpec(eps=o["eps"].to(dev()).contiguous(), masks=o["masks"].to(torch.uint8).to(dev()).contiguous())
+    for q in w.params:
+        q.grad = None
+    with forced_variant(code, bwd_particles=pb) as fv:
+        st, inp, status = ops.rollout(w.model, w.policy, nz, o["x0"].to(dev()), w.T, o["p"])
+        c, s = ops.expected_cost(w.cost, st)
+        c.backward()
+        fv.check(sharding_optional=(key == "ur5_400"), lean_expected=(key == "se300") if code >= 200 else None)
+    assert int(status.item()) == 0
+    es = float((st.detach().cpu() - o["states"]).abs().max())
+    eu = float((inp.detach().cpu() - o["inputs"]).abs().max())
+    ec = abs(float(c) - o["cost"]) / abs(o["cost"])
+    eg = max(float((q.grad.cpu().reshape(o["grads"][k].shape) - o["grads"][k]).abs().max()) / float(o["grads"][k].abs().max())
+             for q, k in zip(w.params, ["log_ls", "centers", "weight"]))
+    ACHIEVED[(key, code, pb)] = (es, eu, ec, eg)
+    print("real-size parity %s code %d bwd %d: states %.2e inputs %.2e cost rel %.2e grad rel %.2e" % (key, code, pb, es, eu, ec, eg))
+    assert es < 1e-9 and eu < 2e-9
+    assert ec < 1e-11
+    assert eg < 1e-9
+
+
+@pytest.mark.parametrize("code", [0, 16])
+def test_long_horizon_against_the_oracle_at_n300(code):
+    """T = 150, M = 32, N = 300 (SE), the oracle's own operands and noise, on the automatic dispatch (the lean GP-sharded kernel) and
+    on the 16-particle tile kernel: the only place long-horizon error growth at the real N would show.  SURVEY 8c: abs 1e-6 on
+    states, rel 1e-6 on gradients."""
+    from gpu_helpers import dev, forced_variant
+    from mc_pilco_amd import hipabi, ops
+
+    key = "se300_long"
+    o = oracle_answer(key)
+    w = hip_workload_on_oracle_operands(key)
+    assert w.T == 150 and w.model.gps[0].N == 300
+    nz = ops.NoiseSpec(eps=o["eps"].to(dev()).contiguous(), masks=o["masks"].to(torch.uint8).to(dev()).contiguous())
+    for q in w.params:
+        q.grad = None
+    with forced_variant(code) as fv:
+        st, inp, status = ops.rollout(w.model, w.policy, nz, o["x0"].to(dev()), w.T, o["p"])
+        c, s = ops.expected_cost(w.cost, st)
+        c.backward()
+        fv.check()
+        if code == 0:
+            assert hipabi.lib().mcp_debug_last_fwd_lean() == 1  # what bench.py's headline runs
+    assert int(status.item()) == 0
+    es = float((st.detach().cpu() - o["states"]).abs().max())
+    eu = float((inp.detach().cpu() - o["inputs"]).abs().max())
+    print("long horizon code %d: states %.2e inputs %.2e cost rel %.2e" % (code, es, eu, abs(float(c) - o["cost"]) / abs(o["cost"])))
+    assert es < 1e-6 and eu < 1e-6
+    assert abs(float(c) - o["cost"]) < 1e-8 * abs(o["cost"])
+    for q, k in zip(w.params, ["log_ls", "centers", "weight"]):
+        g = o["grads"][k]
+        assert float((q.grad.cpu().reshape(g.shape) - g).abs().max()) < 1e-6 * float(g.abs().max()), k
+
+
+def test_lean_kernel_draws_the_same_dropout_bits_and_noise_as_the_general_one():
+    """Philox mode (what every benchmark number runs in): the lean kernel's dropout decisions and process noise are the general
+    kernels' -- identical counters, so the trajectories agree to rounding (different summation orders), far below what one flipped
+    keep bit or a different normal would cause."""
+    from gpu_helpers import dev, forced_variant
+    from mc_pilco_amd import hipabi, ops, workloads
+
+    w = workloads.build("c1", device=dev(), M=96, T=10)
+    torch.manual_seed(4)
+    x0 = w.sample_x0()
+    outs = {}
+    with torch.no_grad():
+        for code in (4, 104, 204, 201):
+            with forced_variant(code) as fv:
+                outs[code] = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=11, call=3), x0, w.T, w.p_drop)
+                fv.check(lean_expected=True if code >= 200 else None)
+    for code in (104, 204, 201):
+        assert int(outs[code][2].item()) == 0
+        assert float((outs[code][0] - outs[4][0]).abs().max()) < 5e-9 and float((outs[code][1] - outs[4][1]).abs().max()) < 5e-9
+    assert torch.equal(outs[204][0], outs[201][0]) and torch.equal(outs[204][1], outs[201][1])  # the lean kernel does not depend on P
+
+
+@pytest.mark.parametrize("pb", [1, 2, 4])
+@pytest.mark.parametrize("code", [1, 2, 4, 16, 101, 102, 104, 116, 201, 202, 204])
+@pytest.mark.parametrize("key", ["se300", "sep2_300", "ur5_400"])
 def test_every_variant_against_the_oracle_at_real_training_set_sizes(key, code, pb):
     from gpu_helpers import dev, forced_variant
     from mc_pilco_amd import ops

@@ -216,6 +216,51 @@ def test_reinforce_policy_trace(golden, tag):
     assert relerr(pp.log_ls.detach(), fx[tag + "_final_log_ls"]) < 1e-8
 
 
+@pytest.mark.parametrize("tag", ["step", "init"])
+def test_reinforce_policy_nan_branches(golden, tag):
+    """The NaN branches of the optimizer loop (MC_PILCO.py:430-456, 479-501, 573-607), driven in the reference by a cost object that
+    returns NaN on chosen calls: ten retries, the re-initialisation (its torch.rand draws reproduced bit for bit), counters /
+    optimizer / dropout reset, the length of the returned cost list; and the re-initialisation during the warm-up rollout."""
+    fx = golden("policy_nan_trace")
+    m, c = _speed_model_from(fx)
+    pp = orc.PolicyPar(torch.log(T(fx["pol_ls"])).reshape(1, -1), T(fx["pol_centers"]), T(fx["pol_weight"]), c["u_max"], "angles", angle=[2],
+                       non_angle=[0, 1, 3])
+    cost_fn = lambda st: orc.cart_pole_cost(st, T(c["cost_target"]), T(c["cost_ls"]), c["cost_angle_index"], c["cost_pos_index"])
+    reinit = dict(lenghtscales_par=np.ones(5), centers_par=np.array([np.pi, np.pi, np.pi, 1.0, 1.0]), weight_par=10.0)
+    torch.manual_seed(int(fx[tag + "_seed"]))
+    cl, sl, info = orc.reinforce_policy(m, pp, T(fx["x0_mean"]), T(fx["x0_var"]), int(fx["M"]), 10, cost_fn, num_opt_steps=int(fx[tag + "_opt_steps"]),
+                                        lr=0.01, p_dropout=0.25, nan_calls=[int(i) for i in fx[tag + "_nan_calls"]], policy_reinit_dict=reinit)
+    assert (info["n_retry"], info["n_reinit"], info["n_init_reinit"], info["cost_calls"]) == (
+        int(fx[tag + "_n_retry"]), int(fx[tag + "_n_reinit"]), int(fx[tag + "_n_init_reinit"]), int(fx[tag + "_cost_calls"]))
+    assert len(cl) == len(fx[tag + "_cost_list"]) and bool(torch.isfinite(cl).all())
+    assert relerr(cl, fx[tag + "_cost_list"]) < 1e-8
+    assert relerr(sl, fx[tag + "_std_list"]) < 1e-7
+    assert float((info["last_states"] - T(fx[tag + "_last_states"])).abs().max()) < 1e-7
+    for q, k in zip(info["after_reinit"], ["log_ls", "centers", "weight"]):
+        assert float((q - T(fx[tag + "_after_" + k])).abs().max()) == 0.0, k  # the same torch.rand draws at the same point of the stream
+    assert relerr(pp.centers.detach(), fx[tag + "_final_centers"]) < 1e-8
+    assert relerr(pp.weight.detach(), fx[tag + "_final_weight"]) < 1e-8
+    assert relerr(pp.log_ls.detach(), fx[tag + "_final_log_ls"]) < 1e-8
+
+
+@pytest.mark.parametrize("name,deg", [("fit_trace_se", 0), ("fit_trace_se_poly2", 2)])
+def test_fit_model_trajectories(golden, name, deg):
+    """GP_prior.fit_model as Model_learning.train_gp_likelihood drives it (GP_prior.py:179-230, Model_learning.py:398-421): 20 Adam
+    epochs on N=80 -- the loss of every epoch and every hyper-parameter after every epoch."""
+    fx = golden(name)
+    pw = None if deg == 0 else [fx["poly_w%d" % k] for k in range(1, deg + 1)]
+    h = hyper(fx["lengthscales"], float(fx["sigma_n"]), 1.0, pw)
+    losses, traj = orc.fit_model(h, T(fx["X"]), T(fx["Y"]), int(fx["n_epoch"]), float(fx["lr"]))
+    assert relerr(losses, fx["losses"]) < 1e-9
+    pre = "" if deg == 0 else "gp_list.0."
+    keys = [pre + "sigma_n_log", pre + "log_lengthscales_par", pre + "log_lambda_par"] + ["gp_list.1.gp_list.%d.Sigma_pos_par" % k for k in range(deg)]
+    for i, key in enumerate(keys):
+        ref = fx["traj__" + key]
+        got = torch.stack([t[i].reshape(-1) for t in traj]).numpy()
+        assert np.abs(got - ref.reshape(got.shape)).max() < 1e-8, key
+    assert fx["losses"][-1] < fx["losses"][0] - 10.0  # (the run does train)
+
+
 def test_delta_state_model_step(golden):
     from mc_pilco_amd import synthetic as sy
 
