@@ -201,10 +201,13 @@ int mcp_posterior_bwd(int M, int D, const double* gmu, const double* gvar, const
 /* ---- fused particle rollout (MC_PILCO.apply_policy, policy_learning/MC_PILCO.py:615-674:
  * T-loop of Model_learning.get_next_state (Model_learning.py:210-229,685-718) and the policy
  * forward (Policy.py:242-265,323-335,389-403)) ----------------------------------------- */
+#define MCP_FWD_NO_GP_SHARDING 2 /* flag in mcp_rollout_fwd's particle_pred argument */
 size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_policy* policy, int M, int T);
 /* x0 [M][S] -> states [T][M][S], inputs [T][M][U].  jac [T-1][M][G][D] (d delta_g/d z, sampling
  * included) is written when non-NULL and is what mcp_rollout_bwd consumes.
- * particle_pred==0 -> delta = posterior mean (Model_learning.py:707-708).  T==1 evaluates the
+ * particle_pred: bit 0 clear -> delta = posterior mean (Model_learning.py:707-708); bit 1 (MCP_FWD_NO_GP_SHARDING) -> never launch
+ * GP-sharded even though a workspace is passed (the repeat of a step that reported MCP_STATUS_SYNC: the workspace still carries the
+ * packed operand copies of the wide / narrow kernels, only the hand-off between workgroups is given up).  T==1 evaluates the
  * policy only (Policy.forward); in that case `model` may be NULL.
  * workspace (optional, mcp_rollout_workspace_bytes): with it, small swarms run GP-sharded -- the G
  * workgroups of a particle cluster each evaluate one GP and hand each other the sampled increments

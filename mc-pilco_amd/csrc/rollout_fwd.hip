@@ -2148,6 +2148,8 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
                                const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
                                size_t workspace_bytes, void* stream) {
   if (!noise || !x0 || !states || !inputs || !status || !policy || M <= 0 || T <= 0) return MCP_ERR_ARG;
+  const bool no_gp_sharding = (particle_pred & MCP_FWD_NO_GP_SHARDING) != 0;  // (the recovery path after MCP_STATUS_SYNC keeps its workspace)
+  particle_pred &= 1;
   mcp_model stub;
   if (!model) {
     if (T != 1) return MCP_ERR_ARG;  // without a dynamics model only the policy can be evaluated
@@ -2209,7 +2211,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   // resident at one workgroup per CU; smallest cluster size first (most CUs busy)
   g_last_sharded = 0;
   g_last_lean = 0;
-  if (g_gp_sharding != 0 && model->G >= 2 && T > 1 && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
+  if (g_gp_sharding != 0 && !no_gp_sharding && model->G >= 2 && T > 1 && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
       (g_force_ppw == 0 || (g_gp_sharding == 1 && g_force_ppw != 16))) {
     const int cus = device_cu_count();
     int NC1 = 0;
@@ -2258,7 +2260,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
       return MCP_OK;
     }
   }
-  if ((P0 == 16 || g_force_ppw == 0) && g_gp_sharding != 0 && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
+  if ((P0 == 16 || g_force_ppw == 0) && g_gp_sharding != 0 && !no_gp_sharding && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
       tile_sharded_cluster(model, policy, a.NpadMax, M, T) > 0) {
     // swarms beyond one resident grid of the small-tile kernel, up to 2048 particles at two GPs: the 16-particle kernel GP-sharded --
     // twice the workgroups, each with one GP's contractions (tools/sweep_fwd_swarm.py, cart-pole shape, forward ms: M=1024 3.8 vs 4.9

@@ -19,6 +19,7 @@ ERRORS = {-1: "MCP_ERR_ARG", -2: "MCP_ERR_LIMIT", -3: "MCP_ERR_WORKSPACE", -4: "
 ABI_VERSION = 4
 COMM_ID_BYTES = 128
 STATUS_NAN, STATUS_NONPOS_VAR, STATUS_NOT_SPD, STATUS_SYNC = 1, 2, 4, 8
+FWD_NO_GP_SHARDING = 2  # flag in mcp_rollout_fwd's particle_pred argument (MCP_FWD_NO_GP_SHARDING)
 POLICY_PLAIN, POLICY_ANGLES, POLICY_TRAJ = 0, 1, 2
 COST_CARTPOLE, COST_TRAJ = 0, 1
 

@@ -347,8 +347,8 @@ def _mc(model):
 
 def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, noise: NoiseSpec, x0, T, p_drop, particle_pred=True, need_jac=True,
                         meas: Optional[MeasSpec] = None, gp_sharding=True):
-    """model None (only with T == 1) evaluates the policy alone.  gp_sharding False: no hand-off workspace is passed, so the
-    library never launches GP-sharded (the recovery path after MCP_STATUS_SYNC)."""
+    """model None (only with T == 1) evaluates the policy alone.  gp_sharding False: the library never launches GP-sharded (the
+    recovery path after MCP_STATUS_SYNC) -- by a flag, the workspace with the kernels' packed operand copies is still passed."""
     dev = policy.device if model is None else model.device
     x0 = x0.detach().to(device=dev, dtype=DT).contiguous()
     M = x0.shape[0]
@@ -363,10 +363,11 @@ def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, nois
     meas_buf = torch.empty(T, M, policy.S, dtype=DT, device=dev) if meas is not None else None
     _set_meas(policy, meas, T, M, meas_buf)
     # workspace: the hand-off granules of the GP-sharded launch (small swarms); the library zeroes what it uses
-    nbytes = abi.lib().mcp_rollout_workspace_bytes(_mc(model), C.byref(pc), M, T) if (model is not None and T > 1 and gp_sharding) else 0
+    nbytes = abi.lib().mcp_rollout_workspace_bytes(_mc(model), C.byref(pc), M, T) if (model is not None and T > 1) else 0
     ws = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev) if nbytes else None
     try:
-        abi.check(abi.lib().mcp_rollout_fwd(_mc(model), C.byref(pc), C.byref(nz), M, T, int(bool(particle_pred)), abi.ptr(x0),
+        abi.check(abi.lib().mcp_rollout_fwd(_mc(model), C.byref(pc), C.byref(nz), M, T,
+                                            int(bool(particle_pred)) | (0 if gp_sharding else abi.FWD_NO_GP_SHARDING), abi.ptr(x0),
                                             abi.ptr(states), abi.ptr(inputs), abi.ptr(jac), abi.ptr(status), abi.ptr(ws), nbytes, abi.stream()),
                   "mcp_rollout_fwd")
     finally:

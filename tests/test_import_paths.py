@@ -127,5 +127,5 @@ def test_hand_off_timeout_switches_to_the_unsharded_kernels():
     assert obj.gp_sharding is False                                                                # ... on the unsharded kernels
     # flags that arrive summed over ranks (sharding.StepReducer) are read the same way
     obj.gp_sharding = True
-    assert obj._rollout_failed(torch.tensor([0.0, 3.0], dtype=torch.float64)) is True and obj.gp_sharding is False
-    assert obj._rollout_failed(torch.tensor([0.0, 0.0], dtype=torch.float64)) is False
+    assert obj._rollout_failed(torch.tensor([0.0, 3.0, 0.0], dtype=torch.float64)) is True and obj.gp_sharding is False
+    assert obj._rollout_failed(torch.tensor([0.0, 0.0, 0.0], dtype=torch.float64)) is False
