@@ -532,6 +532,11 @@ def main():
             out["loop"] = {"what": "MC_PILCO.reinforce_policy of the drop-in package, 100 optimizer steps at the c1 shape (monitors, NaN check, "
                                    "Adam, printing included)", "value": M * T / s_loop, "unit": "particle-steps/s", "cost_first": c_first,
                            "cost_last": c_last}
+            note("GP hyper-parameter training (fit_model), N=300, 2 GPs, 100 epochs each")
+            s_ep, n_tr = workloads.time_fit_model(dev, 300, 100)
+            out["fit_model"] = {"what": "Model_learning.reinforce_model on the drop-in package: Adam on the marginal likelihood, full batch, "
+                                        "N=%d training points, D=6, 2 GPs one after the other, 100 epochs each" % n_tr,
+                                "ms_per_epoch_per_gp": 1e3 * s_ep, "epochs_per_s": 1.0 / s_ep}
         if world == 1 and not args.no_cpu:
             # the cores this process may actually run on (the box gives one GPU's share of the host, not os.cpu_count())
             ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

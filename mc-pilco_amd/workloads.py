@@ -220,3 +220,33 @@ def time_reinforce_policy(device, steps=100, pms=False):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
     return el / steps, float(out[0][0]), float(out[0][-1])
+
+
+def time_fit_model(device, N=300, epochs=100):
+    """Seconds per epoch per GP of GP hyper-parameter training on the device at the cart-pole size: Model_learning.reinforce_model
+    (Model_learning.py:398-421 -> GP_prior.fit_model, GP_prior.py:179-230) on the drop-in classes, 2 GPs, Adam, full batch."""
+    import contextlib
+    import io
+    import time
+
+    from .gpr_lib.Likelihood import Gaussian_likelihood as Likelihood
+    from .model_learning import Model_learning as ML
+
+    c = sy.CARTPOLE
+    rbf = dict(active_dims=np.arange(6), lengthscales_init=np.ones(6), flg_train_lengthscales=True, lambda_init=np.ones(1), flg_train_lambda=False,
+               sigma_n_init=np.ones(1), sigma_n_num=None, flg_train_sigma_n=True, dtype=DT, device=device)
+    par = dict(num_gp=2, T_sampling=c["Ts"], angle_indeces=c["angle"], not_angle_indeces=c["not_angle"], vel_indeces=c["vel"],
+               not_vel_indeces=c["not_vel"], dtype=DT, device=device, init_dict_list=[rbf] * 2)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ml = ML.Speed_Model_learning_RBF_angle_state(**par)
+        for xs, us in sy.cartpole_rollouts(n_roll=(N + 59) // 60):
+            ml.add_data(np.asarray(xs), np.asarray(us))
+        opt = dict(f_optimizer="lambda p : torch.optim.Adam(p, lr=0.01)", criterion=Likelihood.Marginal_log_likelihood, N_epoch=10, N_epoch_print=100000)
+        ml.reinforce_model([opt, opt])  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        opt["N_epoch"] = epochs
+        ml.reinforce_model([opt, opt])
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    return el / (2 * epochs), int(ml.gp_inputs.shape[0])
