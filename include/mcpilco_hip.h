@@ -68,6 +68,9 @@ typedef struct mcp_kernel {
   const double* w1;       /* [D+1]    MPK_1 weights s^2 (NULL when poly_deg==0)        */
   const double* w20;      /* [D]      MPK_2 first-factor weights  (NULL unless deg==2) */
   const double* w21;      /* [D]      MPK_2 second-factor weights                      */
+  const double* scal;     /* optional, device: [lambda, sigma_n2, mean] -- when non-NULL these override the three by-value
+                             fields above (GP training keeps its hyper-parameters on the device: GP_prior.fit_model's epoch
+                             then needs no device->host round trip to fill this descriptor)                              */
 } mcp_kernel;
 
 /* One pretrained GP = what Model_learning.pretrain_gp caches (model_learning/Model_learning.py:

@@ -26,6 +26,8 @@ void mcp_debug_set_fwd_lean(int mode);
 int mcp_debug_last_fwd_lean(void);
 /* small-tile kernel: xlds -1 automatic / 0 never stage the small operands in LDS; gb = GPs per pass (0 = as many as fit) */
 void mcp_debug_set_fwd_mode(int xlds, int gb);
+/* Cholesky / triangular inverse: 1 (default) the MFMA-blocked kernels, 0 the round-1/2 forms */
+void mcp_debug_set_chol_mfma(int on);
 /* backward sweep: particles per workgroup 1 / 2 / 4; 0 = automatic */
 void mcp_debug_set_bwd_particles(int pb);
 /* device buffers of 16 uint64 per-phase cycle totals of one workgroup (NULL = off); the forward kernels stamp workgroup

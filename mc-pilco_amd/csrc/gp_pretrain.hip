@@ -17,7 +17,7 @@ __global__ void cov_build_kernel(mcp_kernel kn, int N1, const double* __restrict
   int i = blockIdx.y;
   if (i >= N1 || j >= N2) return;
   double k = kern_eval(kn, X1 + (size_t)i * kn.D, 1, X2 + (size_t)j * kn.D, 1);
-  if (add_noise && i == j) k += kn.sigma_n2;
+  if (add_noise && i == j) k += kern_sigma_n2(kn);
   K[(size_t)i * ldk + j] = k;
 }
 
@@ -25,7 +25,7 @@ __global__ void cov_diag_kernel(mcp_kernel kn, int N, const double* __restrict__
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   double k = kern_diag(kn, X + (size_t)i * kn.D, 1);
-  diag[i] = add_noise ? k + kn.sigma_n2 : k;
+  diag[i] = add_noise ? k + kern_sigma_n2(kn) : k;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -236,6 +236,218 @@ __global__ __launch_bounds__(256) void tri_inverse_wave_kernel(int N, const doub
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// MFMA-blocked forms of the two kernels above (round 3; GP_prior.forward's torch.cholesky / torch.inverse, GP_prior.py:106-110,
+// once per GP per trial in pretrain and once per EPOCH in GP_prior.fit_model, GP_prior.py:179-230).  One workgroup of 16 waves
+// per matrix; the matrix stays in L2 / the CU's L1, every 16x16 block product runs on v_mfma_f64_16x16x4_f64:
+//   A operand  lane l -> A[i = l & 15][k = l >> 4],   B operand  lane l -> B[k = l >> 4][j = l & 15],
+//   accumulator register r of lane l -> D[(l >> 4) + 4 r][l & 15]          (so register u of an accumulator IS the B operand of
+//   step u of a following product: D2 = A2 * D needs no data movement).
+// The 16x16 diagonal blocks are factored / inverted by ONE wave in registers: lane c holds column c, scalars travel by v_readlane
+// (the LDS form above spends ~13 k cycles per block in volatile round trips; this one ~5 k).
+// Measured at N = 300 (tools/time_fit_model.py, rocprofv3): see DESIGN.md 4.5.
+// ---------------------------------------------------------------------------------------
+#define CM_NT 512
+#define CM_NW (CM_NT / 64)
+typedef double v4d_p __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double lane_get(double v, int l) {  // l: a compile-time constant after unrolling
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+// lane c (= lane & 15; the four 16-lane rows of the wave work redundantly) holds column c of an upper-triangular 16x16 block in
+// x[0..15] (x[r] = U[r][c], 0 below the diagonal).  Returns column c of U^-1 in w[].  inv_d[r] = 1 / U[r][r].
+__device__ __forceinline__ void tri16_inverse(const double (&x)[16], const double (&inv_d)[16], int c, double (&w)[16]) {
+#pragma unroll
+  for (int m = 0; m < 16; ++m) w[m] = 0.0;
+#pragma unroll
+  for (int r = 15; r >= 0; --r) {
+    double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int m = r + 1; m < 16; ++m) s = fma(-lane_get(x[r], m), w[m], s);  // U[r][m] w[m]  (w[m] = 0 for m > c)
+    w[r] = s * inv_d[r];
+  }
+}
+
+__global__ __launch_bounds__(CM_NT) void chol_factor_mfma_kernel(int N, double* __restrict__ A, int lda, double* __restrict__ logdet,
+                                                                 uint32_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* ui = smem;        // [16][16]  U_kk^-1 (row m, column r at ui[m * 16 + r])
+  double* pn = smem + 256;  // [16][ncp] the row panel of this block row
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, li = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NBK = (N + 15) >> 4;
+  double ld_acc = 0.0;  // wave 0, lanes 0..15: sum of log U[c][c] over the block rows
+  uint32_t bad = 0;
+  for (int kbk = 0; kbk < NBK; ++kbk) {
+    const int kb = kbk << 4, nb = min(16, N - kb);
+    const int j0 = kb + 16, nc = N > j0 ? N - j0 : 0, nct = (nc + 15) >> 4, ncp = nct << 4;
+    // (1) diagonal block: factor in registers, write back, invert
+    if (wv == 0) {
+      const int c = li;
+      double x[16], inv_d[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[r] = (r <= c && c < nb) ? A[(size_t)(kb + r) * lda + kb + c] : (r == c ? 1.0 : 0.0);  // identity beyond N
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const double dk = lane_get(x[k], k);
+        if (!(dk > 0.0)) bad |= MCP_STATUS_NOT_SPD;
+        const double sd = sqrt(dk), is = 1.0 / sd;
+        inv_d[k] = is;
+        const double uk = c == k ? sd : (c > k ? x[k] * is : 0.0);
+        x[k] = uk;
+#pragma unroll
+        for (int r = k + 1; r < 16; ++r) x[r] = fma(-lane_get(uk, r), uk, x[r]);  // (only rows r <= c are meaningful)
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (r > c) x[r] = 0.0;
+        if (lane < 16 && r < nb && c < nb) A[(size_t)(kb + r) * lda + kb + c] = x[r];
+      }
+      if (lane < 16 && c < nb) {
+        double dcc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dcc = r == c ? x[r] : dcc;
+        ld_acc += log(dcc);
+      }
+      double w[16];
+      tri16_inverse(x, inv_d, c, w);
+      if (lane < 16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ui[r * 16 + c] = w[r];
+      }
+    }
+    __syncthreads();
+    // (2) row panel P = U_kk^-T A[kb:kb+16, j0:N]:  D[i = r][j] = sum_m W[m][r] A[kb + m][j0 + j]
+    for (int tile = wv; tile < nct; tile += CM_NW) {
+      const int col = j0 + 16 * tile + li;
+      v4d_p acc = {0.0, 0.0, 0.0, 0.0};
+      double av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = ui[(4 * u + kq) * 16 + li];
+        const int row = kb + 4 * u + kq;
+        bv[u] = (col < N && row < N) ? A[(size_t)row * lda + col] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = kq + 4 * r;
+        const bool ok = col < N && kb + i < N;
+        if (ok) A[(size_t)(kb + i) * lda + col] = acc[r];
+        pn[i * ncp + 16 * tile + li] = ok ? acc[r] : 0.0;
+      }
+    }
+    __syncthreads();
+    // (3) trailing update, blocks (I, J), I <= J, of the upper triangle:  T[i][j] -= sum_m P[m][16 I + i] P[m][16 J + j]
+    const int nblk = nct * (nct + 1) / 2;
+    for (int bidx = wv; bidx < nblk; bidx += CM_NW) {
+      int I = 0, rem = bidx;
+      while (rem >= nct - I) {
+        rem -= nct - I;
+        ++I;
+      }
+      const int J = I + rem;
+      const int col = j0 + 16 * J + li;
+      v4d_p acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = j0 + 16 * I + kq + 4 * r;
+        acc[r] = (row < N && col < N) ? A[(size_t)row * lda + col] : 0.0;
+      }
+      double av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = -pn[(4 * u + kq) * ncp + 16 * I + li];
+        bv[u] = pn[(4 * u + kq) * ncp + 16 * J + li];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = j0 + 16 * I + kq + 4 * r;
+        if (row < N && col < N) A[(size_t)row * lda + col] = acc[r];
+      }
+    }
+    __syncthreads();
+  }
+  // zero the strictly lower part (torch.cholesky(upper=True) returns zeros there; the trailing updates wrote scratch into the
+  // lower halves of the diagonal blocks)
+  for (int idx = tid; idx < N * N; idx += CM_NT) {
+    const int r = idx / N, c = idx - r * N;
+    if (c < r) A[(size_t)r * lda + c] = 0.0;
+  }
+  if (wv == 0) {
+    const double tot = wave_sum(lane < 16 ? ld_acc : 0.0);
+    if (lane == 0) *logdet = 2.0 * tot;
+  }
+  if (bad) atomicOr(status, bad);
+}
+
+// Uinv = U^-1 by 16x16 blocks, one workgroup: the diagonal blocks W_I = U_II^-1 in registers (one wave each), then block diagonal
+// d = 1, 2, ...:  Uinv[I][J] = - W_I sum_{K = I+1..J} U[I][K] Uinv[K][J],  J = I + d  (every term was finished in an earlier stage).
+__global__ __launch_bounds__(CM_NT) void tri_inverse_block_kernel(int N, const double* __restrict__ U, int ldu, double* __restrict__ Ui, int ldi) {
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, li = lane & 15;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NBK = (N + 15) >> 4;
+  for (int idx = tid; idx < N * N; idx += CM_NT) {  // zeros below the diagonal (and everywhere a block is not written)
+    const int r = idx / N, c = idx - r * N;
+    if (c < r) Ui[(size_t)r * ldi + c] = 0.0;
+  }
+  for (int kbk = wv; kbk < NBK; kbk += CM_NW) {
+    const int kb = kbk << 4, nb = min(16, N - kb), c = li;
+    double x[16], inv_d[16], w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = (r <= c && c < nb) ? U[(size_t)(kb + r) * ldu + kb + c] : (r == c ? 1.0 : 0.0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) inv_d[r] = 1.0 / lane_get(x[r], r);
+    tri16_inverse(x, inv_d, c, w);
+    if (lane < 16 && c < nb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (r < nb && r <= c) Ui[(size_t)(kb + r) * ldi + kb + c] = w[r];
+    }
+  }
+  __syncthreads();
+  for (int d = 1; d < NBK; ++d) {
+    for (int I = wv; I + d < NBK; I += CM_NW) {
+      const int J = I + d;
+      const int col = 16 * J + li;
+      v4d_p acc = {0.0, 0.0, 0.0, 0.0};
+      for (int K = I + 1; K <= J; ++K) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ar = 16 * I + li, ac = 16 * K + 4 * u + kq;   // A[i = li][k]   = U[16 I + i][16 K + k]
+          const int br = 16 * K + 4 * u + kq;                     // B[k][j = li]   = Uinv[16 K + k][16 J + j]
+          av[u] = (ar < N && ac < N) ? U[(size_t)ar * ldu + ac] : 0.0;
+          bv[u] = (br < N && col < N) ? Ui[(size_t)br * ldi + col] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+      }
+      // - W_I S: register u of the accumulator is row 4 u + kq of S -- the B operand of step u
+      v4d_p out = {0.0, 0.0, 0.0, 0.0};
+      double wa[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ar = 16 * I + li, ac = 16 * I + 4 * u + kq;
+        wa[u] = (ar < N && ac < N) ? -Ui[(size_t)ar * ldi + ac] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) out = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[u], acc[u], out, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * I + kq + 4 * r;
+        if (row < N && col < N) Ui[(size_t)row * ldi + col] = out[r];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Kinv[i][j] = sum_{m >= max(i,j)} Ui[i][m] Ui[j][m]
 __global__ void kinv_from_uinv_kernel(int N, const double* __restrict__ Ui, int ldi, double* __restrict__ Kinv, int ldk) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -310,7 +522,7 @@ __global__ __launch_bounds__(MCP_WAVE) void sod_select_kernel(mcp_kernel kn, int
   int n = 1;
   if (lane == 0) {
     idx_out[0] = 0;
-    Uw[0] = sqrt(kern_diag(kn, X, 1) + kn.sigma_n2);
+    Uw[0] = sqrt(kern_diag(kn, X, 1) + kern_sigma_n2(kn));
   }
   __threadfence_block();
   for (int i = 1; i < N; ++i) {
@@ -332,7 +544,7 @@ __global__ __launch_bounds__(MCP_WAVE) void sod_select_kernel(mcp_kernel kn, int
     if (sqrt(var) > thr) {
       for (int s = lane; s < n; s += MCP_WAVE) Uw[(size_t)s * N + n] = kv[s];
       if (lane == 0) {
-        Uw[(size_t)n * N + n] = sqrt(kii + kn.sigma_n2 - nrm);
+        Uw[(size_t)n * N + n] = sqrt(kii + kern_sigma_n2(kn) - nrm);
         idx_out[n] = i;
       }
       n += 1;
@@ -374,7 +586,7 @@ __global__ __launch_bounds__(256) void nll_grad_kernel(mcp_kernel kn, int N, con
     }
     double w = Kinv[(size_t)i * ldk + j] - ai * alpha[j];
     wm[j] = w;
-    wk[j] = w * kn.lambda * exp(-dist);
+    wk[j] = w * kern_lambda(kn) * exp(-dist);
     fa[j] = A;
     fb[j] = Bv;
   }
@@ -455,9 +667,19 @@ extern "C" int mcp_cov_diag(const mcp_kernel* kern, int N, const double* X, int 
   return MCP_OK;
 }
 
+static int g_chol_mfma = 1;  // test hook: 0 = the round-1/2 kernels (scalar trailing update, one wave per column of the inverse)
+extern "C" void mcp_debug_set_chol_mfma(int on) { g_chol_mfma = on; }
+
 extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32_t* status, void* stream) {
   if (!A || !logdet || !status || N <= 0 || lda < N) return MCP_ERR_ARG;
   if (N > 1152) return MCP_ERR_LIMIT;  // row panel [16][N] must fit the 160 KiB LDS
+  if (g_chol_mfma && N > 16) {
+    const size_t lds = sizeof(double) * (256 + (size_t)16 * (N + 16));
+    MCP_ENSURE_MAX_LDS(chol_factor_mfma_kernel);
+    hipLaunchKernelGGL(chol_factor_mfma_kernel, dim3(1), dim3(CM_NT), lds, (hipStream_t)stream, N, A, lda, logdet, status);
+    MCP_LAUNCH_CHECK();
+    return MCP_OK;
+  }
   size_t lds = sizeof(double) * ((size_t)CH_NB * (CH_NB + 1) + (size_t)CH_NB * N);
   MCP_ENSURE_MAX_LDS(chol_factor_kernel);
   hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(CH_NT), lds, (hipStream_t)stream, N, A, lda, logdet, status);
@@ -468,7 +690,9 @@ extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32
 extern "C" int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream) {
   if (!U || !Uinv || !Kinv || N <= 0 || ldu < N || ldi < N || ldk < N) return MCP_ERR_ARG;
   if (N > 16384) return MCP_ERR_LIMIT;
-  if (N <= 64 * TW_KM)
+  if (g_chol_mfma && N > 16 && N <= 1152)
+    hipLaunchKernelGGL(tri_inverse_block_kernel, dim3(1), dim3(CM_NT), 0, (hipStream_t)stream, N, U, ldu, Uinv, ldi);
+  else if (N <= 64 * TW_KM)
     hipLaunchKernelGGL(tri_inverse_wave_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, U, ldu, Uinv, ldi);
   else
     hipLaunchKernelGGL(tri_inverse_kernel, dim3((N + TI_NT - 1) / TI_NT), dim3(TI_NT), sizeof(double) * N, (hipStream_t)stream, N, U,

@@ -206,13 +206,18 @@ __host__ __device__ inline uint32_t drop_threshold(double p) {
 // ---------------------------------------------------------------------------------------
 // covariance function  k(a, b)  with a, b given as strided vectors (element d at a[d*sa])
 // ---------------------------------------------------------------------------------------
+// the descriptor's three scalars: by value, or from device memory when kn.scal is set (include/mcpilco_hip.h)
+__device__ __forceinline__ double kern_lambda(const mcp_kernel& kn) { return kn.scal ? kn.scal[0] : kn.lambda; }
+__device__ __forceinline__ double kern_sigma_n2(const mcp_kernel& kn) { return kn.scal ? kn.scal[1] : kn.sigma_n2; }
+__device__ __forceinline__ double kern_mean(const mcp_kernel& kn) { return kn.scal ? kn.scal[2] : kn.mean; }
+
 __device__ __forceinline__ double kern_eval(const mcp_kernel& kn, const double* a, int sa, const double* b, int sb) {
   double dist = 0.0;
   for (int d = 0; d < kn.D; ++d) {
     double r = (a[d * sa] - b[d * sb]) * kn.inv_ls[d];
     dist = fma(r, r, dist);
   }
-  double k = kn.lambda * exp(-dist);
+  double k = kern_lambda(kn) * exp(-dist);
   if (kn.poly_deg >= 1) {
     double p1 = kn.w1[kn.D];
     for (int d = 0; d < kn.D; ++d) p1 = fma(kn.w1[d] * a[d * sa], b[d * sb], p1);
@@ -231,7 +236,7 @@ __device__ __forceinline__ double kern_eval(const mcp_kernel& kn, const double* 
 }
 
 __device__ __forceinline__ double kern_diag(const mcp_kernel& kn, const double* a, int sa) {
-  double k = kn.lambda;
+  double k = kern_lambda(kn);
   if (kn.poly_deg >= 1) {
     double p1 = kn.w1[kn.D];
     for (int d = 0; d < kn.D; ++d) p1 = fma(kn.w1[d] * a[d * sa], a[d * sa], p1);

@@ -79,8 +79,8 @@ __device__ __forceinline__ void stage_gp_tables(const mcp_gp* gps, const double*
       e.Xt = gp.Xt;
       e.X = gp.X;
       e.alpha = gp.alpha;
-      e.lambda = gp.kern.lambda;
-      e.mean = gp.kern.mean;
+      e.lambda = kern_lambda(gp.kern);
+      e.mean = kern_mean(gp.kern);
       e.var_scale = var_scale ? var_scale[g] : 1.0;
       e.N = gp.N;
       e.Npad = gp.Npad;

@@ -248,6 +248,38 @@ class Sum_Independent_GP(Combine_GP):
     def get_mean(self, X):
         return self.gp_list[0].get_mean(X)
 
+    def kernel_spec_dev(self) -> ops.KernelSpec:
+        """kernel_spec without any device->host transfer (see RBF.kernel_spec_dev)."""
+        from .Stationary_GP import RBF
+
+        se, w1, w20, w21 = None, None, None, None
+        leaves = list(self._leaves())
+        for gp in leaves:
+            part = gp.kernel_spec_dev()
+            if isinstance(gp, RBF):
+                if se is not None:
+                    raise NotImplementedError("at most one squared-exponential term per GP on the HIP path")
+                se = part
+            if part.w1 is not None:
+                w1 = part.w1 if w1 is None else w1 + part.w1
+            if part.w20 is not None:
+                if w20 is not None:
+                    raise NotImplementedError("at most one degree-2 polynomial term per GP on the HIP path")
+                w20, w21 = part.w20, part.w21
+        dev = self.device
+        D = (se or leaves[0].kernel_spec_dev()).D
+        z = torch.zeros(1, dtype=torch.float64, device=dev)
+        if w20 is not None and w1 is None:
+            w1 = torch.zeros(D + 1, dtype=torch.float64, device=dev)
+        sig2 = self.get_sigma_n_2().detach().reshape(-1)[:1].to(torch.float64) if self.GP_with_noise else z
+        first = self.gp_list[0]
+        mean = first.mean_par.detach().reshape(-1)[:1].to(torch.float64) if hasattr(first, "mean_par") else z
+        lam = se.scal[0:1] if se is not None else z
+        scal = torch.cat([lam, sig2, mean]).contiguous()
+        nan = float("nan")
+        ls = se.lengthscales if se is not None else torch.ones(D, dtype=torch.float64, device=dev)
+        return ops.KernelSpec(ls, nan, nan, nan, w1, w20, w21, scal=scal)
+
     def kernel_spec(self) -> ops.KernelSpec:
         se, w1, w20, w21 = None, None, None, None
         for gp in self._leaves():

@@ -54,6 +54,22 @@ class MPK_GP(Linear_GP):
         """Squared diagonal weights of each factor: list over d of [(k-d) exp(par_d)]^2."""
         return ops.mpk_weights(self.Sigma_pos_par.detach().cpu(), self.poly_deg)
 
+    def kernel_spec_dev(self) -> ops.KernelSpec:
+        """kernel_spec with everything left on the device (weights from the parameters by torch ops, noise in mcp_kernel.scal)."""
+        D, dev = self.num_features, self.device
+        w = ops.mpk_weights(self.Sigma_pos_par.detach().to(torch.float64), self.poly_deg)
+        ones = torch.ones(D, dtype=torch.float64, device=dev)
+        z = torch.zeros(1, dtype=torch.float64, device=dev)
+        sig2 = self.get_sigma_n_2().detach().reshape(-1)[:1].to(torch.float64) if self.GP_with_noise else z
+        scal = torch.cat([z, sig2, z]).contiguous()
+        nan = float("nan")
+        if self.poly_deg == 1:
+            w1 = w[0] if self.flg_offset else torch.cat([w[0], z])
+            return ops.KernelSpec(ones, nan, nan, nan, w1, None, None, scal=scal)
+        if self.poly_deg == 2 and not self.flg_offset:
+            return ops.KernelSpec(ones, nan, nan, nan, torch.zeros(D + 1, dtype=torch.float64, device=dev), w[0], w[1], scal=scal)
+        raise NotImplementedError("the HIP kernels implement MPK degree 1 (with or without offset) and degree 2 (without offset)")
+
     def kernel_spec(self) -> ops.KernelSpec:
         D = self.num_features
         w = self.factor_weights()

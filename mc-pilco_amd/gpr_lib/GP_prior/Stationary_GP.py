@@ -59,6 +59,16 @@ class RBF(Stationary_GP):
     def get_mean(self, X):
         return self.mean_par.detach().reshape(1, -1).repeat(X.shape[0], 1)
 
+    def kernel_spec_dev(self) -> ops.KernelSpec:
+        """The descriptor with its three scalars left ON THE DEVICE (mcp_kernel.scal): no device->host transfer, so an epoch of
+        GP_prior.fit_model never waits for the GPU (the host enqueues the next epoch while the last one runs)."""
+        z = torch.zeros(1, dtype=torch.float64, device=self.device)
+        sig2 = self.get_sigma_n_2().detach().reshape(-1)[:1].to(torch.float64) if self.GP_with_noise else z
+        scal = torch.cat([torch.exp(self.log_lambda_par.detach()).reshape(-1)[:1].to(torch.float64), sig2,
+                          self.mean_par.detach().reshape(-1)[:1].to(torch.float64)]).contiguous()
+        nan = float("nan")
+        return ops.KernelSpec(self.lengthscales().to(torch.float64), nan, nan, nan, scal=scal)
+
     def kernel_spec(self) -> ops.KernelSpec:
         # the three scalars of the descriptor in ONE device->host transfer
         sig2_t = self.get_sigma_n_2().detach().reshape(-1)[:1] if self.GP_with_noise else torch.zeros(1, dtype=self.dtype, device=self.device)

@@ -28,7 +28,7 @@ dptr = C.c_void_p
 
 class Kernel(C.Structure):
     _fields_ = [("D", C.c_int32), ("poly_deg", C.c_int32), ("lam", C.c_double), ("sigma_n2", C.c_double), ("mean", C.c_double),
-                ("inv_ls", dptr), ("w1", dptr), ("w20", dptr), ("w21", dptr)]
+                ("inv_ls", dptr), ("w1", dptr), ("w20", dptr), ("w21", dptr), ("scal", dptr)]
 
 
 class GP(C.Structure):
@@ -105,6 +105,7 @@ _SIGS = {
     "mcp_debug_set_gp_sharding": (None, [C.c_int]),
     "mcp_debug_last_gp_sharded": (C.c_int, []),
     "mcp_debug_set_fwd_lean": (None, [C.c_int]),
+    "mcp_debug_set_chol_mfma": (None, [C.c_int]),
     "mcp_debug_last_fwd_lean": (C.c_int, []),
 }
 EXPORTED = [k for k in _SIGS if not k.startswith("mcp_debug")]

@@ -28,7 +28,7 @@ def nll_loss_and_grad(gp, X, Y):
     from .gpr_lib.GP_prior import Sparse_GP, Stationary_GP
 
     dev = gp.device
-    spec = gp.kernel_spec()
+    spec = gp.kernel_spec_dev()  # hyper-parameters stay on the device: the epoch has no device->host round trip
     Xc = gp._cols(X)
     N, D = Xc.shape
     K = ops.cov_build(spec, Xc, None, noise=gp.GP_with_noise)

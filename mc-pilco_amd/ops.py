@@ -55,6 +55,7 @@ class KernelSpec:
     w1: Optional[torch.Tensor] = None
     w20: Optional[torch.Tensor] = None
     w21: Optional[torch.Tensor] = None
+    scal: Optional[torch.Tensor] = None  # device [lambda, sigma_n2, mean]: overrides the three floats (no host round trip to fill them)
     _keep: dict = field(default_factory=dict, repr=False, compare=False)
 
     @property
@@ -91,6 +92,7 @@ class KernelSpec:
         k.inv_ls = ops_["inv_ls"].data_ptr()
         for name in ("w1", "w20", "w21"):
             setattr(k, name, None if ops_[name] is None else ops_[name].data_ptr())
+        k.scal = None if self.scal is None else self.scal.data_ptr()
         return k
 
 

@@ -86,6 +86,43 @@ def test_cholesky_sizes():
         assert abs(float(logdet) - np.linalg.slogdet(K)[1]) < 1e-10 * max(1.0, abs(np.linalg.slogdet(K)[1]))
 
 
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_cholesky_and_inverse_kernels_both_forms(mfma):
+    """The MFMA-blocked Cholesky / triangular inverse of round 3 and the round-1/2 forms behind them (mcp_debug_set_chol_mfma), at
+    sizes around every block edge (16-wide blocks, partial last block, one block only), at the benchmark's N = 300, the UR5 model's
+    N = 400 and near the limit; a Gram-like ill-conditioned matrix (cond ~1e6) as the GP training sees it; upper-triangular outputs
+    (zeros below the diagonal, as torch.cholesky(upper=True) / torch.inverse(U) return them); the not-SPD flag from a late pivot."""
+    from gpu_helpers import G
+    from mc_pilco_amd import hipabi, ops
+
+    hipabi.lib().mcp_debug_set_chol_mfma(mfma)
+    try:
+        rs = np.random.RandomState(1)
+        for N in (17, 31, 32, 33, 47, 48, 100, 300, 400, 1000):
+            A = rs.randn(N, N + 3)
+            K = A @ A.T / (N + 3) + 0.1 * np.eye(N)
+            U, logdet, status = ops.chol_factor(G(K))
+            assert int(status.item()) == 0
+            Ui, Kinv = ops.chol_inverse(U)
+            assert float(torch.tril(U, -1).abs().max()) == 0.0 and float(torch.tril(Ui, -1).abs().max()) == 0.0
+            assert relerr(U.t() @ U, K) < 1e-13
+            assert relerr(Ui @ U, np.eye(N)) < 1e-11
+            assert relerr(Kinv, np.linalg.inv(K)) < 1e-10
+            assert abs(float(logdet) - np.linalg.slogdet(K)[1]) < 1e-10 * max(1.0, abs(np.linalg.slogdet(K)[1]))
+        x = np.linspace(0.0, 4.0, 300)[:, None]
+        K = np.exp(-((x - x.T) / 0.6) ** 2) + 1e-4 * np.eye(300)  # SE Gram + noise: cond ~ 1e6
+        U, logdet, status = ops.chol_factor(G(K))
+        assert int(status.item()) == 0
+        _, Kinv = ops.chol_inverse(U)
+        ref = np.linalg.inv(K)
+        assert relerr(Kinv, ref) < 1e-8 and abs(float(logdet) - np.linalg.slogdet(K)[1]) < 1e-8 * abs(np.linalg.slogdet(K)[1])
+        K = np.eye(40)
+        K[37, 37] = -1.0  # the pivot of a late block
+        assert ops.status_flags(ops.chol_factor(G(K))[2])["not_spd"]
+    finally:
+        hipabi.lib().mcp_debug_set_chol_mfma(1)
+
+
 def test_sod_indices_exact(golden):
     from gpu_helpers import G, spec_from
     from mc_pilco_amd import ops
