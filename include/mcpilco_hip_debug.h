@@ -30,6 +30,10 @@ void mcp_debug_set_fwd_mode(int xlds, int gb);
 void mcp_debug_set_chol_mfma(int on);
 /* backward sweep: particles per workgroup 1 / 2 / 4; 0 = automatic */
 void mcp_debug_set_bwd_particles(int pb);
+/* backward sweep of small swarms: -1 (default) the latency-lean kernel where it applies (automatic particle count only), 0 never;
+   1 when the last mcp_rollout_bwd ran it */
+void mcp_debug_set_bwd_lean(int mode);
+int mcp_debug_last_bwd_lean(void);
 /* device buffers of 16 uint64 per-phase cycle totals of one workgroup (NULL = off); the forward kernels stamp workgroup
    `block` (0 by default; the partner of workgroup 0 in a 2-way GP-sharded launch of the small-tile kernel is workgroup 8) */
 void mcp_debug_set_stamp_buffer(void* device_u64x16); /* (the lean small-swarm kernel writes 24 slots: pass 32) */

@@ -73,5 +73,8 @@ if __name__ == "__main__":
     elif "--variant-fwd" in sys.argv:  # the same, recompiling rollout_fwd.hip only
         i = sys.argv.index("--variant-fwd")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], only=["rollout_fwd.hip"]))
+    elif "--variant-bwd" in sys.argv:  # the same, recompiling rollout_bwd.hip only
+        i = sys.argv.index("--variant-bwd")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], only=["rollout_bwd.hip"]))
     else:
         build(force="--force" in sys.argv)

@@ -108,12 +108,25 @@ __device__ __forceinline__ void wave_sum_first(double (&v)[N], int n) {
   }
 }
 
+// v[l] + v[l ^ 16] and v[l] + v[l ^ 32] in every lane, with gfx950's row / half swaps (v_permlane16_swap: odd rows of the first operand <->
+// even rows of the second; v_permlane32_swap: upper half <-> lower half) on two copies of v: VALU speed, where __shfl_xor (ds_bpermute)
+// is an LDS round trip.  Same bits as v + __shfl_xor(v, 16 / 32) (the addition commutes).
+__device__ __forceinline__ double sum_xor16(double v) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double sum_xor32(double v) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+  return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
 // Eight wave sums at once by pair-halving: at every stage two values are folded into one register -- a lane keeps the value its
 // own lane-index bit selects and receives the partner lane's copy of the same value -- so the live values halve (8 -> 4 -> 2 -> 1)
 // while the lanes that hold a given value's partial sums spread over the wave: 7 exchanges + 3 single-value all-reduce stages
 // instead of 8 x 6 (wave_sum_multi).  On return lane l holds the wave total of value (l & 7), in every lane.
 // Exchanges: lane ^ 1, ^ 2 by quad_perm; ^ 4 by row_shl:4 / row_shr:4 under bank masks (which also pick, per bank, WHICH of the
-// two values is fetched: no select on the receive side); ^ 8 by row_ror:8; ^ 16, ^ 32 through the LDS crossbar (ds_bpermute).
+// two values is fetched: no select on the receive side); ^ 8 by row_ror:8; ^ 16, ^ 32 by the row / half swap instructions.
 template <int CTRL, int BANK>
 __device__ __forceinline__ double dpp_merge(double old, double v) {
   int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, BANK, false);
@@ -136,9 +149,40 @@ __device__ __forceinline__ double wave_sum_pack8(const double (&v)[8], int lane)
   // lane ^ 4: banks 0, 2 (bit 2 clear) keep x[0] and fetch x[0] of lane + 4; banks 1, 3 keep x[1] and fetch x[1] of lane - 4
   double y = (b2 ? x[1] : x[0]) + dpp_merge<0x114, 0xA>(dpp_merge<0x104, 0x5>(0.0, x[0]), x[1]);
   y += dpp_take<0x128, 0xf>(y);  // lane ^ 8: row_ror:8
-  y += __shfl_xor(y, 16);
-  y += __shfl_xor(y, 32);
-  return y;
+  return sum_xor32(sum_xor16(y));  // lane ^ 16, ^ 32
+}
+
+// sin and cos of a state angle.  The library's sincos carries the Payne-Hanek reduction for huge arguments (~200 instructions, 40 bytes
+// of scratch per lane) on the one-wave chains that bound the small-swarm kernels (phase S forward, the adjoint chain backward: ~1.5 k
+// cycles per step each).  Angles of a rollout are O(10): three-term Cody-Waite reduction by pi/2 (exact first product for |n| < 2^20)
+// and the fdlibm kernel polynomials -- absolute error <= 2.1e-16 (<= 2.4 ulp next to the zeros) for |x| < 1e5, checked against long
+// double over 2e7 arguments; any lane beyond that (or NaN / inf) sends the whole wave through the library routine.
+__device__ __forceinline__ void sincos_fast(double x, double* sp, double* cp) {
+  if (__builtin_expect(__ballot(!(fabs(x) < 1.0e5)) != 0ull, 0)) {
+    sincos(x, sp, cp);
+    return;
+  }
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  double r = fma(-fn, 1.57079632673412561417e+00, x);
+  r = fma(-fn, 6.07710050630396597660e-11, r);
+  r = fma(-fn, 2.02226624879595063154e-21, r);
+  const int n = (int)fn;
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double sr = fma(r * z, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const double s = (n & 1) ? cr : sr, c = (n & 1) ? sr : cr;
+  *sp = (n & 2) ? -s : s;
+  *cp = ((n + 1) & 2) ? -c : c;
 }
 
 // ---------------------------------------------------------------------------------------

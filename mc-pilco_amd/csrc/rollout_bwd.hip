@@ -12,6 +12,7 @@
 // policy features) are wave64 DPP sums meeting in LDS.  Workgroup partial gradients go to a slab
 // that grad_reduce_kernel sums in a fixed order (deterministic, no atomics).
 #include "rollout_common.h"
+#include <type_traits>
 
 using namespace mcp;
 
@@ -349,13 +350,13 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         // trig of this step's angles (used now by the GP feature map, next iteration by the policy's)
         if (lane < S && need_trig) {
           double sv, cv;
-          sincos(r[oX + lane], &sv, &cv);
+          sincos_fast(r[oX + lane], &sv, &cv);
           sn[lane] = sv;
           cs[lane] = cv;
         }
         if (pms && lane < S && pi_ang >= 0) {
           double sv, cv;
-          sincos(r[oM + lane], &sv, &cv);
+          sincos_fast(r[oM + lane], &sv, &cv);
           snm[lane] = sv;
           csm[lane] = cv;
         }
@@ -599,6 +600,429 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Latency-lean backward sweep: small swarms (one particle per workgroup), narrow class
+// ---------------------------------------------------------------------------------------
+// At M <= 512 every workgroup of the sweep above is resident and walks its particle's T steps alone: the launch takes T times the
+// latency of ONE step, and a step of the general kernel is a chain of ~6 LDS round trips between 10-lane stages (4.7 k cycles) followed
+// by the whole RBF stage (exp, Philox, distances: 3.2 k) behind a barrier.  What actually depends on the adjoint of step t + 1 is
+// small; this kernel takes everything else off the chain:
+//   * wave 0 owns the chain and nothing else (the basis functions live in waves 1 .. NWB).  Lane roles: lanes 0..S-1 a state each,
+//     lanes 8..8+PF-1 a policy feature each, lanes 16..16+U-1 an input each.  Per step it reads the NWB partial feature adjoints of the
+//     columns ITS role needs straight from the RBF waves' LDS rows (one batch of reads, one latency), forms the adjoint of x_{t+1} in
+//     registers, fetches the 2 G entries the integrator needs with v_readlane (uniform indices), and finishes x_t's adjoint and the
+//     pre-squash adjoint with 2 G + 2 fused multiply-adds against operands it prepared a step earlier:
+//       xb_s  = gx_s + own_s xn_s + sum_g [s = vel_g] Ts xn_{pos_g} + sum_g db_g Jx[g][s],   Jx = dz/dx_s folded into d delta_g/dz
+//       ab_k  = (gu_k + sum_g db_g J[g][u_k]) (1 - tanh^2)
+//     (the general kernel forms zb = J^T db first and maps it through the feature map afterwards: three more LDS round trips).
+//   * between the two barriers of a step (while the other waves run the RBF stage) wave 0 prepares step t - 1: sincos of the angles,
+//     Jx, the policy features of x_{t-1} for the RBF waves, tanh'; its record elements come straight from global memory into the lanes
+//     that use them, two steps ahead (two register stages, the time loop unrolled by two).
+//   * the RBF waves compute exp(-dist), the dropout bit and the scaled distances of step t BEFORE the barrier that publishes ab_t
+//     (all of it depends on x_t only), so that behind it only the multiply-adds and the 8-value wave sum remain.
+// Same gradients as the general kernel up to summation order (tests/test_gpu_parity.py compares them on every policy kind it covers).
+#define BL_GM 4    // GPs
+#define BL_FL0 8   // first feature lane of wave 0
+#define BL_UL0 16  // first input lane of wave 0
+// (scalar members only: with arrays inside, part of the struct stayed a stack object -- two of its prefetched values went through
+//  scratch with the wait for the load right behind it)
+template <int GM>
+struct BlStage {
+  double xs, gb, uu, ja0, jb0, ja1, jb1, ja2, jb2, ja3, jb3;
+};
+template <int g, int GM>
+__device__ __forceinline__ double& bl_ja(BlStage<GM>& s) {
+  if constexpr (g == 0) return s.ja0;
+  else if constexpr (g == 1) return s.ja1;
+  else if constexpr (g == 2) return s.ja2;
+  else return s.ja3;
+}
+template <int g, int GM>
+__device__ __forceinline__ double& bl_jb(BlStage<GM>& s) {
+  if constexpr (g == 0) return s.jb0;
+  else if constexpr (g == 1) return s.jb1;
+  else if constexpr (g == 2) return s.jb2;
+  else return s.jb3;
+}
+template <int g, int GM, typename F>
+__device__ __forceinline__ void bl_for_g(F&& f) {
+  if constexpr (g < GM) {
+    f(std::integral_constant<int, g>());
+    bl_for_g<g + 1, GM>(f);
+  }
+}
+#ifndef BL_SW
+#define BL_SW 1  // the RBF wave whose intervals are stamped (diagnostic builds: build.py --variant)
+#endif
+#define BL_STAMP(k)                                          \
+  do {                                                       \
+    if (a.stamps && lane == 0 && blockIdx.x == 0 && slot == 0) { \
+      unsigned long long now_ = clock64();                   \
+      s_stamp[k] += now_ - last_stamp; /* (LDS: a global read-modify-write would wait for the prefetch in flight) */ \
+      last_stamp = now_;                                     \
+    }                                                        \
+  } while (0)
+
+template <int GM>
+__global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) void rollout_bwd_lat_kernel(BwdArgs a) {
+  constexpr int PFM = 8, UM = 2;
+  __shared__ double s_red_[2][4][8];  // [slot][RBF wave][feature]: the wave's sum over its basis functions of the feature adjoint
+  __shared__ double s_sf_[2][PFM];    // policy features of the step the RBF waves prepare
+  __shared__ double s_ab_[2][UM];     // adjoint of the pre-squash activation
+  __shared__ double s_invl[PFM];
+  __shared__ double s_fin_[2][PFM + UM];
+  __shared__ double s_cen[PFM][256];  // RBF centres, [feature][basis]: read before the barrier only, so they need not sit in registers
+  __shared__ int s_role[64][8];       // wave 0: what a lane loads (read in the prefetch, off the chain)
+  __shared__ unsigned long long s_stamp[16];
+  const mcp_model& md = a.model;
+  const mcp_policy& pl = a.pol;
+  // two particle slots per workgroup (each: one chain wave + the RBF waves behind it), so that M <= 512 particles are ONE resident round:
+  // a 5-wave workgroup needs 3 waves on one SIMD, two of them do not share a CU, and 400 single-slot workgroups ran as two rounds
+  const int WPS = (int)(blockDim.x >> 7);  // waves per slot
+  const int slot = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) >= WPS ? 1 : 0);
+  const int tid = threadIdx.x - slot * WPS * 64, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double (*s_red)[8] = s_red_[slot];
+  double* s_sf = s_sf_[slot];
+  double* s_ab = s_ab_[slot];
+  double* s_fin = s_fin_[slot];
+  const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
+  const int nna = md.n_not_angle, na = md.n_angle, pn = pl.n_non_angle, pa = pl.n_angle;
+  const bool drop = pl.p_drop > 0.0;
+  const double keep_scale = 1.0 / (1.0 - pl.p_drop);
+  const uint32_t drop_thr = drop_threshold(pl.p_drop);
+  unsigned long long last_stamp = clock64();
+  const unsigned long long t_begin = last_stamp, w_begin = a.stamps ? wall_clock64() : 0;
+
+  if (tid < PFM) {
+    if (slot == 0) s_invl[tid] = tid < PF ? exp(-pl.log_ls[tid]) : 0.0;
+    s_sf[tid] = 0.0;
+  }
+  if (tid < 32) (&s_red[0][0])[tid] = 0.0;  // rows of absent waves and columns beyond PF stay zero: the chain reads them unconditionally
+  if (tid < UM) s_ab[tid] = 0.0;
+  if (threadIdx.x < 16) s_stamp[threadIdx.x] = 0;
+  __syncthreads();
+
+  // ---- RBF threads: basis b = tid - 64 --------------------------------------------------------------------------------------
+  const int b = tid - 64;
+  const int m = imin((int)blockIdx.x * 2 + slot, M - 1);
+  const bool valid = (int)blockIdx.x * 2 + slot < M;  // (an odd swarm's last slot idles through the barriers)
+  const bool act = valid && wv > 0 && b < B;
+  const int bs = wv > 0 ? b : 0;  // column of s_cen
+  double gc[PFM], wgt[UM], gw[UM];
+#pragma unroll
+  for (int q = 0; q < PFM; ++q) {
+    if (wv > 0 && slot == 0) s_cen[q][bs] = (b < B && q < PF) ? pl.centers[(size_t)b * PF + q] : 0.0;
+    gc[q] = 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < UM; ++k) {
+    wgt[k] = (act && k < U) ? pl.weight[(size_t)k * B + b] : 0.0;
+    gw[k] = 0.0;
+  }
+
+  // ---- wave 0: lane roles (uniform reads of the descriptors, compared with the lane: no per-lane indexing of kernel arguments) ----
+  const bool st_lane = lane < S, ft_lane = lane >= BL_FL0 && lane < BL_FL0 + PF, in_lane = lane >= BL_UL0 && lane < BL_UL0 + U;
+  const int fq = lane - BL_FL0, uk = lane - BL_UL0;
+  int src = 0, ftype = 0;            // state whose value the lane loads; what it makes of it: 0 x, 1 cos x, 2 sin x
+  int i0 = 0, i1 = 0, i2 = 0;        // feature columns whose adjoints the lane gathers
+  double k0 = 0.0;
+  bool pang = false, zang = false;
+  int ia = -1, ib = -1;              // columns of d delta_g/dz the lane needs
+  double own = 0.0, umax = 1.0;
+  int gvel = -1;
+  if (wv == 0) {
+    if (st_lane) {
+      src = lane;
+      if (pl.kind == MCP_POLICY_ANGLES) {
+        for (int i = 0; i < pn; ++i)
+          if (pl.non_angle[i] == lane) { i0 = i; k0 = 1.0; }
+        for (int i = 0; i < pa; ++i)
+          if (pl.angle[i] == lane) { i1 = pn + i; i2 = pn + pa + i; pang = true; }
+      } else {
+        i0 = lane;
+        k0 = 1.0;
+      }
+      for (int i = 0; i < nna; ++i)
+        if (md.not_angle[i] == lane) ia = i;
+      for (int i = 0; i < na; ++i)
+        if (md.angle[i] == lane) { ia = nna + i; ib = nna + na + i; zang = true; }
+      bool isv = false, isp = false;
+      for (int g = 0; g < G; ++g) {
+        if (md.vel[g] == lane) { isv = true; gvel = g; }
+        if (md.not_vel[g] == lane) isp = true;
+      }
+      own = (isv ? 1.0 : 0.0) + (isp ? 1.0 : 0.0);
+    } else if (ft_lane) {
+      i0 = fq;
+      k0 = 1.0;
+      src = fq;
+      if (pl.kind == MCP_POLICY_ANGLES) {
+        for (int i = 0; i < pn; ++i)
+          if (i == fq) src = pl.non_angle[i];
+        for (int i = 0; i < pa; ++i) {
+          if (pn + i == fq) { src = pl.angle[i]; ftype = 1; }
+          if (pn + pa + i == fq) { src = pl.angle[i]; ftype = 2; }
+        }
+      }
+    } else if (in_lane) {
+      ia = nna + 2 * na + uk;
+      for (int k = 0; k < U; ++k)
+        if (k == uk) umax = pl.u_max[k];
+    }
+  }
+  const bool need_trig = na > 0 || (pl.kind == MCP_POLICY_ANGLES && pa > 0);
+  const bool has_j = ia >= 0;
+  const double rumax = 1.0 / umax;
+  if (wv == 0 && slot == 0) {
+    s_role[lane][0] = src;
+    s_role[lane][1] = ia;
+    s_role[lane][2] = ib;
+    s_role[lane][3] = ftype;
+  }
+  __syncthreads();
+
+  double glacc = 0.0, gbacc = 0.0;
+  {
+    if (wv == 0) {
+      // ================= the chain =================
+      // (no selects on the loaded values here: a select is a use, and the wait it needs would turn the prefetch into a round trip --
+      //  every lane loads from a valid address, what a lane has no use for is masked where it is consumed, in prep)
+      // Loads run tt = T-1, T-2, ... one call after the other: uniform running element offsets (scalar registers, one subtraction per array
+      // and call) plus a constant 32-bit offset per lane -- the address arithmetic of the first version (64-bit products per load) was
+      // half of this wave's work between the barriers.
+      const int4 ro = *reinterpret_cast<const int4*>(&s_role[lane][0]);  // src, ia, ib, ftype
+      const unsigned lx = (unsigned)ro.x, lja = (unsigned)imax(ro.y, 0), ljb = (unsigned)imax(ro.z, 0);
+      size_t oS = ((size_t)(T - 1) * M + m) * S, oU = ((size_t)(T - 1) * M + m) * U, oJ = ((size_t)(T - 1) * M + m) * G * D;
+      const size_t dS = (size_t)M * S, dU = (size_t)M * U, dJ = (size_t)M * G * D;
+      int tl = T - 1;  // the step the next call loads
+      auto load = [&](BlStage<GM>& st) {
+        st.xs = a.states[oS + lx];
+        double gv = 0.0, uv = 0.0;
+        if (a.g_states && st_lane) gv = a.g_states[oS + (unsigned)lane];
+        if (in_lane) {
+          if (a.g_inputs) gv = a.g_inputs[oU + (unsigned)uk];
+          uv = a.inputs[oU + (unsigned)uk];
+        }
+        st.gb = gv;
+        st.uu = uv;
+        if (tl < T - 1) {
+          bl_for_g<0, GM>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            const unsigned gg = (unsigned)(imin(g, G - 1) * D);
+            bl_ja<g>(st) = a.jac[oJ + (gg + lja)];
+            bl_jb<g>(st) = a.jac[oJ + (gg + ljb)];
+          });
+        } else {
+          bl_for_g<0, GM>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            bl_ja<g>(st) = 0.0;
+            bl_jb<g>(st) = 0.0;
+          });
+        }
+        --tl;
+        oS -= dS;
+        oU -= dU;
+        oJ -= dJ;
+      };
+      double Jc[GM], gbase = 0.0, sq = 1.0, k1n = 0.0, k2n = 0.0, fn = 0.0;  // operands of the step the chain runs next
+      double k1p = 0.0, k2p = 0.0, fprev = 0.0;                               // feature map / feature of the step after it
+      auto prep = [&](BlStage<GM>& st) {
+        double sv = 0.0, cv = 1.0;
+        if (need_trig) sincos_fast(st.xs, &sv, &cv);
+        bl_for_g<0, GM>([&](auto gc) {
+          constexpr int g = decltype(gc)::value;
+          const double ja = bl_ja<g>(st), jb = bl_jb<g>(st);
+          const double jc = zang ? fma(ja, cv, -(jb * sv)) : ja;
+          Jc[g] = (g < G && has_j) ? jc : 0.0;
+        });
+        gbase = st.gb;
+        const double th = st.uu * rumax;
+        sq = (in_lane && pl.squash) ? 1.0 - th * th : 1.0;
+        k1n = pang ? -sv : 0.0;
+        k2n = pang ? cv : 0.0;
+        fn = ro.w == 0 ? st.xs : (ro.w == 1 ? cv : sv);
+        if (ft_lane) s_sf[fq] = fn;
+      };
+      double xb = 0.0;
+      auto gather = [&]() -> double {  // the feature adjoints of the step just finished by the RBF waves, mapped to this lane's role
+        const double c0 = ((s_red[0][i0] + s_red[1][i0]) + s_red[2][i0]) + s_red[3][i0];
+        const double c1 = ((s_red[0][i1] + s_red[1][i1]) + s_red[2][i1]) + s_red[3][i1];
+        const double c2 = ((s_red[0][i2] + s_red[1][i2]) + s_red[2][i2]) + s_red[3][i2];
+        return fma(k2p, c2, fma(k1p, c1, k0 * c0));
+      };
+      auto chain = [&](bool last) {
+        double s = 0.0;
+        if (!last) {
+          s = gather();
+          glacc = fma(-fprev, s, glacc);  // feature lanes: - f_q(t+1) * (adjoint of f_q(t+1))
+        }
+        const double xn = xb + s;  // state lanes: adjoint of x_{t+1}
+        double val = fma(own, xn, gbase);
+#pragma unroll
+        for (int g = 0; g < GM; ++g) {
+          if (g < G) {
+            const int lv = md.vel[g], lp = md.not_vel[g];
+            const double xnv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xn), lv), __builtin_amdgcn_readlane(__double2loint(xn), lv));
+            const double xnp = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xn), lp), __builtin_amdgcn_readlane(__double2loint(xn), lp));
+            const double dbg = fma(0.5 * md.Ts, xnp, xnv);
+            val = fma(g == gvel ? md.Ts : 0.0, xnp, val);
+            val = fma(dbg, Jc[g], val);
+          }
+        }
+        xb = val;
+        const double abv = val * sq;
+        if (in_lane) {
+          s_ab[uk] = abv;
+          if (valid) gbacc += abv;
+        }
+      };
+      BlStage<GM> stA, stB;
+      load(stA);  // T - 1
+      prep(stA);
+      if (T >= 2) load(stA);  // T - 2
+      if (T >= 3) load(stB);  // T - 3
+      lds_barrier();
+      BL_STAMP(11);
+      auto step = [&](int t, BlStage<GM>& sx) {  // sx holds the record of step t - 1
+        chain(t == T - 1);
+        BL_STAMP(8);
+        lds_barrier();
+        BL_STAMP(9);
+        k1p = k1n;
+        k2p = k2n;
+        fprev = fn;
+        if (t > 0) {
+          prep(sx);
+          if (t >= 3) load(sx);  // t - 3
+        }
+        BL_STAMP(10);
+        lds_barrier();
+        BL_STAMP(11);
+      };
+      int t = T - 1;
+      for (; t >= 1; t -= 2) {
+        step(t, stA);
+        step(t - 1, stB);
+      }
+      if (t == 0) step(0, stA);
+      // adjoint of x_0
+      {
+        const double s = gather();
+        glacc = fma(-fprev, s, glacc);
+        if (a.g_x0 && st_lane && valid) a.g_x0[(size_t)m * S + lane] = xb + s;
+      }
+    } else {
+      // ================= the RBF waves =================
+      lds_barrier();
+      uint32_t kwo[4] = {0u, 0u, 0u, 0u};
+      for (int t = T - 1; t >= 0; --t) {
+        // before the barrier: everything of step t that depends on x_t only
+        // dropout keep word of (t, basis b): word b & 3 of the Philox block of (t, b >> 2).  The four lanes of a quad would all compute the
+        // same block: instead, every fourth step lane j of the quad draws the block of step t - j and the lanes pass each other the word
+        // of the receiver's basis (quad_perm rotations) -- a quarter of the Philox work per step.
+        uint32_t kwd = 0xFFFFFFFFu;
+        uint8_t mk8 = 1;
+        if (drop) {
+          if (a.nz.masks) {
+            mk8 = a.nz.masks[((size_t)t * M + m) * B + imin(b, B - 1)];
+          } else {
+            const int ph = (T - 1 - t) & 3;
+            if (ph == 0) {
+              const int cq = b & 3;
+              const u32x4 rnd = philox_draw(a.nz, m, imax(t - cq, 0), MCP_STREAM_MASK, (uint32_t)(imin(b, B - 1) >> 2));
+              uint32_t rc[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {  // rotation r: lane i receives from lane (i + r) & 3 that lane's word i
+                const int wi = (cq - r) & 3;
+                const uint32_t snd = wi == 0 ? rnd.x : wi == 1 ? rnd.y : wi == 2 ? rnd.z : rnd.w;
+                rc[r] = r == 0 ? snd
+                               : (uint32_t)(r == 1 ? __builtin_amdgcn_update_dpp(0, (int)snd, 0x39, 0xf, 0xf, false)
+                                                   : r == 2 ? __builtin_amdgcn_update_dpp(0, (int)snd, 0x4E, 0xf, 0xf, false)
+                                                            : __builtin_amdgcn_update_dpp(0, (int)snd, 0x93, 0xf, 0xf, false));
+              }
+#pragma unroll
+              for (int o = 0; o < 4; ++o) {  // the word of step t - o came with rotation (o - cq) & 3
+                const int r = (o - cq) & 3;
+                kwo[o] = r == 0 ? rc[0] : r == 1 ? rc[1] : r == 2 ? rc[2] : rc[3];
+              }
+            }
+            kwd = ph == 0 ? kwo[0] : ph == 1 ? kwo[1] : ph == 2 ? kwo[2] : kwo[3];
+          }
+        }
+        double e[PFM], dist = 0.0;  // e_q = 2 rr_q / l_q: d dist / d s_q
+#pragma unroll
+        for (int q = 0; q < PFM; ++q) {
+          const double il = s_invl[q], rr = (s_sf[q] - s_cen[q][bs]) * il;
+          dist = fma(rr, rr, dist);
+          e[q] = 2.0 * rr * il;
+        }
+        const double phi = exp(-dist);
+        double mk = 1.0;
+        if (drop) mk = (a.nz.masks ? (mk8 != 0) : (kwd >= drop_thr)) ? keep_scale : 0.0;
+        const double pm = act ? phi * mk : 0.0;
+        if (wv == BL_SW) BL_STAMP(12);
+        lds_barrier();
+        if (wv == BL_SW) BL_STAMP(13);
+        // behind it: what depends on the adjoint
+        double phibar = 0.0;
+#pragma unroll
+        for (int k = 0; k < UM; ++k) {
+          const double abk = s_ab[k];
+          gw[k] = fma(abk, pm, gw[k]);
+          phibar = fma(wgt[k], abk, phibar);
+        }
+        const double dd = -pm * phibar;
+        double t2v[8];
+#pragma unroll
+        for (int q = 0; q < PFM; ++q) {
+          t2v[q] = dd * e[q];  // adjoint of feature q through basis b; the centre's is its negative
+          gc[q] -= t2v[q];
+        }
+        const double tot = wave_sum_pack8(t2v, lane);
+        if (lane < 8) s_red[wv - 1][lane] = tot;
+        if (wv == BL_SW) BL_STAMP(14);
+        lds_barrier();
+        if (wv == BL_SW) BL_STAMP(15);
+      }
+    }
+  }
+
+  // ---- this workgroup's partial parameter gradients (the slab layout of the general kernel) -----------------------------------
+  const int nparam = PF + B * PF + U * B;
+  double* out = a.slab + (size_t)m * (nparam + (pl.bias ? U : 0));  // one slab per particle
+  if (act) {
+#pragma unroll
+    for (int q = 0; q < PFM; ++q)
+      if (q < PF) out[PF + (size_t)b * PF + q] = gc[q];
+#pragma unroll
+    for (int k = 0; k < UM; ++k)
+      if (k < U) out[PF + (size_t)B * PF + (size_t)k * B + b] = gw[k];
+  }
+  __syncthreads();  // (the chain's last reads of s_red are done)
+  if (wv > 0) {
+    double cg[8];
+#pragma unroll
+    for (int q = 0; q < PFM; ++q) cg[q] = act ? -s_cen[q][bs] * gc[q] : 0.0;  // - sum_b c_bq dJ/dc_bq
+    const double tot = wave_sum_pack8(cg, lane);
+    if (lane < 8) s_red[wv - 1][lane] = tot;
+  } else {
+    if (ft_lane) s_fin[fq] = glacc;
+    if (in_lane) s_fin[PFM + uk] = gbacc;
+  }
+  __syncthreads();
+  if (valid && tid < PF) out[tid] = (((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid]) + s_fin[tid];
+  if (valid && pl.bias && tid < U) out[nparam + tid] = s_fin[PFM + tid];
+  if (a.stamps && blockIdx.x == 0 && threadIdx.x >= 8 && threadIdx.x < 16) a.stamps[threadIdx.x] = s_stamp[threadIdx.x];
+  if (a.stamps && tid == 0) {  // diagnostic: spread of the workgroups' run times (core cycles) and start / end times (100 MHz wall clock)
+    atomicMax(&a.stamps[0], clock64() - t_begin);
+    atomicMin(&a.stamps[1], clock64() - t_begin);
+    atomicMin(&a.stamps[2], w_begin);
+    atomicMax(&a.stamps[3], w_begin);
+    atomicMax(&a.stamps[4], wall_clock64());
+  }
+}
+
 // sum the per-workgroup slabs in a fixed order (deterministic, no atomics): 64 parameters per workgroup, its 4 waves take a
 // quarter of the slabs each (4 independent partial sums per thread keep loads in flight), partials meet in LDS.  (One thread per
 // parameter walking all slabs left 5 workgroups on the device: 34 us for 3.9 MB at the headline shape.)
@@ -641,6 +1065,32 @@ static unsigned long long* g_bwd_stamps = nullptr;  // diagnostic hook
 extern "C" void mcp_debug_set_bwd_stamp_buffer(void* p) { g_bwd_stamps = (unsigned long long*)p; }
 static int g_force_bwd_pb = 0;  // test hook: particles per workgroup of the backward sweep (0 = automatic)
 extern "C" void mcp_debug_set_bwd_particles(int pb) { g_force_bwd_pb = pb; }
+static int g_bwd_lean = -1;  // test hook: -1 automatic (the lean sweep where it applies), 0 never
+static int g_last_bwd_lean = 0;
+extern "C" void mcp_debug_set_bwd_lean(int v) { g_bwd_lean = v; }
+extern "C" int mcp_debug_last_bwd_lean(void) { return g_last_bwd_lean; }
+// what rollout_bwd_lat_kernel covers: the narrow class with its lane roles (states on lanes 0-7, features on 8-15, inputs on 16-17),
+// up to 256 basis functions, plain / angle policies on the true state, disjoint index lists
+static bool bwd_lean_applies(const mcp_model* md, const mcp_policy* pl, int T) {
+  if (T < 2 || md->G < 1 || md->G > BL_GM || md->S > 8 || pl->P > 8 || pl->U > 2 || pl->B > 256 || md->U != pl->U) return false;
+  if (pl->kind != MCP_POLICY_PLAIN && pl->kind != MCP_POLICY_ANGLES) return false;
+  if (pl->meas.n > 0) return false;
+  if (pl->kind == MCP_POLICY_PLAIN && pl->P != md->S) return false;
+  if (md->n_not_angle + 2 * md->n_angle + md->U != md->D) return false;
+  for (int i = 0; i < md->n_angle; ++i)
+    for (int j = 0; j < md->n_not_angle; ++j)
+      if (md->angle[i] == md->not_angle[j]) return false;
+  if (pl->kind == MCP_POLICY_ANGLES) {
+    if (pl->n_non_angle + 2 * pl->n_angle != pl->P) return false;
+    for (int i = 0; i < pl->n_angle; ++i)
+      for (int j = 0; j < pl->n_non_angle; ++j)
+        if (pl->angle[i] == pl->non_angle[j]) return false;
+  }
+  for (int g = 0; g < md->G; ++g)
+    for (int h = 0; h < g; ++h)
+      if (md->vel[g] == md->vel[h]) return false;
+  return true;
+}
 static int bwd_threads(int B) { return imax(64, ((B + 63) / 64) * 64); }
 static int bwd_blocks(int M) { return imin(M, 1024); }
 
@@ -712,6 +1162,19 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   if (PB != 1 && PB != 2 && PB != 4) return MCP_ERR_ARG;
   int NT = imax(bwd_threads(policy->B), 64 * PB);
   int rc = MCP_ERR_LIMIT;
+  g_last_bwd_lean = 0;
+  if (g_bwd_lean != 0 && !g_force_bwd_pb && PB == 1 && M <= 1024 && model != &stub && bwd_lean_applies(model, policy, T)) {
+    // small swarm, narrow class: the latency-lean sweep (wave 0 = the chain, the basis functions in the waves behind it)
+    const int grid = (M + 1) / 2, nt = 2 * (64 + bwd_threads(policy->B));  // two particle slots per workgroup
+    if (model->G <= 2)
+      hipLaunchKernelGGL(rollout_bwd_lat_kernel<2>, dim3(grid), dim3(nt), 0, st, a);
+    else
+      hipLaunchKernelGGL(rollout_bwd_lat_kernel<BL_GM>, dim3(grid), dim3(nt), 0, st, a);
+    MCP_LAUNCH_CHECK();
+    g_last_bwd_lean = 1;
+    rc = M;  // slabs: one per particle
+    PB = 0;
+  }
   // register budget: 3*PFM + 2*UM doubles of per-thread accumulators plus the prefetched record; the launch bound is the
   // tightest that fits the thread count, capped so that two 256-thread workgroups share a CU
   for (; PB >= 1 && rc == MCP_ERR_LIMIT; PB >>= 1) {

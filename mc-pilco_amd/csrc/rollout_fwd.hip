@@ -427,8 +427,8 @@ __device__ __forceinline__ void phase_v(const GpL* gpl, int g0, const int* tab, 
       // fold rows j+1 (lanes 32..63) into rows j (lanes 0..31)
 #pragma unroll
       for (int p = 0; p < P; ++p) {
-        acc[0][p] += __shfl_xor(acc[0][p], 32);
-        acc[1][p] += __shfl_xor(acc[1][p], 32);
+        acc[0][p] = sum_xor32(acc[0][p]);
+        acc[1][p] = sum_xor32(acc[1][p]);
       }
     }
     double* slot = part + (c + wv) * 128 * P;  // slot id = chunk + wave: unique, contiguous per chunk
@@ -891,9 +891,9 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         if (is_bad(xn) || is_bad(xm)) bad |= MCP_STATUS_NAN;
       }
       double sn = 0.0, cs = 0.0;
-      if (zi_ang >= 0 || pi_ang >= 0) sincos(xn, &sn, &cs);
+      if (zi_ang >= 0 || pi_ang >= 0) sincos_fast(xn, &sn, &cs);
       double snm = sn, csm = cs;  // trig of the measured value (policy features)
-      if (pms && pi_ang >= 0 && xm != xn) sincos(xm, &snm, &csm);
+      if (pms && pi_ang >= 0 && xm != xn) sincos_fast(xm, &snm, &csm);
       // GP input z = [x[not_angle], sin x[angle], cos x[angle], u]   (Model_learning.py:670-683)
       if (zi_plain >= 0) z[op * D + zi_plain] = xn;
       if (zi_ang >= 0) {
@@ -1659,7 +1659,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
           if (is_bad(xn)) bad |= MCP_STATUS_NAN;
         }
         double sn = 0.0, cs = 0.0;
-        if (zi_ang >= 0 || pi_ang >= 0) sincos(xn, &sn, &cs);
+        if (zi_ang >= 0 || pi_ang >= 0) sincos_fast(xn, &sn, &cs);
         // GP input z = [x[not_angle], sin x[angle], cos x[angle], u]   (Model_learning.py:670-683); raw and divided by its lengthscale
         const double* il = kpar + KP_INVLS(D);
         if (zi_plain >= 0) {

@@ -119,9 +119,7 @@ __device__ __forceinline__ size_t xch_slot(int cluster, int t, int G, int g, int
 typedef double v4d_t __attribute__((ext_vector_type(4)));
 // sum over the 4 lanes l, l^16, l^32, l^48 (the 4 feature groups of an MFMA operand column)
 __device__ __forceinline__ double fold_kk(double v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
+  return sum_xor32(sum_xor16(v));
 }
 
 // forward rollout with 16 particles per workgroup (rollout_fwd_tile.hip); MCP_ERR_LIMIT when the problem does not fit it

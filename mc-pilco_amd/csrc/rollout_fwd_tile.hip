@@ -1108,9 +1108,9 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     }
     if (own) {
       double sn = 0.0, cs = 0.0;
-      if (zi_ang >= 0 || pi_ang >= 0) sincos(xn, &sn, &cs);
+      if (zi_ang >= 0 || pi_ang >= 0) sincos_fast(xn, &sn, &cs);
       double snm = sn, csm = cs;  // trig of the measured value (policy features)
-      if (PMS && pi_ang >= 0 && xm != xn) sincos(xm, &snm, &csm);
+      if (PMS && pi_ang >= 0 && xm != xn) sincos_fast(xm, &snm, &csm);
       if (zi_plain >= 0) z[op * D + zi_plain] = xn;
       if (zi_ang >= 0) {
         z[op * D + nna + zi_ang] = sn;

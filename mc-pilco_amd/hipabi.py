@@ -107,6 +107,8 @@ _SIGS = {
     "mcp_debug_set_fwd_lean": (None, [C.c_int]),
     "mcp_debug_set_chol_mfma": (None, [C.c_int]),
     "mcp_debug_last_fwd_lean": (C.c_int, []),
+    "mcp_debug_set_bwd_lean": (None, [C.c_int]),
+    "mcp_debug_last_bwd_lean": (C.c_int, []),
 }
 EXPORTED = [k for k in _SIGS if not k.startswith("mcp_debug")]
 

@@ -65,14 +65,16 @@ class forced_variant:
     workgroup, all GPs in the workgroup; 16 = the 16-particle matrix-core kernel; 101 / 102 / 104 / 116 = the GP-sharded launch
     (G workgroups per cluster of 1 / 2 / 4 / 16 particles, met by a per-step hand-off) on the GENERAL kernels; 201 / 202 / 204 =
     the GP-sharded launch on the latency-lean kernel of narrow SE-only models (``rollout_fwd_lat_kernel``; models it does not
-    cover run the general sharded kernel).  ``check()`` asserts that the forced variant is the one that ran."""
+    cover run the general sharded kernel).  The backward sweep follows: forced codes run the general sweep with 1 / 2 / 4 particles
+    per workgroup, codes 0 and 2xx the automatic one (the latency-lean sweep ``rollout_bwd_lat_kernel`` where it applies).
+    ``check()`` asserts that the forced variant is the one that ran."""
 
     def __init__(self, code, bwd_particles=None):
         self.code = code
         self.ppw = code % 100
         self.sharded = code >= 100
         self.lean = code >= 200
-        self.pb = bwd_particles if bwd_particles is not None else {0: 0, 1: 1, 2: 2, 4: 4, 16: 4}[self.ppw]
+        self.pb = bwd_particles if bwd_particles is not None else (0 if self.lean else {0: 0, 1: 1, 2: 2, 4: 4, 16: 4}[self.ppw])
 
     def __enter__(self):
         from mc_pilco_amd import hipabi

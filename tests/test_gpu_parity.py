@@ -693,3 +693,43 @@ def test_wide_class_with_a_different_subset_size_per_gp():
     for key, (st, inp) in outs.items():
         assert float((st - ref[0]).abs().max()) < 1e-9, key
         assert float((inp - ref[1]).abs().max()) < 1e-9, key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [("c1", 400, 150, 0.25, "philox"), ("c1", 37, 2, 0.25, "philox"), ("c1", 64, 9, 0.0, "philox"), ("c1", 48, 12, 0.25, "masks"),
+                                  ("c3", 96, 20, 0.25, "philox")])
+def test_lean_backward_sweep_matches_the_general_one(case):
+    """rollout_bwd_lat_kernel (small swarms: wave 0 runs the adjoint chain from registers, the RBF waves prepare their step ahead of the
+    barrier) against the general sweep on the same rollout: all three policy gradients and dJ/dx0 to 1e-11 relative (different
+    summation order only), with in-kernel dropout bits, with mask buffers, without dropout, at T = 2 and at the headline size."""
+    from gpu_helpers import dev
+    from mc_pilco_amd import hipabi, ops, workloads
+
+    name, M, Tn, p, mode = case
+    w = workloads.build(name, device=dev(), M=M, T=Tn, p_drop=p)
+    torch.manual_seed(3)
+    x0 = w.sample_x0().requires_grad_(True)
+    if mode == "masks":
+        B = w.policy.centers.shape[0]
+        nz = ops.NoiseSpec(eps=torch.randn(Tn - 1, M, len(w.model.gps), dtype=torch.float64, device=dev()),
+                           masks=(torch.rand(Tn, M, B, device=dev()) >= p).to(torch.uint8).contiguous())
+    else:
+        nz = ops.NoiseSpec(seed=21, call=4)
+    L = hipabi.lib()
+    res = {}
+    try:
+        for lean in (1, 0):
+            L.mcp_debug_set_bwd_lean(-1 if lean else 0)
+            for q in w.params:
+                q.grad = None
+            x0.grad = None
+            st, inp, status = ops.rollout(w.model, w.policy, nz, x0, w.T, w.p_drop)
+            c, s = ops.expected_cost(w.cost, st)
+            (c + 0.3 * s + 1e-3 * (inp ** 2).sum()).backward()  # (a cost on the inputs too: dJ/du_t enters the chain)
+            assert L.mcp_debug_last_bwd_lean() == lean
+            res[lean] = [q.grad.detach().clone() for q in w.params] + [x0.grad.detach().clone()]
+    finally:
+        L.mcp_debug_set_bwd_lean(-1)
+    for ga, gb in zip(res[1], res[0]):
+        assert torch.isfinite(gb).all()
+        assert float((ga - gb).abs().max()) <= 1e-11 * float(gb.abs().max()), (float((ga - gb).abs().max()), float(gb.abs().max()))

@@ -36,12 +36,18 @@ w.params[0].grad = None
 st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=10), x0, w.T, w.p_drop)
 c, sd = ops.expected_cost(w.cost, st)
 buf2 = torch.zeros(16, dtype=torch.int64, device=dev)
+buf2[1] = buf2[2] = 1 << 62
 hipabi.lib().mcp_debug_set_bwd_stamp_buffer(buf2.data_ptr())
 c.backward()
 torch.cuda.synchronize()
 hipabi.lib().mcp_debug_set_bwd_stamp_buffer(None)
 v2 = buf2.cpu().tolist()
-print("bwd per step cycles: serial(wave0) %.0f | barrier1 %.0f | RBF stage %.0f | park+barrier2 %.0f" % tuple(x / w.T for x in (v2[8], v2[9], v2[10], v2[11])))
+if hipabi.lib().mcp_debug_last_bwd_lean():
+    print("bwd (lean sweep) workgroup run times: max %d min %d core cycles; first start -> last start %.1f us, first start -> last end %.1f us" % (v2[0], v2[1], (v2[3] - v2[2]) / 100.0, (v2[4] - v2[2]) / 100.0))
+    print("bwd (lean sweep) per step cycles, wave 0: chain %.0f | wait at barrier 1 %.0f | prepare next step %.0f | wait at barrier 2 %.0f" % tuple(x / w.T for x in (v2[8], v2[9], v2[10], v2[11])))
+    print("bwd (lean sweep) per step cycles, wave 1: before barrier 1 (exp, Philox, distances) %.0f | wait %.0f | after it (fma, wave sum) %.0f | wait at barrier 2 %.0f" % tuple(x / w.T for x in (v2[12], v2[13], v2[14], v2[15])))
+else:
+    print("bwd per step cycles: serial(wave0) %.0f | barrier1 %.0f | RBF stage %.0f | park+barrier2 %.0f" % tuple(x / w.T for x in (v2[8], v2[9], v2[10], v2[11])))
 print("workload", name, "T", w.T, "M", w.M, "ppw forced", ppw, "launched", hipabi.lib().mcp_debug_last_particles_per_wg(), "gp-sharded", hipabi.lib().mcp_debug_last_gp_sharded(), "lean", hipabi.lib().mcp_debug_last_fwd_lean(), "total cycles", tot, "-> per step", tot / (w.T - 1))
 print("tile kernel detail (wave 0, per step, all GPs): K setup %.0f, K tiles %.0f | J setup %.0f, J batches %.0f cyc" % tuple(v[i] / (w.T - 1) for i in (12, 13, 14, 15)))
 print("J finish (wave 0, per step, all GPs): wait for the other waves %.0f, park + barrier %.0f, add + barrier %.0f cyc" % tuple(v[i] / (w.T - 1) for i in (9, 10, 11)))
