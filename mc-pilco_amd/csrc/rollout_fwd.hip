@@ -1140,10 +1140,12 @@ struct LatFixed {
   static constexpr int gpl = rt + 64;
   static constexpr int kpar = gpl + GPL_DOUBLES;
   static constexpr int role = ((kpar + 5 * RL_MAXD + 2) + 1) & ~1;          // [64][16] ints: roles of the threads of wave 0 in the serial section
-  static constexpr int stl = role + 64 * 8;                    // [16 + 8] u64 phase-cycle totals (diagnostic)
+  static constexpr int sro = role + 64 * 8;                    // [64][8]: phase S of thread (p, s): 6 int LDS addresses (in doubles) | 4 scale factors
+  static constexpr int dump = sro + 64 * 8;                    // where phase S writes what a state component does not feed
+  static constexpr int stl = dump + 2;                         // [16 + 8] u64 phase-cycle totals (diagnostic)
   static constexpr int end = stl + 24;
 };
-static_assert(LatFixed::red % 2 == 0 && LatFixed::rt % 2 == 0 && LatFixed::zs % 2 == 0 && LatFixed::role % 2 == 0 && LatFixed::end % 2 == 0, "16-byte alignment of the v2d regions");
+static_assert(LatFixed::red % 2 == 0 && LatFixed::rt % 2 == 0 && LatFixed::zs % 2 == 0 && LatFixed::role % 2 == 0 && LatFixed::sro % 2 == 0 && LatFixed::end % 2 == 0, "16-byte alignment of the v2d regions");
 struct LatLayout {
   int gs, kb, vb, xe, xq, al, cen, wgt, mk, total;  // offsets in doubles
 };
@@ -1582,6 +1584,36 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     ro[RO_N] = 0;
   }
   lds_barrier();
+  // phase S as a table: thread (p, s) writes x, sin x or cos x to at most two GP-input slots (raw and divided by the lengthscale) and two
+  // policy-feature slots; the slot addresses and scale factors are read in ONE batch at the top of the phase and every write is
+  // unconditional (unused ones go to a dump word) -- as tests on the role indices each slot was its own LDS read -> multiply -> write
+  // round trip behind a branch: 7 dependent round trips per step on the wave that bounds the step
+  if (tid0 < P * S) {
+    const int* ro = role + tid0 * 16;
+    const int op = ro[RO_OP], os = ro[RO_OS], zi_plain = ro[RO_ZPLAIN], zi_ang = ro[RO_ZANG], pi_plain = ro[RO_PPLAIN], pi_ang = ro[RO_PANG];
+    int* si = reinterpret_cast<int*>(smem + LatFixed::sro + tid0 * 8);
+    double* sd = smem + LatFixed::sro + tid0 * 8 + 4;
+    const double* il = kpar + KP_INVLS(D);
+    const int zA = zi_ang >= 0 ? nna + zi_ang : zi_plain, zB = zi_ang >= 0 ? nna + na + zi_ang : -1;
+    int pA, pB = -1;
+    if (pl.kind == MCP_POLICY_ANGLES) {
+      pA = pi_ang >= 0 ? pol_nna + pi_ang : pi_plain;
+      pB = pi_ang >= 0 ? pol_nna + pol_na + pi_ang : -1;
+    } else {
+      pA = os;
+    }
+    si[0] = zA >= 0 ? LatFixed::z + op * D + zA : LatFixed::dump;
+    si[1] = zB >= 0 ? LatFixed::z + op * D + zB : LatFixed::dump;
+    si[2] = zA >= 0 ? LatFixed::zs + op * RL_ZD + zA : LatFixed::dump;
+    si[3] = zB >= 0 ? LatFixed::zs + op * RL_ZD + zB : LatFixed::dump;
+    si[4] = pA >= 0 ? LatFixed::sf + op * RL_PFM + pA : LatFixed::dump;
+    si[5] = pB >= 0 ? LatFixed::sf + op * RL_PFM + pB : LatFixed::dump;
+    si[6] = si[7] = 0;
+    sd[0] = zA >= 0 ? il[zA] : 0.0;
+    sd[1] = zB >= 0 ? il[zB] : 0.0;
+    sd[2] = pA >= 0 ? pol[pA] : 0.0;
+    sd[3] = pB >= 0 ? pol[pB] : 0.0;
+  }
   for (int it = tid0; it < RL_PFM * Bp; it += RF_NT) {
     const int q = it / Bp, b = it - q * Bp;
     cen[it] = (q < PF && b < B) ? pl.centers[(size_t)b * PF + q] * pol[q] : 0.0;
@@ -1648,10 +1680,14 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     if (wv == 0) {
       const int* ro = role + lane * 16;
       const int4 r0 = *reinterpret_cast<const int4*>(ro), r1 = *reinterpret_cast<const int4*>(ro + 4);
-      const int op = r0.x, os = r0.y, zi_plain = r0.z, zi_ang = r0.w, pi_plain = r1.x, pi_ang = r1.y;
+      const int op = r0.x, os = r0.y, zi_ang = r0.w, pi_ang = r1.y;
       const bool own = lane < P * S;
       const bool ovalid = own && (m0 + op < Mend);
       if (own) {
+        const double* srow = smem + LatFixed::sro + lane * 8;
+        const int4 sa = *reinterpret_cast<const int4*>(srow);
+        const int2 sb = *reinterpret_cast<const int2*>(srow + 2);
+        const v2d sc0 = *reinterpret_cast<const v2d*>(srow + 4), sc1 = *reinterpret_cast<const v2d*>(srow + 6);
         double* xc = xs + cur * P * S;
         xc[op * S + os] = xn;
         if (ovalid) {
@@ -1660,28 +1696,15 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
         }
         double sn = 0.0, cs = 0.0;
         if (zi_ang >= 0 || pi_ang >= 0) sincos_fast(xn, &sn, &cs);
-        // GP input z = [x[not_angle], sin x[angle], cos x[angle], u]   (Model_learning.py:670-683); raw and divided by its lengthscale
-        const double* il = kpar + KP_INVLS(D);
-        if (zi_plain >= 0) {
-          z[op * D + zi_plain] = xn;
-          zs[op * RL_ZD + zi_plain] = xn * il[zi_plain];
-        }
-        if (zi_ang >= 0) {
-          z[op * D + nna + zi_ang] = sn;
-          z[op * D + nna + na + zi_ang] = cs;
-          zs[op * RL_ZD + nna + zi_ang] = sn * il[nna + zi_ang];
-          zs[op * RL_ZD + nna + na + zi_ang] = cs * il[nna + na + zi_ang];
-        }
-        // policy features (Policy.py:326-333: [x_nonangle, COS, SIN];  :397-399: [x, x*_t - x]), divided by their lengthscales
-        if (pl.kind == MCP_POLICY_ANGLES) {
-          if (pi_plain >= 0) sf[op * RL_PFM + pi_plain] = xn * pol[pi_plain];
-          if (pi_ang >= 0) {
-            sf[op * RL_PFM + pol_nna + pi_ang] = cs * pol[pol_nna + pi_ang];
-            sf[op * RL_PFM + pol_nna + pol_na + pi_ang] = sn * pol[pol_nna + pol_na + pi_ang];
-          }
-        } else {
-          sf[op * RL_PFM + os] = xn * pol[os];
-        }
+        // GP input z = [x[not_angle], sin x[angle], cos x[angle], u]   (Model_learning.py:670-683), raw and divided by its lengthscale;
+        // policy features (Policy.py:326-333: [x_nonangle, COS, SIN]; plain policy: x) divided by theirs: slots and factors from the table
+        const double vz = zi_ang >= 0 ? sn : xn, vp = pi_ang >= 0 ? cs : xn;
+        smem[sa.x] = vz;
+        smem[sa.y] = cs;
+        smem[sa.z] = vz * sc0.x;
+        smem[sa.w] = cs * sc0.y;
+        smem[sb.x] = vp * sc1.x;
+        smem[sb.y] = sn * sc1.y;
       }
     }
     if (wv == 0) RL_SUB(15);
@@ -2132,6 +2155,13 @@ static int lean_items_per_thread(int P, int NpadMax) {  // 0: the shape has no i
 static bool lean_applies(const mcp_model* m, const mcp_policy* p, int P, int NpadMax, int maxdeg) {
   if (maxdeg != 0 || m->G < 2) return false;
   if (p->meas.n > 0 || p->kind == MCP_POLICY_TRAJ) return false;  // (measurement models and trajectory policies: the general kernel)
+  for (int i = 0; i < m->n_angle; ++i)  // (phase S writes a state component to the plain OR the sin / cos slots)
+    for (int j = 0; j < m->n_not_angle; ++j)
+      if (m->angle[i] == m->not_angle[j]) return false;
+  if (p->kind == MCP_POLICY_ANGLES)
+    for (int i = 0; i < p->n_angle; ++i)
+      for (int j = 0; j < p->n_non_angle; ++j)
+        if (p->angle[i] == p->non_angle[j]) return false;
   for (int g = 0; g < m->G; ++g)
     if (m->gp[g].Npad < 32) return false;  // (every GP needs two row tiles at least)
   if (m->D - m->U > RL_DSM || m->U > RL_UM || p->P > RL_PFM) return false;

@@ -324,7 +324,7 @@ __device__ __forceinline__ void tile_j_load(TileJBatch<DEG, NDQ>& b, PT Xt, PT a
   for (int u = 0; u < 4; ++u) {
     const int j = imin(jb + 4 * u + kk, Npad - 1);
     b.a0[u] = Xt[(size_t)cc0 * xpitch + j];
-    b.a1[u] = (!ONE_RT && RT > 1) ? Xt[(size_t)cc1 * xpitch + j] : 0.0;
+    b.a1[u] = (ONE_RT || RT > 1) ? Xt[(size_t)cc1 * xpitch + j] : 0.0;  // (ONE_RT: rows 4 .. 7 of the 4-row operand form, see tile_j_consume)
     b.al[u] = al[j];
   }
   if (DEG >= 2) {
@@ -360,6 +360,27 @@ __device__ __forceinline__ void tile_j_consume(const TileJBatch<DEG, NDQ>& b, co
       bv[u][3] = vv[u] * Bq[u];
       bv[u][4] = vv[u] * Aq[u];
     }
+  }
+  if constexpr (ONE_RT) {
+    // Cart-pole class (D + 1 <= 8 rows of [X^T; 1]): the 16x16x4 product would compute 16 rows for the 7 that exist.  v_mfma_f64_4x4x4_4b
+    // (four independent 4x4x4 products, one per group of 4 particles; lane l = 16 k + 4 blk + e: A_blk[i = e][k], B_blk[k][j = e], D at
+    // lane 16 i + 4 blk + j) takes rows c = 0..3 and 4..7 as two A operands against the SAME B operand the wide form uses (lane (k, p) ->
+    // W[j0 + k][p]), and its result lands exactly where registers 0 and 1 of the wide form's accumulator would be (lane (i, p) -> rows i
+    // and 4 + i): 2 small instructions instead of one wide one per weight kind, at a quarter of the pipe time each -- and nothing
+    // downstream (parking, the 8-way add, phase F) changes.
+    const int ci = n & 3;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (jb + 4 * u >= j1) continue;  // (wave-uniform)
+      const double av0 = ci < D ? b.a0[u] : (ci == D ? 1.0 : 0.0);
+      const double av1 = 4 + ci < D ? b.a1[u] : (4 + ci == D ? 1.0 : 0.0);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        acc[0][ct].x = __builtin_amdgcn_mfma_f64_4x4x4f64(av0, bv[u][ct], acc[0][ct].x, 0, 0, 0);
+        acc[0][ct].y = __builtin_amdgcn_mfma_f64_4x4x4f64(av1, bv[u][ct], acc[0][ct].y, 0, 0, 0);
+      }
+    }
+    return;
   }
   const int c0 = n, c1 = 16 + n;
 #pragma unroll
@@ -398,7 +419,7 @@ __device__ __forceinline__ void tile_phase_j(const GpL& gp, PT Xt, PT al, int xp
     zwa[i] = dv ? kp[KP_W20(D) + d] * zz : 0.0;
     zwb[i] = dv ? kp[KP_W21(D) + d] * zz : 0.0;
   }
-  const int cc0 = imin(n, D - 1), cc1 = imin(16 + n, D - 1);
+  const int cc0 = ONE_RT ? imin(n & 3, D - 1) : imin(n, D - 1), cc1 = ONE_RT ? imin(4 + (n & 3), D - 1) : imin(16 + n, D - 1);
   const int nbat = (j1 - j0 + 15) >> 4;
   if (dbg && lane == 0) { unsigned long long now = clock64(); dbg[14] += now - tq0; tq0 = now; }
   TileJBatch<DEG, NDQ> b0, b1;
@@ -902,7 +923,7 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
 // BIG selects the operand-group counts: small problems (D <= 8, policy features <= 8, inputs <= 2: cart-pole class) keep two
 // feature groups per product in registers, everything else eight.  One kernel per class: compiling both paths into one
 // function made the register allocator spill the small path's long-lived values for the benefit of the big one.
-// CLS: 0 = cart-pole class (D, policy features <= 8, inputs <= 2, N <= 512), 1 = UR5 class (<= 24, <= 24, <= 6, N <= 512), 2 = any
+// CLS: 0 = cart-pole class (D <= 7, policy features <= 8, inputs <= 2, N <= 512), 1 = UR5 class (<= 24, <= 24, <= 6, N <= 512), 2 = any
 // PMS: the policy is evaluated on a simulated measurement (mcp_meas, MC_PILCO4PMS.apply_policy) instead of the true state
 // GSH: a.gsh_cs workgroups per 16-particle tile, each evaluates G / gsh_cs consecutive GPs (and, redundantly, the policy); they hand
 // each other the sampled increments once per step exactly as the small-tile kernel's GP-sharded launch does (rollout_fwd.hip).
@@ -1174,7 +1195,12 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     TL_STAMP(2);
     if (t == T - 1) break;
 
-    for (int g = gbeg; g < gend; ++g) {
+    for (int gi = gbeg; gi < gend; ++gi) {
+      // The GPs of a step are independent: odd steps walk them backwards.  A workgroup streams every Kinv of its range once per step,
+      // and the XCD's L2 (4 MB) sees the same cyclic sweep from all its workgroups: walked in the same order every step, a range that
+      // nearly fills the cache (UR5 shape: 3 x 1.28 MB) is evicted just before it comes round again -- measured: every byte re-fetched
+      // from the fabric every step.  Back and forth, the last GPs of one step are the first of the next while they are still resident.
+      const int g = (t & 1) ? gbeg + gend - 1 - gi : gi;
       asm volatile("" : "+v"(lane));  // (again per GP: nothing derived from the ids stays live across the GP loop)
       asm volatile("" : "+v"(tid));
       asm volatile("" : "+s"(wv));
@@ -1435,8 +1461,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         }
       }
 #undef TL_R
-      if (g == gbeg && edraw && t + 1 < T - 1) draw_eps(t + 1);
-      if (GSH && wv == 0 && g == gend - 1) {
+      if (gi == gbeg && edraw && t + 1 < T - 1) draw_eps(t + 1);
+      if (GSH && wv == 0 && gi == gend - 1) {
         // collect the other workgroups' increments (rollout_fwd.hip): lane -> (other GP, particle, half), 64 granules per pass,
         // each pass re-read until every tag matches
         const int nown = gend - gbeg, ngr = (G - nown) * P * 2;
@@ -1555,7 +1581,7 @@ int launch_fwd_tile(const FwdArgs& a, hipStream_t st) {
   if (!fwd_tile_fits(&a.model, &a.pol)) return MCP_ERR_LIMIT;
   if (tile_xj_pack(a, st) != MCP_OK) return MCP_ERR_LAUNCH;
   const int D = a.model.D, PF = a.pol.P, U = a.model.U;
-  const int cls = a.NpadMax > 512 ? 2 : ((D <= 8 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2));
+  const int cls = a.NpadMax > 512 ? 2 : ((D <= 7 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2));  // (class 0: D + 1 <= 8 rows of [X^T; 1], phase J)
   // one instantiation per (highest polynomial degree, class): no code or registers for kernel terms the model does not have
   switch (cls * 3 + a.maxdeg) {
     case 0: return launch_tile_deg<0, 0>(a, st);
@@ -1576,7 +1602,7 @@ int launch_fwd_tile_sharded(const FwdArgs& a, hipStream_t st) {
   if (!fwd_tile_fits(&a.model, &a.pol) || a.gsh_cs < 2 || a.gsh_cs > a.model.G || !a.xch) return MCP_ERR_LIMIT;
   const int D = a.model.D, PF = a.pol.P, U = a.model.U;
   if (a.NpadMax > 512) return MCP_ERR_LIMIT;
-  const int cls = (D <= 8 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2);
+  const int cls = (D <= 7 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2);
   if (cls == 2) return MCP_ERR_LIMIT;
   if (tile_xj_pack(a, st) != MCP_OK) return MCP_ERR_LAUNCH;
   switch (cls * 3 + a.maxdeg) {
