@@ -121,6 +121,15 @@ __device__ __forceinline__ double sum_xor32(double v) {
   const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
   return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
 }
+// within every quad of lanes: lane i receives v of lane (i - k4) & 3 (k4 a constant after unrolling) -- DPP quad_perm, VALU speed, where
+// __shfl is an LDS round trip (ds_bpermute).  Used to hand the four words of a Philox block round the four lanes that share it.
+__device__ __forceinline__ uint32_t quad_from_back(uint32_t v, int k4) {
+  k4 &= 3;
+  if (k4 == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x93, 0xf, 0xf, false);  // quad_perm [3,0,1,2]
+  if (k4 == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // [2,3,0,1]
+  if (k4 == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x39, 0xf, 0xf, false);  // [1,2,3,0]
+  return v;
+}
 // Eight wave sums at once by pair-halving: at every stage two values are folded into one register -- a lane keeps the value its
 // own lane-index bit selects and receives the partner lane's copy of the same value -- so the live values halve (8 -> 4 -> 2 -> 1)
 // while the lanes that hold a given value's partial sums spread over the wave: 7 exchanges + 3 single-value all-reduce stages

@@ -175,15 +175,19 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   // where sb_q = sum_b t2/l_q is the feature adjoint the serial wave forms anyway: it accumulates -s_q sb_q per step, and the
   // centre term is one product with the finished dJ/dcentres at the end.  (3 PFM -> 2 PFM [1 PFM] doubles of live state per
   // thread: the UR5 class no longer updates spilled accumulators through scratch every step.)
+  // The RBF stage works on SCALED quantities: centres and policy features already divided by the lengthscales (rr = s_q/l_q - c_bq/l_q: one
+  // subtraction per feature and basis, no factor to fetch), centre gradients accumulated without their 1/l_q (applied once at the end) and the
+  // feature adjoints summed over the bases before THEIR 1/l_q (applied once per feature by the serial wave): per (particle, basis, feature)
+  // 4 vector instructions and 2 LDS operands where the unscaled form had 7 and 3 -- the stage is issue bound on large swarms.
   lds_t cen_l = (lds_t)(smem + L.cen);
   double cen[CENREG ? PFM : 1], gc[PFM], wgt[UM], gw[UM];
 #pragma unroll
   for (int q = 0; q < PFM; ++q) {
-    if (CENREG) cen[q] = (act && q < PF) ? pl.centers[(size_t)b * PF + q] : 0.0;
+    if (CENREG) cen[q] = (act && q < PF) ? pl.centers[(size_t)b * PF + q] * exp(-pl.log_ls[q < PF ? q : 0]) : 0.0;
     gc[q] = 0.0;
   }
   if (!CENREG)
-    for (int q = 0; q < PF; ++q) cen_l[q * NT + tid] = act ? pl.centers[(size_t)b * PF + q] : 0.0;
+    for (int q = 0; q < PF; ++q) cen_l[q * NT + tid] = act ? pl.centers[(size_t)b * PF + q] * exp(-pl.log_ls[q]) : 0.0;
 #define BW_CEN(q) (CENREG ? cen[CENREG ? (q) : 0] : cen_l[(q) * NT + tid])
 #pragma unroll
   for (int k = 0; k < UM; ++k) {
@@ -326,6 +330,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
           if (lane < PF) {
             double s = 0.0;
             for (int w = 0; w < NW; ++w) s += redp[w * PF + lane];
+            s *= invl[lane];  // (the RBF stage sums the feature adjoints without their 1 / l_q)
             sb[lane] = s;
             glacc = fma(-fprev, s, glacc);  // fprev: this lane's policy feature of step t+1
           }
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
           } else {
             f = r[oM + lane];
           }
-          sf[lane] = f;
+          sf[lane] = f * invl[lane];  // (scaled: what the RBF stage subtracts the scaled centres from)
           fprev = f;
         }
         __builtin_amdgcn_wave_barrier();
@@ -431,7 +436,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
             const int ws = (cq + k4) & 3;
             const uint32_t snd = ws == 0 ? rnd.x : ws == 1 ? rnd.y : ws == 2 ? rnd.z : rnd.w;
             const int src = (cq - k4) & 3;  // lane of the quad that drew for slot src % PB; it sends word[cq]
-            const uint32_t rcv = (uint32_t)__shfl((int)snd, (lane & ~3) | src);
+            const uint32_t rcv = quad_from_back(snd, k4);
 #pragma unroll
             for (int p = 0; p < PB; ++p)
               if ((src % PB) == p) kw[p] = rcv;
@@ -446,6 +451,12 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         clds_t abp = ab_all + p * PS;
         const bool pv = mbase + p < M;
         double dd = 0.0;  // adjoint of dist_b (0 for idle threads and empty slots, so they add nothing below)
+        constexpr bool KEEPRR = PFM > BW_MASK_FROM && MAXNT <= 512;  // (the 1024-thread forms have 128 registers: they read twice)
+        double rrk[KEEPRR ? PFM : 1];  // wide classes: the scaled differences, kept for the adjoint pass (no second LDS pass)
+        if constexpr (KEEPRR) {
+#pragma unroll
+          for (int q = 0; q < PFM; ++q) rrk[q] = 0.0;
+        }
         if (act && pv) {
           double dist = 0.0;
           if constexpr (PFM > BW_MASK_FROM) {
@@ -455,18 +466,18 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
 #pragma unroll
             for (int q0 = 0; q0 < PFM; q0 += 8) {
               if (q0 < PF) {
-                double sv[8], cv[8], iv[8];
+                double sv[8], cv[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                   const int q = imin(q0 + i, PF - 1);
                   sv[i] = sfp[q];
                   cv[i] = CENREG ? cen[CENREG ? imin(q0 + i, PFM - 1) : 0] : cen_l[q * NT + tid];  // (register centres: 0 beyond PF)
-                  iv[i] = invl[q];
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                  double rr = (sv[i] - cv[i]) * iv[i];
+                  double rr = sv[i] - cv[i];
                   rr = q0 + i < PF ? rr : 0.0;
+                  if constexpr (KEEPRR) rrk[KEEPRR ? q0 + i : 0] = rr;
                   dist = fma(rr, rr, dist);
                 }
               }
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
 #pragma unroll
             for (int q = 0; q < PFM; ++q) {
               if (q < PF) {
-                double rr = (sfp[q] - BW_CEN(q)) * invl[q];
+                double rr = sfp[q] - BW_CEN(q);
                 dist = fma(rr, rr, dist);
               }
             }
@@ -501,6 +512,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
           }
           dd = -phi * mk * phibar;
         }
+        const double dd2 = 2.0 * dd;
         // 8 features at a time: their wave sums interleave (ILP) without keeping all PFM partial products live
 #pragma unroll
         for (int q0 = 0; q0 < PFM; q0 += 8) {
@@ -512,18 +524,22 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
               double v = 0.0;
               if constexpr (PFM > BW_MASK_FROM) {
                 if (q < PFM) {
-                  const int qc = imin(q, PF - 1);
-                  const double il = invl[qc];
-                  const double rr = (sfp[qc] - (CENREG ? cen[CENREG ? q : 0] : cen_l[qc * NT + tid])) * il;
-                  const double t2 = q < PF ? 2.0 * dd * rr : 0.0;
-                  gc[q < PFM ? q : 0] = fma(-t2, il, gc[q < PFM ? q : 0]);
-                  v = t2 * il;
+                  double t2;
+                  if constexpr (KEEPRR) {
+                    t2 = dd2 * rrk[KEEPRR ? q : 0];  // (rrk is zero beyond PF and for idle threads)
+                  } else {
+                    const int qc = imin(q, PF - 1);
+                    const double rr = sfp[qc] - (CENREG ? cen[CENREG ? q : 0] : cen_l[qc * NT + tid]);
+                    t2 = q < PF ? dd2 * rr : 0.0;
+                  }
+                  gc[q < PFM ? q : 0] -= t2;
+                  v = t2;
                 }
               } else if (q < PFM && q < PF) {
-                double rr = (sfp[q] - BW_CEN(q)) * invl[q];
-                double t2 = 2.0 * dd * rr;
-                gc[q] = fma(-t2, invl[q], gc[q]);
-                v = t2 * invl[q];
+                double rr = sfp[q] - BW_CEN(q);
+                double t2 = dd2 * rr;
+                gc[q] -= t2;
+                v = t2;
               }
               t2v[i] = v;
             }
@@ -543,6 +559,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       if (lane < PF) {
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += redp[w * PF + lane];
+        s *= invl[lane];
         sb[lane] = s;
         glacc = fma(-fprev, s, glacc);
       }
@@ -570,7 +587,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   if (act) {
 #pragma unroll
     for (int q = 0; q < PFM; ++q)
-      if (q < PF) out[PF + (size_t)b * PF + q] = gc[q];
+      if (q < PF) out[PF + (size_t)b * PF + q] = gc[q] * invl[q];  // (accumulated without the 1 / l_q)
 #pragma unroll
     for (int k = 0; k < UM; ++k)
       if (k < U) out[PF + (size_t)B * PF + (size_t)k * B + b] = gw[k];
@@ -580,7 +597,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
 #pragma unroll
   for (int q = 0; q < PFM; ++q) {
     if (q < PF) {
-      double sm = wave_sum(act ? -BW_CEN(q) * gc[q] : 0.0);  // - sum_b c_bq dJ/dc_bq
+      double sm = wave_sum(act ? -BW_CEN(q) * gc[q] : 0.0);  // - sum_b c_bq dJ/dc_bq  (scaled centre x unscaled gradient: the 1 / l_q cancel)
       if (lane == 0) red[wv * PF + q] = sm;
     }
   }
@@ -712,7 +729,7 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   double gc[PFM], wgt[UM], gw[UM];
 #pragma unroll
   for (int q = 0; q < PFM; ++q) {
-    if (wv > 0 && slot == 0) s_cen[q][bs] = (b < B && q < PF) ? pl.centers[(size_t)b * PF + q] : 0.0;
+    if (wv > 0 && slot == 0) s_cen[q][bs] = (b < B && q < PF) ? pl.centers[(size_t)b * PF + q] * exp(-pl.log_ls[q]) : 0.0;  // (scaled, like the features)
     gc[q] = 0.0;
   }
 #pragma unroll
@@ -773,6 +790,9 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   const bool need_trig = na > 0 || (pl.kind == MCP_POLICY_ANGLES && pa > 0);
   const bool has_j = ia >= 0;
+  // 1 / l_q of the feature columns this lane gathers (the RBF waves sum l_q x adjoint) and of the feature it publishes
+  const double il1 = s_invl[i1], il2 = s_invl[i2], ilf = ft_lane ? s_invl[fq] : 0.0;
+  k0 *= s_invl[i0];
   const double rumax = 1.0 / umax;
   if (wv == 0 && slot == 0) {
     s_role[lane][0] = src;
@@ -839,10 +859,10 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         gbase = st.gb;
         const double th = st.uu * rumax;
         sq = (in_lane && pl.squash) ? 1.0 - th * th : 1.0;
-        k1n = pang ? -sv : 0.0;
-        k2n = pang ? cv : 0.0;
+        k1n = pang ? -sv * il1 : 0.0;  // (with the 1 / l of the feature columns they weigh)
+        k2n = pang ? cv * il2 : 0.0;
         fn = ro.w == 0 ? st.xs : (ro.w == 1 ? cv : sv);
-        if (ft_lane) s_sf[fq] = fn;
+        if (ft_lane) s_sf[fq] = fn * ilf;
       };
       double xb = 0.0;
       auto gather = [&]() -> double {  // the feature adjoints of the step just finished by the RBF waves, mapped to this lane's role
@@ -950,12 +970,11 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             kwd = ph == 0 ? kwo[0] : ph == 1 ? kwo[1] : ph == 2 ? kwo[2] : kwo[3];
           }
         }
-        double e[PFM], dist = 0.0;  // e_q = 2 rr_q / l_q: d dist / d s_q
+        double e[PFM], dist = 0.0;  // e_q = rr_q = s_q / l_q - c_bq / l_q (features and centres are stored scaled)
 #pragma unroll
         for (int q = 0; q < PFM; ++q) {
-          const double il = s_invl[q], rr = (s_sf[q] - s_cen[q][bs]) * il;
-          dist = fma(rr, rr, dist);
-          e[q] = 2.0 * rr * il;
+          e[q] = s_sf[q] - s_cen[q][bs];
+          dist = fma(e[q], e[q], dist);
         }
         const double phi = exp(-dist);
         double mk = 1.0;
@@ -972,11 +991,11 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
           gw[k] = fma(abk, pm, gw[k]);
           phibar = fma(wgt[k], abk, phibar);
         }
-        const double dd = -pm * phibar;
+        const double dd = -2.0 * pm * phibar;
         double t2v[8];
 #pragma unroll
         for (int q = 0; q < PFM; ++q) {
-          t2v[q] = dd * e[q];  // adjoint of feature q through basis b; the centre's is its negative
+          t2v[q] = dd * e[q];  // l_q x the adjoint of feature q through basis b (the 1 / l_q: once per feature, in the chain's gather)
           gc[q] -= t2v[q];
         }
         const double tot = wave_sum_pack8(t2v, lane);
@@ -994,7 +1013,7 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   if (act) {
 #pragma unroll
     for (int q = 0; q < PFM; ++q)
-      if (q < PF) out[PF + (size_t)b * PF + q] = gc[q];
+      if (q < PF) out[PF + (size_t)b * PF + q] = gc[q] * s_invl[q];  // (accumulated without the 1 / l_q)
 #pragma unroll
     for (int k = 0; k < UM; ++k)
       if (k < U) out[PF + (size_t)B * PF + (size_t)k * B + b] = gw[k];

@@ -721,7 +721,7 @@ __device__ __forceinline__ void tile_polr_consume(const double (&cb)[NQ], const 
         // equivalently lane c' receives, from lane r = (c' - k4) & 3 (the drawer for particle kq + 4 r), word[c']
         const uint32_t snd = ws == 0 ? rnd.x : ws == 1 ? rnd.y : ws == 2 ? rnd.z : rnd.w;
         const int src = (cq - k4) & 3;
-        const uint32_t rcv = (uint32_t)__shfl((int)snd, (lane & ~3) | src);
+        const uint32_t rcv = quad_from_back(snd, k4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) wr[r] = (src == r) ? rcv : wr[r];
       }
@@ -849,7 +849,7 @@ __device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const d
         const int ws = (cq + k4) & 3;
         const uint32_t snd = ws == 0 ? rnd.x : ws == 1 ? rnd.y : ws == 2 ? rnd.z : rnd.w;
         const int src = (cq - k4) & 3;
-        const uint32_t rcv = (uint32_t)__shfl((int)snd, (lane & ~3) | src);
+        const uint32_t rcv = quad_from_back(snd, k4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) wr[r] = (src == r) ? rcv : wr[r];
       }
