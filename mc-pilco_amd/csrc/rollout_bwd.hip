@@ -15,6 +15,7 @@
 #include <type_traits>
 
 using namespace mcp;
+typedef double bw_v2d __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------
 // backward rollout: reverse-time adjoint, one thread per basis function
@@ -43,8 +44,11 @@ struct BwdArgs {
     }                                               \
   } while (0)
 
+#define BW_RT 12    // doubles per lane in the role table of the register chain
+#define BW_FL0 16   // its first policy-feature lane (states on lanes 0-15, features on 16-47, inputs on 48-55)
+#define BW_UL0 48
 struct BwdLayout {
-  int invl, rec, xn, xb, zb, db, ab, sf, sb, sn, cs, snm, csm, cmv, cnv, nvx, red, gla, cen, itab, total;
+  int invl, rec, xn, xb, zb, db, ab, sf, sb, sn, cs, snm, csm, cmv, cnv, nvx, red, gla, cen, itab, rtab, total;
   int pstride;  // doubles between the per-particle copies of xn..cs
 };
 __host__ __device__ inline int bwd_rec_len(int S, int U, int D, int G, bool pms = false) { return 2 * S + 2 * U + G * D + (pms ? S : 0); }
@@ -80,6 +84,7 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
   L.gla = take(PB * (PF + MCP_MAX_INPUT));    // the serial waves' shares of dJ/dlog_lengthscales and dJ/dbias at the end of the sweep
   L.cen = take(cen_lds ? PF * NW * 64 : 0);  // RBF centres, transposed [q][thread] (wide policy classes)
   L.itab = take((2 * MCP_MAX_GP + 2 * MCP_MAX_STATE + MCP_MAX_INPUT + 1) / 2 + 1);
+  L.rtab = take(pms ? 0 : 64 * BW_RT);  // lane roles of the register chain (serial section without a measurement model)
   L.total = o;
   return L;
 }
@@ -102,7 +107,9 @@ __host__ __device__ inline BwdLayout bwd_layout(int S, int U, int D, int G, int 
 // alone with wave-level ordering (latency bound, so PB chains on PB waves cost the time of one); the RBF network stage
 // uses the whole workgroup, thread b looping over the PB particles (its gradient accumulators are shared by all
 // particles anyway): two workgroup barriers per time step for PB particle-steps.
-template <int PFM, int UM, int MAXNT, int WPE, int PB>
+// PMS: the policy sees a measurement model (mcp_meas); a template parameter so that the two forms of the serial section -- the register
+// chain, and the LDS-staged chain with the measurement adjoint -- do not hold each other's lane-role registers live.
+template <int PFM, int UM, int MAXNT, int WPE, int PB, bool PMS>
 __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
@@ -112,7 +119,11 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
   const mcp_meas& ms = pl.meas;
-  const bool pms = ms.n > 0;
+  constexpr bool pms = PMS;
+  // the register chain serves the wide classes (C5 backward 9.2 -> 8.4 ms).  On the narrow class at 2-4 particles per workgroup the sweep is issue
+  // bound with four 256-thread workgroups per CU and must stay within 128 registers for that: the chain's batch of operands then spills (24-40
+  // VGPRs) and the gain measured 1.5 % (C3 backward 1.64 -> 1.62 ms) -- not kept; small swarms of the narrow class run rollout_bwd_lat_kernel.
+  constexpr bool FASTCHAIN = !PMS && PFM > 8;
   constexpr bool CENREG = PFM <= 8;  // narrow policies keep their centres in registers; wider ones in LDS (transposed: conflict-free)
   const BwdLayout L = bwd_layout(S, U, D, G, PF, NW, PB, pms, !CENREG);
   const int NR = bwd_rec_len(S, U, D, G, pms);
@@ -226,6 +237,83 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     if (md.vel[g] == lane) pos_of_vel = md.not_vel[g];
   const double umax_lane = (serial && lane < U) ? pl.u_max[lane] : 1.0;
   const bool need_trig = (zi_ang >= 0) || (pi_ang >= 0);
+  // ---- role table of the register chain (no measurement model) --------------------------------------------------------------
+  // The serial section used to hand its intermediate vectors from one 10-lane stage to the next through LDS (six round trips per
+  // step on the one wave everything waits for).  Without a measurement model it now runs from registers: lane roles -- lanes 0..S-1 a
+  // state each, BW_FL0.. a policy feature each, BW_UL0.. an input each --; a lane reads the record entries and the partial feature
+  // adjoints ITS role needs in one batch, the 2 G entries the integrator needs come by v_readlane, and the adjoints of x_t and of the
+  // pre-squash activation are 2 G + 2 fused multiply-adds against the lane's own columns of d delta/dz (rollout_bwd_lat_kernel has the
+  // derivation).  What a lane loads and gathers is fixed for the rollout: one 96-byte table row per lane, read back every step.
+  double* rtab = smem + L.rtab;
+  const bool any_trig = md.n_angle > 0 || (pl.kind == MCP_POLICY_ANGLES && pl.n_angle > 0);
+  if (FASTCHAIN && wv == 0) {
+    const bool st_l = lane < S, ft_l = lane >= BW_FL0 && lane < BW_FL0 + PF, in_l = lane >= BW_UL0 && lane < BW_UL0 + U;
+    const int fq = lane - BW_FL0, uk = lane - BW_UL0;
+    int src = 0, ftype = 0, i0 = 0, i1 = 0, i2 = 0, ia = -1, ib = -1, gvel = -1, flags = 0;
+    double k0 = 0.0, k1c = 0.0, k2c = 0.0, ilf = 0.0, own = 0.0, rum = 1.0;
+    const int pn = pl.n_non_angle, pa = pl.n_angle;
+    if (st_l) {
+      src = lane;
+      flags |= 1;
+      if (pl.kind == MCP_POLICY_ANGLES) {
+        for (int i = 0; i < pn; ++i)
+          if (pl.non_angle[i] == lane) { i0 = i; k0 = 1.0; }
+        for (int i = 0; i < pa; ++i)
+          if (pl.angle[i] == lane) { i1 = pn + i; i2 = pn + pa + i; k1c = 1.0; k2c = 1.0; flags |= 16; }
+      } else if (pl.kind == MCP_POLICY_TRAJ) {
+        i0 = lane;
+        k0 = 1.0;
+        i1 = S + lane;
+        k1c = -1.0;
+      } else {
+        i0 = lane;
+        k0 = 1.0;
+      }
+      for (int i = 0; i < nna_g; ++i)
+        if (md.not_angle[i] == lane) ia = i;
+      for (int i = 0; i < na_g; ++i)
+        if (md.angle[i] == lane) { ia = nna_g + i; ib = nna_g + na_g + i; flags |= 8; }
+      bool isv = false, isp = false;
+      for (int g = 0; g < G; ++g) {
+        if (md.vel[g] == lane) { isv = true; gvel = g; }
+        if (md.not_vel[g] == lane) isp = true;
+      }
+      own = (isv ? 1.0 : 0.0) + (isp ? 1.0 : 0.0);
+    } else if (ft_l) {
+      flags |= 2;
+      i0 = fq;
+      k0 = 1.0;
+      src = fq;
+      if (pl.kind == MCP_POLICY_ANGLES) {
+        for (int i = 0; i < pn; ++i)
+          if (i == fq) src = pl.non_angle[i];
+        for (int i = 0; i < pa; ++i) {
+          if (pn + i == fq) { src = pl.angle[i]; ftype = 1; }
+          if (pn + pa + i == fq) { src = pl.angle[i]; ftype = 2; }
+        }
+      } else if (pl.kind == MCP_POLICY_TRAJ && fq >= S) {
+        src = fq - S;
+        ftype = 3;
+      }
+    } else if (in_l) {
+      flags |= 4;
+      ia = nna_g + 2 * na_g + uk;
+      for (int k = 0; k < U; ++k)
+        if (k == uk) rum = 1.0 / pl.u_max[k];
+    }
+    if (ia >= 0) flags |= 32;
+    // 1 / l_q of the feature columns the lane gathers (the RBF stage sums l_q x adjoint) and of the feature it publishes
+    auto ilq = [&](int q) { return exp(-pl.log_ls[imin(q, PF - 1)]); };
+    k0 *= ilq(i0);
+    k1c *= ilq(i1);
+    k2c *= ilq(i2);
+    if (ft_l) ilf = ilq(fq);
+    int* ri = reinterpret_cast<int*>(rtab + lane * BW_RT);
+    ri[0] = src; ri[1] = imax(ia, 0); ri[2] = imax(ib, 0); ri[3] = i0;
+    ri[4] = i1; ri[5] = i2; ri[6] = flags | (ftype << 8); ri[7] = gvel;
+    double* rd = rtab + lane * BW_RT + 4;
+    rd[0] = k0; rd[1] = k1c; rd[2] = k2c; rd[3] = ilf; rd[4] = own; rd[5] = rum;
+  }
   lds_barrier();
 
   const int NRP = PB * NR;
@@ -294,6 +382,8 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   double glacc = 0.0;  // serial waves, lane q < PF: - sum over this wave's particle-steps of s_q sb_q
   double gbacc = 0.0;  // serial waves, lane k < U: dJ/dbias_k = sum over this wave's particle-steps of the pre-squash adjoint
   double fprev = 0.0;  // the policy feature this lane formed in the previous iteration of the sweep (= of step t+1)
+  double tgt_c = 0.0;                       // register chain, trajectory policies: the target entry of the step to come
+  double xbr = 0.0, kp1 = 0.0, kp2 = 0.0;  // register chain: adjoint of x_t without the policy path; feature-map coefficients of step t+1
   unsigned long long last_stamp = clock64();
   for (int mbase = blockIdx.x * PB; mbase < M; mbase += gridDim.x * PB) {
     const int msp = imin(mbase + sp, M - 1);  // particle of this wave's serial chain
@@ -306,6 +396,12 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     }
     prefetch(pre, T - 1, mbase);
     park(pre, cur);
+    xbr = 0.0;
+    kp1 = kp2 = 0.0;
+    if (FASTCHAIN && serial && pl.kind == MCP_POLICY_TRAJ) {
+      const int* ri = reinterpret_cast<const int*>(rtab + lane * BW_RT);
+      tgt_c = (ri[6] >> 8) == 3 ? pl.target_traj[(size_t)(T - 1) * S + ri[0]] : 0.0;
+    }
     lds_barrier();
     for (int t = T - 1; t >= 0; --t) {
       // thread / lane ids are laundered per step: what the unrolled feature loops derive from them (LDS addresses, predicates) is
@@ -317,104 +413,183 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       }
       const int b = tid;
       BW_STAMP(11);
-      if (t > 0) prefetch(pre, t - 1, mbase);
+      // the next step's record: issued at the top by the waves that have no chain to run, BEHIND the chain by the serial waves (the loads
+      // have the whole RBF stage to land; their registers and ~50 address instructions stay off the chain)
+      if (t > 0 && !(FASTCHAIN && serial)) prefetch(pre, t - 1, mbase);
       // ---- serial section: wave p for particle slot p -----------------------------------------------
       if (serial) {
-        // the record of this step was parked before the last workgroup barrier and is not written again until the next one:
-        // plain loads (the compiler may batch them), unlike the section's own scratch arrays, which need program order
-        clds_t r = (clds_t)(smem + L.rec) + cur * NRP + sp * NR;
-        const vlds_t redp = red + sp * NW * PF;
-        const bool last = (t == T - 1);
-        if (!last) {
-          // finish step t+1: adjoint of the policy features -> adjoint of x_{t+1}
-          if (lane < PF) {
-            double s = 0.0;
-            for (int w = 0; w < NW; ++w) s += redp[w * PF + lane];
-            s *= invl[lane];  // (the RBF stage sums the feature adjoints without their 1 / l_q)
-            sb[lane] = s;
-            glacc = fma(-fprev, s, glacc);  // fprev: this lane's policy feature of step t+1
-          }
-          __builtin_amdgcn_wave_barrier();
-          if (lane < S) {
-            double s;
-            if (pl.kind == MCP_POLICY_ANGLES) {
-              s = (pi_plain >= 0) ? sb[pi_plain] : 0.0;
-              if (pi_ang >= 0) s += -sb[pl.n_non_angle + pi_ang] * snm[lane] + sb[pl.n_non_angle + pl.n_angle + pi_ang] * csm[lane];
-            } else if (pl.kind == MCP_POLICY_TRAJ) {
-              s = sb[lane] - sb[S + lane];
+        if constexpr (FASTCHAIN) {
+          // ---- the register chain (see the role table above) ----
+          const double* rrow = rtab + lane * BW_RT;
+          const int4 ra = *reinterpret_cast<const int4*>(rrow), rb = *reinterpret_cast<const int4*>(rrow + 2);
+          const bw_v2d rk01 = *reinterpret_cast<const bw_v2d*>(rrow + 4), rk2f = *reinterpret_cast<const bw_v2d*>(rrow + 6),
+                       row_ = *reinterpret_cast<const bw_v2d*>(rrow + 8);
+          const int fl = rb.z & 255, ftype = rb.z >> 8;
+          const bool st_l = fl & 1, ft_l = fl & 2, in_l = fl & 4, zang = fl & 8, pang = fl & 16, has_j = fl & 32;
+          const int uk = in_l ? lane - BW_UL0 : 0;
+          clds_t r = (clds_t)(smem + L.rec) + cur * NRP + sp * NR;
+          const bool last = (t == T - 1);
+          // one batch of LDS reads: the record entries of this lane's role, its columns of d delta/dz, the partial feature adjoints
+          const double xs = r[oX + ra.x];
+          const double gb = r[st_l ? oGX + lane : oGU + uk];
+          const double uu = r[oU + uk];
+          constexpr int GMX = MCP_MAX_GP;
+          double Ja[GMX], Jb[GMX];
+#pragma unroll
+          for (int g = 0; g < GMX; ++g) {
+            if (g < G) {
+              Ja[g] = r[oJ + g * D + ra.y];
+              Jb[g] = r[oJ + g * D + ra.z];
             } else {
-              s = sb[lane];
+              Ja[g] = Jb[g] = 0.0;
             }
-            if (pms) s = meas_adjoint(s, t + 1);
-            xn[lane] = xb[lane] + s;
+          }
+          double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+          if (!last) {
+            const vlds_t redp = red + sp * NW * PF;
+            for (int w0 = 0; w0 < NW; w0 += 2) {  // (two waves' partials per pass: six reads in flight)
+              const int wa = w0, wb = imin(w0 + 1, NW - 1);
+              const double a0 = ((clds_t)redp)[wa * PF + ra.w], a1 = ((clds_t)redp)[wa * PF + rb.x], a2 = ((clds_t)redp)[wa * PF + rb.y];
+              const double b0 = ((clds_t)redp)[wb * PF + ra.w], b1 = ((clds_t)redp)[wb * PF + rb.x], b2 = ((clds_t)redp)[wb * PF + rb.y];
+              const bool okb = w0 + 1 < NW;
+              c0 += a0;
+              c1 += a1;
+              c2 += a2;
+              c0 += okb ? b0 : 0.0;
+              c1 += okb ? b1 : 0.0;
+              c2 += okb ? b2 : 0.0;
+            }
+          }
+          const double tgt = tgt_c;  // (trajectory policies: loaded a step ahead)
+          if (pl.kind == MCP_POLICY_TRAJ && ftype == 3 && t > 0) tgt_c = pl.target_traj[(size_t)(t - 1) * S + ra.x];
+          double sv = 0.0, cv = 1.0;
+          if (any_trig) sincos_fast(xs, &sv, &cv);
+          const double fn = ftype == 0 ? xs : (ftype == 1 ? cv : (ftype == 2 ? sv : tgt - xs));
+          if (ft_l) sf[lane - BW_FL0] = fn * rk2f.y;  // (scaled: what the RBF stage subtracts the scaled centres from)
+          const double s = last ? 0.0 : fma(kp2, c2, fma(kp1, c1, rk01.x * c0));
+          if (!last) glacc = fma(-fprev, s, glacc);  // feature lanes: - f_q(t+1) * (adjoint of f_q(t+1))
+          const double xnr = xbr + s;                 // state lanes: adjoint of x_{t+1}
+          double val = fma(row_.x, xnr, gb);
+#pragma unroll
+          for (int g = 0; g < GMX; ++g) {
+            if (g < G) {
+              const int lv = md.vel[g], lp = md.not_vel[g];
+              const double xnv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xnr), lv), __builtin_amdgcn_readlane(__double2loint(xnr), lv));
+              const double xnp = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xnr), lp), __builtin_amdgcn_readlane(__double2loint(xnr), lp));
+              const double dbg = fma(0.5 * md.Ts, xnp, xnv);
+              const double jc = zang ? fma(Ja[g], cv, -(Jb[g] * sv)) : Ja[g];
+              val = fma(g == rb.w ? md.Ts : 0.0, xnp, val);
+              val = fma(dbg, has_j ? jc : 0.0, val);
+            }
+          }
+          xbr = val;
+          const double th = uu * row_.y;
+          const double abv = (in_l && pl.squash) ? val * (1.0 - th * th) : val;
+          if (in_l) {
+            ab[uk] = abv;
+            if (spvalid) gbacc += abv;
+          }
+          kp1 = pang ? -sv * rk01.y : rk01.y;
+          kp2 = pang ? cv * rk2f.x : 0.0;
+          fprev = fn;
+        } else {
+          // the record of this step was parked before the last workgroup barrier and is not written again until the next one:
+          // plain loads (the compiler may batch them), unlike the section's own scratch arrays, which need program order
+          clds_t r = (clds_t)(smem + L.rec) + cur * NRP + sp * NR;
+          const vlds_t redp = red + sp * NW * PF;
+          const bool last = (t == T - 1);
+          if (!last) {
+            // finish step t+1: adjoint of the policy features -> adjoint of x_{t+1}
+            if (lane < PF) {
+              double s = 0.0;
+              for (int w = 0; w < NW; ++w) s += redp[w * PF + lane];
+              s *= invl[lane];  // (the RBF stage sums the feature adjoints without their 1 / l_q)
+              sb[lane] = s;
+              glacc = fma(-fprev, s, glacc);  // fprev: this lane's policy feature of step t+1
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < S) {
+              double s;
+              if (pl.kind == MCP_POLICY_ANGLES) {
+                s = (pi_plain >= 0) ? sb[pi_plain] : 0.0;
+                if (pi_ang >= 0) s += -sb[pl.n_non_angle + pi_ang] * snm[lane] + sb[pl.n_non_angle + pl.n_angle + pi_ang] * csm[lane];
+              } else if (pl.kind == MCP_POLICY_TRAJ) {
+                s = sb[lane] - sb[S + lane];
+              } else {
+                s = sb[lane];
+              }
+              if (pms) s = meas_adjoint(s, t + 1);
+              xn[lane] = xb[lane] + s;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // through the integrator:  x_{t+1}[vel] = x[vel] + delta ; x_{t+1}[pos] = x[pos] + Ts x[vel] + Ts/2 delta
+            if (lane < G) db[lane] = xn[t_vel[lane]] + 0.5 * md.Ts * xn[t_pos[lane]];
+          }
+          // trig of this step's angles (used now by the GP feature map, next iteration by the policy's)
+          if (lane < S && need_trig) {
+            double sv, cv;
+            sincos_fast(r[oX + lane], &sv, &cv);
+            sn[lane] = sv;
+            cs[lane] = cv;
+          }
+          if (pms && lane < S && pi_ang >= 0) {
+            double sv, cv;
+            sincos_fast(r[oM + lane], &sv, &cv);
+            snm[lane] = sv;
+            csm[lane] = cv;
           }
           __builtin_amdgcn_wave_barrier();
-          // through the integrator:  x_{t+1}[vel] = x[vel] + delta ; x_{t+1}[pos] = x[pos] + Ts x[vel] + Ts/2 delta
-          if (lane < G) db[lane] = xn[t_vel[lane]] + 0.5 * md.Ts * xn[t_pos[lane]];
-        }
-        // trig of this step's angles (used now by the GP feature map, next iteration by the policy's)
-        if (lane < S && need_trig) {
-          double sv, cv;
-          sincos_fast(r[oX + lane], &sv, &cv);
-          sn[lane] = sv;
-          cs[lane] = cv;
-        }
-        if (pms && lane < S && pi_ang >= 0) {
-          double sv, cv;
-          sincos_fast(r[oM + lane], &sv, &cv);
-          snm[lane] = sv;
-          csm[lane] = cv;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // through the GP Jacobian and the integrator's direct paths
-        if (lane < D) {
-          double s = 0.0;
-          if (!last)
-            for (int g = 0; g < G; ++g) s = fma(db[g], r[oJ + g * D + lane], s);
-          zb[lane] = s;
-        }
-        double xbv = 0.0;
-        if (lane < S) {
-          xbv = r[oGX + lane];
-          if (!last) {
-            if (g_vel >= 0) xbv += xn[lane] + md.Ts * xn[pos_of_vel];
-            if (g_pos >= 0) xbv += xn[lane];
+          // through the GP Jacobian and the integrator's direct paths
+          if (lane < D) {
+            double s = 0.0;
+            if (!last)
+              for (int g = 0; g < G; ++g) s = fma(db[g], r[oJ + g * D + lane], s);
+            zb[lane] = s;
           }
-        }
-        // policy features of x_t  (Policy.py:326-333: [x_nonangle, COS, SIN];  :397-399: [x, x*_t - x])
-        if (lane < PF) {
-          double f;
-          if (pl.kind == MCP_POLICY_ANGLES) {
-            const int pn = pl.n_non_angle, pa_ = pl.n_angle;
-            if (lane < pn)
-              f = r[oM + t_pna[lane]];
-            else if (lane < pn + pa_)
-              f = csm[t_pan[lane - pn]];
-            else
-              f = snm[t_pan[lane - pn - pa_]];
-          } else if (pl.kind == MCP_POLICY_TRAJ) {
-            f = (lane < S) ? r[oM + lane] : pl.target_traj[(size_t)t * S + (lane - S)] - r[oM + lane - S];
-          } else {
-            f = r[oM + lane];
+          double xbv = 0.0;
+          if (lane < S) {
+            xbv = r[oGX + lane];
+            if (!last) {
+              if (g_vel >= 0) xbv += xn[lane] + md.Ts * xn[pos_of_vel];
+              if (g_pos >= 0) xbv += xn[lane];
+            }
           }
-          sf[lane] = f * invl[lane];  // (scaled: what the RBF stage subtracts the scaled centres from)
-          fprev = f;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // through the GP feature map z=[x_na, sin, cos, u]; adjoint of the pre-squash activation
-        if (lane < S) {
-          if (zi_plain >= 0) xbv += zb[zi_plain];
-          if (zi_ang >= 0) xbv += zb[nna_g + zi_ang] * cs[lane] - zb[nna_g + na_g + zi_ang] * sn[lane];
-          xb[lane] = xbv;
-        }
-        if (lane < U) {
-          double ubar = r[oGU + lane] + zb[nna_g + 2 * na_g + lane];
-          double th = r[oU + lane] / umax_lane;  // = tanh(a/u_max)
-          const double abv = pl.squash ? ubar * (1.0 - th * th) : ubar;
-          ab[lane] = abv;
-          if (spvalid) gbacc += abv;
+          // policy features of x_t  (Policy.py:326-333: [x_nonangle, COS, SIN];  :397-399: [x, x*_t - x])
+          if (lane < PF) {
+            double f;
+            if (pl.kind == MCP_POLICY_ANGLES) {
+              const int pn = pl.n_non_angle, pa_ = pl.n_angle;
+              if (lane < pn)
+                f = r[oM + t_pna[lane]];
+              else if (lane < pn + pa_)
+                f = csm[t_pan[lane - pn]];
+              else
+                f = snm[t_pan[lane - pn - pa_]];
+            } else if (pl.kind == MCP_POLICY_TRAJ) {
+              f = (lane < S) ? r[oM + lane] : pl.target_traj[(size_t)t * S + (lane - S)] - r[oM + lane - S];
+            } else {
+              f = r[oM + lane];
+            }
+            sf[lane] = f * invl[lane];  // (scaled: what the RBF stage subtracts the scaled centres from)
+            fprev = f;
+          }
+          __builtin_amdgcn_wave_barrier();
+          // through the GP feature map z=[x_na, sin, cos, u]; adjoint of the pre-squash activation
+          if (lane < S) {
+            if (zi_plain >= 0) xbv += zb[zi_plain];
+            if (zi_ang >= 0) xbv += zb[nna_g + zi_ang] * cs[lane] - zb[nna_g + na_g + zi_ang] * sn[lane];
+            xb[lane] = xbv;
+          }
+          if (lane < U) {
+            double ubar = r[oGU + lane] + zb[nna_g + 2 * na_g + lane];
+            double th = r[oU + lane] / umax_lane;  // = tanh(a/u_max)
+            const double abv = pl.squash ? ubar * (1.0 - th * th) : ubar;
+            ab[lane] = abv;
+            if (spvalid) gbacc += abv;
+          }
         }
       }
+      if (FASTCHAIN && t > 0 && serial) prefetch(pre, t - 1, mbase);
       BW_STAMP(8);
       lds_barrier();
       BW_STAMP(9);
@@ -554,7 +729,23 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       lds_barrier();
     }
     // finish step 0: adjoint of x_0
-    if (serial) {
+    if constexpr (FASTCHAIN) {
+     if (serial) {
+      const double* rrow = rtab + lane * BW_RT;
+      const int4 ra = *reinterpret_cast<const int4*>(rrow), rb = *reinterpret_cast<const int4*>(rrow + 2);
+      const double k0 = rrow[4];
+      clds_t redp = (clds_t)(red + sp * NW * PF);
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+      for (int w = 0; w < NW; ++w) {
+        c0 += redp[w * PF + ra.w];
+        c1 += redp[w * PF + rb.x];
+        c2 += redp[w * PF + rb.y];
+      }
+      const double s = fma(kp2, c2, fma(kp1, c1, k0 * c0));
+      glacc = fma(-fprev, s, glacc);
+      if ((rb.z & 1) && a.g_x0 && spvalid) a.g_x0[(size_t)msp * S + lane] = xbr + s;
+     }
+    } else if (serial) {
       const vlds_t redp = red + sp * NW * PF;
       if (lane < PF) {
         double s = 0.0;
@@ -601,8 +792,13 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       if (lane == 0) red[wv * PF + q] = sm;
     }
   }
-  if (serial && lane < PF) gla[sp * PF + lane] = glacc;
-  if (serial && lane < U) gla[PB * PF + sp * U + lane] = gbacc;
+  if (FASTCHAIN) {  // (register chain: feature q sits on lane BW_FL0 + q, input k on lane BW_UL0 + k)
+    if (serial && lane >= BW_FL0 && lane < BW_FL0 + PF) gla[sp * PF + lane - BW_FL0] = glacc;
+    if (serial && lane >= BW_UL0 && lane < BW_UL0 + U) gla[PB * PF + sp * U + lane - BW_UL0] = gbacc;
+  } else {
+    if (serial && lane < PF) gla[sp * PF + lane] = glacc;
+    if (serial && lane < U) gla[PB * PF + sp * U + lane] = gbacc;
+  }
   lds_barrier();
   for (int it = tid; it < PF; it += NT) {
     double sm = 0.0;
@@ -1121,6 +1317,13 @@ extern "C" size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_
   return bwd > fwd ? bwd : fwd;
 }
 
+template <int PFM, int UM, int MAXNT, int WPE, int PB, bool PMS>
+static int launch_bwd_pms(const BwdArgs& a, int grid, int NT, size_t lds, hipStream_t st) {
+  MCP_ENSURE_MAX_LDS(rollout_bwd_kernel<PFM, UM, MAXNT, WPE, PB, PMS>);
+  hipLaunchKernelGGL((rollout_bwd_kernel<PFM, UM, MAXNT, WPE, PB, PMS>), dim3(grid), dim3(NT), lds, st, a);
+  MCP_LAUNCH_CHECK();
+  return grid;
+}
 template <int PFM, int UM, int MAXNT, int WPE, int PB>
 static int launch_bwd(const BwdArgs& a, int NT, hipStream_t st) {
   if (NT > MAXNT || NT < 64 * PB) return MCP_ERR_LIMIT;
@@ -1131,10 +1334,7 @@ static int launch_bwd(const BwdArgs& a, int NT, hipStream_t st) {
   BwdLayout L = bwd_layout(md.S, md.U, md.D, md.G, a.pol.P, NT / 64, PB, pms, PFM > 8);
   const size_t lds = sizeof(double) * (size_t)L.total;
   if (lds > MCP_LDS_LIMIT) return MCP_ERR_LIMIT;
-  MCP_ENSURE_MAX_LDS(rollout_bwd_kernel<PFM, UM, MAXNT, WPE, PB>);
-  hipLaunchKernelGGL((rollout_bwd_kernel<PFM, UM, MAXNT, WPE, PB>), dim3(grid), dim3(NT), lds, st, a);
-  MCP_LAUNCH_CHECK();
-  return grid;
+  return pms ? launch_bwd_pms<PFM, UM, MAXNT, WPE, PB, true>(a, grid, NT, lds, st) : launch_bwd_pms<PFM, UM, MAXNT, WPE, PB, false>(a, grid, NT, lds, st);
 }
 
 extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T,
