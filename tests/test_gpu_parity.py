@@ -233,8 +233,10 @@ def test_rollout_cost_gradient_vs_reference(golden, name, kind, ppw):
     assert relerr(pol.weight.grad, fx["g_weight"]) < gt
 
 
-def test_rollout_vs_oracle_seeded_c1_shape():
-    """Config-1 shape at a size the oracle finishes in seconds: N=300, M=64, T=20, oracle-drawn noise."""
+@pytest.mark.parametrize("angle_shift", [0.0, 2.0 * np.pi * 50000.0])
+def test_rollout_vs_oracle_seeded_c1_shape(angle_shift):
+    """Config-1 shape at a size the oracle finishes in seconds: N=300, M=64, T=20, oracle-drawn noise.  Second case: the pole angle
+    starts 50 000 turns away -- beyond the range of the kernels' own sincos (|x| < 1e5), so every wave takes the library routine."""
     from gpu_helpers import G, dev, spec_from
     from mc_pilco_amd import ops
     from mc_pilco_amd import synthetic as sy
@@ -251,6 +253,7 @@ def test_rollout_vs_oracle_seeded_c1_shape():
     torch.manual_seed(5)
     e0, eps, masks = orc.draw_noise(M, 4, 2, 200, Tn, p)
     x0 = orc.sample_x0(T(c["x0_mean"]), T(c["x0_var"]), M, e0)
+    x0[:, 2] += angle_shift
     cost_fn = lambda st: orc.cart_pole_cost(st, T(c["cost_target"]), T(c["cost_ls"]), 2, 0)
     oc, os_, og, ost, oin = orc.policy_grad_step(m, pp, x0, Tn, cost_fn, p, eps, masks)
     # HIP path, pretrain included (Gram -> Cholesky -> inverse -> alpha on the device)
@@ -733,3 +736,56 @@ def test_lean_backward_sweep_matches_the_general_one(case):
     for ga, gb in zip(res[1], res[0]):
         assert torch.isfinite(gb).all()
         assert float((ga - gb).abs().max()) <= 1e-11 * float(gb.abs().max()), (float((ga - gb).abs().max()), float(gb.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G_,angles", [(3, False), (3, True), (4, False)])
+def test_lean_kernels_on_models_with_three_and_four_gps(G_, angles):
+    """The latency-lean forward and backward kernels on narrow models with more than two GPs (their 4-GP instantiations: clusters of G
+    workgroups meeting in the hand-off forward, rollout_bwd_lat_kernel<4> backward), against the general kernels on the same rollout:
+    a synthetic G-joint system (G positions + G velocities, one input; optionally the first position an angle), plain policy."""
+    from gpu_helpers import G, dev, forced_variant, spec_from
+    from mc_pilco_amd import hipabi, ops
+
+    rng = np.random.RandomState(40 + G_)
+    S, U, N, B, M, Tn, p = 2 * G_, 1, 48, 40, 24, 9, 0.25
+    angle = [0] if angles else []
+    not_angle = [i for i in range(S) if i not in angle]
+    D = len(not_angle) + 2 * len(angle) + U
+    fwd_lean_ok = D <= 8 and D - U <= 6  # (the forward kernel's lane roles; the backward one takes all three shapes)
+    Z = rng.randn(N, D) * 0.8
+    gps = []
+    for g in range(G_):
+        sp = spec_from(1.0 + rng.rand(D), 0.05, lam=0.5 + 0.1 * g)
+        K = ops.cov_build(sp, G(Z), None, noise=True)
+        Uc, _, stt = ops.chol_factor(K)
+        assert int(stt.item()) == 0
+        _, Kinv = ops.chol_inverse(Uc)
+        alpha = ops.gp_alpha(Kinv, G(0.05 * rng.randn(N)), 0.0)
+        gps.append(ops.PackedGP(sp, G(Z), alpha, Kinv))
+    model = ops.PackedModel(gps, S, U, 0.05, angle, not_angle, list(range(G_, 2 * G_)), list(range(G_)))
+    mk = lambda: ops.PackedPolicy("plain", S, G(np.zeros((1, S))).requires_grad_(True), G(rng.randn(B, S)).requires_grad_(True),
+                                  G(0.3 * rng.randn(U, B)).requires_grad_(True), [2.0], True)
+    rs = rng.get_state()
+    x0 = G(0.3 * rng.randn(M, S))
+    nz = ops.NoiseSpec(seed=5, call=2)
+    L = hipabi.lib()
+    res = {}
+    try:
+        for lean in (1, 0):
+            rng.set_state(rs)
+            pol = mk()
+            L.mcp_debug_set_bwd_lean(-1 if lean else 0)
+            with forced_variant(0 if lean else 104):
+                x0v = x0.clone().requires_grad_(True)
+                st, inp, status = ops.rollout(model, pol, nz, x0v, Tn, p)
+                ((st ** 2).mean() + 0.1 * (inp ** 2).mean()).backward()
+                assert bool(L.mcp_debug_last_fwd_lean()) == bool(lean and fwd_lean_ok) and bool(L.mcp_debug_last_bwd_lean()) == bool(lean)
+            assert int(status.item()) == 0
+            res[lean] = [st.detach().clone(), inp.detach().clone(), pol.log_ls.grad.clone(), pol.centers.grad.clone(), pol.weight.grad.clone(),
+                         x0v.grad.clone()]
+    finally:
+        L.mcp_debug_set_bwd_lean(-1)
+    for a_, b_ in zip(res[1], res[0]):
+        assert torch.isfinite(b_).all()
+        assert float((a_ - b_).abs().max()) <= 1e-10 * max(1e-30, float(b_.abs().max())), (float((a_ - b_).abs().max()), float(b_.abs().max()))
