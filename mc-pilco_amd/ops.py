@@ -414,6 +414,7 @@ class RolloutFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, log_ls, centers, weight, bias, model, policy, noise, T, p_drop, particle_pred, meas=None, gp_sharding=True):
         need = any(ctx.needs_input_grad[:5])
+        ctx.set_materialize_grads(False)  # (an output the cost does not use -- usually the inputs -- arrives as None, not as a zero-filled tensor)
         out = rollout_forward_raw(model, policy, noise, x0, T, p_drop, particle_pred, need_jac=need, meas=meas, gp_sharding=gp_sharding)
         states, inputs, jac, status = out[:4]
         ctx.model, ctx.policy, ctx.noise, ctx.p_drop = model, policy, noise, p_drop
@@ -428,6 +429,8 @@ class RolloutFunction(torch.autograd.Function):
         states, inputs, jac = ctx.saved_tensors
         if not ctx.has_jac:
             jac = None
+        if g_states is None and g_inputs is None:  # (nothing downstream depends on the rollout)
+            g_states = torch.zeros_like(states)
         g_ls, g_c, g_w, g_x0, g_b = rollout_backward_raw(ctx.model, ctx.policy, ctx.noise, states, inputs, jac, g_states, g_inputs, ctx.p_drop,
                                                          want_gx0=ctx.needs_input_grad[0], meas=ctx.meas, meas_buf=ctx.meas_buf)
         if g_b is not None:
@@ -506,6 +509,7 @@ class ExpectedCostFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, states, cost, group, counts):
+        ctx.set_materialize_grads(False)
         mom, _, _ = cost_moments(cost, states)
         M = states.shape[1]
         if group is not None:
@@ -525,6 +529,8 @@ class ExpectedCostFunction(torch.autograd.Function):
     def backward(ctx, g_cost, _g_std):
         (states,) = ctx.saved_tensors
         T, M, _ = states.shape
+        if g_cost is None:  # (only the std output is used downstream: this operator carries no gradient through it, as before)
+            return torch.zeros_like(states), None, None, None
         g = torch.empty_like(states)
         st = states.contiguous()
         gc = g_cost.detach().to(dtype=DT).reshape(1).contiguous()  # stays on the device: no host sync
