@@ -33,6 +33,7 @@ struct BwdArgs {
   double* slab;  // [gridDim.x][nparam]
   double* g_x0;
   unsigned long long* stamps;  // diagnostic only: per-stage cycle totals of workgroup 0 (slots 8..11)
+  int m_base, slab_accum;      // rollout_bwd_lat_kernel: first particle of this launch; its slabs add to what an earlier launch left
 };
 
 #define BW_STAMP(k)                                 \
@@ -835,6 +836,9 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
 //     (all of it depends on x_t only), so that behind it only the multiply-adds and the 8-value wave sum remain.
 // Same gradients as the general kernel up to summation order (tests/test_gpu_parity.py compares them on every policy kind it covers).
 #define BL_GM 4    // GPs
+#ifndef BL_MAX_M
+#define BL_MAX_M 3072  // largest swarm the lean sweep takes (tools/sweep_bwd_particles.py on a 256-CU device: it wins up to ~3000 particles)
+#endif
 #define BL_FL0 8   // first feature lane of wave 0
 #define BL_UL0 16  // first input lane of wave 0
 // (scalar members only: with arrays inside, part of the struct stayed a stack object -- two of its prefetched values went through
@@ -918,8 +922,11 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   // ---- RBF threads: basis b = tid - 64 --------------------------------------------------------------------------------------
   const int b = tid - 64;
-  const int m = imin((int)blockIdx.x * 2 + slot, M - 1);
-  const bool valid = (int)blockIdx.x * 2 + slot < M;  // (an odd swarm's last slot idles through the barriers)
+  // (swarms beyond 512 particles: one launch per 512, a.m_base = its first particle -- a loop over the rounds inside the kernel cost the
+  //  one-round form its register allocation: the chain's LDS reads serialised, 0.19 -> 0.21 ms at M = 400)
+  const int mg = a.m_base + (int)blockIdx.x * 2 + slot;
+  const int m = imin(mg, M - 1);
+  const bool valid = mg < M;  // (an odd swarm's last slot idles through the barriers)
   const bool act = valid && wv > 0 && b < B;
   const int bs = wv > 0 ? b : 0;  // column of s_cen
   double gc[PFM], wgt[UM], gw[UM];
@@ -1062,9 +1069,20 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       };
       double xb = 0.0;
       auto gather = [&]() -> double {  // the feature adjoints of the step just finished by the RBF waves, mapped to this lane's role
-        const double c0 = ((s_red[0][i0] + s_red[1][i0]) + s_red[2][i0]) + s_red[3][i0];
-        const double c1 = ((s_red[0][i1] + s_red[1][i1]) + s_red[2][i1]) + s_red[3][i1];
-        const double c2 = ((s_red[0][i2] + s_red[1][i2]) + s_red[2][i2]) + s_red[3][i2];
+        // all twelve reads in flight before the first add (the pin: with fewer registers at hand the allocator reused one destination
+        // for all of them and the chain waited for six LDS round trips one after the other -- seen in the ISA, 0.7 k -> 1.15 k cycles)
+        double r0[4], r1[4], r2[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          r0[w] = s_red[w][i0];
+          r1[w] = s_red[w][i1];
+          r2[w] = s_red[w][i2];
+        }
+        asm volatile("" ::"v"(r0[0]), "v"(r0[1]), "v"(r0[2]), "v"(r0[3]), "v"(r1[0]), "v"(r1[1]), "v"(r1[2]), "v"(r1[3]), "v"(r2[0]), "v"(r2[1]),
+                     "v"(r2[2]), "v"(r2[3]));
+        const double c0 = ((r0[0] + r0[1]) + r0[2]) + r0[3];
+        const double c1 = ((r1[0] + r1[1]) + r1[2]) + r1[3];
+        const double c2 = ((r2[0] + r2[1]) + r2[2]) + r2[3];
         return fma(k2p, c2, fma(k1p, c1, k0 * c0));
       };
       auto chain = [&](bool last) {
@@ -1205,14 +1223,22 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   // ---- this workgroup's partial parameter gradients (the slab layout of the general kernel) -----------------------------------
   const int nparam = PF + B * PF + U * B;
-  double* out = a.slab + (size_t)m * (nparam + (pl.bias ? U : 0));  // one slab per particle
+  double* out = a.slab + (size_t)(mg & 1023) * (nparam + (pl.bias ? U : 0));  // one slab per particle (modulo the 1024 the workspace holds)
+  const bool accum = a.slab_accum != 0;  // (this launch's particles share their slabs with an earlier launch's: add)
   if (act) {
 #pragma unroll
     for (int q = 0; q < PFM; ++q)
-      if (q < PF) out[PF + (size_t)b * PF + q] = gc[q] * s_invl[q];  // (accumulated without the 1 / l_q)
+      if (q < PF) {
+        double* o = out + PF + (size_t)b * PF + q;
+        const double v = gc[q] * s_invl[q];  // (accumulated without the 1 / l_q)
+        *o = accum ? *o + v : v;
+      }
 #pragma unroll
     for (int k = 0; k < UM; ++k)
-      if (k < U) out[PF + (size_t)B * PF + (size_t)k * B + b] = gw[k];
+      if (k < U) {
+        double* o = out + PF + (size_t)B * PF + (size_t)k * B + b;
+        *o = accum ? *o + gw[k] : gw[k];
+      }
   }
   __syncthreads();  // (the chain's last reads of s_red are done)
   if (wv > 0) {
@@ -1226,8 +1252,11 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (in_lane) s_fin[PFM + uk] = gbacc;
   }
   __syncthreads();
-  if (valid && tid < PF) out[tid] = (((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid]) + s_fin[tid];
-  if (valid && pl.bias && tid < U) out[nparam + tid] = s_fin[PFM + tid];
+  if (valid && tid < PF) {
+    const double v = (((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid]) + s_fin[tid];
+    out[tid] = accum ? out[tid] + v : v;
+  }
+  if (valid && pl.bias && tid < U) out[nparam + tid] = accum ? out[nparam + tid] + s_fin[PFM + tid] : s_fin[PFM + tid];
   if (a.stamps && blockIdx.x == 0 && threadIdx.x >= 8 && threadIdx.x < 16) a.stamps[threadIdx.x] = s_stamp[threadIdx.x];
   if (a.stamps && tid == 0) {  // diagnostic: spread of the workgroups' run times (core cycles) and start / end times (100 MHz wall clock)
     atomicMax(&a.stamps[0], clock64() - t_begin);
@@ -1368,13 +1397,15 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   a.slab = (double*)workspace;
   a.g_x0 = g_x0;
   a.stamps = g_bwd_stamps;
+  a.m_base = 0;
+  a.slab_accum = 0;
   hipStream_t st = (hipStream_t)stream;
   const int PF = policy->P, U = policy->U;
   // particles per workgroup: large swarms are latency bound per workgroup, so several particles share one sweep; small
   // swarms keep one particle per workgroup to spread over the CUs
   // (two 256-thread workgroups per CU are resident: one particle per workgroup while M of them fit in one round, then 2, then 4;
   //  measured, tools/sweep_bwd_particles.py: M=800 1.74 / 1.34 / 1.92 ms, M=2000 3.24 / 2.51 / 2.07 ms for 1 / 2 / 4)
-  int PB = g_force_bwd_pb ? g_force_bwd_pb : (M > 1024 ? 4 : (M > 512 ? 2 : 1));
+  int PB = g_force_bwd_pb ? g_force_bwd_pb : (M > 2816 ? 4 : (M > 512 ? 2 : 1));  // (round 3, after the RBF stage's diet: 2 particles win up to ~2800, tools/sweep_bwd_particles.py)
   if (!g_force_bwd_pb && (PF > 16 || U > 4)) PB = M > 1024 ? 4 : 1;  // wide policies: four particles per sweep on large swarms where the
                                                                       // instantiation exists (> 256 basis functions), else two
                                                                       // (tools/time_bwd.py, UR5 shape, M = 2000, T = 300: 18.1 / 15.5 / 14.5 ms for 1 / 2 / 4)
@@ -1382,16 +1413,21 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   int NT = imax(bwd_threads(policy->B), 64 * PB);
   int rc = MCP_ERR_LIMIT;
   g_last_bwd_lean = 0;
-  if (g_bwd_lean != 0 && !g_force_bwd_pb && PB == 1 && M <= 1024 && model != &stub && bwd_lean_applies(model, policy, T)) {
+  if (g_bwd_lean != 0 && !g_force_bwd_pb && M <= BL_MAX_M && model != &stub && bwd_lean_applies(model, policy, T)) {
     // small swarm, narrow class: the latency-lean sweep (wave 0 = the chain, the basis functions in the waves behind it)
-    const int grid = (M + 1) / 2, nt = 2 * (64 + bwd_threads(policy->B));  // two particle slots per workgroup
-    if (model->G <= 2)
-      hipLaunchKernelGGL(rollout_bwd_lat_kernel<2>, dim3(grid), dim3(nt), 0, st, a);
-    else
-      hipLaunchKernelGGL(rollout_bwd_lat_kernel<BL_GM>, dim3(grid), dim3(nt), 0, st, a);
-    MCP_LAUNCH_CHECK();
+    const int nt = 2 * (64 + bwd_threads(policy->B));  // two particle slots per workgroup
+    for (int mb = 0; mb < M; mb += 512) {           // one launch per 512 particles = 256 workgroups: a resident round each
+      const int grid = (imin(M - mb, 512) + 1) / 2;
+      a.m_base = mb;
+      a.slab_accum = mb >= 1024;
+      if (model->G <= 2)
+        hipLaunchKernelGGL(rollout_bwd_lat_kernel<2>, dim3(grid), dim3(nt), 0, st, a);
+      else
+        hipLaunchKernelGGL(rollout_bwd_lat_kernel<BL_GM>, dim3(grid), dim3(nt), 0, st, a);
+      MCP_LAUNCH_CHECK();
+    }
     g_last_bwd_lean = 1;
-    rc = M;  // slabs: one per particle
+    rc = imin(M, 1024);  // slabs: one per particle, modulo the 1024 the workspace holds
     PB = 0;
   }
   // register budget: 3*PFM + 2*UM doubles of per-thread accumulators plus the prefetched record; the launch bound is the

@@ -700,11 +700,12 @@ def test_wide_class_with_a_different_subset_size_per_gp():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [("c1", 400, 150, 0.25, "philox"), ("c1", 37, 2, 0.25, "philox"), ("c1", 64, 9, 0.0, "philox"), ("c1", 48, 12, 0.25, "masks"),
-                                  ("c3", 96, 20, 0.25, "philox")])
+                                  ("c3", 96, 20, 0.25, "philox"), ("c1", 1333, 7, 0.25, "philox"), ("c1", 600, 5, 0.25, "masks")])
 def test_lean_backward_sweep_matches_the_general_one(case):
     """rollout_bwd_lat_kernel (small swarms: wave 0 runs the adjoint chain from registers, the RBF waves prepare their step ahead of the
     barrier) against the general sweep on the same rollout: all three policy gradients and dJ/dx0 to 1e-11 relative (different
-    summation order only), with in-kernel dropout bits, with mask buffers, without dropout, at T = 2 and at the headline size."""
+    summation order only), with in-kernel dropout bits, with mask buffers, without dropout, at T = 2, at the headline size, and beyond 512
+    particles, where 256 workgroups walk several particles per slot (an uneven number of rounds at M = 1333 and 600)."""
     from gpu_helpers import dev
     from mc_pilco_amd import hipabi, ops, workloads
 

@@ -3,10 +3,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mcp_boot, torch
 from mc_pilco_amd import hipabi, ops, workloads
 dev = torch.device("cuda", 0)
-for name, M in [("c1", 400), ("c1", 800), ("c1", 1024), ("c1", 2000), ("c1", 4000)]:
+"""Diagnostic: backward sweep time per particles-per-workgroup setting over the swarm size (0 = the automatic choice, which below 513 particles
+is the latency-lean sweep).   python tools/sweep_bwd_particles.py [workload]"""
+wl = sys.argv[1] if len(sys.argv) > 1 else "c1"
+for name, M in [(wl, 400), (wl, 800), (wl, 1024), (wl, 1536), (wl, 2000), (wl, 2560), (wl, 3072), (wl, 4000)]:
     w = workloads.build(name, device=dev, M=M)
     x0 = w.sample_x0()
-    for pb in (1, 2, 4):
+    for pb in (0, 1, 2, 4):
         hipabi.lib().mcp_debug_set_bwd_particles(pb)
         ts = []
         for i in range(4):
