@@ -422,6 +422,17 @@ __device__ __forceinline__ void tile_phase_j(const GpL& gp, PT Xt, PT al, int xp
   const int cc0 = ONE_RT ? imin(n & 3, D - 1) : imin(n, D - 1), cc1 = ONE_RT ? imin(4 + (n & 3), D - 1) : imin(16 + n, D - 1);
   const int nbat = (j1 - j0 + 15) >> 4;
   if (dbg && lane == 0) { unsigned long long now = clock64(); dbg[14] += now - tq0; tq0 = now; }
+  if constexpr (DEG >= 2 && NDQ > 2) {
+    // wide classes with the degree-2 kernel: one operand batch at a time.  Two in flight (72 VGPRs beside 10 accumulator tiles and the 12
+    // factor operands) put 38-95 registers of these instantiations into scratch, reloaded inside this loop.
+    TileJBatch<DEG, NDQ> b0;
+    for (int b = 0; b < nbat; ++b) {
+      tile_j_load<DEG, NDQ, PT, ONE_RT>(b0, Xt, al, xpitch, Npad, D, RT, cc0, cc1, j0 + 16 * b, kk, n);
+      tile_j_consume<DEG, NDQ, ONE_RT>(b0, zwa, zwb, D, RT, Npad, j0 + 16 * b, j1, kk, n, ks, kv, acc);
+    }
+    if (dbg && lane == 0) dbg[15] += clock64() - tq0;
+    return;
+  }
   TileJBatch<DEG, NDQ> b0, b1;
   tile_j_load<DEG, NDQ, PT, ONE_RT>(b0, Xt, al, xpitch, Npad, D, RT, cc0, cc1, j0, kk, n);
   for (int b = 0; b + 1 < nbat; b += 2) {

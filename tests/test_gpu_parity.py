@@ -368,7 +368,7 @@ def test_pms_philox_mode_is_reproducible_and_shard_invariant():
     assert float((t16[0] - a[0]).abs().max()) < 1e-9 and float((t16[1] - a[1]).abs().max()) < 1e-9
 
 
-@pytest.mark.parametrize("case", [("cartpole", 0, 20, 17, 3), ("cartpole", 2, 33, 5, 2), ("cartpole", 1, 16, 1, 4), ("ur5", 1, 17, 3, 3),
+@pytest.mark.parametrize("case", [("cartpole", 0, 20, 17, 3), ("cartpole", 2, 33, 5, 2), ("cartpole", 1, 16, 1, 4), ("ur5", 1, 17, 3, 3), ("ur5", 2, 40, 19, 3),
                                   ("cartpole", 0, 130, 35, 4)])
 def test_kernel_variants_agree_on_odd_shapes(case):
     """Every forward variant (1, 2, 4, 16 particles per workgroup; GP-sharded clusters of 1, 2, 4) and backward sweep width (1, 2, 4) on shapes that exercise
