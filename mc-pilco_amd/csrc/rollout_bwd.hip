@@ -124,8 +124,8 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   // the register chain serves the wide classes (C5 backward 9.2 -> 8.4 ms).  On the narrow class at 2-4 particles per workgroup the sweep is issue
   // bound with four 256-thread workgroups per CU and must stay within 128 registers for that: the chain's batch of operands then spills (24-40
   // VGPRs) and the gain measured 1.5 % (C3 backward 1.64 -> 1.62 ms) -- not kept; small swarms of the narrow class run rollout_bwd_lat_kernel.
-  constexpr bool FASTCHAIN = !PMS && PFM > 8;
-  constexpr bool CENREG = PFM <= 8;  // narrow policies keep their centres in registers; wider ones in LDS (transposed: conflict-free)
+  constexpr bool FASTCHAIN = !PMS && PFM > 8 && MAXNT <= 512;  // (the 1024-thread forms have 128 registers: the LDS-staged chain)
+  constexpr bool CENREG = PFM <= 8 && MAXNT <= 512;  // narrow policies keep their centres in registers; wider ones -- and the 1024-thread forms with their 128 registers -- in LDS (transposed: conflict-free)
   const BwdLayout L = bwd_layout(S, U, D, G, PF, NW, PB, pms, !CENREG);
   const int NR = bwd_rec_len(S, U, D, G, pms);
   const int PS = L.pstride;
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     for (int t = T - 1; t >= 0; --t) {
       // thread / lane ids are laundered per step: what the unrolled feature loops derive from them (LDS addresses, predicates) is
       // recomputed where it is used instead of being hoisted out of the sweep, kept live next to the accumulators and spilled
-      if (BW_LAUNDER(PFM, PB)) {
+      if (BW_LAUNDER(PFM, PB) || MAXNT > 512) {  // (the 1024-thread forms: 128 registers)
         asm volatile("" : "+v"(tid));
         lane = tid & 63;
         pf_tid = pf_split ? tid - 64 * PB : tid;
@@ -1360,7 +1360,7 @@ static int launch_bwd(const BwdArgs& a, int NT, hipStream_t st) {
   const bool pms = a.pol.meas.n > 0;
   if (PB * bwd_rec_len(md.S, md.U, md.D, md.G, pms) > BW_RPT * (NT / 64 > PB ? NT - 64 * PB : NT)) return MCP_ERR_LIMIT;
   const int grid = imin((a.M + PB - 1) / PB, 1024);
-  BwdLayout L = bwd_layout(md.S, md.U, md.D, md.G, a.pol.P, NT / 64, PB, pms, PFM > 8);
+  BwdLayout L = bwd_layout(md.S, md.U, md.D, md.G, a.pol.P, NT / 64, PB, pms, PFM > 8 || MAXNT > 512);
   const size_t lds = sizeof(double) * (size_t)L.total;
   if (lds > MCP_LDS_LIMIT) return MCP_ERR_LIMIT;
   return pms ? launch_bwd_pms<PFM, UM, MAXNT, WPE, PB, true>(a, grid, NT, lds, st) : launch_bwd_pms<PFM, UM, MAXNT, WPE, PB, false>(a, grid, NT, lds, st);

@@ -233,10 +233,11 @@ def test_rollout_cost_gradient_vs_reference(golden, name, kind, ppw):
     assert relerr(pol.weight.grad, fx["g_weight"]) < gt
 
 
-@pytest.mark.parametrize("angle_shift", [0.0, 2.0 * np.pi * 50000.0])
-def test_rollout_vs_oracle_seeded_c1_shape(angle_shift):
+@pytest.mark.parametrize("angle_shift,B", [(0.0, 200), (2.0 * np.pi * 50000.0, 200), (0.0, 300)])
+def test_rollout_vs_oracle_seeded_c1_shape(angle_shift, B):
     """Config-1 shape at a size the oracle finishes in seconds: N=300, M=64, T=20, oracle-drawn noise.  Second case: the pole angle
-    starts 50 000 turns away -- beyond the range of the kernels' own sincos (|x| < 1e5), so every wave takes the library routine."""
+    starts 50 000 turns away -- beyond the range of the kernels' own sincos (|x| < 1e5), so every wave takes the library routine.
+    Third case: 300 basis functions -- the backward sweep's 1024-thread form (more than 256 basis functions, 128 registers per thread)."""
     from gpu_helpers import G, dev, spec_from
     from mc_pilco_amd import ops
     from mc_pilco_amd import synthetic as sy
@@ -246,12 +247,12 @@ def test_rollout_vs_oracle_seeded_c1_shape(angle_shift):
     hyp = [hyper(c["lengthscales"], c["sigma_n"]) for _ in range(2)]
     caches = [orc.pretrain_gp(hyp[g], T(Z), T(Ys[g])) for g in range(2)]
     m = orc.SpeedModel(hyp, caches, c["Ts"], c["angle"], c["not_angle"], c["vel"], c["not_vel"])
-    pi = sy.cartpole_policy_init()
+    pi = sy.cartpole_policy_init(B=B)
     pp = orc.PolicyPar(torch.log(T(pi["lengthscales"])).reshape(1, -1), T(pi["centers"]), T(pi["weight"]), c["u_max"], "angles", angle=[2],
                        non_angle=[0, 1, 3])
     M, Tn, p = 64, 20, 0.25
     torch.manual_seed(5)
-    e0, eps, masks = orc.draw_noise(M, 4, 2, 200, Tn, p)
+    e0, eps, masks = orc.draw_noise(M, 4, 2, B, Tn, p)
     x0 = orc.sample_x0(T(c["x0_mean"]), T(c["x0_var"]), M, e0)
     x0[:, 2] += angle_shift
     cost_fn = lambda st: orc.cart_pole_cost(st, T(c["cost_target"]), T(c["cost_ls"]), 2, 0)
