@@ -77,8 +77,18 @@ class GP_prior(torch.nn.Module):
         """The active columns of X as a contiguous float64 GPU matrix."""
         X = X.to(device=self.device, dtype=torch.float64)
         ad = self._active()
-        if ad is not None and not (ad.numel() == X.shape[1] and bool((ad == torch.arange(X.shape[1], device=ad.device)).all())):
-            X = X[:, ad]
+        if ad is not None:
+            # "the active dimensions are all columns, in order" is decided ONCE per (index tensor, width): the comparison reads a device
+            # tensor back -- a host sync -- and this runs in every epoch of GP training and every pretrain
+            key = (id(ad), int(ad.numel()), int(X.shape[1]))
+            cache = self.__dict__.setdefault("_cols_identity", {})
+            ident = cache.get(key)
+            if ident is None:
+                ident = ad.numel() == X.shape[1] and bool((ad.detach().cpu() == torch.arange(X.shape[1])).all())
+                cache.clear()
+                cache[key] = ident
+            if not ident:
+                X = X[:, ad]
         return X.contiguous()
 
     def _active(self):
