@@ -150,7 +150,15 @@ def ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream():
+    """The current HIP stream of the current device (every launch goes there).  Through torch's raw-handle getter where this build has
+    it: ``torch.cuda.current_stream()`` builds a Stream object per call, ~11 us -- 3-5 of them per optimizer step / training epoch."""
+    if _raw_stream is not None and _cur_device is not None:
+        return C.c_void_p(_raw_stream(_cur_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -11,4 +11,4 @@ pr.enable()
 s, n = workloads.time_fit_model(dev, 300, 200)
 pr.disable()
 print("ms per epoch per GP", 1e3 * s)
-pstats.Stats(pr).sort_stats("tottime").print_stats(35)
+pstats.Stats(pr).sort_stats("cumulative").print_stats(40)
