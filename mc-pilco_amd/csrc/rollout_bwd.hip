@@ -11,6 +11,10 @@
 // time steps and all particles the workgroup visits; per-step cross-basis sums (the adjoint of the
 // policy features) are wave64 DPP sums meeting in LDS.  Workgroup partial gradients go to a slab
 // that grad_reduce_kernel sums in a fixed order (deterministic, no atomics).
+//
+// Two kernels:  rollout_bwd_kernel<PFM, UM, MAXNT, WPE, PB, PMS>  -- the general sweep (any class, 1 / 2 / 4 particles per workgroup, measurement
+// models), and  rollout_bwd_lat_kernel<GM>  -- narrow plain / angle policies on swarms up to 3072 particles: one chain wave per particle working
+// from registers beside RBF waves that prepare their step ahead of the barrier.
 #include "rollout_common.h"
 #include <type_traits>
 
