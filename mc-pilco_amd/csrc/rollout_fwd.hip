@@ -1728,6 +1728,13 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
       if (t < T - 1) {
 #pragma unroll
         for (int r = 0; r < KR; ++r) {
+          // (the last round holds N P - (KR - 1) 512 items: at N = 300, P = 4 three of the eight waves; the others skip it -- wave-uniform)
+          if (r == KR - 1 && r > 0 && ((wv * 64 + r * RF_NT) >> LP) >= Npad) {
+            ds[r] = 0.0;
+#pragma unroll
+            for (int k = 0; k < RL_UM; ++k) xin[r][k] = 0.0;
+            continue;
+          }
           const int j = imin((tid + r * RF_NT) >> LP, Npad - 1);
           double xv[RL_DSM];
 #pragma unroll
@@ -1821,6 +1828,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
       const double lambda = gpl[0].lambda;
 #pragma unroll
       for (int r = 0; r < KR; ++r) {
+        if (r == KR - 1 && r > 0 && ((wv * 64 + r * RF_NT) >> LP) >= Npad) continue;  // (no item of this wave in the last round)
         const int it = tid + r * RF_NT;
         const int j = it >> LP;
         double dd = ds[r];
