@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MCP_ABI_VERSION 4
+#define MCP_ABI_VERSION 5 /* 5: mcp_kernel.scal, MCP_FWD_NO_GP_SHARDING, MCP_STATUS_NEG_VAR, mcp_nll_epoch, mcp_adam_step_guarded (round 4) */
 
 #define MCP_OK 0
 #define MCP_ERR_ARG (-1)       /* null pointer / non-positive size                       */
@@ -39,7 +39,7 @@ extern "C" {
 #define MCP_ERR_COMM (-5)      /* RCCL is not loadable / no communicator / a collective failed */
 
 #define MCP_STATUS_NAN 1u         /* a NaN was produced in a state / input / cost          */
-#define MCP_STATUS_NONPOS_VAR 2u  /* a GP posterior variance <= 0 (torch Normal would raise) */
+#define MCP_STATUS_NONPOS_VAR 2u  /* a FINITE GP posterior variance <= 0 (torch Normal raises ValueError); a NaN variance sets MCP_STATUS_NAN only */
 #define MCP_STATUS_NOT_SPD 4u     /* Cholesky met a non-positive pivot                     */
 #define MCP_STATUS_SYNC 8u        /* GP-sharded rollout: a partner workgroup never arrived   */
 
@@ -265,6 +265,48 @@ int mcp_cost_sums(int T, int M, const double* moments, const double* shift, doub
 /* sums [2T] added over all ranks (n_total particles) -> out[0] = sum_t mean_m c, out[1] = sum_t unbiased std_m c
  * (Cost_function.py:32-36 on the pooled swarm); mean_out [T] (optional) receives the pooled mean per time step. */
 int mcp_cost_finalize_sums(int T, int64_t n_total, const double* sums, const double* shift, double* out, double* mean_out,
+                           void* stream);
+
+/* ---- the optimizer loop's bookkeeping on the device (MC_PILCO.reinforce_policy, policy_learning/MC_PILCO.py:475-607) ----------
+ * The reference decides on the host, from torch.isnan(cost), whether a rollout counts, and so reads every step's cost back before
+ * it can launch the next one.  These two entry points take the same decisions from device memory after each ATTEMPT (rollout +
+ * cost + adjoint sweep), so the host may enqueue the next attempt at once and read the outcome (a small record) one attempt late:
+ *   - an attempt FAILS when its cost is NaN (or flags / status say so: hand-off time-out, non-positive variance): nothing is
+ *     updated, the next attempt is the retry (:479-501: "Cost is NaN: try sampling again", at most MCP_OPT_MAX_ATTEMPTS);
+ *   - it is VOID while the loop waits for the host: after the tenth failure in a row (re-initialisation, :573-607), after the
+ *     lr / exit condition fired (`pending`, :540-567), after step n_steps;
+ *   - otherwise it COUNTS: parameters updated, cost_list / std_list [step] written, the cost-difference monitors advanced
+ *     (ES1, ES2, diff_cost_ratio, :503-519), step += 1.
+ * mcp_opt_state lives in device memory, zero-initialised (+ cost_prev = the warm-up cost, :462) by the caller; the caller resets
+ * it (memset on the stream) when it builds a new optimizer or re-initialises the policy. */
+#define MCP_OPT_MAX_ATTEMPTS 10
+#define MCP_OPT_MAX_TENSORS 8
+#define MCP_OPT_RECORD_DOUBLES 12
+typedef struct mcp_opt_state {
+  int64_t step;           /* optimizer steps taken since the last (re-)initialisation = next index of cost_list            */
+  int64_t attempt;        /* failed attempts of the current step                                                          */
+  int64_t pending;        /* 1: the lr / exit condition fired at the last counted attempt; cleared by the host            */
+  int64_t adam_t;         /* steps of the CURRENT optimizer (Adam's bias correction); the host zeroes it with a new one   */
+  int64_t total_attempts; /* every attempt seen, whatever became of it                                                    */
+  double es2;             /* ES2_diff_cost                                                                                */
+  double cost_prev;       /* cost_tm1                                                                                     */
+} mcp_opt_state;
+/* torch.optim.Adam's update (weight_decay 0, no amsgrad) of up to MCP_OPT_MAX_TENSORS parameter tensors in ONE launch, applied only
+ * when the attempt counts (state == NULL: always).  params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors device pointers,
+ * numel their sizes; a NULL grad skips that tensor.  Must be enqueued BEFORE mcp_policy_step_commit of the same attempt (it reads
+ * the state that call advances).  Replaces optimizer.step(), MC_PILCO.py:525. */
+int mcp_adam_step_guarded(int n_tensors, double* const* params, const double* const* grads, double* const* exp_avg,
+                          double* const* exp_avg_sq, const int64_t* numel, double lr, double beta1, double beta2, double eps,
+                          const mcp_opt_state* state, int n_steps, const double* cost, const double* flags, const uint32_t* status,
+                          void* stream);
+/* The loop's decisions for one attempt.  cost / std_cost: device scalars of the attempt; flags: optional device [3] doubles (> 0 =
+ * NaN cost, hand-off time-out, non-positive variance -- the all-reduced form of a particle-sharded step), status: optional device
+ * status word of the rollout (either or both may be NULL; a NaN cost always fails).  cost_list / std_list [n_steps], es1 / ratio
+ * [n_steps + 1] (zero-initialised).  record (optional, device, MCP_OPT_RECORD_DOUBLES): [counted, void, step, attempts failed so
+ * far, pending, cost, std, |ratio|, nan, time-out, non-positive variance, total attempts] for the host to read late. */
+int mcp_policy_step_commit(mcp_opt_state* state, int n_steps, const double* cost, const double* std_cost, const double* flags,
+                           const uint32_t* status, double* cost_list, double* std_list, double* es1, double* ratio,
+                           double alpha_diff_cost, double min_step, double min_diff_cost, int num_min_diff_cost, double* record,
                            void* stream);
 
 /* ---- particle sharding: the one collective of an optimizer step --------------------------

@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gp_pretrain.hip", "rollout_fwd.hip", "rollout_fwd_tile.hip", "rollout_bwd.hip", "cost.hip", "comm.hip"]
+SOURCES = ["gp_pretrain.hip", "rollout_fwd.hip", "rollout_fwd_tile.hip", "rollout_bwd.hip", "cost.hip", "policy_opt.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "mcp_device.h"), os.path.join(CSRC, "rollout_common.h"), os.path.join(CSRC, "rollout_fwd_shared.h"),
            os.path.join(os.path.dirname(HERE), "include", "mcpilco_hip.h")]
 LIB = os.path.join(HERE, "libmcpilco_hip.so")

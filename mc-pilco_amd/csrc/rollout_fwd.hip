@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
             store_granule(slot + 1, (unsigned)t + 1u, (unsigned)(bits >> 32));
           }
           if (m0 + p < Mend) {
-            if (a.particle_pred && !(var > 0.0)) bad |= MCP_STATUS_NONPOS_VAR;
+            if (a.particle_pred && var <= 0.0) bad |= MCP_STATUS_NONPOS_VAR;  // (finite and not positive: a NaN variance is MCP_STATUS_NAN, the retry case)
             if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
           }
         } else if (a.jac && m0 + p < Mend) {
@@ -1907,7 +1907,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
           store_granule(slot, (unsigned)t + 1u, (unsigned)bits);
           store_granule(slot + 1, (unsigned)t + 1u, (unsigned)(bits >> 32));
           if (m0 + p < Mend) {
-            if (a.particle_pred && !(var > 0.0)) bad |= MCP_STATUS_NONPOS_VAR;
+            if (a.particle_pred && var <= 0.0) bad |= MCP_STATUS_NONPOS_VAR;  // (finite and not positive: a NaN variance is MCP_STATUS_NAN, the retry case)
             if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
           }
         } else if (a.jac && m0 + p < Mend) {
@@ -2038,7 +2038,7 @@ __global__ __launch_bounds__(RF_NT) void posterior_fwd_kernel(PostArgs a) {
       a.mu[m0 + p] = mu;
       a.var[m0 + p] = var;
       if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
-      if (!(var > 0.0)) bad |= MCP_STATUS_NONPOS_VAR;
+      if (var <= 0.0) bad |= MCP_STATUS_NONPOS_VAR;
     } else if (a.Jmu) {
       double Jm, Jv;
       gp_jac<2>(gpl[0], kpar, D, zp, red, NCOLMAX, p, c, Jm, Jv);

@@ -1441,7 +1441,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
             store_granule(slot + 1, (unsigned)t + 1u, (unsigned)(bits >> 32));
           }
           if (m0 + p < M) {
-            if (a.particle_pred && !(var > 0.0)) bad |= MCP_STATUS_NONPOS_VAR;
+            if (a.particle_pred && var <= 0.0) bad |= MCP_STATUS_NONPOS_VAR;  // (finite and not positive: a NaN variance is MCP_STATUS_NAN, the retry case)
             if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
           }
         } else if (a.jac && m0 + p < M) {

@@ -80,13 +80,15 @@ class GP_prior(torch.nn.Module):
         if ad is not None:
             # "the active dimensions are all columns, in order" is decided ONCE per (index tensor, width): the comparison reads a device
             # tensor back -- a host sync -- and this runs in every epoch of GP training and every pretrain
-            key = (id(ad), int(ad.numel()), int(X.shape[1]))
-            cache = self.__dict__.setdefault("_cols_identity", {})
-            ident = cache.get(key)
-            if ident is None:
-                ident = ad.numel() == X.shape[1] and bool((ad.detach().cpu() == torch.arange(X.shape[1])).all())
-                cache.clear()
-                cache[key] = ident
+            # (the cache HOLDS the index tensor and compares with `is` + its in-place version counter, like _packed(): an id() alone
+            # could be a freed tensor's address handed to a new one, and an in-place edit of active_dims must not go unnoticed)
+            cached = self.__dict__.get("_cols_identity")
+            if cached is not None and cached[0] is ad and cached[1] == getattr(ad, "_version", 0) and cached[2] == int(X.shape[1]):
+                ident = cached[3]
+            else:
+                adt = torch.as_tensor(ad)
+                ident = adt.numel() == X.shape[1] and bool((adt.detach().cpu() == torch.arange(X.shape[1])).all())
+                self.__dict__["_cols_identity"] = (ad, getattr(ad, "_version", 0), int(X.shape[1]), ident)
             if not ident:
                 X = X[:, ad]
         return X.contiguous()

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("MCPILCO_HIP_LIB") or os.path.join(HERE, "libmcpilco_h
 MAX_GP, MAX_STATE, MAX_INPUT, MAX_GPDIM, MAX_PFEAT, MAX_BASIS, MAX_TRAIN = 8, 16, 8, 32, 32, 1024, 1024
 OK = 0
 ERRORS = {-1: "MCP_ERR_ARG", -2: "MCP_ERR_LIMIT", -3: "MCP_ERR_WORKSPACE", -4: "MCP_ERR_LAUNCH", -5: "MCP_ERR_COMM"}
-ABI_VERSION = 4
+ABI_VERSION = 5
 COMM_ID_BYTES = 128
 STATUS_NAN, STATUS_NONPOS_VAR, STATUS_NOT_SPD, STATUS_SYNC = 1, 2, 4, 8
 FWD_NO_GP_SHARDING = 2  # flag in mcp_rollout_fwd's particle_pred argument (MCP_FWD_NO_GP_SHARDING)
@@ -59,6 +59,14 @@ class Noise(C.Structure):
     _fields_ = [("eps", dptr), ("masks", dptr), ("seed", C.c_uint64), ("call", C.c_uint64), ("particle_offset", C.c_int64)]
 
 
+class OptState(C.Structure):
+    _fields_ = [("step", C.c_int64), ("attempt", C.c_int64), ("pending", C.c_int64), ("adam_t", C.c_int64), ("total_attempts", C.c_int64),
+                ("es2", C.c_double), ("cost_prev", C.c_double)]
+
+
+OPT_MAX_ATTEMPTS, OPT_MAX_TENSORS, OPT_RECORD_DOUBLES = 10, 8, 12
+
+
 class Cost(C.Structure):
     _fields_ = [("kind", C.c_int32), ("S", C.c_int32), ("angle_index", C.c_int32), ("pos_index", C.c_int32),
                 ("target_angle", C.c_double), ("target_pos", C.c_double), ("ls_angle", C.c_double), ("ls_pos", C.c_double),
@@ -90,6 +98,10 @@ _SIGS = {
     "mcp_cost_bwd": (C.c_int, [C.POINTER(Cost), C.c_int, C.c_int, dptr, dptr, C.c_double, dptr, dptr]),
     "mcp_cost_sums": (C.c_int, [C.c_int, C.c_int, dptr, dptr, dptr, dptr]),
     "mcp_cost_finalize_sums": (C.c_int, [C.c_int, C.c_int64, dptr, dptr, dptr, dptr, dptr]),
+    "mcp_adam_step_guarded": (C.c_int, [C.c_int, C.POINTER(dptr), C.POINTER(dptr), C.POINTER(dptr), C.POINTER(dptr), C.POINTER(C.c_int64), C.c_double,
+                                        C.c_double, C.c_double, C.c_double, dptr, C.c_int, dptr, dptr, dptr, dptr]),
+    "mcp_policy_step_commit": (C.c_int, [dptr, C.c_int, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_double, C.c_double, C.c_double, C.c_int,
+                                         dptr, dptr]),
     "mcp_comm_unique_id": (C.c_int, [C.c_char_p]),
     "mcp_comm_init": (C.c_int, [C.c_int, C.c_int, C.c_char_p]),
     "mcp_comm_world": (C.c_int, []),

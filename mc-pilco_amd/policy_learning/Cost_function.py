@@ -135,6 +135,30 @@ class Expected_saturated_distance_from_trajectory(_HipExpectedCost):
         return super().local_moments(states_sequence, inputs_sequence, trial_index, m_total, shift)
 
 
+# ---- the two costs as plain functions (Cost_function.py:124-147, 170-182) -----------------------------------------------
+# What a user hands to the generic ``Expected_cost(cost_function=...)``: ordinary differentiable torch ops on the GPU (user-code
+# path; the classes above run the same formulas in the HIP cost kernels).
+def saturated_distance_from_trajectory(states_sequence, inputs_sequence, trial_index, target_traj, lengthscales, flg_var_lengthscales,
+                                       used_indeces):
+    """1 - exp(-sum_i ((x_i - x*_{t,i}) / l_i)^2) over ``used_indeces`` (None: every state); ``flg_var_lengthscales``:
+    ``lengthscales[trial_index]`` is the vector of that trial.  [T,M,S] -> [T,M]."""
+    if used_indeces is None:
+        used_indeces = list(range(states_sequence.shape[2]))
+    tt = torch.as_tensor(target_traj, dtype=states_sequence.dtype, device=states_sequence.device)
+    targets = tt.reshape(tt.shape[0], 1, -1).expand(states_sequence.shape)
+    ls = lengthscales[trial_index] if flg_var_lengthscales else lengthscales
+    ls = torch.as_tensor(ls, dtype=states_sequence.dtype, device=states_sequence.device)
+    d = (states_sequence[:, :, used_indeces] - targets[:, :, used_indeces]) / ls
+    return 1 - torch.exp(-(d * d).sum(2))
+
+
+def cart_pole_cost(states_sequence, inputs_sequence, trial_index, target_state, lengthscales, angle_index, pos_index):
+    """1 - exp(-((|theta| - theta*)/l_theta)^2 - ((x - x*)/l_x)^2);  target_state = [theta*, x*], lengthscales = [l_theta, l_x]."""
+    x = states_sequence[:, :, pos_index]
+    theta = states_sequence[:, :, angle_index]
+    return 1 - torch.exp(-(((torch.abs(theta) - target_state[0]) / lengthscales[0]) ** 2) - ((x - target_state[1]) / lengthscales[1]) ** 2)
+
+
 # ---- simple torch-level variants (Cost_function.py:39-101) -------------------------------------------------------------
 def distance_from_target(states_sequence, inputs_sequence, trial_index, target_state, lengthscales, active_dims):
     d = (states_sequence[:, :, active_dims] - target_state) / lengthscales

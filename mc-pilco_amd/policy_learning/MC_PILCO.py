@@ -66,6 +66,7 @@ class MC_PILCO(torch.nn.Module):
         self.gp_sharding = True    # cleared for good once a GP-sharded launch reports MCP_STATUS_SYNC (co-residency was not there)
         self._reducer = None       # sharding.StepReducer: the one all-reduce of a sharded optimizer step
         self._cost_shift = None    # previous step's pooled per-time-step mean cost (the shift of the summable cost moments)
+        self.pipeline_depth = 1    # reinforce_policy reads an attempt's outcome this many attempts late (0: at once); see there
 
     # ------------------------------------------------------------------------------------------------------------
     # particle sharding
@@ -154,6 +155,7 @@ class MC_PILCO(torch.nn.Module):
             self.last_status = status
             return states, inputs
         # generic (unfused) path: any model / policy object with the reference's step interface
+        self.last_status = None  # (no fused launch: the flags of an earlier fused rollout do not describe this one)
         if world > 1:
             # its noise (torch draws inside get_next_state / the policy's dropout) is per LOCAL particle: identically seeded ranks
             # would simulate correlated shards, not the particles one GPU would
@@ -188,7 +190,7 @@ class MC_PILCO(torch.nn.Module):
             nonpos = (st.reshape(-1)[0] & hipabi.STATUS_NONPOS_VAR) != 0
         return torch.stack([torch.isnan(cost.detach()).reshape(()), sync.reshape(()), nonpos.reshape(())]).to(self.dtype)
 
-    def _cost_backward(self, states, inputs, trial_index, backward=True):
+    def _cost_backward(self, states, inputs, trial_index, backward=True, flags_as_vector=True):
         """Expected cost of the rollout and (``backward``) its gradient in the policy parameters' ``.grad``.
         Returns (cost, std, flags): flags is a device vector, > 0 where [the cost is NaN, a hand-off timed out] -- on EVERY rank
         alike, so all ranks take the same retry decision.
@@ -199,9 +201,10 @@ class MC_PILCO(torch.nn.Module):
         if self.dist_group is None:
             cost, std = self.cost_function(states, inputs, trial_index)
             if backward:
-                # queued before the host looks at the cost (the NaN test is a sync point); gradients of a NaN rollout are discarded
+                # queued before anybody looks at the cost; gradients of a NaN rollout are discarded
                 cost.backward(retain_graph=False)
-            return cost, std, self._step_flags(cost)
+            # (flags_as_vector False: the caller hands the rollout's status word and the cost to mcp_policy_step_commit itself)
+            return cost, std, (self._step_flags(cost) if flags_as_vector else None)
         T = states.shape[0]
         if self._cost_shift is None or self._cost_shift.numel() != T:
             self._cost_shift = torch.zeros(T, dtype=self.dtype, device=states.device)
@@ -222,15 +225,21 @@ class MC_PILCO(torch.nn.Module):
     # policy optimisation
     # ------------------------------------------------------------------------------------------------------------
     def _rollout_failed(self, flags):
-        """Reads the step's flags (ONE device->host transfer).  True when the cost is NaN (data, not an error: MC_PILCO.py:497)
-        or when a GP-sharded launch timed out waiting for a partner workgroup; in the second case the GP-sharded launch forms
-        are switched off for this object (the device was not giving the grid co-residency -- another process, CU masking),
-        so the repeated step runs on the unsharded kernels: never a silently wrong trajectory, never a rank-local raise."""
+        """Reads the step's flags (ONE device->host transfer; warm-up rollout and user code -- the optimizer loop itself reads the
+        record of ``mcp_policy_step_commit``).  True when the cost is NaN (data, not an error: MC_PILCO.py:497) or when a GP-sharded
+        launch timed out waiting for a partner workgroup; in the second case the GP-sharded launch forms are switched off for this
+        object (the device was not giving the grid co-residency -- another process, CU masking), so the repeated step runs on the
+        unsharded kernels: never a silently wrong trajectory, never a rank-local raise."""
         nan, sync, nonpos = (float(v) for v in flags.tolist())
-        if nonpos > 0 and not nan > 0:
+        return self._judge_attempt(nan, sync, nonpos)
+
+    def _judge_attempt(self, nan, sync, nonpos):
+        if nonpos > 0:
             # The reference samples with Normal(mean, sqrt(var)).rsample() (Model_learning.py:704), whose argument validation raises
-            # ValueError on a scale that is not > 0 -- an exactly zero / negative predictive variance is a modelling error there, not a
-            # case of the NaN retry.  Same here (on every rank alike in a sharded run: the flag travels with the step's all-reduce).
+            # ValueError on a scale that is not > 0 -- a zero / negative predictive variance is a modelling error there, not a case of
+            # the NaN retry, whatever the cost of that rollout turns out to be (sqrt of a negative variance makes it NaN).  The kernels
+            # raise this flag for a FINITE variance <= 0 only; a NaN variance (divergence) is MCP_STATUS_NAN, the retry case.  Same on
+            # every rank of a sharded run: the flag travels with the step's all-reduce.
             raise ValueError("Expected parameter scale of the particles' sampling distribution to be > 0: a GP's predictive variance was <= 0 "
                              "(MCP_STATUS_NONPOS_VAR)")
         if sync > 0:
@@ -240,13 +249,43 @@ class MC_PILCO(torch.nn.Module):
             return True
         return nan > 0
 
+    @staticmethod
+    def _plain_adam(opt):
+        """(lr, beta1, beta2, eps) when ``opt`` is a torch.optim.Adam whose update is the textbook one (what every launch script
+        builds: "lambda p, lr : torch.optim.Adam(p, lr)") -- the loop then runs the update itself, guarded on the device
+        (mcp_adam_step_guarded), and never has to wait for a step's outcome.  None: any other optimizer; its own ``step()`` is called,
+        after the host has seen that the attempt counts."""
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return None
+        g = opt.param_groups[0]
+        if (g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False) or g.get("differentiable", False)
+                or g.get("decoupled_weight_decay", False) or isinstance(g["lr"], torch.Tensor)):
+            return None
+        ps = [q for q in g["params"] if q.requires_grad]
+        if not ps or len(ps) > 8 or any(q.dtype != torch.float64 or not q.is_cuda or not q.is_contiguous() for q in ps):
+            return None
+        return float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])
+
     def reinforce_policy(self, T_control, num_particles, trial_index, particles_initial_state_mean, particles_initial_state_var,
                          flg_particles_init_uniform, particles_init_up_bound, particles_init_low_bound, flg_particles_init_multi_gauss,
                          opt_steps_list, lr_list, f_optimizer, num_step_print=10, policy_reinit_dict=None, p_dropout_list=None,
                          std_cost_filt_order=None, std_cost_filt_cutoff=None, max_std_cost=None, alpha_cost=0.99, alpha_input=0.99,
                          alpha_diff_cost=0.99, lr_reduction_ratio=0.5, lr_min=0.001, p_drop_reduction=0.0, min_diff_cost=0.1,
                          num_min_diff_cost=200, min_step=np.inf):
-        """Monte-Carlo policy gradient: at most ``opt_steps_list[trial_index]`` optimizer steps."""
+        """Monte-Carlo policy gradient: at most ``opt_steps_list[trial_index]`` optimizer steps (MC_PILCO.py:375-613).
+
+        One ATTEMPT = rollout + expected cost + adjoint sweep; what the reference then decides on the host from ``torch.isnan(cost)``
+        -- does the attempt count, the cost-difference monitors, the lr / exit condition -- is decided on the device by
+        ``mcp_policy_step_commit`` (and, for a plain Adam, the update itself by ``mcp_adam_step_guarded``), which leaves a small record
+        per attempt.  The host reads that record ``self.pipeline_depth`` attempts late (1: it has already enqueued the next attempt,
+        so the GPU never idles while Python catches up; 0: at once -- the mode with host-drawn "reference" noise, with any other
+        optimizer and in a particle-sharded run).  A failed attempt needs nothing from the host (the next attempt is the retry);
+        where the host must act -- ten failures in a row, the lr / exit condition, the last step -- the device ignores the attempts
+        enqueued meanwhile and the host rewinds the noise counters past them: both depths take exactly the same steps."""
+        import ctypes as C
+
+        from mc_pilco_amd import hipabi as abi
+
         dev, dt = self.device, self.dtype
         horizon = int(T_control / self.T_sampling)
         n_steps = opt_steps_list[trial_index]
@@ -262,11 +301,6 @@ class MC_PILCO(torch.nn.Module):
         # re-initialisations draw where the rest of the noise is drawn: in "reference" mode on the CPU generator (the reference's stream)
         self.control_policy.draw_device = torch.device("cpu") if self.noise_mode == "reference" else None
 
-        def fresh_state():
-            return dict(cost=torch.zeros(n_steps, device=dev, dtype=dt), std=torch.zeros(n_steps, device=dev, dtype=dt),
-                        es1=torch.zeros(n_steps + 1, device=dev, dtype=dt), ratio=torch.zeros(n_steps + 1, device=dev, dtype=dt),
-                        lr=lr_list[trial_index], p_drop=p_drop0, min_diff=min_diff_cost, min_step=min_step, prev_cost=0.0)
-
         # reference value for the cost-difference monitor (policy re-initialised while the cost is NaN)
         with torch.no_grad():
             for _ in range(10):
@@ -279,74 +313,166 @@ class MC_PILCO(torch.nn.Module):
                     continue  # a hand-off time-out, not a NaN: same policy, unsharded kernels
                 print("\nSE filter initialization: Cost is NaN - reinit the policy")
                 self.control_policy.reinit(**policy_reinit_dict)
-        s = fresh_state()
-        es2 = 0.0
-        cost_prev = cost0
-        opt = make_opt(p=self.control_policy.parameters(), lr=s["lr"])
-        step = done = reinits = 0
-        t_mark = time.time()
-        states = inputs = None
-        while step < n_steps:
-            opt.zero_grad()
-            nan = True
-            for _ in range(10):
-                states, inputs = self.apply_policy(p_dropout=s["p_drop"], **sim)
-                # cost + adjoint sweep (+ the one all-reduce of a sharded run) are queued before the host looks at the flags
-                cost, std, flags = self._cost_backward(states, inputs, trial_index)
-                if self._rollout_failed(flags):
+
+        # ---- device-side loop state (mcp_opt_state + the monitors' arrays) ------------------------------------------------------------
+        lib = abi.lib()
+        st = torch.zeros(7, dtype=torch.int64, device=dev)  # mcp_opt_state: step, attempt, pending, adam_t, total_attempts | es2, cost_prev
+        st.view(dt)[6:7].copy_(cost0.detach().reshape(1))   # cost_tm1 = the warm-up cost (MC_PILCO.py:462)
+        cost_list = torch.zeros(n_steps, device=dev, dtype=dt)
+        std_list = torch.zeros(n_steps, device=dev, dtype=dt)
+        es1 = torch.zeros(n_steps + 1, device=dev, dtype=dt)
+        ratio = torch.zeros(n_steps + 1, device=dev, dtype=dt)
+        hs = dict(lr=lr_list[trial_index], p_drop=p_drop0, min_diff=min_diff_cost, min_step=min_step, prev_cost=0.0)  # what the host holds
+        params = [q for q in self.control_policy.parameters()]
+        opt = make_opt(p=self.control_policy.parameters(), lr=hs["lr"])
+        adam = self._plain_adam(opt)
+        depth = int(getattr(self, "pipeline_depth", 1))
+        if adam is None or self.noise_mode == "reference" or self.dist_group is not None:
+            depth = 0
+        ad = {}
+
+        def fresh_adam_state():
+            if adam is not None:
+                ps = [q for q in opt.param_groups[0]["params"] if q.requires_grad]
+                ad.update(ps=ps, m=[torch.zeros_like(q) for q in ps], v=[torch.zeros_like(q) for q in ps],
+                          numel=(C.c_int64 * len(ps))(*[q.numel() for q in ps]))
+                for k in ("m", "v", "ps"):
+                    ad["c_" + k] = (abi.dptr * len(ps))(*[t.data_ptr() for t in ad[k]])
+            st[3:4].zero_()
+
+        fresh_adam_state()
+        ring = [torch.empty(abi.OPT_RECORD_DOUBLES, dtype=dt).pin_memory() for _ in range(depth + 2)]
+        rec_dev = torch.zeros(depth + 2, abi.OPT_RECORD_DOUBLES, dtype=dt, device=dev)
+        seq = [0]
+
+        def enqueue():
+            """One attempt, start to finish, without a host sync."""
+            snap = (self._rollout_calls, torch.cuda.get_rng_state(dev) if depth > 0 else None)
+            for q in params:
+                q.grad = None
+            states, inputs = self.apply_policy(p_dropout=hs["p_drop"], **sim)
+            cost, std, flags = self._cost_backward(states, inputs, trial_index, flags_as_vector=self.dist_group is not None)
+            cptr, sptr = abi.ptr(cost.detach().reshape(1)), abi.ptr(std.detach().reshape(1))
+            status = None if (flags is not None or self.last_status is None) else self.last_status
+            if adam is not None:
+                grads = (abi.dptr * len(ad["ps"]))(*[None if q.grad is None else q.grad.data_ptr() for q in ad["ps"]])
+                abi.check(lib.mcp_adam_step_guarded(len(ad["ps"]), ad["c_ps"], grads, ad["c_m"], ad["c_v"], ad["numel"], float(hs["lr"]), adam[1],
+                                                    adam[2], adam[3], abi.ptr(st), n_steps, cptr, abi.ptr(flags), abi.ptr(status), abi.stream()),
+                          "mcp_adam_step_guarded")
+            slot = seq[0] % (depth + 2)
+            seq[0] += 1
+            abi.check(lib.mcp_policy_step_commit(abi.ptr(st), n_steps, cptr, sptr, abi.ptr(flags), abi.ptr(status), abi.ptr(cost_list),
+                                                 abi.ptr(std_list), abi.ptr(es1), abi.ptr(ratio), float(alpha_diff_cost),
+                                                 float(min(hs["min_step"], 1e300)), float(hs["min_diff"]), int(num_min_diff_cost),
+                                                 abi.ptr(rec_dev[slot]), abi.stream()), "mcp_policy_step_commit")
+            ring[slot].copy_(rec_dev[slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            return dict(states=states, inputs=inputs, rec=ring[slot], ev=ev, snap=snap, cost=cost)
+
+        def read(h):
+            h["ev"].synchronize()
+            return h["rec"].tolist()
+
+        def step_print(k, cost_now, rabs):
+            print("\nOptimization step: ", k)
+            print("cost: ", cost_now)
+            print("cost improvement: ", hs["prev_cost"] - cost_now)
+            print("p_dropout_applied: ", hs["p_drop"])
+            print("current_min_diff_cost; ", hs["min_diff"])
+            print("current_min_step: ", hs["min_step"])
+            print("diff_cost_ratio: ", rabs)
+            print("time elapsed: ", time.time() - hs["t_mark"])
+            hs["prev_cost"] = cost_now
+            hs["t_mark"] = time.time()
+
+        def lr_or_exit(k):
+            """The condition of MC_PILCO.py:540-547 held at step k.  True: leave the loop."""
+            if hs["lr"] > lr_min:
+                print("Optimization_step:", k)
+                print("\nREDUCING THE LEARNING RATE:")
+                hs["lr"] = max(hs["lr"] * lr_reduction_ratio, lr_min)
+                print("lr: ", hs["lr"])
+                hs["min_diff"] = max(hs["min_diff"] / 2, 0.01)
+                hs["min_step"] = k + num_min_diff_cost
+                print("\nREDUCING THE DROPOUT:")
+                hs["p_drop"] = max(hs["p_drop"] - p_drop_reduction, 0.0)
+                print("p_dropout_applied: ", hs["p_drop"])
+                return False
+            print("\nEXIT FROM OPTIMIZATION: diff_cost_ratio < min_diff_cost for num_min_diff_cost steps")
+            return True
+
+        def discard(queue):
+            """The attempts enqueued while the device was waiting for the host: the device ignored them; the noise counters go back
+            to where the first of them found them, so the run continues exactly as one that never enqueued them."""
+            if queue:
+                for h in queue:
+                    r = read(h)
+                    assert r[1] == 1.0 and r[0] == 0.0, "an attempt enqueued past a host decision was not void"
+                self._rollout_calls = queue[0]["snap"][0]
+                if queue[0]["snap"][1] is not None:
+                    torch.cuda.set_rng_state(queue[0]["snap"][1], dev)
+                queue.clear()
+
+        hs["t_mark"] = time.time()
+        queue, last, done, reinits, leave = [], None, 0, 0, False
+        while not leave:
+            queue.append(enqueue())
+            while queue and (len(queue) > depth) and not leave:
+                h = queue.pop(0)
+                counted, void, k, failed, pending, cost_now, _std, rabs, nan, sync, nonpos, _tot = read(h)
+                k = int(k)
+                assert void == 0.0, "the oldest attempt in flight cannot be void"
+                if counted == 0.0:
+                    self._judge_attempt(nan, sync, nonpos)  # (raises on a non-positive variance; switches GP sharding off after a time-out)
                     print("\nCost is NaN: try sampling again")
-                    opt.zero_grad()
-                else:
-                    nan = False
-                    break
-            s["cost"][step] = cost.detach()
-            s["std"][step] = std.detach()
-            with torch.no_grad():  # exponential moving statistics of the cost change
-                diff = cost - cost_prev
-                s["es1"][step + 1] = alpha_diff_cost * s["es1"][step] + (1 - alpha_diff_cost) * diff
-                es2 = alpha_diff_cost * (es2 + (1 - alpha_diff_cost) * (diff - s["es1"][step]) ** 2)
-                cost_prev = s["cost"][step]
-                s["ratio"][step + 1] = alpha_diff_cost * s["ratio"][step] + (1 - alpha_diff_cost) * (s["es1"][step + 1] / es2.sqrt())
-            opt.step()
-            if step % num_step_print == 0:
-                now = float(cost.detach())
-                print("\nOptimization step: ", step)
-                print("cost: ", now)
-                print("cost improvement: ", s["prev_cost"] - now)
-                print("p_dropout_applied: ", s["p_drop"])
-                print("current_min_diff_cost; ", s["min_diff"])
-                print("current_min_step: ", s["min_step"])
-                print("diff_cost_ratio: ", float(torch.abs(s["ratio"][step + 1])))
-                print("time elapsed: ", time.time() - t_mark)
-                s["prev_cost"] = now
-                t_mark = time.time()
-            if step > s["min_step"]:
-                window = torch.abs(s["ratio"][step + 1 - num_min_diff_cost:step + 1])
-                if int(torch.sum(window < s["min_diff"])) >= num_min_diff_cost:
-                    if s["lr"] > lr_min:
-                        print("Optimization_step:", step)
-                        print("\nREDUCING THE LEARNING RATE:")
-                        s["lr"] = max(s["lr"] * lr_reduction_ratio, lr_min)
-                        print("lr: ", s["lr"])
-                        s["min_diff"] = max(s["min_diff"] / 2, 0.01)
-                        s["min_step"] = step + num_min_diff_cost
-                        opt = make_opt(p=self.control_policy.parameters(), lr=s["lr"])
-                        print("\nREDUCING THE DROPOUT:")
-                        s["p_drop"] = max(s["p_drop"] - p_drop_reduction, 0.0)
-                        print("p_dropout_applied: ", s["p_drop"])
-                    else:
-                        print("\nEXIT FROM OPTIMIZATION: diff_cost_ratio < min_diff_cost for num_min_diff_cost steps")
-                        step = n_steps
-            step += 1
-            done += 1
-            if nan:  # ten NaN rollouts in a row: restart from a re-initialised policy
-                reinits += 1
-                print("\nCost is NaN: re-initialize control policy [attempt #" + str(reinits) + "]")
-                self.control_policy.reinit(**policy_reinit_dict)
-                step = done = 0
-                s = fresh_state()
-                opt = make_opt(p=self.control_policy.parameters(), lr=s["lr"])
-        return (s["cost"][0:done].detach().cpu().numpy(), s["std"][0:done].detach().cpu().numpy(), states.detach().cpu().numpy(),
+                    last = h
+                    if failed >= abi.OPT_MAX_ATTEMPTS:
+                        # ten failed attempts in a row (MC_PILCO.py:573-607): the reference takes the step on the failed cost (its monitors
+                        # and messages included) and restarts from a re-initialised policy
+                        discard(queue)
+                        if k % num_step_print == 0:
+                            step_print(k, cost_now, float("nan"))
+                        if k > hs["min_step"]:  # (its lr / exit test looks at the window BEFORE this step's ratio: it may still fire; only the
+                            win = torch.abs(ratio[max(k + 1 - num_min_diff_cost, 0):k + 1])  # messages matter, everything is reset below)
+                            if int(torch.sum(win < hs["min_diff"])) >= num_min_diff_cost and k + 1 >= num_min_diff_cost:
+                                lr_or_exit(k)
+                        reinits += 1
+                        print("\nCost is NaN: re-initialize control policy [attempt #" + str(reinits) + "]")
+                        self.control_policy.reinit(**policy_reinit_dict)
+                        st[0:5].zero_()  # (ES2 and cost_tm1 are NOT reset by the reference: they keep the failed step's values)
+                        for a in (cost_list, std_list, es1, ratio):
+                            a.zero_()
+                        hs.update(lr=lr_list[trial_index], p_drop=p_drop0, min_diff=min_diff_cost, min_step=min_step, prev_cost=0.0)
+                        opt = make_opt(p=self.control_policy.parameters(), lr=hs["lr"])
+                        adam = self._plain_adam(opt)
+                        params = [q for q in self.control_policy.parameters()]
+                        fresh_adam_state()
+                        done = 0
+                    continue
+                # the attempt counted: step k was taken
+                last, done = h, k + 1
+                if adam is None:
+                    opt.step()  # (depth 0: the host knows the attempt counted before it updates)
+                if k % num_step_print == 0:
+                    step_print(k, cost_now, rabs)
+                if pending != 0.0:
+                    discard(queue)
+                    leave = lr_or_exit(k)
+                    if not leave:
+                        opt = make_opt(p=self.control_policy.parameters(), lr=hs["lr"])
+                        adam_now = self._plain_adam(opt)
+                        if (adam_now is None) != (adam is None):
+                            raise RuntimeError("f_optimizer must build the same kind of optimizer on every call")
+                        adam = adam_now
+                        fresh_adam_state()
+                    st[2:3].zero_()
+                if done >= n_steps:
+                    discard(queue)
+                    leave = True
+        discard(queue)
+        states, inputs = last["states"], last["inputs"]
+        return (cost_list[0:done].detach().cpu().numpy(), std_list[0:done].detach().cpu().numpy(), states.detach().cpu().numpy(),
                 inputs.detach().cpu().numpy())
 
     # ------------------------------------------------------------------------------------------------------------
@@ -467,8 +593,10 @@ class MC_PILCO(torch.nn.Module):
             print("MSE gp" + str(i) + ": ", ((targets[i] - means[i]) ** 2).mean())
         return gp_inputs, targets, means, variances
 
-    def get_rollout_prediction_performance(self, data_collection_index, T_rollout=None, add_name=""):
-        pred = self.rollout(data_collection_index, T_rollout=T_rollout)
+    def get_rollout_prediction_performance(self, data_collection_index, T_rollout=None, add_name="", particle_pred=False):
+        """Open-loop rollout of the learned model on the inputs of one interaction (MC_PILCO.py:308-345); ``particle_pred``:
+        sampled instead of mean predictions, as in the reference."""
+        pred = self.rollout(data_collection_index, T_rollout=T_rollout, particle_pred=particle_pred)
         obs = self.state_samples_history[data_collection_index][: pred.shape[0]]
         print("Rollout prediction MSE per state:", np.mean((pred - obs) ** 2, 0))
         return pred, obs, self.input_samples_history[data_collection_index]
@@ -570,6 +698,7 @@ class MC_PILCO4PMS(MC_PILCO):
             states, inputs, status = ops.rollout(ml.packed(), pol.packed(), noise, x, T, p, meas=meas, gp_sharding=self.gp_sharding)
             self.last_status = status
             return states, inputs
+        self.last_status = None  # (no fused launch)
         if world > 1:  # (per-LOCAL-particle torch draws: identically seeded ranks would simulate correlated shards)
             raise NotImplementedError("particle sharding needs the fused rollout (fused=True, Sum_of_gaussians policy, speed-integration model)")
         std_pos = torch.tensor(np.asarray(self.std_meas_noise_sim)[pos], dtype=self.dtype, device=self.device)

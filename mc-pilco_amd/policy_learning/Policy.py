@@ -11,7 +11,9 @@ Dropout noise: ``noise_mode = "philox"`` (in-kernel counter-based generator, def
 drawn exactly like ``torch.nn.functional.dropout`` draws it on the CPU -- parity with the reference).
 ``scale_factor`` (plain ``Sum_of_gaussians`` only, as in the reference) is folded into the operands handed to the kernels.
 ``flg_bias`` adds ``f_linear.bias`` (not dropped out) to the linear layer inside the kernels; its gradient comes out of the adjoint sweep.
-Exploration policies (Random_exploration) run on the host once per trial and are plain numpy.
+Exploration policies (Random_exploration, Sum_of_sinusoids :94-150, PD_controller :406-449) drive the simulated system once per
+trial (61-201 samples): host-side, their ``np.random`` draws in the reference's order so that a seeded launch script collects the
+same data.
 """
 import numpy as np
 import torch
@@ -48,6 +50,10 @@ class Policy(torch.nn.Module):
             u_max = torch.tensor(u_max, dtype=self.dtype, device=self.device)
         return u_max * torch.tanh(u / u_max)
 
+    def f_squash(self, x):
+        """The reference's ``self.f_squash`` (Policy.py:28-33): squashing when ``flg_squash``, identity otherwise."""
+        return self.squashing(x, self.u_max) if self.flg_squash else x
+
     def get_np_policy(self):
         return lambda state, t: self.forward_np(state, t)
 
@@ -66,6 +72,43 @@ class Random_exploration(Policy):
 
     def forward_np(self, state, t=None):
         return (np.asarray(self.u_max) * (2 * np.random.rand(self.input_dim) - 1)).reshape([-1, self.input_dim])
+
+
+class Sum_of_sinusoids(Policy):
+    """Exploration policy: u(t) = squash(sum_i A_i sin(omega_i t + phi_i)) with random amplitudes / frequencies / phases
+    (Policy.py:94-150).  The draws are ``np.random``'s, in the reference's order: amplitudes (rand), omega (choice, rand),
+    phases (choice, rand) -- a launch script seeded with ``np.random.seed`` gets the reference's exploration signal."""
+
+    def __init__(self, state_dim, input_dim, num_sin, omega_min, omega_max, amplitude_min, amplitude_max, flg_squash=False, u_max=1,
+                 dtype=torch.float64, device=torch.device("cpu")):
+        super().__init__(state_dim=state_dim, input_dim=input_dim, flg_squash=flg_squash, u_max=u_max, dtype=dtype, device=device)
+        self.num_sin = num_sin
+        amplitude_min, amplitude_max = np.array(amplitude_min), np.array(amplitude_max)
+        par = lambda a: torch.nn.Parameter(torch.tensor(a, dtype=self.dtype, device=self.device), requires_grad=False)
+        self.amplitudes = par(amplitude_min + (amplitude_max - amplitude_min) * np.random.rand(num_sin, input_dim))
+        self.omega = par(np.random.choice([-1, 1], [num_sin, input_dim]) * (omega_min + (omega_max - omega_min) * np.random.rand(num_sin, input_dim)))
+        self.phases = par(np.random.choice([-1, 1], [num_sin, input_dim]) * (np.pi * (np.random.rand(num_sin, input_dim) - 0.5)))
+
+    def forward(self, states, t, p_dropout=0.0):
+        return self.f_squash(torch.sum(self.amplitudes * torch.sin(self.omega * t + self.phases), dim=0).reshape([-1, self.input_dim]))
+
+
+class PD_controller(Policy):
+    """u = squash(Kp e_q + Kd e_qdot) with e = target_traj[t] - state, gains = sqrt_*_gains^2 (Policy.py:406-449; the UR5 launch
+    script's exploration controller).  Host-side helper for the system simulator; not part of the fused rollout."""
+
+    def __init__(self, state_dim, input_dim, sqrt_Kp_gains, sqrt_Kd_gains, target_traj=None, flg_squash=True, u_max=1.0, flg_trainable=False,
+                 dtype=torch.float64, device=torch.device("cpu")):
+        super().__init__(state_dim=state_dim, input_dim=input_dim, flg_squash=flg_squash, u_max=u_max, dtype=dtype, device=device)
+        self.target_traj = target_traj
+        self.sqrt_Kp_gains = torch.nn.Parameter(torch.tensor(sqrt_Kp_gains, dtype=self.dtype, device=self.device), requires_grad=flg_trainable)
+        self.sqrt_Kd_gains = torch.nn.Parameter(torch.tensor(sqrt_Kd_gains, dtype=self.dtype, device=self.device), requires_grad=flg_trainable)
+
+    def forward(self, states, t, p_dropout=0.0):
+        states = states.reshape([-1, self.state_dim])
+        err = self.target_traj[t, :].reshape(1, -1) - states
+        h = int(self.state_dim / 2)
+        return self.f_squash(self.sqrt_Kp_gains ** 2 * err[:, 0:h] + self.sqrt_Kd_gains ** 2 * err[:, h:])
 
 
 class Sum_of_gaussians(Policy):

@@ -37,7 +37,9 @@ def test_library_exports_every_declared_symbol():
     for n in dbg:
         assert hasattr(lib, n)
     assert set(k for k in hipabi._SIGS if k.startswith("mcp_debug")) == set(dbg)
-    assert lib.mcp_abi_version() == 4
+    # the header, the binding and the built library carry ONE version (a stale library or an old struct layout is rejected at load time)
+    hdr = int(re.search(r"#define MCP_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert lib.mcp_abi_version() == hipabi.ABI_VERSION == hdr == 5
     assert b"gfx950" in lib.mcp_build_info()
 
 
@@ -47,16 +49,20 @@ def test_struct_layout_matches_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "mcpilco_hip.h"\n'
-        "int main(){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\", sizeof(mcp_kernel), sizeof(mcp_gp), sizeof(mcp_model),"
+        "int main(){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu \", sizeof(mcp_kernel), sizeof(mcp_gp), sizeof(mcp_model),"
         " sizeof(mcp_policy), sizeof(mcp_noise), sizeof(mcp_cost), offsetof(mcp_model, gp), offsetof(mcp_policy, log_ls),"
-        " offsetof(mcp_cost, target_traj), sizeof(mcp_meas), offsetof(mcp_policy, meas), offsetof(mcp_meas, pos_noise)); return 0;}\n"
+        " offsetof(mcp_cost, target_traj), sizeof(mcp_meas), offsetof(mcp_policy, meas), offsetof(mcp_meas, pos_noise)); "
+        "printf(\"%zu %zu %zu %d %d %d\\n\", sizeof(mcp_opt_state), offsetof(mcp_opt_state, es2), offsetof(mcp_opt_state, total_attempts),"
+        " MCP_OPT_MAX_ATTEMPTS, MCP_OPT_MAX_TENSORS, MCP_OPT_RECORD_DOUBLES); return 0;}\n"
     )
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     want = [C.sizeof(hipabi.Kernel), C.sizeof(hipabi.GP), C.sizeof(hipabi.Model), C.sizeof(hipabi.Policy), C.sizeof(hipabi.Noise),
             C.sizeof(hipabi.Cost), hipabi.Model.gp.offset, hipabi.Policy.log_ls.offset, hipabi.Cost.target_traj.offset,
-            C.sizeof(hipabi.Meas), hipabi.Policy.meas.offset, hipabi.Meas.pos_noise.offset]
+            C.sizeof(hipabi.Meas), hipabi.Policy.meas.offset, hipabi.Meas.pos_noise.offset,
+            C.sizeof(hipabi.OptState), hipabi.OptState.es2.offset, hipabi.OptState.total_attempts.offset, hipabi.OPT_MAX_ATTEMPTS,
+            hipabi.OPT_MAX_TENSORS, hipabi.OPT_RECORD_DOUBLES]
     assert got == want
 
 

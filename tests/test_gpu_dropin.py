@@ -784,3 +784,99 @@ def test_zero_predictive_variance_raises_like_the_reference_normal():
         MC_PILCO.MC_PILCO._rollout_failed(stub, torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64))
     assert MC_PILCO.MC_PILCO._rollout_failed(stub, torch.tensor([1.0, 0.0, 1.0], dtype=torch.float64)) is True   # NaN: the retry path
     assert MC_PILCO.MC_PILCO._rollout_failed(stub, torch.tensor([0.0, 0.0, 0.0], dtype=torch.float64)) is False
+
+
+# ---- round 4: the optimizer loop without a host sync per step ------------------------------------------------------------------------
+def _nan_on_rollout_calls(obj, nan_calls):
+    """Wraps obj.cost_function: the expected cost is NaN for the rollouts whose number (obj._rollout_calls, the counter that keys the
+    in-kernel noise) is in ``nan_calls`` -- a key that means the same attempt at every pipeline depth."""
+    inner = obj.cost_function
+    nan_calls = set(int(i) for i in nan_calls)
+
+    class Wrapped(torch.nn.Module):
+        def forward(self, states_sequence, inputs_sequence=None, trial_index=None, group=None, counts=None):
+            cost, std = inner(states_sequence, inputs_sequence, trial_index)
+            return (cost * float("nan") if obj._rollout_calls in nan_calls else cost), std
+
+    obj.cost_function = Wrapped()
+
+
+@pytest.mark.parametrize("case", ["plain", "nan_retry", "reinit", "lr_and_exit", "last_step_fails"])
+def test_pipelined_optimizer_loop_takes_exactly_the_synchronous_steps(golden, case):
+    """reinforce_policy with the in-kernel noise, reading each attempt's outcome one attempt late (pipeline_depth 1, the default) against
+    reading it at once (depth 0 -- the mode the reference-noise tests above pin to the reference's own traces): the same cost list,
+    the same final parameters, the same returned particles and the same messages, BIT FOR BIT, through NaN retries, the
+    re-initialisation after ten failures, learning-rate halvings with dropout reduction, the early exit, and a retry on the very last
+    step; afterwards the default generator and the rollout counter stand where the synchronous run leaves them."""
+    fx = golden("policy_opt_trace")
+    kw = dict(opt_steps_list=[7], lr_list=[0.01], p_dropout_list=[0.25])
+    nan_calls = []
+    if case == "nan_retry":
+        nan_calls = [3, 4, 7]                     # two failures of step 1 (rollouts 3, 4), one of step 3
+    elif case == "reinit":
+        nan_calls = list(range(4, 14))            # ten failures of step 2: re-initialisation, then 7 fresh steps
+    elif case == "lr_and_exit":
+        kw = dict(opt_steps_list=[12], lr_list=[0.01], p_dropout_list=[0.25], alpha_diff_cost=0.9, lr_reduction_ratio=0.5, lr_min=0.004,
+                  p_drop_reduction=0.125, min_diff_cost=1e9, num_min_diff_cost=2, min_step=0)
+    elif case == "last_step_fails":
+        nan_calls = [8]                           # (rollout 1 is the warm-up: rollout 8 is the first attempt of step 6, the last)
+    out = {}
+    for depth in (0, 1):
+        obj = _trace_setup(fx)
+        obj.noise_mode = "philox"
+        obj.pipeline_depth = depth
+        _nan_on_rollout_calls(obj, nan_calls)
+        torch.manual_seed(1234)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            res = obj.reinforce_policy(
+                T_control=float(fx["T_control"]), num_particles=int(fx["M"]), trial_index=0, particles_initial_state_mean=T(fx["x0_mean"]),
+                particles_initial_state_var=T(fx["x0_var"]), flg_particles_init_uniform=False, particles_init_up_bound=None,
+                particles_init_low_bound=None, flg_particles_init_multi_gauss=False, f_optimizer="lambda p, lr : torch.optim.Adam(p, lr)",
+                num_step_print=3, policy_reinit_dict=dict(lenghtscales_par=np.ones(5), centers_par=np.array([np.pi, np.pi, np.pi, 1.0, 1.0]),
+                                                          weight_par=10.0), **kw)
+        pol = obj.control_policy
+        import re
+        out[depth] = dict(res=res, calls=obj._rollout_calls, rng=torch.cuda.get_rng_state(dev()).clone(),
+                          par=[q.detach().cpu().numpy().copy() for q in pol.parameters()],
+                          txt=re.sub(r"time elapsed:  [0-9.e+-]+", "time elapsed", buf.getvalue()))
+    a, b = out[0], out[1]
+    for x, y in zip(a["res"], b["res"]):
+        assert x.shape == y.shape and np.array_equal(x, y, equal_nan=True)
+    for x, y in zip(a["par"], b["par"]):
+        assert np.array_equal(x, y)
+    assert a["calls"] == b["calls"] and torch.equal(a["rng"], b["rng"])
+    assert a["txt"] == b["txt"]
+    costs = a["res"][0]
+    assert np.all(np.isfinite(costs))
+    if case == "plain":
+        assert costs.shape == (7,) and "Cost is NaN" not in a["txt"]
+    if case == "nan_retry":
+        assert costs.shape == (7,) and a["txt"].count("try sampling again") == 3 and a["calls"] == 1 + 7 + 3
+    if case == "reinit":
+        assert costs.shape == (7,) and a["txt"].count("try sampling again") == 10 and a["txt"].count("re-initialize control policy") == 1
+        assert a["calls"] == 1 + 2 + 10 + 7
+    if case == "lr_and_exit":
+        assert a["txt"].count("REDUCING THE LEARNING RATE") >= 1 and "EXIT FROM OPTIMIZATION" in a["txt"] and costs.shape[0] < 12
+    if case == "last_step_fails":
+        assert costs.shape == (7,) and a["txt"].count("try sampling again") == 1 and a["calls"] == 1 + 7 + 1
+
+
+def test_optimizer_loop_with_another_optimizer_updates_through_its_own_step(golden):
+    """f_optimizer is the user's: anything but the textbook Adam keeps its own ``step()`` (called once the host has seen that the
+    attempt counts) -- SGD here, with a failed attempt in the middle: the update of a failed attempt must not happen."""
+    fx = golden("policy_opt_trace")
+    obj = _trace_setup(fx)
+    obj.noise_mode = "philox"
+    _nan_on_rollout_calls(obj, [3])
+    w0 = obj.control_policy.f_linear.weight.detach().clone()
+    torch.manual_seed(5)
+    with quiet():
+        costs, _, _, _ = obj.reinforce_policy(
+            T_control=float(fx["T_control"]), num_particles=int(fx["M"]), trial_index=0, particles_initial_state_mean=T(fx["x0_mean"]),
+            particles_initial_state_var=T(fx["x0_var"]), flg_particles_init_uniform=False, particles_init_up_bound=None,
+            particles_init_low_bound=None, flg_particles_init_multi_gauss=False, f_optimizer="lambda p, lr : torch.optim.SGD(p, lr)",
+            num_step_print=100, opt_steps_list=[4], lr_list=[0.01], p_dropout_list=[0.25], policy_reinit_dict=None)
+    assert costs.shape == (4,) and np.all(np.isfinite(costs)) and obj._rollout_calls == 1 + 4 + 1
+    w1 = obj.control_policy.f_linear.weight.detach()
+    assert bool(torch.isfinite(w1).all()) and float((w1 - w0).abs().max()) > 0
