@@ -780,10 +780,19 @@ def test_zero_predictive_variance_raises_like_the_reference_normal():
     assert int(status.item()) & hipabi.STATUS_NONPOS_VAR and not (int(status.item()) & hipabi.STATUS_NAN)
     assert bool(torch.isfinite(st).all())
     stub = types.SimpleNamespace(gp_sharding=True)
+    stub._judge_attempt = lambda *a: MC_PILCO.MC_PILCO._judge_attempt(stub, *a)
     with pytest.raises(ValueError):
         MC_PILCO.MC_PILCO._rollout_failed(stub, torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64))
-    assert MC_PILCO.MC_PILCO._rollout_failed(stub, torch.tensor([1.0, 0.0, 1.0], dtype=torch.float64)) is True   # NaN: the retry path
+    with pytest.raises(ValueError):  # a FINITE variance <= 0 raises whatever the cost came out as (sqrt of a negative variance makes it NaN)
+        MC_PILCO.MC_PILCO._rollout_failed(stub, torch.tensor([1.0, 0.0, 1.0], dtype=torch.float64))
+    assert MC_PILCO.MC_PILCO._rollout_failed(stub, torch.tensor([1.0, 0.0, 0.0], dtype=torch.float64)) is True   # NaN alone: the retry path
     assert MC_PILCO.MC_PILCO._rollout_failed(stub, torch.tensor([0.0, 0.0, 0.0], dtype=torch.float64)) is False
+    # a NaN state (divergence) reaches the GP as a NaN variance: MCP_STATUS_NAN only -- the retry case, not the ValueError
+    x_nan = G(np.zeros((8, S)))
+    x_nan[3, 1] = float("nan")
+    with torch.no_grad():
+        _, _, status = ops.rollout(model, pol, ops.NoiseSpec(seed=1, call=1), x_nan + 1.0, 2, 0.0)
+    assert int(status.item()) & hipabi.STATUS_NAN and not (int(status.item()) & hipabi.STATUS_NONPOS_VAR)
 
 
 # ---- round 4: the optimizer loop without a host sync per step ------------------------------------------------------------------------
