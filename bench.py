@@ -4,7 +4,7 @@ MC_PILCO.reinforce_policy (policy_learning/MC_PILCO.py:484-525) -- fused particl
 expected cost, reverse-time adjoint, [one all-reduce of gradient + cost sums], Adam update -- on
 synthetic cart-pole-shaped data.  Metric: particle-steps/s = M*T / step time, whole job.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c1_script|c3|c4|c5] [--no-cpu] [--no-extra]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c1_script|c2_script|pms_script|ur5_script|c3|c4|c5] [--no-cpu] [--no-extra]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -14,8 +14,8 @@ N > 1 run carries `scaling_reference` = the same per-GPU shard timed on one GPU 
 efficiency of THIS workload can be read off one line) and the latency-bound c1 shard as an extra.
 
 `--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself as child processes -- before
-this process makes any GPU call -- relays rank 0's JSON line and WATCHES the children: a rank that dies, or 180 s
-without any rank finishing while rank 0 is silent, ends the run with a non-zero exit code instead of a hang.
+this process makes any GPU call (after building the library once, in the parent) -- relays rank 0's JSON line and WATCHES the
+children: a rank that dies, or 180 s without a sign of life from ANY rank, ends the run with a non-zero exit code instead of a hang.
 
 Multi-GPU: particles are sharded; the ranks meet in ONE all-reduce per step (RCCL): [gradient | per-time-step cost sums |
 status flags].  Before the workload is built every rank runs a PRE-FLIGHT (one 8-byte all-reduce under a time-out) whose
@@ -53,7 +53,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default=None, help="c1 (default on one GPU), c1_script, c3, c4 (default on N > 1 GPUs), c5")
+    ap.add_argument("--workload", default=None, help="c1 (default on one GPU), c1_script, c2_script, pms_script, ur5_script, c3, c4 (default on N > 1 GPUs), c5")
     ap.add_argument("--particles", type=int, default=0, help="particles per GPU (default: the workload's M)")
     ap.add_argument("--horizon", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline legs")
@@ -81,25 +81,38 @@ def spawn_ranks(args):
     import selectors
     import socket
 
+    # the library is built HERE, once, before any rank starts: a first-time hipcc build inside the children (minutes of silence)
+    # would look like a hang to the watchdog, and N ranks would race for the same object files.  Compiling does not touch the GPU.
+    try:
+        subprocess.check_call([sys.executable, os.path.join(ROOT, "mc-pilco_amd", "build.py")], stdout=sys.stderr)
+    except subprocess.CalledProcessError as e:
+        note("building libmcpilco_hip.so failed (exit code %d)" % e.returncode)
+        raise SystemExit(e.returncode or 1)
+    # the rendezvous port: kept BOUND (SO_REUSEADDR / SO_REUSEPORT) until the children have been started, so that nobody else is
+    # handed the same port in between; rank 0's store binds it with the same options
     s = socket.socket()
+    s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    if hasattr(socket, "SO_REUSEPORT"):
+        s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEPORT, 1)
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
-    s.close()
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
-                                      stderr=subprocess.PIPE if r == 0 else None))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE))
+    s.close()
+    # a sign of life = a byte on rank 0's stdout or on ANY rank's stderr (every rank writes progress notes there), or a child exiting
     sel = selectors.DefaultSelector()
-    for f in (procs[0].stdout, procs[0].stderr):
+    streams = [procs[0].stdout] + [p.stderr for p in procs]
+    for f in streams:
         os.set_blocking(f.fileno(), False)
         sel.register(f, selectors.EVENT_READ)
     out = b""
     last_life = time.monotonic()
-    open_streams = 2
+    open_streams = len(streams)
     rc = None
     while rc is None:
         for key, _ in sel.select(timeout=1.0):
@@ -122,7 +135,7 @@ def spawn_ranks(args):
         elif all(c == 0 for c in codes) and open_streams == 0:
             rc = 0
         elif time.monotonic() - last_life > args.watchdog_seconds:
-            note("watchdog: no progress for %.0f s -- terminating all ranks" % args.watchdog_seconds)
+            note("watchdog: no sign of life from any rank for %.0f s -- terminating all ranks" % args.watchdog_seconds)
             rc = 124
     if rc != 0:
         for p in procs:
@@ -212,7 +225,7 @@ class Runner:
         self.args, self.name, self.dev, self.rank, self.world, self.reducer = args, name, dev, rank, world, reducer
         self.w = workloads.build(name, device=dev, M=M, T=T)
         self.M, self.T = self.w.M, self.w.T
-        self.meas = None
+        self.meas = self.w.meas  # (pms_script carries its own measurement model)
         if args.pms:
             from scipy import signal
 
@@ -226,6 +239,7 @@ class Runner:
         self.flags_sum = torch.zeros(1 + self.STATUS_BITS, dtype=torch.float64, device=dev)  # reduced flags of every step, on every rank alike
         self.shift = torch.zeros(self.T, dtype=torch.float64, device=dev)
         self.flops = workloads.flops_per_particle_step(self.w)
+        self.flops_fwd = workloads.flops_per_particle_step(self.w, forward_only=True)
         self.bits = torch.tensor([1 << b for b in range(self.STATUS_BITS)], dtype=torch.int32, device=dev)
 
     def step(self, i, ev, sharded=None):
@@ -284,6 +298,7 @@ class Runner:
         all block seconds)."""
         torch = self.torch
         sharded = (self.world > 1) if sharded is None else sharded
+        self.rank_block_s = []
         for i in range(warmup):
             self.step(i, None, sharded)
         blocks, fwd, cost, k, nblocks = [], [], None, warmup, 1
@@ -296,12 +311,13 @@ class Runner:
             self.barrier()
             el = time.perf_counter() - t0
             k += steps
-            if self.world > 1 and sharded:
+            if self.world > 1:  # (also without the step's collective: every rank must arrive at the same number of blocks)
                 import torch.distributed as dist
 
-                tmax = torch.tensor([el], dtype=torch.float64, device=self.dev)
+                tmax = torch.tensor([el, -el], dtype=torch.float64, device=self.dev)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                el = float(tmax.item())
+                self.rank_block_s.append((-float(tmax[1].item()), float(tmax[0].item())))  # (fastest rank, slowest rank) of this block
+                el = float(tmax[0].item())
             blocks.append(el)
             fwd.append(sum(a.elapsed_time(b) for (a, b) in evs) / len(evs))
             if len(blocks) == 1 and min_seconds > 0:
@@ -309,6 +325,7 @@ class Runner:
         self.check_flags()
         order = sorted(range(len(blocks)), key=lambda j: blocks[j])
         mid = order[len(order) // 2]
+        self.rank_block_mid = self.rank_block_s[mid] if self.rank_block_s else None
         return blocks[mid], fwd[mid], float(cost.detach()), blocks
 
     def kernel_name(self):
@@ -328,11 +345,15 @@ class Runner:
         small = not name.startswith("rollout_fwd_tile")
         ach = self.flops * self.M * self.T / (fwd_ms * 1e-3) / 1e12
         ach_step = self.flops * self.M * self.T / step_s / 1e12
+        ach_fwd = self.flops_fwd * self.M * self.T / (fwd_ms * 1e-3) / 1e12
         r = {"bound": "l2-stream+latency" if small else "fp64 units (mfma)", "roof": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS,
-             "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "frac_step": ach_step / FP64_PEAK_TFLOPS, "traffic": traffic,
+             "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "frac_fwd_only": ach_fwd / FP64_PEAK_TFLOPS,
+             "frac_step": ach_step / FP64_PEAK_TFLOPS, "traffic": traffic,
+             "alg_flops_fwd_per_particle_step": self.flops_fwd,
              "kernel": name, "kernel_ms": fwd_ms, "alg_flops_per_particle_step": self.flops, "units_per_launch": self.M * self.T,
              "achieved_basis": "algorithmic fwd+bwd flops per particle-step (SURVEY 8d) x M x T / the FORWARD kernel's mean launch time "
-                               "(HIP events on the launch stream); frac_step: the same flops / ms_per_step",
+                               "(HIP events on the launch stream); frac_fwd_only: the forward terms of that figure alone / the same time (what the "
+                               "forward kernel itself executes); frac_step: fwd+bwd flops / ms_per_step",
              "regime": ("T-sequential chain of 4 barrier-separated phases per step + the per-CU L2->CU stream of one Kinv per workgroup and "
                         "step; fp64 flop roof not reachable at M=400 (DESIGN.md 4.1)") if small else
                        "fp64 matrix pipe (MFMA 16x16x4) beside VALU exp / Philox phases"}
@@ -361,12 +382,13 @@ def preflight(dist, torch, dev, args, rank, world):
         x = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(x)
         torch.cuda.synchronize()
-        if int(x.item()) != world:
+        seen = int(x.item())
+        if seen != world:
             raise RuntimeError("all-reduce of ones returned %s on rank %d, expected %d" % (x.item(), rank, world))
     except Exception as e:  # noqa: BLE001
         raise SystemExit("bench: pre-flight all-reduce failed on rank %d (backend %s, transport %s, world %d, device %s): %r"
                          % (rank, args.backend, args.transport, world, dev, e))
-    return time.perf_counter() - t0
+    return time.perf_counter() - t0, seen
 
 
 def time_collective(torch, reducer, n, dev, calls=50):
@@ -425,19 +447,27 @@ def main():
                 dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=tmo)
         except Exception as e:  # noqa: BLE001
             raise SystemExit("bench: init_process_group(%s) failed on rank %d of %d: %r" % (args.backend, rank, world, e))
-        pf = preflight(dist, torch, dev, args, rank, world)
+        pf, ranks_seen = preflight(dist, torch, dev, args, rank, world)
         if rank == 0:
             note("pre-flight all-reduce over %d ranks (%s): %.2f s" % (world, args.backend, pf))
         reducer = sharding.StepReducer(dist.group.WORLD, args.transport)
 
-    if rank == 0:
-        note("building workload %s" % args.workload)
+    note("rank %d: building workload %s" % (rank, args.workload))  # (every rank: its stderr is the launcher's sign of life)
     main_run = Runner(args, args.workload, dev, rank, world, reducer, M=args.particles or None, T=args.horizon or None)
     M, T, w = main_run.M, main_run.T, main_run.w
     nmsg = sum(p.numel() for p in w.params) + 2 * T + 1 + Runner.STATUS_BITS
     if world > 1:
         us = time_collective(torch, reducer, nmsg, dev)
-        collective = {"per_step": 1, "doubles": nmsg, "transport": args.transport, "backend": args.backend, "us_per_call": us}
+        from mc_pilco_amd import hipabi
+
+        # what the collective actually saw: the process group's size, the sum of ones of the pre-flight all-reduce, and (transport
+        # "abi") the size of the C ABI's own RCCL communicator; a second all-reduce of ones through the step's OWN reducer, too
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        reducer.allreduce_(ones)
+        collective = {"per_step": 1, "doubles": nmsg, "transport": args.transport, "backend": args.backend, "us_per_call": us,
+                      "world": dist.get_world_size(), "ranks_seen": ranks_seen, "ranks_seen_by_step_reducer": int(ones.item()),
+                      "transport_world": hipabi.lib().mcp_comm_world() if args.transport == "abi" else None,
+                      "devices": "one GPU per rank" if not args.single_device else "ALL ranks on cuda:0 (rehearsal)"}
         if args.collective_smoke:
             other = "abi" if args.transport == "torch" else "torch"
             try:
@@ -447,6 +477,8 @@ def main():
             except Exception as e:  # noqa: BLE001  (a smoke: reported, not fatal)
                 collective["error_" + other] = repr(e)
     block_s, fwd_ms, last_cost, blocks = main_run.run(args.steps, args.warmup, args.min_seconds)
+    if rank != 0:
+        note("rank %d: timed blocks done" % rank)
     if rank == 0:
         note("%s: %d block(s) of %d steps, median %.3f s" % (args.workload, len(blocks), args.steps, block_s))
     ms_per_step = 1e3 * block_s / args.steps
@@ -480,11 +512,14 @@ def main():
             "config": {"workload": "%s: %s, %d GPs, D=%d, N=%d, B=%d, poly degree %d, M=%d particles/GPU, T=%d, p_dropout=%.2f; step = rollout fwd + cost + "
                                    "adjoint bwd%s + Adam%s" % (args.workload, w.problem["system"], w.model.G, w.model.D, w.model.gps[0].N, w.policy.B,
                                                             w.problem["deg"], M, T, w.p_drop,
-                                                            " + 1 RCCL all-reduce [grad|cost sums|flags]" if world > 1 else "",
+                                                            (" + 1 %s all-reduce [grad|cost sums|flags]" % ("RCCL" if args.backend == "nccl" or args.transport == "abi"
+                                                                                                                    else args.backend)) if world > 1 else "",
                                                             "; policy on measured states (MC_PILCO4PMS)" if args.pms else ""),
                        "particles_per_gpu": M, "particles_total": world * M, "horizon": T, "parallelism": "particle-dp%d" % world,
                        "collective": collective},
             "blocks": len(blocks), "block_ms": [1e3 * b for b in blocks],
+            "rank_ms_per_step": None if not main_run.rank_block_mid else {"fastest_rank": 1e3 * main_run.rank_block_mid[0] / args.steps,
+                                                                         "slowest_rank": 1e3 * main_run.rank_block_mid[1] / args.steps},
             "roofline": roof,
             "kernel_sources_sha16": sha,
             "final_cost": last_cost,
@@ -493,12 +528,13 @@ def main():
         # (a) the SAME per-GPU shard on one GPU, no collective: value x N would be perfect weak scaling of this workload;
         # (b) the latency-bound c1 shard (M = 400 per GPU), sharded, for comparison with the single-GPU headline.
         # Every rank runs both (lockstep: the sharded one contains collectives).
-        ref_s, _, _, _ = main_run.run(max(3, args.steps // 4), 1, 0.0, sharded=False)
         k1 = max(3, args.steps // 4)
+        ref_s, _, _, ref_blocks = main_run.run(k1, 1, min(args.min_seconds, 0.5), sharded=False)
         c1 = Runner(args, "c1", dev, rank, world, reducer)
         c1_s, c1_f, _, _ = c1.run(args.steps, 2, 0.0)
         if rank == 0:
-            out["scaling_reference"] = {"what": "the same %s shard (M=%d) on ONE GPU without the collective, %d steps" % (args.workload, M, k1),
+            out["scaling_reference"] = {"what": "the same %s shard (M=%d) on ONE GPU without the collective, median of %d block(s) of %d steps (every rank "
+                                                "runs its own copy concurrently; slowest rank's clock)" % (args.workload, M, len(ref_blocks), k1),
                                         "value_one_gpu": M * T / (ref_s / k1), "ms_per_step": 1e3 * ref_s / k1,
                                         "efficiency_vs_it": value / (world * M * T / (ref_s / k1))}
             out["extra_workloads"] = [{"workload": "c1 (M=%d per GPU, sharded over %d GPUs: latency bound)" % (c1.M, world), "value": world * c1.M * c1.T / (c1_s / args.steps),
@@ -510,16 +546,20 @@ def main():
             # the other single-GPU configurations of BASELINE.json, measured in the same run: the launch script's own horizon (T=60,
             # SURVEY 8d), c3 (SE+poly(2), M=4000) and c5 (UR5, 6 GPs, D=24, N=400, M=2000, T=300) -- same step definition, fewer steps
             extra = []
-            for name, k in (("c1_script", 20), ("c3", 5), ("c5", 3)):
+            # (same rule as the headline: blocks of exactly k steps, repeated until >= min-seconds have been measured, median block)
+            for name, k in (("c1_script", 20), ("c2_script", 20), ("pms_script", 20), ("ur5_script", 10), ("c3", 5), ("c5", 3)):
                 note("extra workload %s" % name)
                 r = Runner(args, name, dev, rank, world, reducer)
-                e2, f2, c2, _ = r.run(k, 2)
-                note("%s: %d steps in %.3f s" % (name, k, e2))
-                rf = r.roofline(f2, e2 / k, traffic_of(name if name != "c1_script" else None))
+                e2, f2, c2, b2 = r.run(k, 2, args.min_seconds)
+                note("%s: median of %d block(s) of %d steps: %.3f s" % (name, len(b2), k, e2))
+                rf = r.roofline(f2, e2 / k, traffic_of(name if name in ("c3", "c5") else None))
                 rf.pop("achieved_basis")
                 extra.append({"workload": name, "particles": r.M, "horizon": r.T, "N": r.w.model.gps[0].N, "gps": r.w.model.G,
-                              "value": r.M * r.T / (e2 / k), "unit": "particle-steps/s", "ms_per_step": 1e3 * e2 / k, "steps": k, "warmup": 2,
-                              "kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"], "frac": rf["frac"], "roofline": rf, "final_cost": c2})
+                              "poly_degree": r.w.problem["deg"], "measured_states": r.meas is not None,
+                              "value": r.M * r.T / (e2 / k), "unit": "particle-steps/s", "ms_per_step": 1e3 * e2 / k,
+                              "us_per_time_step": 1e3 * 1e3 * e2 / k / r.T, "steps": k, "warmup": 2, "blocks": len(b2),
+                              "kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"], "frac": rf["frac"], "frac_fwd_only": rf["frac_fwd_only"],
+                              "roofline": rf, "final_cost": c2})
                 del r
                 torch.cuda.empty_cache()
             out["extra_workloads"] = extra
@@ -527,16 +567,25 @@ def main():
             note("MC_PILCO.reinforce_policy on the drop-in classes (100 steps)")
             from mc_pilco_amd import workloads
 
-            s_loop, c_first, c_last = workloads.time_reinforce_policy(dev, 100)
+            s_loop, c_first, c_last = workloads.time_reinforce_policy(dev, 300)
             out["loop_ms_per_step"] = 1e3 * s_loop
-            out["loop"] = {"what": "MC_PILCO.reinforce_policy of the drop-in package, 100 optimizer steps at the c1 shape (monitors, NaN check, "
-                                   "Adam, printing included)", "value": M * T / s_loop, "unit": "particle-steps/s", "cost_first": c_first,
-                           "cost_last": c_last}
+            out["loop"] = {"what": "MC_PILCO.reinforce_policy of the drop-in package, 300 optimizer steps at the c1 shape (monitors, NaN retry "
+                                   "logic, lr / exit test from step 200 on, Adam, printing included; outcome of each attempt read one attempt late)",
+                           "value": M * T / s_loop, "unit": "particle-steps/s", "cost_first": c_first, "cost_last": c_last,
+                           "over_bench_step": 1e3 * s_loop / ms_per_step - 1.0}
+            s_loop2, _, _ = workloads.time_reinforce_policy(dev, 300, T_control=3.0)
+            out["loop_c1_script"] = {"what": "the same at the launch script's horizon (T = 60)", "loop_ms_per_step": 1e3 * s_loop2,
+                                     "value": M * 60 / s_loop2, "unit": "particle-steps/s",
+                                     "over_bench_step": 1e3 * s_loop2 / extra[0]["ms_per_step"] - 1.0}
             note("GP hyper-parameter training (fit_model), N=300, 2 GPs, 100 epochs each")
             s_ep, n_tr = workloads.time_fit_model(dev, 300, 100)
             out["fit_model"] = {"what": "Model_learning.reinforce_model on the drop-in package: Adam on the marginal likelihood, full batch, "
-                                        "N=%d training points, D=6, 2 GPs one after the other, 100 epochs each" % n_tr,
+                                        "N=%d training points, D=6, 2 GPs, 100 epochs each" % n_tr,
                                 "ms_per_epoch_per_gp": 1e3 * s_ep, "epochs_per_s": 1.0 / s_ep}
+            note("GP hyper-parameter training (fit_model), UR5 shape: N=400, D=24, 6 GPs, SE+poly(1), 30 epochs each")
+            s_ep6, n_tr6 = workloads.time_fit_model_ur5(dev, 400, 30)
+            out["fit_model_ur5"] = {"what": "the same for the UR5-shaped model: N=%d, D=24, SE + polynomial(1), 6 GPs, 30 epochs each" % n_tr6,
+                                    "ms_per_epoch_all_6_gps": 1e3 * s_ep6, "ms_per_epoch_per_gp": 1e3 * s_ep6 / 6}
         if world == 1 and not args.no_cpu:
             # the cores this process may actually run on (the box gives one GPU's share of the host, not os.cpu_count())
             ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

@@ -21,8 +21,16 @@ CONFIGS = {
     "c3": ("cartpole", 2, 300, 4000, 150),  # configs[2]: SE + polynomial(2), M=4000
     "c4": ("cartpole", 2, 300, 4000, 150),  # configs[3]: the c3 model, M=32000 over 8 GPUs = 4000 particles per GPU (bench.py --gpus N)
     "c5": ("ur5", 1, 400, 2000, 300),       # configs[4]: UR5 12-D state, 6 GPs, SE + polynomial(1)
+    # the reference's own small-swarm launch scripts (their shapes; N = the data of the last trials)
+    "c2_script": ("cartpole", 2, 300, 400, 60),   # test_mcpilco_cartpole.py:51-53,101,199: SE + polynomial(2), M=400, T=3.0/0.05
+    "pms_script": ("cartpole", 0, 300, 400, 90),  # test_mcpilco4pms_cartpole.py:51-53,155-157,171: SE, M=400, T=3.0/(1/30), measured states
+    "ur5_script": ("ur5", 1, 400, 200, 200),      # test_mcpilco_ur5_mujoco.py:58-59,102,195: 6 GPs, D=24, SE + polynomial(1), M=200, T=4.0/0.02
     "tiny": ("cartpole", 0, 48, 16, 6),
     "tiny_ur5": ("ur5", 1, 40, 8, 5),
+}
+# per-workload overrides: sampling time of the data / model, measurement model of MC_PILCO4PMS (pos, vel, noise std, filter cutoff)
+OPTIONS = {
+    "pms_script": dict(Ts=1.0 / 30.0, pms=dict(pos=[0, 2], vel=[1, 3], std=3e-3, fc=0.5)),
 }
 
 
@@ -31,10 +39,11 @@ def numpy_problem(name, N=None, seed=1):
     system, deg, N0, M, T = CONFIGS[name]
     N = N or N0
     rng = np.random.RandomState(seed + 100)
+    opt = OPTIONS.get(name, {})
     if system == "cartpole":
-        c = sy.CARTPOLE
+        c = dict(sy.CARTPOLE, Ts=opt.get("Ts", sy.CARTPOLE["Ts"]))
         n_roll = (N + 59) // 60
-        Z, Ys = sy.gp_io(sy.cartpole_rollouts(n_roll=n_roll, seed=seed), c["angle"], c["not_angle"], c["vel"])
+        Z, Ys = sy.gp_io(sy.cartpole_rollouts(n_roll=n_roll, seed=seed, Ts=c["Ts"]), c["angle"], c["not_angle"], c["vel"])
         pol = sy.cartpole_policy_init(B=c["B"], u_max=c["u_max"], seed=seed)
         kind, extra = "angles", dict(angle=[2], non_angle=[0, 1, 3])
         target = None
@@ -56,7 +65,7 @@ def numpy_problem(name, N=None, seed=1):
                 w.append(0.01 * (0.8 + 0.4 * rng.rand(2 * c["D"])))
             poly.append(w)
     return dict(name=name, system=system, cfg=c, deg=deg, N=N, M=M, T=T, Z=Z, Ys=Ys, poly=poly, policy=pol, policy_kind=kind,
-                policy_extra=extra, target_traj=target)
+                policy_extra=extra, target_traj=target, pms=opt.get("pms"))
 
 
 @dataclass
@@ -72,6 +81,7 @@ class Workload:
     T: int
     p_drop: float
     problem: dict
+    meas: Optional[ops.MeasSpec] = None  # measurement model between particles and policy (MC_PILCO4PMS), None: the true state
 
     def sample_x0(self, M=None, generator=None):
         M = M or self.M
@@ -126,7 +136,14 @@ def build(name, device=None, M=None, T=None, N=None, p_drop=0.25, seed=1) -> Wor
         cost = ops.PackedCost("traj", c["S"], device, target_traj=pb["target_traj"], lengthscales=c["cost_ls"], used=None)
     x0m = torch.as_tensor(c["x0_mean"], dtype=DT).to(device).reshape(1, -1)
     x0s = torch.sqrt(torch.as_tensor(c["x0_var"], dtype=DT)).to(device).reshape(1, -1)
-    return Workload(name, model, policy, cost, [log_ls, centers, weight], x0m, x0s, M, T, p_drop, pb)
+    meas = None
+    if pb.get("pms"):
+        from scipy import signal
+
+        q = pb["pms"]
+        bb, aa = signal.butter(1, q["fc"])
+        meas = ops.MeasSpec(pos=q["pos"], vel=q["vel"], std_pos=[q["std"]] * len(q["pos"]), b=bb, a=aa)
+    return Workload(name, model, policy, cost, [log_ls, centers, weight], x0m, x0s, M, T, p_drop, pb, meas)
 
 
 def policy_grad_step(w: Workload, x0, noise: ops.NoiseSpec, group=None):
@@ -141,10 +158,11 @@ def policy_grad_step(w: Workload, x0, noise: ops.NoiseSpec, group=None):
     return cost.detach(), std.detach(), status
 
 
-def flops_per_particle_step(w: Workload):
-    """SURVEY.md 8d algorithmic flops per particle-step (forward + backward)."""
+def flops_per_particle_step(w: Workload, forward_only=False):
+    """SURVEY.md 8d algorithmic flops per particle-step (forward + backward; ``forward_only``: the forward terms alone -- the GP
+    sums of the first bracket and the policy's forward half)."""
     P, B, U, D = w.policy.P, w.policy.B, w.policy.U, w.model.D
-    f = 6 * B * (P + U + 2)
+    f = (3 if forward_only else 6) * B * (P + U + 2)
     for gp in w.model.gps:
         N = gp.N
         deg = gp.spec.poly_deg
@@ -154,7 +172,8 @@ def flops_per_particle_step(w: Workload):
         if deg >= 2:
             fpoly += (4 * D + 3) * N
         f += 2 * N * N + (3 * D + 8) * N + fpoly  # forward
-        f += (6 * D + 6) * N + fpoly  # backward
+        if not forward_only:
+            f += (6 * D + 6) * N + fpoly  # backward
     return f
 
 
@@ -205,13 +224,14 @@ def dropin_c1(device, pms=False, num_particles=400, T_control=7.5):
     return obj, args
 
 
-def time_reinforce_policy(device, steps=100, pms=False):
-    """(seconds per optimizer step of MC_PILCO.reinforce_policy on the drop-in classes, first cost, last cost)."""
+def time_reinforce_policy(device, steps=100, pms=False, T_control=7.5):
+    """(seconds per optimizer step of MC_PILCO.reinforce_policy on the drop-in classes, first cost, last cost); T_control 7.5 s =
+    150 steps (c1), 3.0 s = the launch script's 60."""
     import contextlib
     import io
     import time
 
-    obj, args = dropin_c1(device, pms=pms)
+    obj, args = dropin_c1(device, pms=pms, T_control=T_control)
     with contextlib.redirect_stdout(io.StringIO()):
         obj.reinforce_policy(opt_steps_list=[10], **args)  # warm-up
         torch.cuda.synchronize()
@@ -250,3 +270,36 @@ def time_fit_model(device, N=300, epochs=100):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
     return el / (2 * epochs), int(ml.gp_inputs.shape[0])
+
+
+def time_fit_model_ur5(device, N=400, epochs=30):
+    """The same for the UR5-shaped model (6 GPs, D=24, SE + polynomial(1), test_mcpilco_ur5_mujoco.py:71-117): seconds per epoch for
+    ALL six GPs (one epoch of each), and N."""
+    import contextlib
+    import io
+    import time
+
+    from .gpr_lib.Likelihood import Gaussian_likelihood as Likelihood
+    from .model_learning import Model_learning as ML
+
+    c = sy.UR5
+    D = c["D"]
+    rbf = dict(active_dims=np.arange(D), lengthscales_init=np.ones(D), flg_train_lengthscales=True, lambda_init=np.ones(1), flg_train_lambda=False,
+               sigma_n_init=np.ones(1), sigma_n_num=None, flg_train_sigma_n=True, dtype=DT, device=device)
+    mpk = dict(active_dims=np.arange(D), poly_deg=1, Sigma_pos_par_init_list=[np.ones(D + 1)], flg_train_Sigma_pos_par_list=[True], dtype=DT,
+               device=device)
+    par = dict(num_gp=6, T_sampling=c["Ts"], angle_indeces=c["angle"], not_angle_indeces=c["not_angle"], vel_indeces=c["vel"],
+               not_vel_indeces=c["not_vel"], dtype=DT, device=device, init_dict_list=[[rbf, mpk]] * 6)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ml = ML.Speed_Model_learning_RBF_MPK_angle_state(**par)
+        for xs, us in sy.ur5_rollouts(n_roll=(N + 199) // 200):
+            ml.add_data(np.asarray(xs), np.asarray(us))
+        opt = dict(f_optimizer="lambda p : torch.optim.Adam(p, lr=0.01)", criterion=Likelihood.Marginal_log_likelihood, N_epoch=5, N_epoch_print=100000)
+        ml.reinforce_model([opt] * 6)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        opt["N_epoch"] = epochs
+        ml.reinforce_model([opt] * 6)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+    return el / epochs, int(ml.gp_inputs.shape[0])
