@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["gp_pretrain.hip", "rollout_fwd.hip", "rollout_fwd_tile.hip", "rollout_bwd.hip", "cost.hip", "policy_opt.hip", "comm.hip"]
+SOURCES = ["gp_pretrain.hip", "rollout_fwd.hip", "rollout_fwd_lean.hip", "rollout_fwd_tile.hip", "rollout_bwd.hip", "cost.hip", "policy_opt.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "mcp_device.h"), os.path.join(CSRC, "rollout_common.h"), os.path.join(CSRC, "rollout_fwd_shared.h"),
            os.path.join(os.path.dirname(HERE), "include", "mcpilco_hip.h")]
 LIB = os.path.join(HERE, "libmcpilco_hip.so")
@@ -47,17 +47,29 @@ def build_variant(tag, defines, verbose=True, only=None):
     return lib
 
 
+def _compile_all(jobs, verbose):
+    """Runs the hipcc commands of the stale sources side by side (one process each, at most the CPU count)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1, int(os.environ.get("MCP_BUILD_JOBS", "8"))))) as ex:
+            list(ex.map(run, jobs))
+
+
 def build(force=False, verbose=True):
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + HEADERS):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
         objs.append(o)
+    _compile_all(jobs, verbose)
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB]
         if verbose:
@@ -73,6 +85,9 @@ if __name__ == "__main__":
     elif "--variant-fwd" in sys.argv:  # the same, recompiling rollout_fwd.hip only
         i = sys.argv.index("--variant-fwd")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], only=["rollout_fwd.hip"]))
+    elif "--variant-lean" in sys.argv:  # the same, recompiling rollout_fwd_lean.hip only
+        i = sys.argv.index("--variant-lean")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], only=["rollout_fwd_lean.hip"]))
     elif "--variant-bwd" in sys.argv:  # the same, recompiling rollout_bwd.hip only
         i = sys.argv.index("--variant-bwd")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], only=["rollout_bwd.hip"]))

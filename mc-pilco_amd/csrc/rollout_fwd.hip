@@ -1088,892 +1088,6 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   if (bad) atomicOr(a.status, bad);
 }
 
-// =======================================================================================
-// Latency-lean GP-sharded kernel for narrow SE-only models (BASELINE.json's headline: cart-pole, M = 400)
-// =======================================================================================
-// Same contract and the same cluster / hand-off protocol as rollout_fwd_kernel<P, true, 0, true>, rebuilt around what the stamps of
-// that kernel show: at M = 400 a step is a chain of barrier-separated phases whose cost is their INSTRUCTION COUNT (a wave issues
-// about one instruction per 5 cycles whatever it is) plus the N^2 product v = Kinv k, which in v_fmac_f64_dpp form costs 10 k cycles
-// of vector issue beside a 9-10 k cycle L2 -> CU stream.
-//   * FOUR workgroup barriers per step instead of eight.  Policy: phi_b w_kb summed over aligned groups of 16 basis functions
-//     inside one DPP row (the same tree whatever P is), group sums to LDS, ONE barrier, then every thread adds the group sums in
-//     a fixed order and squashes for itself -- there is no phase U.  The state-only part of the GP distances (D - U of the D input
-//     dimensions are known once the state is) is formed beside the policy features, so after u only one fused multiply-add per
-//     input and the exp remain (no phase K of its own).
-//   * everything a thread reads repeatedly is pre-scaled and laid out at launch: X^T / l and the policy centres / l (zero padded to
-//     fixed dimension counts: no run-time bounds inside the unrolled loops, padded terms add exact zeros), the published features
-//     are already divided by their lengthscales; per-thread roles of the serial section live in an LDS table and the thread id
-//     goes through an opaque move once per step (what is derived from it is recomputed, not held in registers across phase V).
-//   * phase V on the matrix cores: Kinv as 16 x 8 operand tiles of v_mfma_f64_4x4x4_4b_f64 (kt_pack_kernel), every wave owns whole
-//     row tiles, so v is complete inside a wave: no cross-wave partial sums, no phase "vsum", and the wave goes straight on to its
-//     share of phase J (4x4x4 MFMA as well, the rows it has just produced) without a workgroup barrier in between.
-//   * phase F, the hand-off, the integrator and the next step's phase S run back to back in wave 0 (wave-level ordering only, the
-//     8 partial tiles of phase J summed by 64 lanes at once); the other waves meanwhile draw the next step's dropout decisions and
-//     process noise (never wave 4, which shares wave 0's SIMD).
-// Results do not depend on P (1, 2, 4): equal shards reproduce each other bit for bit, as before.  Covers SE-only models with
-// D <= 8 (<= 6 state-derived + <= 2 inputs), <= 6 policy features, 32 <= Npad <= 384, no measurement model; everything else runs the
-// general kernel above.
-#define RL_DSM 6  // state-derived GP-input dimensions (D - U), zero padded
-#define RL_UM 2   // inputs, zero padded
-#define RL_ZD (RL_DSM + RL_UM)
-#define RL_PFM 6  // policy features, zero padded
-#ifndef RL_NRES
-#define RL_NRES 2  // register buffers kept resident: RL_NRES or RL_NRES + 1, whichever leaves an even number to stream
-#endif
-#ifndef RL_PRE
-#define RL_PRE 0  // register buffers of the Kinv stream issued ahead of the barrier that ends phase K (0, 1, 2): measured equal
-#endif           // within 1 % (what the stream gains the phase before it loses waiting at the full memory queue)
-
-// LDS plan: the regions whose size is bounded by compile-time limits come first, at compile-time offsets (no scalar register per
-// pointer); the ones sized by N and B follow
-#define RL_MAXD RL_MAXD_  // D <= RL_DSM + RL_UM
-struct LatFixed {
-  static constexpr int pol = 0;                                // policy inverse lengthscales | u_max | bias | 1 / u_max
-  static constexpr int xs = pol + RL_PFM + 3 * MCP_MAX_INPUT;  // [2][64] state, double buffered by step parity
-  static constexpr int z = xs + 2 * 64;                        // [P][D] raw GP input (phase F: Jacobians)
-  static constexpr int zs = z + 4 * RL_MAXD;                   // [P][RL_ZD] GP input / lengthscale, zero padded
-  static constexpr int sf = zs + 4 * RL_ZD;                    // [P][RL_PFM] policy features / lengthscale, zero padded
-  static constexpr int dl = sf + 4 * RL_PFM;                   // [P][G] delta_g | abort word
-  static constexpr int eps = dl + 4 * MCP_MAX_GP + 2;          // [2][P] process noise of this workgroup's GP, by step parity
-  static constexpr int red = eps + 2 * 4;                      // [RF_NW][8][8] phase-J partial tiles
-  static constexpr int rt = red + RF_NW * 64;                  // [8][8] their sum (phase F)
-  static constexpr int gpl = rt + 64;
-  static constexpr int kpar = gpl + GPL_DOUBLES;
-  static constexpr int role = ((kpar + 5 * RL_MAXD + 2) + 1) & ~1;          // [64][16] ints: roles of the threads of wave 0 in the serial section
-  static constexpr int sro = role + 64 * 8;                    // [64][8]: phase S of thread (p, s): 6 int LDS addresses (in doubles) | 4 scale factors
-  static constexpr int dump = sro + 64 * 8;                    // where phase S writes what a state component does not feed
-  static constexpr int stl = dump + 2;                         // [16 + 8] u64 phase-cycle totals (diagnostic)
-  static constexpr int end = stl + 24;
-};
-static_assert(LatFixed::red % 2 == 0 && LatFixed::rt % 2 == 0 && LatFixed::zs % 2 == 0 && LatFixed::role % 2 == 0 && LatFixed::sro % 2 == 0 && LatFixed::end % 2 == 0, "16-byte alignment of the v2d regions");
-struct LatLayout {
-  int gs, kb, vb, xe, xq, al, cen, wgt, mk, total;  // offsets in doubles
-};
-__host__ __device__ inline int lat_ng(int B) { return (B + 15) >> 4; }                 // groups of 16 basis functions
-__host__ __device__ inline int lat_ngp(int B) { return ((lat_ng(B) + 7) >> 3) << 3; }  // padded to whole chunks of 8 (zeros)
-__host__ __device__ inline LatLayout lat_layout(int P, int B, int Npad) {
-  LatLayout L;
-  int o = LatFixed::end;
-  auto take = [&](int n) {
-    int r = o;
-    o += (n + 1) & ~1;
-    return r;
-  };
-  const int Bp = lat_ng(B) * 16;
-  L.gs = take(RL_UM * P * lat_ngp(B));
-  L.kb = take((Npad + 32) * P);   // (+ KT_ZROWS zero rows)
-  L.vb = take(Npad * P * 2);      // phase-J weights W[j][2p + a]
-  L.xe = take(8 * Npad);          // [X^T; 1; 0] (phase J's A operand)
-  L.xq = take(RL_ZD * Npad);
-  L.al = take(Npad);
-  L.cen = take(RL_PFM * Bp);
-  L.wgt = take(RL_UM * Bp);
-  L.mk = take((P * ((B + 3) / 4) + 1) / 2);
-  L.total = o;
-  return L;
-}
-// role table entries (ints) of a thread of wave 0
-enum { RO_OP, RO_OS, RO_ZPLAIN, RO_ZANG, RO_PPLAIN, RO_PANG, RO_GVEL, RO_GPOS, RO_VELOFPOS, RO_PMPOS, RO_PMVEL, RO_PMPAIR, RO_FP, RO_FC, RO_OM, RO_N };
-
-// ---- Kinv as MFMA operand tiles (lean kernel, phase V) ----------------------------------------------------------------
-// v = Kinv k for P <= 4 particles is [N x N] x [N x 4]: v_mfma_f64_4x4x4_4b_f64 -- four independent 4x4x4 products per
-// instruction -- takes a [16 rows x 4 columns] block of Kinv against k[4 columns][4 particles] with every lane busy, where
-// the 16x16x4 form would run 3/4 empty.  (Measured, tools/v4_bench.hip: the v_fmac_f64_dpp form of the general kernel costs
-// 10.2 k cycles of vector issue per step beside a 9.4 k stream, 12.7 k together; the MFMA form overlaps with the stream.)
-// Operand layout of the instruction (tools/mfma4x4_probe.hip): lane l = 16 k + 4 blk + e;  A: A_blk[i = e][k],  B: B_blk[k][j = e],
-// D: lane 16 i + 4 blk + j.  A tile = 16 rows x 8 columns of Kinv in that lane order, two doubles per lane (columns J0 + k and
-// J0 + 4 + k): one global_load_dwordx4 = 1 KB contiguous per wave feeds two MFMAs.  Wave w owns the row tiles
-// [rt0(w), rt0(w + 1)) for ALL columns -- every v_i is complete inside one wave: no cross-wave partial sums -- and its tiles are
-// stored in the order it streams them:  [w][column group jg][row tile r][lane][2].  Built once per rollout in the caller's
-// workspace (kt_pack_kernel; 2 x 0.7 MB for the cart-pole model).
-// The row tiles of a GP are dealt to the waves in parts of 2 or 3 (all 8 waves from 16 row tiles on; 2 <= row tiles <= 24,
-// i.e. 32 <= Npad <= 384): a register buffer is then always 6 CONSECUTIVE tiles of the wave's stream -- two column groups x 3 row
-// tiles or three groups x 2 -- so the loads, the double buffering and the resident buffers are one code path; only the wiring of
-// the 12 MFMAs of a buffer (which accumulator, which k operand) differs.
-#define KT_NL 6
-__host__ __device__ inline int kt_waves(int nrtt) { return nrtt >= 2 * RF_NW ? RF_NW : (nrtt >= 2 ? nrtt / 2 : 1); }
-__host__ __device__ inline int kt_rt0(int nrtt, int w) {
-  const int nw = kt_waves(nrtt);
-  return w >= nw ? nrtt : (nrtt * w) / nw;
-}
-__global__ void kt_pack_kernel(mcp_model md, double* __restrict__ kt, int stride) {
-  const mcp_gp& gp = md.gp[blockIdx.y];
-  const int Npad = gp.Npad, nrtt = Npad >> 4, njg = Npad >> 3;
-  double* out = kt + (size_t)blockIdx.y * stride;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < Npad * Npad; idx += gridDim.x * blockDim.x) {
-    // idx = ((rt * njg + jg) * 64 + l) * 2 + h  in "row tile major" numbering; the destination re-orders the tiles per wave
-    const int h = idx & 1, l = (idx >> 1) & 63, tile = idx >> 7;
-    const int rt = tile / njg, jg = tile - rt * njg;
-    int w = 0;
-    while (w + 1 < RF_NW && kt_rt0(nrtt, w + 1) <= rt) ++w;
-    const int r0 = kt_rt0(nrtt, w), nrt = kt_rt0(nrtt, w + 1) - r0;
-    const int row = 16 * rt + 4 * ((l >> 2) & 3) + (l & 3), col = 8 * jg + 4 * h + (l >> 4);
-    out[((size_t)r0 * njg + (size_t)jg * nrt + (rt - r0)) * 128 + 2 * l + h] = gp.Kinv[(size_t)row * Npad + col];
-  }
-  // a wave's last register buffer may run up to 5 tiles past its stream (those tiles meet k = 0): what lies behind the last stream of a
-  // GP must be finite -- the next GP's tiles are, the gap before them (a GP with fewer rows than the largest) and the slack behind
-  // the last GP are zeroed here
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < KT_NL * 128; idx += gridDim.x * blockDim.x) {
-    const size_t pos = (size_t)Npad * Npad + idx;
-    if (pos < (size_t)stride || blockIdx.y + 1 == gridDim.y) out[pos] = 0.0;
-  }
-}
-
-// One instruction = four independent 4x4x4 products.  Through the BUILTIN, not inline asm: the compiler then knows the
-// instruction and inserts the wait states its results need before a vector instruction may read them (it likes to copy
-// accumulators with v_mov_b64 where branches meet; behind an asm statement those copies read registers the matrix core has not
-// written yet -- seen as wrong trajectories the moment the copies landed right behind an MFMA).  Measured equal in speed
-// (tools/v4_bench.hip, both forms).
-__device__ __forceinline__ void mfma4(double& acc, double a, double b) {
-#ifdef RLX_NOFMA  // experiment: the stream alone
-  asm volatile("" : "+v"(acc) : "v"(a), "v"(b));
-#else
-  acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, acc, 0, 0, 0);
-#endif
-}
-
-// buffer b of this wave's stream = its tiles [6 b, 6 b + 6) (p: the lane's slot of tile 0).  A buffer may run past the end of the
-// stream: those tiles are the next wave's (the workspace ends with a buffer of slack) and meet k = 0.
-__device__ __forceinline__ void kt_load(v2d (&A)[KT_NL], gptr2_t p, int b) {
-  const gptr2_t pb = p + (size_t)b * (KT_NL * 64);
-#ifdef RLX_NOLOAD  // experiment: the MFMAs alone
-#pragma unroll
-  for (int s = 0; s < KT_NL; ++s) asm volatile("" : "=v"(A[s]) : "v"(pb));
-  return;
-#endif
-#pragma unroll
-  for (int s = 0; s < KT_NL; ++s) A[s] = pb[s * 64];
-}
-// the B operands of a buffer, one per column group (2 groups of 3 tiles, or 3 groups of 2): lane l -> k[8 jg + (l >> 4)][l & 3] and
-// k[8 jg + 4 + (l >> 4)][l & 3]   (kb is [j][P] with KT_ZROWS zero rows behind row Npad: the groups past the end of a stream read
-// zeros, nothing is clamped or selected).  `ka` = this lane's address of group 0 (lanes of absent particles borrow particle 0:
-// their output columns are never stored); the three reads are one base register + immediate offsets.
-#define KT_ZROWS 32
-template <int P>
-__device__ __forceinline__ void kt_readk(v2d (&K)[3], const double* ka, int g) {
-  const double* kp = ka + g * (8 * P);
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    K[q].x = kp[q * 8 * P];
-    K[q].y = kp[q * 8 * P + 4 * P];
-  }
-}
-// 12 MFMAs; two accumulator sets (first / second half of a column group): the same accumulator comes up again 2 nrt MFMAs later.
-// The two wirings keep their own accumulators (a wave only ever takes one of them): nothing to copy where the branches meet.
-// One wait for the whole buffer (the pin), not one per tile: the wave's instruction issue is what bounds the phase.
-__device__ __forceinline__ void kt_use(const v2d (&A)[KT_NL], const v2d (&K)[3], int nrt, double (&acc3)[2][3], double (&acc2)[2][2]) {
-  asm volatile("" ::"v"(A[0]), "v"(A[1]), "v"(A[2]), "v"(A[3]), "v"(A[4]), "v"(A[5]), "v"(K[0]), "v"(K[1]), "v"(K[2]));
-  if (nrt == 3) {  // wave-uniform
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-#pragma unroll
-      for (int r = 0; r < 3; ++r) mfma4(acc3[0][r], A[3 * q + r].x, K[q].x);
-#pragma unroll
-      for (int r = 0; r < 3; ++r) mfma4(acc3[1][r], A[3 * q + r].y, K[q].y);
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-#pragma unroll
-      for (int r = 0; r < 2; ++r) mfma4(acc2[0][r], A[2 * q + r].x, K[q].x);
-#pragma unroll
-      for (int r = 0; r < 2; ++r) mfma4(acc2[1][r], A[2 * q + r].y, K[q].y);
-    }
-  }
-}
-// this wave's whole stream, double buffered; bufA / bufB hold buffers nres and nres + 1 already when npre says so (issued ahead of
-// the barrier).  The steady-state loop issues its reloads UNCONDITIONALLY (nb - nres is even and >= 2, kt_resident_count): with a
-// test around the reloads the compiler must assume at every use that no younger loads are outstanding and waits for vmcnt(5..0) --
-// for the OTHER buffer's loads as well, i.e. no double buffering at all (seen in the ISA).
-template <int P>
-__device__ __forceinline__ void kt_stream(gptr2_t p, int nrt, int njg, const double* kb, int lane, double (&acc3)[2][3], double (&acc2)[2][2],
-                                          const v2d (&res)[RL_NRES + 1][KT_NL], int nres, v2d (&bufA)[KT_NL], v2d (&bufB)[KT_NL],
-                                          int npre) {
-  const int nb = (nrt * njg + KT_NL - 1) / KT_NL;
-  const int gpb = nrt == 3 ? 2 : 3;  // column groups per buffer
-  const double* ka = kb + (lane >> 4) * P + ((lane & 3) < P ? (lane & 3) : 0);
-  int b = nres;
-  v2d kA[3], kB[3];
-  if (npre < 1) kt_load(bufA, p, b);
-  kt_readk<P>(kA, ka, b * gpb);
-  if (npre < 2) kt_load(bufB, p, b + 1);
-  kt_readk<P>(kB, ka, (b + 1) * gpb);
-#pragma unroll
-  for (int r = 0; r < RL_NRES + 1; ++r) {
-    if (r < nres) {  // wave-uniform
-      v2d kR[3];
-      kt_readk<P>(kR, ka, r * gpb);
-      kt_use(res[r], kR, nrt, acc3, acc2);
-    }
-  }
-  for (; b + 2 < nb; b += 2) {
-    kt_use(bufA, kA, nrt, acc3, acc2);
-    kt_load(bufA, p, b + 2);
-    kt_readk<P>(kA, ka, (b + 2) * gpb);
-    kt_use(bufB, kB, nrt, acc3, acc2);
-    kt_load(bufB, p, b + 3);
-    kt_readk<P>(kB, ka, (b + 3) * gpb);
-  }
-  kt_use(bufA, kA, nrt, acc3, acc2);
-  kt_use(bufB, kB, nrt, acc3, acc2);
-}
-// how many of a wave's nb register buffers stay resident: at most RL_NRES, leaving an even number >= 2 to stream (the double-buffered
-// loop then needs no test around its reloads)
-__device__ __forceinline__ int kt_resident_count(int nb) {
-  int nres = imin(RL_NRES, nb - 2);
-  if (nres < 0) nres = 0;
-  if ((nb - nres) & 1) nres += (nb - nres >= 3) ? 1 : -1;  // (the register array has RL_NRES + 1 slots; nb >= 2 always)
-  return nres;
-}
-// the tail of phase V: v is complete in this wave, so it forms the two phase-J weights of its rows on the spot,
-//   W[j][2p] = kse_j alpha_j,  W[j][2p+1] = kse_j v_j     (D lane = 16 i + 4 blk + p: row 16 rt + 4 blk + i, particle p)
-template <int P>
-__device__ __forceinline__ void kt_tail(double (&acc3)[2][3], double (&acc2)[2][2], int rt0, int nrt, const double* kb, const double* al_l,
-                                        double* vb, int lane) {
-  const int p = lane & 3;
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    if (r < nrt && p < P) {
-      const int row = 16 * (rt0 + r) + 4 * ((lane >> 2) & 3) + (lane >> 4);
-      double v = acc3[0][r] + acc3[1][r];
-      if (r < 2) v += acc2[0][r] + acc2[1][r];  // (the wiring this wave did not take left its accumulators at zero)
-      const double kse = kb[row * P + p], alj = al_l[row];
-      v2d w;
-      w.x = kse * alj;
-      w.y = kse * v;
-      *reinterpret_cast<v2d*>(__builtin_assume_aligned(vb + 2 * (row * P + p), 16)) = w;
-    }
-  }
-}
-
-// sum over the 16 lanes of a DPP row; the total lands in lane 15 of the row (shifted-in lanes read zero)
-__device__ __forceinline__ double row16_sum(double v) {
-  v += dpp_take<0x111, 0xf>(v);  // row_shr:1
-  v += dpp_take<0x112, 0xf>(v);  // row_shr:2
-  v += dpp_take<0x114, 0xf>(v);  // row_shr:4
-  v += dpp_take<0x118, 0xf>(v);  // row_shr:8
-  return v;
-}
-
-template <int P>
-struct LatLog2 {
-  static constexpr int v = P == 4 ? 2 : (P == 2 ? 1 : 0);
-};
-
-// KR = phase-K items per thread: Npad * P <= KR * RF_NT
-// phase stamps of the lean kernel: accumulated in LDS (no global round trip inside the step), written out once at the end
-#define RL_STAMP(k)                           \
-  do {                                        \
-    if (stamping && tid == 0) {               \
-      unsigned long long now_ = clock64();    \
-      stl[k] += now_ - last_stamp;            \
-      last_stamp = now_;                      \
-    }                                         \
-  } while (0)
-#define RL_SUB(k)                             \
-  do {                                        \
-    if (stamping && lane == 0) {              \
-      unsigned long long now_ = clock64();    \
-      stl[k] += now_ - sub_stamp;             \
-      sub_stamp = now_;                       \
-    }                                         \
-  } while (0)
-// phase J of the lean kernel on the 4x4x4 MFMA:  R[c][n] = sum_j Xe[c][j] W[j][n],  Xe = [X^T; 1; 0] (8 rows),  W (N x 2P, 8 columns
-// at most).  One instruction = blocks (row half, column half) x 4 training points.  A wave sums over the rows it has just
-// produced in phase V (its own row tiles: 32 or 48 training points) -- no workgroup barrier between the two phases -- and stores
-// its partial tile to red[wave][8][8], ONE unconditional store per lane.
-template <int P>
-__device__ __forceinline__ void lean_j(const double* xe, const double* vb, double* red, int Npad, int j0, int nu, int wv, int lane) {
-  const int kq = lane >> 4, blk = (lane >> 2) & 3, e = lane & 3;
-  const double* ap = xe + (4 * (blk >> 1) + e) * Npad + j0 + kq;
-  const double* bp = vb + (j0 + kq) * (2 * P) + 4 * (blk & 1) + e;  // (P < 4: columns >= 2P read a neighbour's weights; those output columns are never used)
-  double acc0 = 0.0, acc1 = 0.0;
-  for (int u0 = 0; u0 < nu; u0 += 4) {  // nu = 8 or 12
-    double av[4], bw[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      av[u] = ap[4 * (u0 + u)];
-      bw[u] = bp[4 * (u0 + u) * (2 * P)];
-    }
-    asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(bw[0]), "+v"(bw[1]), "+v"(bw[2]), "+v"(bw[3]));
-    mfma4(acc0, av[0], bw[0]);
-    mfma4(acc1, av[1], bw[1]);
-    mfma4(acc0, av[2], bw[2]);
-    mfma4(acc1, av[3], bw[3]);
-  }
-  // D lane = 16 i + 4 blk + j: row 4 (blk >> 1) + i, column 4 (blk & 1) + j
-  red[wv * 64 + (4 * (blk >> 1) + kq) * 8 + 4 * (blk & 1) + e] = acc0 + acc1;
-}
-
-// phase stamps of the lean kernel: accumulated in LDS (no global round trip inside the step), written out once at the end
-#define RL_STAMP(k)                           \
-  do {                                        \
-    if (stamping && tid == 0) {               \
-      unsigned long long now_ = clock64();    \
-      stl[k] += now_ - last_stamp;            \
-      last_stamp = now_;                      \
-    }                                         \
-  } while (0)
-#define RL_SUB(k)                             \
-  do {                                        \
-    if (stamping && lane == 0) {              \
-      unsigned long long now_ = clock64();    \
-      stl[k] += now_ - sub_stamp;             \
-      sub_stamp = now_;                       \
-    }                                         \
-  } while (0)
-// phase J of the lean kernel on the 4x4x4 MFMA:  R[c][n] = sum_j Xe[c][j] W[j][n],  Xe = [X^T; 1; 0] (8 rows),  W (N x 2P, 8 columns
-// at most).  One instruction = blocks (row half, column half) x 4 training points; the 8 waves split N (whole shares of `jper`
-// points: the tables are zero beyond N), their partial tiles go to red[wave][8][8], ONE unconditional store per lane.
-template <int P>
-__device__ __forceinline__ void lean_j(const double* xe, const double* vb, double* red, int Np8, int jper, int wv, int lane) {
-  const int kq = lane >> 4, blk = (lane >> 2) & 3, e = lane & 3;
-  const double* ap = xe + (4 * (blk >> 1) + e) * Np8 + wv * jper + kq;
-  const double* bp = vb + (wv * jper + kq) * (2 * P) + 4 * (blk & 1) + e;  // (P < 4: columns >= 2P read a neighbour's weights; those output columns are never used)
-  const int nu = jper >> 2;
-  double acc0 = 0.0, acc1 = 0.0;
-  for (int u0 = 0; u0 < nu; u0 += 10) {
-    double av[10], bw[10];
-#pragma unroll
-    for (int u = 0; u < 10; ++u) {
-      const int uc = imin(u0 + u, nu - 1);
-      av[u] = ap[4 * uc];
-      bw[u] = bp[4 * uc * (2 * P)];
-    }
-    asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]), "+v"(av[8]), "+v"(av[9]),
-                 "+v"(bw[0]), "+v"(bw[1]), "+v"(bw[2]), "+v"(bw[3]), "+v"(bw[4]), "+v"(bw[5]), "+v"(bw[6]), "+v"(bw[7]), "+v"(bw[8]), "+v"(bw[9]));
-#pragma unroll
-    for (int u = 0; u < 10; u += 2) {
-      if (u0 + u < nu) mfma4(acc0, av[u], bw[u]);          // (uniform tests)
-      if (u0 + u + 1 < nu) mfma4(acc1, av[u + 1], bw[u + 1]);
-    }
-  }
-  // D lane = 16 i + 4 blk + j: row 4 (blk >> 1) + i, column 4 (blk & 1) + j
-  red[wv * 64 + (4 * (blk >> 1) + kq) * 8 + 4 * (blk & 1) + e] = acc0 + acc1;
-}
-
-template <int P, int KR>
-__global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  constexpr int LP = LatLog2<P>::v;
-  const mcp_model& md = a.model;
-  const mcp_policy& pl = a.pol;
-  const int tid0 = threadIdx.x;
-  const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
-  const int DS = D - U;
-  const int Npad = a.NpadMax;
-  const int NG = lat_ng(B), NGP = lat_ngp(B), Bp = NG * 16, BQ = (B + 3) >> 2;
-  const LatLayout L = lat_layout(P, B, Npad);
-  double* pol = smem + LatFixed::pol;
-  double* umax_l = pol + RL_PFM;
-  double* bias_l = umax_l + MCP_MAX_INPUT;
-  double* iumax_l = bias_l + MCP_MAX_INPUT;
-  double* xs = smem + LatFixed::xs;  // [2][P][S] double-buffered
-  double* z = smem + LatFixed::z;
-  double* zs = smem + LatFixed::zs;
-  double* sf = smem + LatFixed::sf;
-  double* dl = smem + LatFixed::dl;
-  double* epsb = smem + LatFixed::eps;
-  double* red = smem + LatFixed::red;
-  double* rtot = smem + LatFixed::rt;
-  GpL* gpl = reinterpret_cast<GpL*>(smem + LatFixed::gpl);
-  double* kpar = smem + LatFixed::kpar;
-  int* role = reinterpret_cast<int*>(smem + LatFixed::role);
-  unsigned long long* stl = reinterpret_cast<unsigned long long*>(smem + LatFixed::stl);  // phase-cycle totals (diagnostic)
-  const bool stamping = a.stamps && blockIdx.x == a.stamp_block;
-  double* gs = smem + L.gs;
-  double* kb = smem + L.kb;
-  double* vb = smem + L.vb;
-  double* xe = smem + L.xe;
-  double* xq = smem + L.xq;
-  double* al_l = smem + L.al;
-  double* cen = smem + L.cen;
-  double* wgt = smem + L.wgt;
-  int* mk = reinterpret_cast<int*>(smem + L.mk);
-  int cluster, myg;
-  {
-    const int b = blockIdx.x, grp = b / (8 * G), r = b - grp * 8 * G;
-    cluster = grp * 8 + (r & 7);
-    myg = r >> 3;
-    if (cluster >= a.nclusters) return;  // padding blocks of the last group of 8 clusters
-  }
-  const int gcluster = a.m_off / P + cluster;  // cluster index in the whole swarm (hand-off slots)
-  const bool writer = myg == 0;                // states / inputs are identical in the workgroups of a cluster: one of them stores
-  int* abortw = reinterpret_cast<int*>(dl + P * G);
-  if (tid0 == 0) *abortw = 0;
-  if (tid0 < 24) stl[tid0] = 0;
-  const int m0 = a.m_off + cluster * P;
-  const int Mend = a.m_off + a.m_cnt;
-  uint32_t bad = 0;
-  const bool drop = pl.p_drop > 0.0;
-  const double keep_scale = 1.0 / (1.0 - pl.p_drop);
-  const uint32_t drop_thr = drop_threshold(pl.p_drop);
-  const int nna = md.n_not_angle, na = md.n_angle;
-  const int pol_nna = pl.n_non_angle, pol_na = pl.n_angle;
-  const double Ts = md.Ts;
-
-  // ---- one-time staging ------------------------------------------------------------------
-  for (int it = tid0; it < PF; it += RF_NT) pol[it] = exp(-pl.log_ls[it]);
-  if (tid0 < U) {
-    const double um = pl.u_max[tid0];
-    umax_l[tid0] = um;
-    iumax_l[tid0] = 1.0 / um;
-    bias_l[tid0] = pl.bias ? pl.bias[tid0] : 0.0;
-  }
-  const mcp_gp* gps_l = md.gp + myg;
-  stage_gp_tables(gps_l, md.var_scale + myg, 1, D, gpl, kpar, tid0);
-  {
-    const mcp_gp& gp = gps_l[0];
-    for (int it = tid0; it < 8 * Npad; it += RF_NT) {  // [X^T; 1; 0]
-      const int d = it / Npad, j = it - d * Npad;
-      xe[it] = d < D ? (j < gp.Npad ? gp.Xt[(size_t)d * gp.Npad + j] : 0.0) : (d == D ? 1.0 : 0.0);
-    }
-    for (int it = tid0; it < Npad; it += RF_NT) al_l[it] = it < gp.Npad ? gp.alpha[it] : 0.0;
-    for (int it = tid0; it < Npad * P * 2; it += RF_NT) vb[it] = 0.0;
-  }
-  for (int it = tid0; it < RL_UM * Bp; it += RF_NT) {
-    const int k = it / Bp, b = it - k * Bp;
-    wgt[it] = (k < U && b < B) ? pl.weight[(size_t)k * B + b] : 0.0;
-  }
-  for (int it = tid0; it < RL_UM * P * NGP; it += RF_NT) gs[it] = 0.0;  // (the padding groups stay zero)
-  for (int it = tid0; it < KT_ZROWS * P; it += RF_NT) kb[gps_l[0].Npad * P + it] = 0.0;  // (zero rows behind THIS GP's k: phase V's out-of-range operands)
-  for (int it = tid0; it < P * RL_ZD; it += RF_NT) zs[it] = 0.0;
-  for (int it = tid0; it < P * RL_PFM; it += RF_NT) sf[it] = 0.0;
-  // roles of the threads of wave 0 in the serial section (read back from LDS every step: values derived from the thread id would
-  // otherwise be hoisted out of the time loop and held in registers across every phase).  Thread (p, s) = p * S + s owns state
-  // component s of particle p; thread (p, c) = p * (D + 1) + c evaluates column c of phase F for particle p.
-  double xn = 0.0;  // the owned state component (threads < P * S)
-  if (tid0 < 64) {
-    const bool own = tid0 < P * S;
-    const int op = own ? tid0 / S : 0, os = own ? tid0 - op * S : 0;
-    int zi_plain = -1, zi_ang = -1, pi_plain = -1, pi_ang = -1, g_vel = -1, g_pos = -1, vel_of_pos = 0;
-    if (own) {
-      for (int i = 0; i < nna; ++i)
-        if (md.not_angle[i] == os) zi_plain = i;
-      for (int i = 0; i < na; ++i)
-        if (md.angle[i] == os) zi_ang = i;
-      if (pl.kind == MCP_POLICY_ANGLES) {
-        for (int i = 0; i < pol_nna; ++i)
-          if (pl.non_angle[i] == os) pi_plain = i;
-        for (int i = 0; i < pol_na; ++i)
-          if (pl.angle[i] == os) pi_ang = i;
-      }
-      for (int g = 0; g < G; ++g) {
-        if (md.vel[g] == os) g_vel = g;
-        if (md.not_vel[g] == os) {
-          g_pos = g;
-          vel_of_pos = md.vel[g];
-        }
-      }
-      xn = a.x0[(size_t)imin(m0 + op, Mend - 1) * S + os];
-    }
-    int* ro = role + tid0 * 16;
-    ro[RO_OP] = op;
-    ro[RO_OS] = os;
-    ro[RO_ZPLAIN] = zi_plain;
-    ro[RO_ZANG] = zi_ang;
-    ro[RO_PPLAIN] = pi_plain;
-    ro[RO_PANG] = pi_ang;
-    ro[RO_GVEL] = g_vel;
-    ro[RO_GPOS] = g_pos;
-    ro[RO_VELOFPOS] = vel_of_pos;
-    ro[RO_PMPOS] = ro[RO_PMVEL] = ro[RO_PMPAIR] = 0;
-    ro[RO_FP] = tid0 / (D + 1);
-    ro[RO_FC] = tid0 % (D + 1);
-    ro[RO_OM] = imin(m0 + op, Mend - 1);
-    ro[RO_N] = 0;
-  }
-  lds_barrier();
-  // phase S as a table: thread (p, s) writes x, sin x or cos x to at most two GP-input slots (raw and divided by the lengthscale) and two
-  // policy-feature slots; the slot addresses and scale factors are read in ONE batch at the top of the phase and every write is
-  // unconditional (unused ones go to a dump word) -- as tests on the role indices each slot was its own LDS read -> multiply -> write
-  // round trip behind a branch: 7 dependent round trips per step on the wave that bounds the step
-  if (tid0 < P * S) {
-    const int* ro = role + tid0 * 16;
-    const int op = ro[RO_OP], os = ro[RO_OS], zi_plain = ro[RO_ZPLAIN], zi_ang = ro[RO_ZANG], pi_plain = ro[RO_PPLAIN], pi_ang = ro[RO_PANG];
-    int* si = reinterpret_cast<int*>(smem + LatFixed::sro + tid0 * 8);
-    double* sd = smem + LatFixed::sro + tid0 * 8 + 4;
-    const double* il = kpar + KP_INVLS(D);
-    const int zA = zi_ang >= 0 ? nna + zi_ang : zi_plain, zB = zi_ang >= 0 ? nna + na + zi_ang : -1;
-    int pA, pB = -1;
-    if (pl.kind == MCP_POLICY_ANGLES) {
-      pA = pi_ang >= 0 ? pol_nna + pi_ang : pi_plain;
-      pB = pi_ang >= 0 ? pol_nna + pol_na + pi_ang : -1;
-    } else {
-      pA = os;
-    }
-    si[0] = zA >= 0 ? LatFixed::z + op * D + zA : LatFixed::dump;
-    si[1] = zB >= 0 ? LatFixed::z + op * D + zB : LatFixed::dump;
-    si[2] = zA >= 0 ? LatFixed::zs + op * RL_ZD + zA : LatFixed::dump;
-    si[3] = zB >= 0 ? LatFixed::zs + op * RL_ZD + zB : LatFixed::dump;
-    si[4] = pA >= 0 ? LatFixed::sf + op * RL_PFM + pA : LatFixed::dump;
-    si[5] = pB >= 0 ? LatFixed::sf + op * RL_PFM + pB : LatFixed::dump;
-    si[6] = si[7] = 0;
-    sd[0] = zA >= 0 ? il[zA] : 0.0;
-    sd[1] = zB >= 0 ? il[zB] : 0.0;
-    sd[2] = pA >= 0 ? pol[pA] : 0.0;
-    sd[3] = pB >= 0 ? pol[pB] : 0.0;
-  }
-  for (int it = tid0; it < RL_PFM * Bp; it += RF_NT) {
-    const int q = it / Bp, b = it - q * Bp;
-    cen[it] = (q < PF && b < B) ? pl.centers[(size_t)b * PF + q] * pol[q] : 0.0;
-  }
-  for (int it = tid0; it < RL_ZD * Npad; it += RF_NT) {
-    const int r = it / Npad, j = it - r * Npad;
-    const int d = r < RL_DSM ? (r < DS ? r : -1) : (r - RL_DSM < U ? DS + r - RL_DSM : -1);
-    xq[it] = (d >= 0) ? xe[d * Npad + j] * kpar[KP_INVLS(D) + d] : 0.0;
-  }
-  int cur = 0;
-
-  // the random numbers of step `ts`: process noise of this workgroup's GP by wave 1, dropout decisions (one Philox block per 4 basis
-  // functions, bit-packed) by waves 2, 3, 5, 6, 7 -- never waves 0 and 4 (wave 0 runs the serial section meanwhile, wave 4 shares its SIMD)
-  auto draw_step = [&](int ts, int wv, int lane) {
-    if (wv == 1) {
-      if (lane < P && ts < T - 1) {
-        double ev = 0.0;
-        if (a.particle_pred) {
-          const int mm = imin(m0 + lane, Mend - 1);
-          ev = a.nz.eps ? a.nz.eps[((size_t)ts * M + mm) * G + myg] : philox_normal(a.nz, mm, ts, myg);
-        }
-        epsb[(ts & 1) * P + lane] = ev;
-      }
-    } else if (wv >= 2 && wv != 4 && drop && !a.nz.masks) {
-      const int ti = (wv - 2 - (wv > 4 ? 1 : 0)) * 64 + lane;
-      for (int it = ti; it < P * BQ; it += 5 * 64) {
-        const int p = it / BQ, q = it - p * BQ;
-        const u32x4 r = philox_draw(a.nz, imin(m0 + p, Mend - 1), ts, MCP_STREAM_MASK, (uint32_t)q);
-        mk[it] = (int)(r.x >= drop_thr) | ((int)(r.y >= drop_thr) << 1) | ((int)(r.z >= drop_thr) << 2) | ((int)(r.w >= drop_thr) << 3);
-      }
-    }
-  };
-  draw_step(0, __builtin_amdgcn_readfirstlane(tid0 >> 6), tid0 & 63);
-  lds_barrier();  // tables (incl. the chunk table written by thread 0) visible to every wave
-  // this wave's share of Kinv: the row tiles [vrt0, vrt0 + vnrt) of its GP, as MFMA operand tiles in streaming order; the first
-  // RL_NRES register buffers of the stream stay in registers for the whole rollout
-  const int vnpad = __builtin_amdgcn_readfirstlane(gpl[0].Npad), vnjg = vnpad >> 3;
-  int vrt0, vnrt;
-  {
-    const int w = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    vrt0 = kt_rt0(vnpad >> 4, w);
-    vnrt = kt_rt0(vnpad >> 4, w + 1) - vrt0;
-  }
-  const gptr2_t vp = (gptr2_t)(a.kt + (size_t)myg * a.kt_stride + (size_t)vrt0 * vnjg * 128) + (tid0 & 63);
-  const int vnt = vnrt * vnjg;  // tiles in this wave's stream
-  v2d vres[RL_NRES + 1][KT_NL];  // (+ 1: a wave whose buffer count has the other parity keeps one more or one fewer)
-  int nres = 0;
-  if (vnrt > 0) {
-    nres = kt_resident_count((vnt + KT_NL - 1) / KT_NL);
-#pragma unroll
-    for (int r = 0; r < RL_NRES + 1; ++r)
-      if (r < nres) kt_load(vres[r], vp, r);
-  }
-  unsigned long long last_stamp = clock64(), sub_stamp = last_stamp;
-
-  for (int t = 0; t < T; ++t) {
-    // the thread id goes through an opaque move once per step: what is derived from it is recomputed where it is used (a handful
-    // of integer instructions) instead of being hoisted out of the time loop and kept in registers across phase V
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // ---- phase S (wave 0): publish x_t and everything derived from a single state component ------
-    if (wv == 0) {
-      const int* ro = role + lane * 16;
-      const int4 r0 = *reinterpret_cast<const int4*>(ro), r1 = *reinterpret_cast<const int4*>(ro + 4);
-      const int op = r0.x, os = r0.y, zi_ang = r0.w, pi_ang = r1.y;
-      const bool own = lane < P * S;
-      const bool ovalid = own && (m0 + op < Mend);
-      if (own) {
-        const double* srow = smem + LatFixed::sro + lane * 8;
-        const int4 sa = *reinterpret_cast<const int4*>(srow);
-        const int2 sb = *reinterpret_cast<const int2*>(srow + 2);
-        const v2d sc0 = *reinterpret_cast<const v2d*>(srow + 4), sc1 = *reinterpret_cast<const v2d*>(srow + 6);
-        double* xc = xs + cur * P * S;
-        xc[op * S + os] = xn;
-        if (ovalid) {
-          if (writer) a.states[((size_t)t * M + m0 + op) * S + os] = xn;
-          if (is_bad(xn)) bad |= MCP_STATUS_NAN;
-        }
-        double sn = 0.0, cs = 0.0;
-        if (zi_ang >= 0 || pi_ang >= 0) sincos_fast(xn, &sn, &cs);
-        // GP input z = [x[not_angle], sin x[angle], cos x[angle], u]   (Model_learning.py:670-683), raw and divided by its lengthscale;
-        // policy features (Policy.py:326-333: [x_nonangle, COS, SIN]; plain policy: x) divided by theirs: slots and factors from the table
-        const double vz = zi_ang >= 0 ? sn : xn, vp = pi_ang >= 0 ? cs : xn;
-        smem[sa.x] = vz;
-        smem[sa.y] = cs;
-        smem[sa.z] = vz * sc0.x;
-        smem[sa.w] = cs * sc0.y;
-        smem[sb.x] = vp * sc1.x;
-        smem[sb.y] = sn * sc1.y;
-      }
-    }
-    if (wv == 0) RL_SUB(15);
-    lds_barrier();  // B0
-    if (*abortw) {  // uniform: a partner never arrived (set by wave 0 in the previous step's hand-off)
-      bad |= MCP_STATUS_SYNC;
-      break;
-    }
-    RL_STAMP(0);
-    // ---- policy + state-only part of the GP distances --------------------------------------------
-    const int pK = tid & (P - 1);  // particle of this thread's phase-K items (RF_NT % P == 0)
-    double ds[KR], xin[KR][RL_UM];
-    {
-      const int row = tid >> 4, e16 = tid & 15;
-      const int pP = row & (P - 1);  // particle of this DPP row in the policy phase (32 rows per round, 32 % P == 0)
-      double sfr[RL_PFM], zr[RL_DSM];
-#pragma unroll
-      for (int q = 0; q < RL_PFM; ++q) sfr[q] = sf[pP * RL_PFM + q];
-#pragma unroll
-      for (int d = 0; d < RL_DSM; ++d) zr[d] = zs[pK * RL_ZD + d];
-      if (t < T - 1) {
-#pragma unroll
-        for (int r = 0; r < KR; ++r) {
-          // (the last round holds N P - (KR - 1) 512 items: at N = 300, P = 4 three of the eight waves; the others skip it -- wave-uniform)
-          if (r == KR - 1 && r > 0 && ((wv * 64 + r * RF_NT) >> LP) >= Npad) {
-            ds[r] = 0.0;
-#pragma unroll
-            for (int k = 0; k < RL_UM; ++k) xin[r][k] = 0.0;
-            continue;
-          }
-          const int j = imin((tid + r * RF_NT) >> LP, Npad - 1);
-          double xv[RL_DSM];
-#pragma unroll
-          for (int d = 0; d < RL_DSM; ++d) xv[d] = xq[d * Npad + j];
-#pragma unroll
-          for (int k = 0; k < RL_UM; ++k) xin[r][k] = xq[(RL_DSM + k) * Npad + j];
-          double acc = 0.0;
-#pragma unroll
-          for (int d = 0; d < RL_DSM; ++d) {
-            const double rr = zr[d] - xv[d];
-            acc = fma(rr, rr, acc);
-          }
-          ds[r] = acc;
-        }
-      }
-      const int NPR = NG << LP;  // (basis group, particle) pairs, particle fastest
-      for (int pr0 = 0; pr0 < NPR; pr0 += 32) {
-        const int pr = pr0 + row;
-        const int g = pr >> LP;
-        const int b = imin(g, NG - 1) * 16 + e16;
-        double cv[RL_PFM], wv_[RL_UM];
-#pragma unroll
-        for (int q = 0; q < RL_PFM; ++q) cv[q] = cen[q * Bp + b];
-#pragma unroll
-        for (int k = 0; k < RL_UM; ++k) wv_[k] = wgt[k * Bp + b];
-        int kbits = 0;
-        if (drop) {
-          if (a.nz.masks)
-            kbits = (b < B && a.nz.masks[((size_t)t * M + imin(m0 + pP, Mend - 1)) * B + b] != 0) ? 1 : 0;
-          else
-            kbits = (mk[pP * BQ + imin(b >> 2, BQ - 1)] >> (b & 3)) & 1;  // (b >= B: weight 0, whatever the bit)
-        }
-        double dist = 0.0;
-#pragma unroll
-        for (int q = 0; q < RL_PFM; ++q) {
-          const double rr = sfr[q] - cv[q];
-          dist = fma(rr, rr, dist);
-        }
-        double phi = exp(-dist);
-        if (drop) phi = kbits ? phi * keep_scale : 0.0;
-#pragma unroll
-        for (int k = 0; k < RL_UM; ++k) {
-          if (k < U) {  // uniform
-            const double sgrp = row16_sum(wv_[k] * phi);
-            if (e16 == 15 && pr < NPR) gs[(k * P + pP) * NGP + g] = sgrp;
-          }
-        }
-      }
-    }
-    lds_barrier();  // B1
-    RL_STAMP(1);
-    // ---- u = u_max tanh((W phi + b) / u_max): every thread adds the group sums of its own particle in the same fixed order ----
-    double ur[RL_UM];
-#pragma unroll
-    for (int k = 0; k < RL_UM; ++k) {
-      ur[k] = 0.0;
-      if (k < U) {  // uniform
-        const double* gk = gs + (k * P + pK) * NGP;
-        double s = 0.0;
-#pragma unroll 1
-        for (int g0 = 0; g0 < NGP; g0 += 8) {
-          const v2d a0 = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(gk + g0, 16));
-          const v2d a1 = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(gk + g0 + 2, 16));
-          const v2d a2 = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(gk + g0 + 4, 16));
-          const v2d a3 = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(gk + g0 + 6, 16));
-          s += ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
-        }
-        s += bias_l[k];
-        const double um = umax_l[k];
-        const double u = pl.squash ? um * fast_tanh(s * iumax_l[k]) : s;
-        ur[k] = u * kpar[KP_INVLS(D) + DS + k];
-        if (tid < P) {  // thread p publishes the raw input of particle p (phase F's Jacobians, the inputs array)
-          z[tid * D + DS + k] = u;
-          if (m0 + tid < Mend) {
-            if (t == T - 1 && writer) a.inputs[((size_t)t * M + m0 + tid) * U + k] = u;
-            if (is_bad(u)) bad |= MCP_STATUS_NAN;
-          }
-        }
-      }
-    }
-    if (t == T - 1) break;
-    // ---- phase V, first half: issue the head of this wave's Kinv stream (independent of k) ----
-    v2d bufA[KT_NL], bufB[KT_NL];
-    if (RL_PRE > 0 && vnrt > 0) {
-      kt_load(bufA, vp, nres);
-      if (RL_PRE > 1) kt_load(bufB, vp, nres + 1);
-    }
-    // ---- phase K, second half: the input dimensions and the exp ----
-    {
-      const int Nown = gpl[0].N;
-      const double lambda = gpl[0].lambda;
-#pragma unroll
-      for (int r = 0; r < KR; ++r) {
-        if (r == KR - 1 && r > 0 && ((wv * 64 + r * RF_NT) >> LP) >= Npad) continue;  // (no item of this wave in the last round)
-        const int it = tid + r * RF_NT;
-        const int j = it >> LP;
-        double dd = ds[r];
-#pragma unroll
-        for (int k = 0; k < RL_UM; ++k) {
-          const double rr = ur[k] - xin[r][k];
-          dd = fma(rr, rr, dd);
-        }
-        const double kv = j < Nown ? lambda * exp(-dd) : 0.0;
-        if (j < Npad) kb[it] = kv;
-      }
-    }
-    lds_barrier();  // B2
-    RL_STAMP(3);
-    // ---- phase V, second half: v = Kinv k on the 4x4x4 MFMA, then the phase-J weights of this wave's rows ----
-    const unsigned long long tv0_ = stamping ? clock64() : 0;
-    if (vnrt > 0) {
-      double acc3[2][3], acc2[2][2];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) acc3[0][r] = acc3[1][r] = 0.0;
-#pragma unroll
-      for (int r = 0; r < 2; ++r) acc2[0][r] = acc2[1][r] = 0.0;
-      kt_stream<P>(vp, vnrt, vnjg, kb, lane, acc3, acc2, vres, nres, bufA, bufB, RL_PRE);
-      kt_tail<P>(acc3, acc2, vrt0, vnrt, kb, al_l, vb, lane);
-      if (stamping && lane == 0) stl[16 + wv] += clock64() - tv0_;  // this wave's own phase V
-      // ---- phase J over the rows this wave has just finished (wave-level ordering only) ----
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const unsigned long long tj0_ = (stamping && wv == 0) ? clock64() : 0;
-      lean_j<P>(xe, vb, red, Npad, 16 * vrt0, 4 * vnrt, wv, lane);
-      if (stamping && tid == 0) stl[12] += clock64() - tj0_;
-    } else {
-      red[wv * 64 + lane] = 0.0;  // (a wave without rows)
-    }
-    lds_barrier();  // B4
-    RL_STAMP(6);
-    if (wv == 0) {
-      sub_stamp = stamping ? clock64() : 0;
-      // ---- phase F: sample delta and fold the sampling into d delta/dz; hand-off; integrate ------------
-      const int* ro = role + lane * 16;
-      const int4 r0 = *reinterpret_cast<const int4*>(ro), r1 = *reinterpret_cast<const int4*>(ro + 4), r2 = *reinterpret_cast<const int4*>(ro + 8),
-                 r3 = *reinterpret_cast<const int4*>(ro + 12);
-      {  // the 8 waves' partial tiles, added in wave order: lane l -> element (c = l >> 3, n = l & 7)
-        double rv[RF_NW];
-#pragma unroll
-        for (int w = 0; w < RF_NW; ++w) rv[w] = red[w * 64 + lane];
-        double sr = rv[0];
-#pragma unroll
-        for (int w = 1; w < RF_NW; ++w) sr += rv[w];
-        rtot[lane] = sr;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane < P * (D + 1)) {
-        const int p = r3.x, c = r3.y;
-        const GpL& gp = gpl[0];
-        const double vscale = gp.var_scale;
-        // R[D][2p] = sum_j k_j alpha_j,  R[D][2p+1] = k^T Kinv k;  R[c][.] the same sums weighted by X_jc
-        const v2d RD = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(rtot + D * 8 + 2 * p, 16));
-        const v2d RC = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(rtot + imin(c, D - 1) * 8 + 2 * p, 16));
-        const double mu = gp.mean + RD.x;
-        const double var = (gp.lambda - RD.y) * vscale;  // k(z,z) = lambda: Stationary_GP.py:172-181
-        double eps = 0.0, wj = 0.0, sd = 0.0;
-        if (a.particle_pred) {
-          eps = epsb[(t & 1) * P + p];
-          sd = sqrt(var);
-          wj = eps / (2.0 * sd);
-        }
-        if (c == D) {
-          const double dv = a.particle_pred ? fma(sd, eps, mu) : mu;
-          dl[p * G + myg] = dv;
-          const unsigned long long bits = (unsigned long long)__double_as_longlong(dv);
-          gu64_t slot = (gu64_t)a.xch + xch_slot(gcluster, t, G, myg, P) + 2 * p;
-          store_granule(slot, (unsigned)t + 1u, (unsigned)bits);
-          store_granule(slot + 1, (unsigned)t + 1u, (unsigned)(bits >> 32));
-          if (m0 + p < Mend) {
-            if (a.particle_pred && var <= 0.0) bad |= MCP_STATUS_NONPOS_VAR;  // (finite and not positive: a NaN variance is MCP_STATUS_NAN, the retry case)
-            if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
-          }
-        } else if (a.jac && m0 + p < Mend) {
-          // centred sums  sum_j w_j (z_c - X_jc) = z_c R[D][.] - R[c][.]
-          const double il = kpar[KP_INVLS(D) + c], il2 = il * il, zc = z[p * D + c];
-          const double Jmu = -2.0 * il2 * fma(zc, RD.x, -RC.x);
-          const double Jvar = 4.0 * il2 * fma(zc, RD.y, -RC.y);
-          a.jac[(((size_t)t * M + m0 + p) * G + myg) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
-        }
-      }
-      RL_SUB(9);
-      {
-        // collect the other GPs' increments: lane -> (other GP, particle, half); every pass re-reads every granule
-        const unsigned long long tx0_ = stamping ? clock64() : 0;
-        const int ngr = (G - 1) * P * 2;
-        const bool act = lane < ngr;
-        const int go = act ? lane / (2 * P) : 0, r = act ? lane - go * 2 * P : 0;
-        const int gq = go < myg ? go : go + 1;
-        gu64_t slot = (gu64_t)a.xch + xch_slot(gcluster, t, G, gq, P) + r;
-        unsigned val = 0;
-        bool done = false;
-        for (unsigned spins = 0; spins < RF_SPIN_LIMIT; ++spins) {
-          bool ok = true;
-          if (act) {
-            const unsigned long long x = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            val = (unsigned)x;
-            ok = (unsigned)(x >> 32) == (unsigned)t + 1u;
-          }
-          if (__all(ok)) {
-            done = true;
-            break;
-          }
-          __builtin_amdgcn_s_sleep(2);
-        }
-        if (act) reinterpret_cast<unsigned*>(dl)[2 * ((r >> 1) * G + gq) + (r & 1)] = val;
-        if (!done && lane == 0) *abortw = 1;
-        if (stamping && lane == 0) stl[8] += clock64() - tx0_;
-      }
-      RL_SUB(10);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      // ---- integrate:  v' = v + delta ;  q' = q + Ts v + Ts/2 delta   (Model_learning.py:711-716) ----
-      if (lane < P * S) {
-        const int op = r0.x, os = r0.y, g_vel = r1.z, g_pos = r1.w, vel_of_pos = r2.x;
-        const double* xc = xs + cur * P * S + op * S;
-        double nx = 0.0;
-        if (g_vel >= 0) nx = xc[os] + dl[op * G + g_vel];
-        if (g_pos >= 0) nx = xc[os] + Ts * xc[vel_of_pos] + 0.5 * Ts * dl[op * G + g_pos];
-        xn = nx;
-      }
-      if (writer && lane < P * U) {  // the inputs of this step (off the critical path here); U <= 2
-        const int ip = U == 1 ? lane : lane >> 1, ik = U == 1 ? 0 : lane & 1;
-        if (m0 + ip < Mend) a.inputs[((size_t)t * M + m0 + ip) * U + ik] = z[ip * D + DS + ik];
-      }
-    } else {
-      draw_step(t + 1, wv, lane);
-    }
-    cur ^= 1;  // x_{t+1} goes to the other buffer
-    RL_STAMP(7);
-    if (wv == 0) sub_stamp = stamping ? clock64() : 0;
-  }
-  if (stamping && tid0 < 24) a.stamps[tid0] += stl[tid0];  // (the stamp buffer of this kernel has 24 slots: tools/phase_stamps.py)
-  if (bad) atomicOr(a.status, bad);
-}
-
 // ---------------------------------------------------------------------------------------
 // single-step posterior (GP_prior.get_estimate_from_alpha) through the same phases
 // ---------------------------------------------------------------------------------------
@@ -2148,40 +1262,6 @@ static int launch_fwd_sharded(const FwdArgs& a, size_t lds, hipStream_t st) {
   return a.maxdeg == 0 ? launch_fwd_deg<P, true, 0, true>(a, lds, st) : launch_fwd_deg<P, true, 2, true>(a, lds, st);
 }
 
-// the latency-lean GP-sharded kernel: narrow SE-only models (cart-pole class); KR = phase-K items per thread
-template <int P, int KR>
-static int launch_fwd_lean_kr(const FwdArgs& a, size_t lds, hipStream_t st) {
-  MCP_ENSURE_MAX_LDS(rollout_fwd_lat_kernel<P, KR>);
-  hipLaunchKernelGGL((rollout_fwd_lat_kernel<P, KR>), dim3(gsh_grid(a.nclusters, a.model.G)), dim3(RF_NT), lds, st, a);
-  MCP_LAUNCH_CHECK();
-  return MCP_OK;
-}
-static int lean_items_per_thread(int P, int NpadMax) {  // 0: the shape has no instantiation
-  if (NpadMax < 32 || NpadMax > 384) return 0;  // phase V deals 2 .. 24 row tiles of 16 to the waves in parts of 2 or 3
-  return P == 4 ? 3 : (P == 2 ? 2 : 1);         // Npad * P <= KR * RF_NT
-}
-static bool lean_applies(const mcp_model* m, const mcp_policy* p, int P, int NpadMax, int maxdeg) {
-  if (maxdeg != 0 || m->G < 2) return false;
-  if (p->meas.n > 0 || p->kind == MCP_POLICY_TRAJ) return false;  // (measurement models and trajectory policies: the general kernel)
-  for (int i = 0; i < m->n_angle; ++i)  // (phase S writes a state component to the plain OR the sin / cos slots)
-    for (int j = 0; j < m->n_not_angle; ++j)
-      if (m->angle[i] == m->not_angle[j]) return false;
-  if (p->kind == MCP_POLICY_ANGLES)
-    for (int i = 0; i < p->n_angle; ++i)
-      for (int j = 0; j < p->n_non_angle; ++j)
-        if (p->angle[i] == p->non_angle[j]) return false;
-  for (int g = 0; g < m->G; ++g)
-    if (m->gp[g].Npad < 32) return false;  // (every GP needs two row tiles at least)
-  if (m->D - m->U > RL_DSM || m->U > RL_UM || p->P > RL_PFM) return false;
-  if (P * m->S > 64 || P * (m->D + 1) > 64 || (m->G - 1) * P * 2 > 64 || m->D > RL_MAXD) return false;  // wave 0 carries the serial section
-  return lean_items_per_thread(P, NpadMax) > 0;
-}
-static int launch_fwd_lean(const FwdArgs& a, int P, size_t lds, hipStream_t st) {
-  if (P == 4) return launch_fwd_lean_kr<4, 3>(a, lds, st);
-  if (P == 2) return launch_fwd_lean_kr<2, 2>(a, lds, st);
-  return launch_fwd_lean_kr<1, 1>(a, lds, st);
-}
-
 extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
                                const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
                                size_t workspace_bytes, void* stream) {
@@ -2270,18 +1350,18 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
       FwdLayout L = fwd_layout(P, model->S, model->U, model->D, model->G, policy->P, policy->B, a.NpadMax, a.maxdeg, 1, NC1, true, 1);
       size_t lds = sizeof(double) * (size_t)L.total;
       bool lean = false;
-      if (g_fwd_lean != 0 && a.kt && lean_applies(model, policy, P, a.NpadMax, a.maxdeg)) {
-        const LatLayout LL = lat_layout(P, policy->B, a.NpadMax);
-        if (sizeof(double) * (size_t)LL.total <= MCP_LDS_LIMIT) {
+      if (g_fwd_lean != 0 && a.kt) {
+        const size_t ll = fwd_lean_lds_bytes(model, policy, P, a.NpadMax, a.maxdeg);  // 0: the lean kernel does not take this shape
+        if (ll > 0 && ll <= MCP_LDS_LIMIT) {
           lean = true;
-          lds = sizeof(double) * (size_t)LL.total;
+          lds = ll;
         }
       }
       if (lds > MCP_LDS_LIMIT) break;
       if (hipMemsetAsync(workspace, 0, rollout_xch_bytes(M, model->G), st) != hipSuccess) return MCP_ERR_LAUNCH;
       if (lean) {  // Kinv of every GP as MFMA operand tiles, in each wave's streaming order
-        hipLaunchKernelGGL(kt_pack_kernel, dim3(64, model->G), dim3(256), 0, st, *model, (double*)a.kt, a.kt_stride);
-        MCP_LAUNCH_CHECK();
+        const int rcp = launch_fwd_lean_pack(a, st);
+        if (rcp != MCP_OK) return rcp;
       }
       g_last_ppw = P;
       g_last_sharded = nchunk;

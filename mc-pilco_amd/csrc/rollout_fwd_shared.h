@@ -128,5 +128,10 @@ int launch_fwd_tile(const FwdArgs& a, hipStream_t st);
 // the shape has no sharded instantiation
 int launch_fwd_tile_sharded(const FwdArgs& a, hipStream_t st);
 bool fwd_tile_fits(const mcp_model* model, const mcp_policy* policy);
+// the latency-lean GP-sharded kernel of small swarms (rollout_fwd_lean.hip): dynamic LDS it needs for this shape at P particles per
+// workgroup (0: it does not take the shape), the packing of Kinv into its operand tiles (a.kt), the launch itself
+size_t fwd_lean_lds_bytes(const mcp_model* model, const mcp_policy* policy, int P, int NpadMax, int maxdeg);
+int launch_fwd_lean_pack(const FwdArgs& a, hipStream_t st);
+int launch_fwd_lean(const FwdArgs& a, int P, size_t lds, hipStream_t st);
 
 }  // namespace mcp
