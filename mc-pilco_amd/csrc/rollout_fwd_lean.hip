@@ -33,8 +33,20 @@ using namespace mcp;
 //     8 partial tiles of phase J summed by 64 lanes at once); the other waves meanwhile draw the next step's dropout decisions and
 //     process noise (never wave 4, which shares wave 0's SIMD).
 // Results do not depend on P (1, 2, 4): equal shards reproduce each other bit for bit, as before.  Covers SE-only models with
-// D <= 8 (<= 6 state-derived + <= 2 inputs), <= 6 policy features, 32 <= Npad <= 384, no measurement model; everything else runs the
-// general kernel above.
+// D <= 8 (<= 6 state-derived + <= 2 inputs), <= 6 policy features, 32 <= Npad <= 384; everything else runs the general kernel
+// (rollout_fwd.hip).
+//
+// Round 4: the template parameters MAXDEG and PMS extend the kernel to the reference's other small-swarm launch scripts:
+//   * MAXDEG = 1, 2 -- SE + Volterra polynomial kernels (gpr_lib/GP_prior/Sparse_GP.py:559-737; test_mcpilco_cartpole.py:67-101), all GPs
+//     of the model of the same degree.  With p1_j = w1_D + sum_d w1_d z_d X_jd, A_j = sum_d w20_d z_d X_jd, B_j = sum_d w21_d z_d X_jd:
+//     k_j = kse_j + p1_j + A_j B_j.  The three bilinear forms ride in the policy + K(state) pass (one product z_d X_jd per dimension
+//     feeds all of them), phase V is unchanged (its operand is the total k), and phase J takes NW = 4 / 6 weight columns per particle
+//     instead of 2:  [kse alpha | kse v | v | k v]  and, degree 2,  [.. | v B | v A]  (in that order, slot-major: W[j][s P + p]) --
+//     the alpha-weighted polynomial sums need no column at all: they are launch constants contracted with z
+//     (sum_j alpha_j, sum_j alpha_j X_jd, sum_j alpha_j X_jc X_je), formed by an otherwise idle wave while the others finish phase K.
+//   * PMS -- the measurement model of MC_PILCO4PMS.apply_policy (policy_learning/MC_PILCO.py:808-906, mcp_meas): phase S also produces
+//     what the policy sees (noisy positions, backward-difference velocities through the first-order filter: three carried values per
+//     lane); the position noise of step t is drawn two steps ahead by the lanes of wave 1 that draw the process noise.
 #define RL_DSM 6  // state-derived GP-input dimensions (D - U), zero padded
 #define RL_UM 2   // inputs, zero padded
 #define RL_ZD (RL_DSM + RL_UM)
@@ -57,9 +69,12 @@ struct LatFixed {
   static constexpr int sf = zs + 4 * RL_ZD;                    // [P][RL_PFM] policy features / lengthscale, zero padded
   static constexpr int dl = sf + 4 * RL_PFM;                   // [P][G] delta_g | abort word
   static constexpr int eps = dl + 4 * MCP_MAX_GP + 2;          // [2][P] process noise of this workgroup's GP, by step parity
-  static constexpr int red = eps + 2 * 4;                      // [RF_NW][8][8] phase-J partial tiles
-  static constexpr int rt = red + RF_NW * 64;                  // [8][8] their sum (phase F)
-  static constexpr int gpl = rt + 64;
+  static constexpr int red = eps + 2 * 4;                      // [RF_NW][NCG <= 3][8][8] phase-J partial tiles
+  static constexpr int rt = red + RF_NW * 3 * 64;              // [NCG][8][8] their sum (phase F)
+  static constexpr int pc = rt + 3 * 64;                       // polynomial constants: kc1 | kcA | kcB [8 each, by xq row] | w1_D | sum alpha | AXX [8][8]
+  static constexpr int fz = pc + 24 + 4 + 64;                  // per step, z-only polynomial terms: [P][4] mpoly, kzz, Sa, Sb | [P][8][2] qB_c, qA_c
+  static constexpr int pn = fz + 4 * 4 + 4 * 8 * 2;            // [2][32] position measurement noise by step parity (PMS)
+  static constexpr int gpl = pn + 2 * 32;
   static constexpr int kpar = gpl + GPL_DOUBLES;
   static constexpr int role = ((kpar + 5 * RL_MAXD + 2) + 1) & ~1;          // [64][16] ints: roles of the threads of wave 0 in the serial section
   static constexpr int sro = role + 64 * 8;                    // [64][8]: phase S of thread (p, s): 6 int LDS addresses (in doubles) | 4 scale factors
@@ -67,13 +82,17 @@ struct LatFixed {
   static constexpr int stl = dump + 2;                         // [16 + 8] u64 phase-cycle totals (diagnostic)
   static constexpr int end = stl + 24;
 };
+static_assert(LatFixed::pc % 2 == 0 && LatFixed::fz % 2 == 0 && LatFixed::gpl % 2 == 0, "16-byte alignment");
 static_assert(LatFixed::red % 2 == 0 && LatFixed::rt % 2 == 0 && LatFixed::zs % 2 == 0 && LatFixed::role % 2 == 0 && LatFixed::sro % 2 == 0 && LatFixed::end % 2 == 0, "16-byte alignment of the v2d regions");
 struct LatLayout {
   int gs, kb, vb, xe, xq, al, cen, wgt, mk, total;  // offsets in doubles
 };
 __host__ __device__ inline int lat_ng(int B) { return (B + 15) >> 4; }                 // groups of 16 basis functions
 __host__ __device__ inline int lat_ngp(int B) { return ((lat_ng(B) + 7) >> 3) << 3; }  // padded to whole chunks of 8 (zeros)
-__host__ __device__ inline LatLayout lat_layout(int P, int B, int Npad) {
+// phase-J weight columns per particle, column groups of 8 (one 4x4x4 B operand each)
+__host__ __device__ constexpr int lat_nw(int deg) { return deg == 0 ? 2 : (deg == 1 ? 4 : 6); }
+__host__ __device__ constexpr int lat_ncg(int P, int deg) { return (P * lat_nw(deg) + 7) / 8; }
+__host__ __device__ inline LatLayout lat_layout(int P, int B, int Npad, int maxdeg) {
   LatLayout L;
   int o = LatFixed::end;
   auto take = [&](int n) {
@@ -84,7 +103,7 @@ __host__ __device__ inline LatLayout lat_layout(int P, int B, int Npad) {
   const int Bp = lat_ng(B) * 16;
   L.gs = take(RL_UM * P * lat_ngp(B));
   L.kb = take((Npad + 32) * P);   // (+ KT_ZROWS zero rows)
-  L.vb = take(Npad * P * 2);      // phase-J weights W[j][2p + a]
+  L.vb = take(Npad * P * lat_nw(maxdeg) + 8);  // phase-J weights: W[j][2p + a] (SE only), W[j][s P + p] (polynomial); + the last column group's overhang
   L.xe = take(8 * Npad);          // [X^T; 1; 0] (phase J's A operand)
   L.xq = take(RL_ZD * Npad);
   L.al = take(Npad);
@@ -249,7 +268,9 @@ __device__ __forceinline__ int kt_resident_count(int nb) {
 }
 // the tail of phase V: v is complete in this wave, so it forms the two phase-J weights of its rows on the spot,
 //   W[j][2p] = kse_j alpha_j,  W[j][2p+1] = kse_j v_j     (D lane = 16 i + 4 blk + p: row 16 rt + 4 blk + i, particle p)
-template <int P>
+// Polynomial kernels (MAXDEG > 0): phase K left  W[j][0 P + p] = kse alpha (final),  [1 P + p] = kse,  [4 P + p] = B,  [5 P + p] = A  and the
+// total k in kb; the tail turns them into  [1] kse v,  [2] v,  [3] k v,  [4] v B,  [5] v A.
+template <int P, int MAXDEG>
 __device__ __forceinline__ void kt_tail(double (&acc3)[2][3], double (&acc2)[2][2], int rt0, int nrt, const double* kb, const double* al_l,
                                         double* vb, int lane) {
   const int p = lane & 3;
@@ -259,11 +280,28 @@ __device__ __forceinline__ void kt_tail(double (&acc3)[2][3], double (&acc2)[2][
       const int row = 16 * (rt0 + r) + 4 * ((lane >> 2) & 3) + (lane >> 4);
       double v = acc3[0][r] + acc3[1][r];
       if (r < 2) v += acc2[0][r] + acc2[1][r];  // (the wiring this wave did not take left its accumulators at zero)
-      const double kse = kb[row * P + p], alj = al_l[row];
-      v2d w;
-      w.x = kse * alj;
-      w.y = kse * v;
-      *reinterpret_cast<v2d*>(__builtin_assume_aligned(vb + 2 * (row * P + p), 16)) = w;
+      if (MAXDEG == 0) {
+        const double kse = kb[row * P + p], alj = al_l[row];
+        v2d w;
+        w.x = kse * alj;
+        w.y = kse * v;
+        *reinterpret_cast<v2d*>(__builtin_assume_aligned(vb + 2 * (row * P + p), 16)) = w;
+      } else {
+        double* w = vb + row * (P * lat_nw(MAXDEG)) + p;
+        const double kt = kb[row * P + p], kse = w[P];
+        double pb_ = 0.0, pa_ = 0.0;
+        if (MAXDEG >= 2) {
+          pb_ = w[4 * P];
+          pa_ = w[5 * P];
+        }
+        w[P] = kse * v;
+        w[2 * P] = v;
+        w[3 * P] = kt * v;
+        if (MAXDEG >= 2) {
+          w[4 * P] = v * pb_;
+          w[5 * P] = v * pa_;
+        }
+      }
     }
   }
 }
@@ -327,57 +365,97 @@ __device__ __forceinline__ void lean_j(const double* xe, const double* vb, doubl
   red[wv * 64 + (4 * (blk >> 1) + kq) * 8 + 4 * (blk & 1) + e] = acc0 + acc1;
 }
 
-// phase stamps of the lean kernel: accumulated in LDS (no global round trip inside the step), written out once at the end
-#define RL_STAMP(k)                           \
-  do {                                        \
-    if (stamping && tid == 0) {               \
-      unsigned long long now_ = clock64();    \
-      stl[k] += now_ - last_stamp;            \
-      last_stamp = now_;                      \
-    }                                         \
-  } while (0)
-#define RL_SUB(k)                             \
-  do {                                        \
-    if (stamping && lane == 0) {              \
-      unsigned long long now_ = clock64();    \
-      stl[k] += now_ - sub_stamp;             \
-      sub_stamp = now_;                       \
-    }                                         \
-  } while (0)
-// phase J of the lean kernel on the 4x4x4 MFMA:  R[c][n] = sum_j Xe[c][j] W[j][n],  Xe = [X^T; 1; 0] (8 rows),  W (N x 2P, 8 columns
-// at most).  One instruction = blocks (row half, column half) x 4 training points; the 8 waves split N (whole shares of `jper`
-// points: the tables are zero beyond N), their partial tiles go to red[wave][8][8], ONE unconditional store per lane.
-template <int P>
-__device__ __forceinline__ void lean_j(const double* xe, const double* vb, double* red, int Np8, int jper, int wv, int lane) {
+// The same with NCG > 1 column groups of 8 (polynomial kernels: NW P = 16 or 24 columns at P = 4): the A operand of a step is shared by
+// the groups, each group keeps its own accumulator pair; partial tiles to red[wave][group][8][8].  W is [j][NCOL] (slot-major columns
+// s P + p); the last group may reach up to 7 columns past NCOL -- into the next row, finite values whose output columns nobody reads.
+template <int NCOL, int NCG>
+__device__ __forceinline__ void lean_j_groups(const double* xe, const double* vb, double* red, int Npad, int j0, int nu, int wv, int lane) {
   const int kq = lane >> 4, blk = (lane >> 2) & 3, e = lane & 3;
-  const double* ap = xe + (4 * (blk >> 1) + e) * Np8 + wv * jper + kq;
-  const double* bp = vb + (wv * jper + kq) * (2 * P) + 4 * (blk & 1) + e;  // (P < 4: columns >= 2P read a neighbour's weights; those output columns are never used)
-  const int nu = jper >> 2;
-  double acc0 = 0.0, acc1 = 0.0;
-  for (int u0 = 0; u0 < nu; u0 += 10) {
-    double av[10], bw[10];
+  const double* ap = xe + (4 * (blk >> 1) + e) * Npad + j0 + kq;
+  const double* bp = vb + (j0 + kq) * NCOL + 4 * (blk & 1) + e;
+  double acc[NCG][2];
 #pragma unroll
-    for (int u = 0; u < 10; ++u) {
-      const int uc = imin(u0 + u, nu - 1);
-      av[u] = ap[4 * uc];
-      bw[u] = bp[4 * uc * (2 * P)];
-    }
-    asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]), "+v"(av[7]), "+v"(av[8]), "+v"(av[9]),
-                 "+v"(bw[0]), "+v"(bw[1]), "+v"(bw[2]), "+v"(bw[3]), "+v"(bw[4]), "+v"(bw[5]), "+v"(bw[6]), "+v"(bw[7]), "+v"(bw[8]), "+v"(bw[9]));
+  for (int g = 0; g < NCG; ++g) acc[g][0] = acc[g][1] = 0.0;
+  for (int u0 = 0; u0 < nu; u0 += 4) {  // nu = 8 or 12
+    double av[4], bw[NCG][4];
 #pragma unroll
-    for (int u = 0; u < 10; u += 2) {
-      if (u0 + u < nu) mfma4(acc0, av[u], bw[u]);          // (uniform tests)
-      if (u0 + u + 1 < nu) mfma4(acc1, av[u + 1], bw[u + 1]);
+    for (int u = 0; u < 4; ++u) {
+      av[u] = ap[4 * (u0 + u)];
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) bw[g][u] = bp[4 * (u0 + u) * NCOL + 8 * g];
     }
+    asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));
+#pragma unroll
+    for (int g = 0; g < NCG; ++g) asm volatile("" : "+v"(bw[g][0]), "+v"(bw[g][1]), "+v"(bw[g][2]), "+v"(bw[g][3]));
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) mfma4(acc[g][u & 1], av[u], bw[g][u]);
   }
-  // D lane = 16 i + 4 blk + j: row 4 (blk >> 1) + i, column 4 (blk & 1) + j
-  red[wv * 64 + (4 * (blk >> 1) + kq) * 8 + 4 * (blk & 1) + e] = acc0 + acc1;
+#pragma unroll
+  for (int g = 0; g < NCG; ++g) red[(wv * NCG + g) * 64 + (4 * (blk >> 1) + kq) * 8 + 4 * (blk & 1) + e] = acc[g][0] + acc[g][1];
 }
 
-template <int P, int KR>
+// The z-only part of a polynomial kernel's posterior (MAXDEG > 0), per particle and step, by ONE otherwise idle wave between u and
+// the end of phase K -- off wave 0's serial section.  With zw = w (*) z:
+//   qB_c = sum_e w21_e z_e AXX[c][e] (= sum_j alpha_j B_j X_jc),  qA_c likewise with w20          -> fz[P*4 + (p*8 + c)*2 + {0, 1}]
+//   mpoly = w1_D sum alpha + sum_d w1_d z_d aX_d + sum_d w20_d z_d qB_d   (= sum_j alpha_j (p1_j + A_j B_j))
+//   kzz   = lambda + w1_D + sum_d w1_d z_d^2 + Sa Sb,   Sa = sum_d w20_d z_d^2,  Sb = sum_d w21_d z_d^2        -> fz[p*4 + {0,1,2,3}]
+// Lane (p, c), c < 8 (P * 8 <= 32 lanes); the sums over c by one DPP reduction inside the particle's group of 8 lanes.
+template <int P, int MAXDEG>
+__device__ __forceinline__ void lean_prefz(const double* z, const double* kpar, const double* pc, double* fz, double lambda, int D, int lane) {
+  const int p = (lane >> 3) & 3, c = lane & 7;
+  const bool act = lane < P * 8 && c < D;
+  const int cc = c < D ? c : 0, pp = p < P ? p : 0;
+  double qB = 0.0, qA = 0.0;
+  const double zc = z[pp * D + cc];
+  const double w1c = kpar[KP_W1(D) + cc], w20c = MAXDEG >= 2 ? kpar[KP_W20(D) + cc] : 0.0, w21c = MAXDEG >= 2 ? kpar[KP_W21(D) + cc] : 0.0;
+  if (MAXDEG >= 2) {
+    double ze[RL_MAXD], a20[RL_MAXD], a21[RL_MAXD], ax[RL_MAXD];
+#pragma unroll
+    for (int e = 0; e < RL_MAXD; ++e) {
+      const int ee = e < D ? e : 0;
+      ze[e] = z[pp * D + ee];
+      a20[e] = kpar[KP_W20(D) + ee];
+      a21[e] = kpar[KP_W21(D) + ee];
+      ax[e] = pc[28 + cc * 8 + e];  // AXX[c][e] (zero for e >= D)
+    }
+#pragma unroll
+    for (int e = 0; e < RL_MAXD; ++e) {
+      qB = fma(a21[e] * ze[e], ax[e], qB);
+      qA = fma(a20[e] * ze[e], ax[e], qA);
+    }
+  }
+  // per-(p, c) terms, then the sums over c of one particle: lanes p*8 .. p*8+7 (one aligned group of 8 lanes inside a DPP row)
+  double t[5];
+  t[0] = act ? fma(w20c * zc, qB, (w1c * zc) * kpar[KP_AX(D) + cc]) : 0.0;  // -> mpoly
+  t[1] = act ? (w1c * zc) * zc : 0.0;                                        // -> p1(z, z)
+  t[2] = act ? (w20c * zc) * zc : 0.0;                                       // -> Sa
+  t[3] = act ? (w21c * zc) * zc : 0.0;                                       // -> Sb
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {  // sum over the group's 8 lanes: lane ^ 1, lane ^ 2 (quad_perm), then lane + 4 (row_shl:4): the lanes c < 4 hold the total
+    t[i] += dpp_take<0xB1, 0xf>(t[i]);
+    t[i] += dpp_take<0x4E, 0xf>(t[i]);
+    t[i] += dpp_take<0x104, 0xf>(t[i]);
+  }
+  if (act && MAXDEG >= 2) {
+    fz[P * 4 + (p * 8 + c) * 2] = qB;
+    fz[P * 4 + (p * 8 + c) * 2 + 1] = qA;
+  }
+  if (lane < P * 8 && c == 0) {
+    const double w1D = pc[24], sal = pc[25];
+    fz[p * 4 + 0] = fma(w1D, sal, t[0]);
+    fz[p * 4 + 1] = (lambda + (w1D + t[1])) + t[2] * t[3];
+    fz[p * 4 + 2] = t[2];
+    fz[p * 4 + 3] = t[3];
+  }
+}
+
+template <int P, int KR, int MAXDEG, bool PMS>
 __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int LP = LatLog2<P>::v;
+  constexpr int NWC = lat_nw(MAXDEG), NCOL = P * NWC, NCG = lat_ncg(P, MAXDEG);  // phase-J weight columns: per particle, in all, groups of 8
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
   const int tid0 = threadIdx.x;
@@ -385,7 +463,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   const int DS = D - U;
   const int Npad = a.NpadMax;
   const int NG = lat_ng(B), NGP = lat_ngp(B), Bp = NG * 16, BQ = (B + 3) >> 2;
-  const LatLayout L = lat_layout(P, B, Npad);
+  const LatLayout L = lat_layout(P, B, Npad, MAXDEG);
   double* pol = smem + LatFixed::pol;
   double* umax_l = pol + RL_PFM;
   double* bias_l = umax_l + MCP_MAX_INPUT;
@@ -398,6 +476,9 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   double* epsb = smem + LatFixed::eps;
   double* red = smem + LatFixed::red;
   double* rtot = smem + LatFixed::rt;
+  double* pc = smem + LatFixed::pc;    // polynomial constants (MAXDEG > 0)
+  double* fz = smem + LatFixed::fz;    // z-only polynomial terms of the step (MAXDEG > 0)
+  double* pnz = smem + LatFixed::pn;   // position measurement noise (PMS)
   GpL* gpl = reinterpret_cast<GpL*>(smem + LatFixed::gpl);
   double* kpar = smem + LatFixed::kpar;
   int* role = reinterpret_cast<int*>(smem + LatFixed::role);
@@ -451,7 +532,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
       xe[it] = d < D ? (j < gp.Npad ? gp.Xt[(size_t)d * gp.Npad + j] : 0.0) : (d == D ? 1.0 : 0.0);
     }
     for (int it = tid0; it < Npad; it += RF_NT) al_l[it] = it < gp.Npad ? gp.alpha[it] : 0.0;
-    for (int it = tid0; it < Npad * P * 2; it += RF_NT) vb[it] = 0.0;
+    for (int it = tid0; it < Npad * NCOL + 8; it += RF_NT) vb[it] = 0.0;
   }
   for (int it = tid0; it < RL_UM * Bp; it += RF_NT) {
     const int k = it / Bp, b = it - k * Bp;
@@ -499,7 +580,21 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     ro[RO_GVEL] = g_vel;
     ro[RO_GPOS] = g_pos;
     ro[RO_VELOFPOS] = vel_of_pos;
-    ro[RO_PMPOS] = ro[RO_PMVEL] = ro[RO_PMPAIR] = 0;
+    // measurement model (PMS): thread (p, s) produces the measurement of its own component; a velocity thread rebuilds the noisy position
+    // of its pair from the pair's lane (same noise value) -- rollout_fwd.hip, phase S
+    int pm_pos = -1, pm_vel = -1, pm_pair = tid0;
+    if (PMS && own) {
+      for (int i = 0; i < pl.meas.n; ++i) {
+        if (pl.meas.pos[i] == os) pm_pos = i;
+        if (pl.meas.vel[i] == os) {
+          pm_vel = i;
+          pm_pair = op * S + pl.meas.pos[i];
+        }
+      }
+    }
+    ro[RO_PMPOS] = pm_pos;
+    ro[RO_PMVEL] = pm_vel;
+    ro[RO_PMPAIR] = pm_pair;
     ro[RO_FP] = tid0 / (D + 1);
     ro[RO_FC] = tid0 % (D + 1);
     ro[RO_OM] = imin(m0 + op, Mend - 1);
@@ -531,6 +626,13 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     si[4] = pA >= 0 ? LatFixed::sf + op * RL_PFM + pA : LatFixed::dump;
     si[5] = pB >= 0 ? LatFixed::sf + op * RL_PFM + pB : LatFixed::dump;
     si[6] = si[7] = 0;
+    if (PMS) {  // (the spare double of the row: std of this component's pair's position noise)
+      const int pi = ro[RO_PMPOS] >= 0 ? ro[RO_PMPOS] : ro[RO_PMVEL];
+      double std = 0.0;
+      for (int i = 0; i < pl.meas.n; ++i)
+        if (i == pi) std = pl.meas.std_pos[i];  // (uniform index into the by-value argument)
+      sd[-1] = std;
+    }
     sd[0] = zA >= 0 ? il[zA] : 0.0;
     sd[1] = zB >= 0 ? il[zB] : 0.0;
     sd[2] = pA >= 0 ? pol[pA] : 0.0;
@@ -545,6 +647,38 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     const int d = r < RL_DSM ? (r < DS ? r : -1) : (r - RL_DSM < U ? DS + r - RL_DSM : -1);
     xq[it] = (d >= 0) ? xe[d * Npad + j] * kpar[KP_INVLS(D) + d] : 0.0;
   }
+  if (MAXDEG > 0) {
+    // launch constants of the polynomial terms.  The bilinear forms are evaluated on SCALED operands (z_d / l_d)(X_jd / l_d), the tables
+    // the SE distance already reads: their weights carry l_d^2.  Rows of xq: r < RL_DSM a state-derived dimension, RL_DSM + k an input.
+    if (tid0 < RL_ZD) {
+      const int r = tid0, d = r < RL_DSM ? (r < DS ? r : -1) : (r - RL_DSM < U ? DS + r - RL_DSM : -1);
+      const int dd = d >= 0 ? d : 0;
+      const double il = kpar[KP_INVLS(D) + dd], l2 = 1.0 / (il * il);
+      pc[r] = d >= 0 ? kpar[KP_W1(D) + dd] * l2 : 0.0;
+      pc[8 + r] = (d >= 0 && MAXDEG >= 2) ? kpar[KP_W20(D) + dd] * l2 : 0.0;
+      pc[16 + r] = (d >= 0 && MAXDEG >= 2) ? kpar[KP_W21(D) + dd] * l2 : 0.0;
+    }
+    if (tid0 == 8) {
+      pc[24] = kpar[KP_W1(D) + D];
+      pc[26] = pc[27] = 0.0;
+    }
+    if (tid0 >= 64 && tid0 < 128) {  // sum_j alpha_j (wave 1)
+      double sa = 0.0;
+      for (int j = tid0 - 64; j < Npad; j += 64) sa += al_l[j];
+      sa = wave_sum(sa);
+      if (tid0 == 64) pc[25] = sa;
+    }
+    if (tid0 >= 128 && tid0 < 192) {  // AXX[c][e] = sum_j alpha_j X_jc X_je (rows / columns >= D: zero)
+      const int c = (tid0 - 128) >> 3, e = tid0 & 7;
+      double sx = 0.0;
+      if (MAXDEG >= 2 && c < D && e < D)
+        for (int j = 0; j < Npad; ++j) sx = fma(al_l[j] * xe[c * Npad + j], xe[e * Npad + j], sx);
+      pc[28 + c * 8 + e] = sx;
+    }
+    for (int it = tid0; it < 4 * 4 + 4 * 8 * 2; it += RF_NT) fz[it] = 0.0;
+  }
+  if (PMS)
+    for (int it = tid0; it < 2 * 32; it += RF_NT) pnz[it] = 0.0;
   int cur = 0;
 
   // the random numbers of step `ts`: process noise of this workgroup's GP by wave 1, dropout decisions (one Philox block per 4 basis
@@ -558,6 +692,16 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
           ev = a.nz.eps ? a.nz.eps[((size_t)ts * M + mm) * G + myg] : philox_normal(a.nz, mm, ts, myg);
         }
         epsb[(ts & 1) * P + lane] = ev;
+      }
+      if (PMS) {
+        // position measurement noise of step ts + 1 (phase S of that step reads it BEFORE the step's first barrier, so it is drawn one
+        // step earlier than the process noise): lane P + (p, pair); same draw as the general kernel: (particle, step, pair, stream POS)
+        const int e = lane - P, np = pl.meas.n;
+        if (e >= 0 && e < P * np && ts + 1 < T) {
+          const int pp = e / np, pi = e - pp * np, mm = imin(m0 + pp, Mend - 1);
+          pnz[((ts + 1) & 1) * 32 + e] = pl.meas.pos_noise ? pl.meas.pos_noise[((size_t)ts * M + mm) * np + pi]
+                                                          : philox_normal(a.nz, mm, ts + 1, pi, MCP_STREAM_POS);
+        }
       }
     } else if (wv >= 2 && wv != 4 && drop && !a.nz.masks) {
       const int ti = (wv - 2 - (wv > 4 ? 1 : 0)) * 64 + lane;
@@ -590,6 +734,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
       if (r < nres) kt_load(vres[r], vp, r);
   }
   unsigned long long last_stamp = clock64(), sub_stamp = last_stamp;
+  double pm_prev_np = 0.0, pm_prev_nv = 0.0, pm_prev_mv = 0.0;  // PMS: previous noisy position / noisy velocity / filtered velocity of this lane's pair
 
   for (int t = 0; t < T; ++t) {
     // the thread id goes through an opaque move once per step: what is derived from it is recomputed where it is used (a handful
@@ -605,6 +750,31 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
       const int op = r0.x, os = r0.y, zi_ang = r0.w, pi_ang = r1.y;
       const bool own = lane < P * S;
       const bool ovalid = own && (m0 + op < Mend);
+      // what the policy sees of this component: the state itself, or (PMS, MC_PILCO.py:873-903) its simulated measurement
+      double xm = xn;
+      if (PMS) {
+        const int4 r2 = *reinterpret_cast<const int4*>(ro + 8);
+        const int pm_pos = r2.y, pm_vel = r2.z;
+        const double xpair = __shfl(xn, r2.w);  // (all of wave 0 takes part; lanes without a pair read themselves)
+        if (own) {
+          const int pi = pm_pos >= 0 ? pm_pos : pm_vel;
+          double npos = pm_pos >= 0 ? xn : xpair;
+          if (pi >= 0 && t > 0) npos = fma(smem[LatFixed::sro + lane * 8 + 3], pnz[(t & 1) * 32 + op * pl.meas.n + pi], npos);
+          if (pm_pos >= 0) xm = npos;
+          if (pm_vel >= 0) {
+            if (t == 0) {  // (at t = 0 the measurement is the true state, :856)
+              pm_prev_nv = xn;
+              pm_prev_mv = xn;
+            } else {
+              const double nv = (npos - pm_prev_np) / Ts;
+              xm = (pl.meas.b0 * nv + pl.meas.b1 * pm_prev_nv - pl.meas.a1 * pm_prev_mv) / pl.meas.a0;
+              pm_prev_nv = nv;
+              pm_prev_mv = xm;
+            }
+            pm_prev_np = npos;
+          }
+        }
+      }
       if (own) {
         const double* srow = smem + LatFixed::sro + lane * 8;
         const int4 sa = *reinterpret_cast<const int4*>(srow);
@@ -613,20 +783,25 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
         double* xc = xs + cur * P * S;
         xc[op * S + os] = xn;
         if (ovalid) {
-          if (writer) a.states[((size_t)t * M + m0 + op) * S + os] = xn;
-          if (is_bad(xn)) bad |= MCP_STATUS_NAN;
+          if (writer) {
+            a.states[((size_t)t * M + m0 + op) * S + os] = xn;
+            if (PMS) pl.meas.meas[((size_t)t * M + m0 + op) * S + os] = xm;
+          }
+          if (is_bad(xn) || (PMS && is_bad(xm))) bad |= MCP_STATUS_NAN;
         }
         double sn = 0.0, cs = 0.0;
         if (zi_ang >= 0 || pi_ang >= 0) sincos_fast(xn, &sn, &cs);
+        double snm = sn, csm = cs;  // trig of the measured value (policy features)
+        if (PMS && pi_ang >= 0 && xm != xn) sincos_fast(xm, &snm, &csm);
         // GP input z = [x[not_angle], sin x[angle], cos x[angle], u]   (Model_learning.py:670-683), raw and divided by its lengthscale;
         // policy features (Policy.py:326-333: [x_nonangle, COS, SIN]; plain policy: x) divided by theirs: slots and factors from the table
-        const double vz = zi_ang >= 0 ? sn : xn, vp = pi_ang >= 0 ? cs : xn;
+        const double vz = zi_ang >= 0 ? sn : xn, vp = pi_ang >= 0 ? csm : xm;
         smem[sa.x] = vz;
         smem[sa.y] = cs;
         smem[sa.z] = vz * sc0.x;
         smem[sa.w] = cs * sc0.y;
         smem[sb.x] = vp * sc1.x;
-        smem[sb.y] = sn * sc1.y;
+        smem[sb.y] = snm * sc1.y;
       }
     }
     if (wv == 0) RL_SUB(15);
@@ -639,6 +814,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     // ---- policy + state-only part of the GP distances --------------------------------------------
     const int pK = tid & (P - 1);  // particle of this thread's phase-K items (RF_NT % P == 0)
     double ds[KR], xin[KR][RL_UM];
+    double p1s[MAXDEG >= 1 ? KR : 1], pAs[MAXDEG >= 2 ? KR : 1], pBs[MAXDEG >= 2 ? KR : 1];  // polynomial kernels: the three bilinear forms of an item
     {
       const int row = tid >> 4, e16 = tid & 15;
       const int pP = row & (P - 1);  // particle of this DPP row in the policy phase (32 rows per round, 32 % P == 0)
@@ -655,6 +831,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
             ds[r] = 0.0;
 #pragma unroll
             for (int k = 0; k < RL_UM; ++k) xin[r][k] = 0.0;
+            if (MAXDEG >= 1) p1s[r] = 0.0;
+            if (MAXDEG >= 2) pAs[r] = pBs[r] = 0.0;
             continue;
           }
           const int j = imin((tid + r * RF_NT) >> LP, Npad - 1);
@@ -670,6 +848,25 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
             acc = fma(rr, rr, acc);
           }
           ds[r] = acc;
+          if (MAXDEG >= 1) {
+            // p1 = w1_D + sum_d w1_d z_d X_jd,  A = sum_d w20_d z_d X_jd,  B = sum_d w21_d z_d X_jd  on the scaled operands: one product
+            // per dimension feeds the three forms (weights w l^2 from the constants table; padded dimensions carry weight zero)
+            double q1 = pc[24], qa = 0.0, qb = 0.0;
+#pragma unroll
+            for (int d = 0; d < RL_DSM; ++d) {
+              const double zx = zr[d] * xv[d];
+              q1 = fma(pc[d], zx, q1);
+              if (MAXDEG >= 2) {
+                qa = fma(pc[8 + d], zx, qa);
+                qb = fma(pc[16 + d], zx, qb);
+              }
+            }
+            p1s[r] = q1;
+            if (MAXDEG >= 2) {
+              pAs[r] = qa;
+              pBs[r] = qb;
+            }
+          }
         }
       }
       const int NPR = NG << LP;  // (basis group, particle) pairs, particle fastest
@@ -760,8 +957,42 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
           dd = fma(rr, rr, dd);
         }
         const double kv = j < Nown ? lambda * exp(-dd) : 0.0;
-        if (j < Npad) kb[it] = kv;
+        if (MAXDEG == 0) {
+          if (j < Npad) kb[it] = kv;
+        } else {
+          // k = kse + p1 + A B (Sparse_GP.py:625-646, GP_prior.py:314-335); the phase-J slots of (j, p) that do not need v: kse alpha (final),
+          // kse, B, A (multiplied by v in the tail of phase V).  Rows j >= N carry zeros in every slot.
+          double q1 = p1s[r], qa = 0.0, qb = 0.0;
+          if (MAXDEG >= 2) {
+            qa = pAs[r];
+            qb = pBs[r];
+          }
+#pragma unroll
+          for (int k = 0; k < RL_UM; ++k) {
+            const double zx = ur[k] * xin[r][k];
+            q1 = fma(pc[RL_DSM + k], zx, q1);
+            if (MAXDEG >= 2) {
+              qa = fma(pc[8 + RL_DSM + k], zx, qa);
+              qb = fma(pc[16 + RL_DSM + k], zx, qb);
+            }
+          }
+          const bool real = j < Nown;
+          double kt = kv + q1;
+          if (MAXDEG >= 2) kt = fma(qa, qb, kt);
+          if (j < Npad) {
+            kb[it] = real ? kt : 0.0;
+            double* w = vb + j * NCOL + pK;
+            w[0] = kv * al_l[j];
+            w[P] = kv;
+            if (MAXDEG >= 2) {
+              w[4 * P] = real ? qb : 0.0;
+              w[5 * P] = real ? qa : 0.0;
+            }
+          }
+        }
       }
+      // the z-only polynomial terms of this step, by wave 7 (no item in the last round of phase K at the headline shape): u is known
+      if (MAXDEG > 0 && wv == RF_NW - 1) lean_prefz<P, MAXDEG>(z, kpar, pc, fz, lambda, D, lane);
     }
     lds_barrier();  // B2
     RL_STAMP(3);
@@ -774,17 +1005,21 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 2; ++r) acc2[0][r] = acc2[1][r] = 0.0;
       kt_stream<P>(vp, vnrt, vnjg, kb, lane, acc3, acc2, vres, nres, bufA, bufB, RL_PRE);
-      kt_tail<P>(acc3, acc2, vrt0, vnrt, kb, al_l, vb, lane);
+      kt_tail<P, MAXDEG>(acc3, acc2, vrt0, vnrt, kb, al_l, vb, lane);
       if (stamping && lane == 0) stl[16 + wv] += clock64() - tv0_;  // this wave's own phase V
       // ---- phase J over the rows this wave has just finished (wave-level ordering only) ----
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const unsigned long long tj0_ = (stamping && wv == 0) ? clock64() : 0;
-      lean_j<P>(xe, vb, red, Npad, 16 * vrt0, 4 * vnrt, wv, lane);
+      if (MAXDEG == 0)
+        lean_j<P>(xe, vb, red, Npad, 16 * vrt0, 4 * vnrt, wv, lane);
+      else
+        lean_j_groups<NCOL, NCG>(xe, vb, red, Npad, 16 * vrt0, 4 * vnrt, wv, lane);
       if (stamping && tid == 0) stl[12] += clock64() - tj0_;
     } else {
-      red[wv * 64 + lane] = 0.0;  // (a wave without rows)
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) red[(wv * NCG + g) * 64 + lane] = 0.0;  // (a wave without rows)
     }
     lds_barrier();  // B4
     RL_STAMP(6);
@@ -794,14 +1029,15 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
       const int* ro = role + lane * 16;
       const int4 r0 = *reinterpret_cast<const int4*>(ro), r1 = *reinterpret_cast<const int4*>(ro + 4), r2 = *reinterpret_cast<const int4*>(ro + 8),
                  r3 = *reinterpret_cast<const int4*>(ro + 12);
-      {  // the 8 waves' partial tiles, added in wave order: lane l -> element (c = l >> 3, n = l & 7)
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {  // the 8 waves' partial tiles, added in wave order: lane l -> element (c = l >> 3, n = 8 g + (l & 7))
         double rv[RF_NW];
 #pragma unroll
-        for (int w = 0; w < RF_NW; ++w) rv[w] = red[w * 64 + lane];
+        for (int w = 0; w < RF_NW; ++w) rv[w] = red[(w * NCG + g) * 64 + lane];
         double sr = rv[0];
 #pragma unroll
         for (int w = 1; w < RF_NW; ++w) sr += rv[w];
-        rtot[lane] = sr;
+        rtot[g * 64 + lane] = sr;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -810,11 +1046,29 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
         const int p = r3.x, c = r3.y;
         const GpL& gp = gpl[0];
         const double vscale = gp.var_scale;
-        // R[D][2p] = sum_j k_j alpha_j,  R[D][2p+1] = k^T Kinv k;  R[c][.] the same sums weighted by X_jc
-        const v2d RD = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(rtot + D * 8 + 2 * p, 16));
-        const v2d RC = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(rtot + imin(c, D - 1) * 8 + 2 * p, 16));
-        const double mu = gp.mean + RD.x;
-        const double var = (gp.lambda - RD.y) * vscale;  // k(z,z) = lambda: Stationary_GP.py:172-181
+        // SE only: R[D][2p] = sum_j k_j alpha_j,  R[D][2p+1] = k^T Kinv k;  R[c][.] the same sums weighted by X_jc.
+        // Polynomial kernels: column s P + p of R, slots s = 0 kse alpha, 1 kse v, 2 v, 3 k v, 4 v B, 5 v A (GP_prior.py:137-155 with
+        // the kernel of GP_prior.py:314-335; the alpha-weighted polynomial sums and k(z, z) come from lean_prefz).
+        const int cc = imin(c, D - 1);
+        auto Rp = [&](int row, int slot) {
+          const int col = slot * P + p;
+          return rtot[(col >> 3) * 64 + row * 8 + (col & 7)];
+        };
+        v2d RD, RC;
+        double mu, var;
+        if (MAXDEG == 0) {
+          RD = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(rtot + D * 8 + 2 * p, 16));
+          RC = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(rtot + cc * 8 + 2 * p, 16));
+          mu = gp.mean + RD.x;
+          var = (gp.lambda - RD.y) * vscale;  // k(z,z) = lambda: Stationary_GP.py:172-181
+        } else {
+          RD.x = Rp(D, 0);
+          RD.y = Rp(D, 1);
+          RC.x = Rp(cc, 0);
+          RC.y = Rp(cc, 1);
+          mu = gp.mean + (RD.x + fz[p * 4 + 0]);
+          var = (fz[p * 4 + 1] - Rp(D, 3)) * vscale;
+        }
         double eps = 0.0, wj = 0.0, sd = 0.0;
         if (a.particle_pred) {
           eps = epsb[(t & 1) * P + p];
@@ -835,8 +1089,19 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
         } else if (a.jac && m0 + p < Mend) {
           // centred sums  sum_j w_j (z_c - X_jc) = z_c R[D][.] - R[c][.]
           const double il = kpar[KP_INVLS(D) + c], il2 = il * il, zc = z[p * D + c];
-          const double Jmu = -2.0 * il2 * fma(zc, RD.x, -RC.x);
-          const double Jvar = 4.0 * il2 * fma(zc, RD.y, -RC.y);
+          double Jmu = -2.0 * il2 * fma(zc, RD.x, -RC.x);
+          double Jvar = 4.0 * il2 * fma(zc, RD.y, -RC.y);
+          if (MAXDEG >= 1) {
+            const double w1c = kpar[KP_W1(D) + c];
+            Jmu = fma(w1c, kpar[KP_AX(D) + c], Jmu);
+            Jvar += 2.0 * w1c * (zc - Rp(c, 2));
+            if (MAXDEG >= 2) {
+              const double a_ = kpar[KP_W20(D) + c], b_ = kpar[KP_W21(D) + c];
+              const double qB = fz[P * 4 + (p * 8 + c) * 2], qA = fz[P * 4 + (p * 8 + c) * 2 + 1];
+              Jmu += a_ * qB + b_ * qA;
+              Jvar += 2.0 * zc * (a_ * fz[p * 4 + 3] + b_ * fz[p * 4 + 2]) - 2.0 * (a_ * Rp(c, 4) + b_ * Rp(c, 5));
+            }
+          }
           a.jac[(((size_t)t * M + m0 + p) * G + myg) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
         }
       }
@@ -899,20 +1164,35 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
 
 // the latency-lean GP-sharded kernel: narrow SE-only models (cart-pole class); KR = phase-K items per thread
 static int gsh_grid(int nclusters, int G) { return ((nclusters + 7) / 8) * 8 * G; }  // (whole groups of 8 clusters: rollout_fwd.hip)
-template <int P, int KR>
-static int launch_fwd_lean_kr(const FwdArgs& a, size_t lds, hipStream_t st) {
-  MCP_ENSURE_MAX_LDS(rollout_fwd_lat_kernel<P, KR>);
-  hipLaunchKernelGGL((rollout_fwd_lat_kernel<P, KR>), dim3(gsh_grid(a.nclusters, a.model.G)), dim3(RF_NT), lds, st, a);
+template <int P, int KR, int MAXDEG, bool PMS>
+static int launch_fwd_lean_i(const FwdArgs& a, size_t lds, hipStream_t st) {
+  MCP_ENSURE_MAX_LDS(rollout_fwd_lat_kernel<P, KR, MAXDEG, PMS>);
+  hipLaunchKernelGGL((rollout_fwd_lat_kernel<P, KR, MAXDEG, PMS>), dim3(gsh_grid(a.nclusters, a.model.G)), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
+}
+template <int P, int KR>
+static int launch_fwd_lean_kr(const FwdArgs& a, size_t lds, hipStream_t st) {
+  const bool pms = a.pol.meas.n > 0;
+  if (a.maxdeg == 0) return pms ? launch_fwd_lean_i<P, KR, 0, true>(a, lds, st) : launch_fwd_lean_i<P, KR, 0, false>(a, lds, st);
+  if (a.maxdeg == 1) return pms ? launch_fwd_lean_i<P, KR, 1, true>(a, lds, st) : launch_fwd_lean_i<P, KR, 1, false>(a, lds, st);
+  return pms ? launch_fwd_lean_i<P, KR, 2, true>(a, lds, st) : launch_fwd_lean_i<P, KR, 2, false>(a, lds, st);
 }
 static int lean_items_per_thread(int P, int NpadMax) {  // 0: the shape has no instantiation
   if (NpadMax < 32 || NpadMax > 384) return 0;  // phase V deals 2 .. 24 row tiles of 16 to the waves in parts of 2 or 3
   return P == 4 ? 3 : (P == 2 ? 2 : 1);         // Npad * P <= KR * RF_NT
 }
 static bool lean_applies(const mcp_model* m, const mcp_policy* p, int P, int NpadMax, int maxdeg) {
-  if (maxdeg != 0 || m->G < 2) return false;
-  if (p->meas.n > 0 || p->kind == MCP_POLICY_TRAJ) return false;  // (measurement models and trajectory policies: the general kernel)
+  if (maxdeg < 0 || maxdeg > 2 || m->G < 2) return false;
+  if (p->kind == MCP_POLICY_TRAJ) return false;  // (trajectory policies: the general kernel)
+  for (int g = 0; g < m->G; ++g)
+    if (m->gp[g].kern.poly_deg != maxdeg) return false;  // (one kernel structure for the whole model, as every launch script builds it)
+  if (p->meas.n > 0) {  // measurement model: wave 1 draws P * n position noises beside the P process noises; one pair per state component
+    if (P + P * p->meas.n > 64 || P * p->meas.n > 32) return false;
+    for (int i = 0; i < p->meas.n; ++i)
+      for (int j = 0; j < p->meas.n; ++j)
+        if ((i != j && (p->meas.pos[i] == p->meas.pos[j] || p->meas.vel[i] == p->meas.vel[j])) || p->meas.pos[i] == p->meas.vel[j]) return false;
+  }
   for (int i = 0; i < m->n_angle; ++i)  // (phase S writes a state component to the plain OR the sin / cos slots)
     for (int j = 0; j < m->n_not_angle; ++j)
       if (m->angle[i] == m->not_angle[j]) return false;
@@ -935,7 +1215,7 @@ int launch_fwd_lean(const FwdArgs& a, int P, size_t lds, hipStream_t st) {
 // dynamic LDS of the lean kernel for this shape at P particles per workgroup; 0: the kernel does not take the shape
 size_t fwd_lean_lds_bytes(const mcp_model* m, const mcp_policy* p, int P, int NpadMax, int maxdeg) {
   if (!lean_applies(m, p, P, NpadMax, maxdeg)) return 0;
-  return sizeof(double) * (size_t)lat_layout(P, p->B, NpadMax).total;
+  return sizeof(double) * (size_t)lat_layout(P, p->B, NpadMax, maxdeg).total;
 }
 // Kinv of every GP as MFMA operand tiles, in each wave's streaming order (into a.kt: the caller's workspace)
 int launch_fwd_lean_pack(const FwdArgs& a, hipStream_t st) {

@@ -220,7 +220,8 @@ def test_rollout_cost_gradient_vs_reference(golden, name, kind, ppw):
         st, inp, status = ops.rollout(model, pol, noise_from(fx), x0, Tn, p)
         c, s = ops.expected_cost(cost, st)
         c.backward()
-        fv.check(sharding_optional=(kind == "ur5" and ppw == 116))  # (the sharded 16-particle kernel exists for G <= 3)
+        # (the sharded 16-particle kernel exists for G <= 3; the lean kernel takes every narrow model: SE, SE + polynomial, SOD subsets)
+        fv.check(sharding_optional=(kind == "ur5" and ppw == 116), lean_expected=(kind != "ur5") if ppw >= 200 else None)
     assert int(status.item()) == 0
     long = Tn > 12
     assert abserr(st, fx["states"]) < (1e-6 if long else 1e-9)
@@ -325,7 +326,7 @@ def test_pms_rollout_cost_gradient_vs_reference(golden, ppw):
     Tn, p = fx["states"].shape[0], float(fx["p_drop"])
     with forced_variant(ppw) as fv:
         st, inp, status = ops.rollout(model, pol, nz, G(fx["x0"]), Tn, p, meas=meas)
-        fv.check()
+        fv.check(lean_expected=True if ppw >= 200 else None)  # (round 4: the lean kernel carries the measurement model too)
         c, s = ops.expected_cost(cost, st)
         c.backward()
     assert int(status.item()) == 0

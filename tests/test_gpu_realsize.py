@@ -113,7 +113,7 @@ def test_rollout_kernels_alone_against_the_oracle_at_real_sizes(key, code, pb):
         st, inp, status = ops.rollout(w.model, w.policy, nz, o["x0"].to(dev()), w.T, o["p"])
         c, s = ops.expected_cost(w.cost, st)
         c.backward()
-        fv.check(sharding_optional=(key == "ur5_400"), lean_expected=(key == "se300") if code >= 200 else None)
+        fv.check(sharding_optional=(key == "ur5_400"), lean_expected=(key in ("se300", "sep2_300")) if code >= 200 else None)
     assert int(status.item()) == 0
     es = float((st.detach().cpu() - o["states"]).abs().max())
     eu = float((inp.detach().cpu() - o["inputs"]).abs().max())
@@ -160,26 +160,30 @@ def test_long_horizon_against_the_oracle_at_n300(code):
         assert float((q.grad.cpu().reshape(g.shape) - g).abs().max()) < 1e-6 * float(g.abs().max()), k
 
 
-def test_lean_kernel_draws_the_same_dropout_bits_and_noise_as_the_general_one():
-    """Philox mode (what every benchmark number runs in): the lean kernel's dropout decisions and process noise are the general
-    kernels' -- identical counters, so the trajectories agree to rounding (different summation orders), far below what one flipped
-    keep bit or a different normal would cause."""
+@pytest.mark.parametrize("name", ["c1", "c2_script", "pms_script"])
+def test_lean_kernel_draws_the_same_dropout_bits_and_noise_as_the_general_one(name):
+    """Philox mode (what every benchmark number runs in): the lean kernel's dropout decisions, process noise and (measurement model)
+    position noise are the general kernels' -- identical counters, so the trajectories agree to rounding (different summation
+    orders), far below what one flipped keep bit or a different normal would cause.  SE, SE + polynomial(2) and the measurement
+    model of MC_PILCO4PMS (every instantiation family of the lean kernel); 1 and 4 particles per workgroup bit for bit."""
     from gpu_helpers import dev, forced_variant
     from mc_pilco_amd import hipabi, ops, workloads
 
-    w = workloads.build("c1", device=dev(), M=96, T=10)
+    w = workloads.build(name, device=dev(), M=96, T=10)
+    assert (w.meas is not None) == (name == "pms_script")
     torch.manual_seed(4)
     x0 = w.sample_x0()
     outs = {}
     with torch.no_grad():
-        for code in (4, 104, 204, 201):
+        for code in (4, 104, 204, 202, 201):
             with forced_variant(code) as fv:
-                outs[code] = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=11, call=3), x0, w.T, w.p_drop)
+                outs[code] = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=11, call=3), x0, w.T, w.p_drop, meas=w.meas)
                 fv.check(lean_expected=True if code >= 200 else None)
-    for code in (104, 204, 201):
+    for code in (104, 204, 202, 201):
         assert int(outs[code][2].item()) == 0
         assert float((outs[code][0] - outs[4][0]).abs().max()) < 5e-9 and float((outs[code][1] - outs[4][1]).abs().max()) < 5e-9
-    assert torch.equal(outs[204][0], outs[201][0]) and torch.equal(outs[204][1], outs[201][1])  # the lean kernel does not depend on P
+    for code in (202, 201):  # the lean kernel does not depend on P
+        assert torch.equal(outs[204][0], outs[code][0]) and torch.equal(outs[204][1], outs[code][1])
 
 
 @pytest.mark.parametrize("pb", [1, 2, 4])
