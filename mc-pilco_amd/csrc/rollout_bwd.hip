@@ -849,7 +849,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
 //  scratch with the wait for the load right behind it)
 template <int GM>
 struct BlStage {
-  double xs, gb, uu, ja0, jb0, ja1, jb1, ja2, jb2, ja3, jb3;
+  double xs, xm, gb, uu, ja0, jb0, ja1, jb1, ja2, jb2, ja3, jb3;  // (xm: the measured state, loaded only with a measurement model)
 };
 template <int g, int GM>
 __device__ __forceinline__ double& bl_ja(BlStage<GM>& s) {
@@ -884,7 +884,11 @@ __device__ __forceinline__ void bl_for_g(F&& f) {
     }                                                        \
   } while (0)
 
-template <int GM>
+// PMS (round 4): the measurement model of MC_PILCO4PMS.apply_policy (mcp_meas).  The policy features of a step are functions of the MEASURED
+// state, so what the chain gathers is dJ/d(measured x_{t+1}); the state lanes map it to dJ/dx_{t+1} through the adjoint of the measurement
+// (general kernel: meas_adjoint) in registers: a velocity lane carries mvb (adjoint of the filtered velocity), a position lane nvb of its pair
+// (adjoint of the finite-difference velocity), the pair's value of the step crosses lanes by v_readlane (uniform pair indices).
+template <int GM, bool PMS>
 __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) void rollout_bwd_lat_kernel(BwdArgs a) {
   constexpr int PFM = 8, UM = 2;
   __shared__ double s_red_[2][4][8];  // [slot][RBF wave][feature]: the wave's sum over its basis functions of the feature adjoint
@@ -997,6 +1001,15 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   }
   const bool need_trig = na > 0 || (pl.kind == MCP_POLICY_ANGLES && pa > 0);
   const bool has_j = ia >= 0;
+  bool pm_vel = false, pm_pos = false;  // this state lane is the velocity / position of a measurement pair
+  if (PMS && wv == 0 && st_lane)
+    for (int i = 0; i < pl.meas.n; ++i) {
+      if (pl.meas.vel[i] == lane) pm_vel = true;
+      if (pl.meas.pos[i] == lane) pm_pos = true;
+    }
+  const double pm_a = PMS ? -pl.meas.a1 / pl.meas.a0 : 0.0, pm_b0 = PMS ? pl.meas.b0 / pl.meas.a0 : 0.0, pm_b1 = PMS ? pl.meas.b1 / pl.meas.a0 : 0.0;
+  const double pm_its = PMS ? 1.0 / md.Ts : 0.0;
+  double pm_cm = 0.0, pm_cn = 0.0;  // carried: mvb_{t+1} (velocity lanes), nvb_{t+1} of the pair (position lanes)
   // 1 / l_q of the feature columns this lane gathers (the RBF waves sum l_q x adjoint) and of the feature it publishes
   const double il1 = s_invl[i1], il2 = s_invl[i2], ilf = ft_lane ? s_invl[fq] : 0.0;
   k0 *= s_invl[i0];
@@ -1025,6 +1038,7 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       int tl = T - 1;  // the step the next call loads
       auto load = [&](BlStage<GM>& st) {
         st.xs = a.states[oS + lx];
+        if (PMS) st.xm = pl.meas.meas[oS + lx];
         double gv = 0.0, uv = 0.0;
         if (a.g_states && st_lane) gv = a.g_states[oS + (unsigned)lane];
         if (in_lane) {
@@ -1057,6 +1071,10 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       auto prep = [&](BlStage<GM>& st) {
         double sv = 0.0, cv = 1.0;
         if (need_trig) sincos_fast(st.xs, &sv, &cv);
+        // the policy's side of the step (feature values, feature-map coefficients): on the measured state
+        double svm = sv, cvm = cv;
+        const double xpol = PMS ? st.xm : st.xs;
+        if (PMS && need_trig) sincos_fast(st.xm, &svm, &cvm);
         bl_for_g<0, GM>([&](auto gc) {
           constexpr int g = decltype(gc)::value;
           const double ja = bl_ja<g>(st), jb = bl_jb<g>(st);
@@ -1066,9 +1084,9 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         gbase = st.gb;
         const double th = st.uu * rumax;
         sq = (in_lane && pl.squash) ? 1.0 - th * th : 1.0;
-        k1n = pang ? -sv * il1 : 0.0;  // (with the 1 / l of the feature columns they weigh)
-        k2n = pang ? cv * il2 : 0.0;
-        fn = ro.w == 0 ? st.xs : (ro.w == 1 ? cv : sv);
+        k1n = pang ? -svm * il1 : 0.0;  // (with the 1 / l of the feature columns they weigh)
+        k2n = pang ? cvm * il2 : 0.0;
+        fn = ro.w == 0 ? xpol : (ro.w == 1 ? cvm : svm);
         if (ft_lane) s_sf[fq] = fn * ilf;
       };
       double xb = 0.0;
@@ -1089,12 +1107,36 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const double c2 = ((r2[0] + r2[1]) + r2[2]) + r2[3];
         return fma(k2p, c2, fma(k1p, c1, k0 * c0));
       };
+      // adjoint of the measurement model at step tt (tt = 0: `first`) -- MC_PILCO.py:881-899, see meas_adjoint of the general kernel:
+      //   mvb_tt = s_vel - a1/a0 mvb_{tt+1};  nvb_tt = b0/a0 mvb_tt + b1/a0 mvb_{tt+1} (0 at tt = 0);  x_tt[pos] gets s_pos + (nvb_tt - nvb_{tt+1})/Ts,
+      //   x_tt[vel] nothing -- except at tt = 0, where the measurement is the true state: x_0[vel] gets mvb_0 + b1/a0 mvb_1
+      auto meas_adj = [&](double s_in, bool first) -> double {
+        const double mvb = pm_vel ? fma(pm_a, pm_cm, s_in) : 0.0;
+        const double nvb = (pm_vel && !first) ? fma(pm_b0, mvb, pm_b1 * pm_cm) : 0.0;
+        double sx = pm_vel ? (first ? fma(pm_b1, pm_cm, mvb) : 0.0) : s_in;
+        double nvp = 0.0;  // nvb_tt of this position lane's pair
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < pl.meas.n) {  // uniform
+            const int lv = pl.meas.vel[i];
+            const double nvi = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(nvb), lv), __builtin_amdgcn_readlane(__double2loint(nvb), lv));
+            if (lane == pl.meas.pos[i]) nvp = nvi;
+          }
+        }
+        if (pm_pos) {
+          sx = fma(nvp - pm_cn, pm_its, s_in);
+          pm_cn = nvp;
+        }
+        if (pm_vel) pm_cm = mvb;
+        return sx;
+      };
       auto chain = [&](bool last) {
         double s = 0.0;
         if (!last) {
           s = gather();
           glacc = fma(-fprev, s, glacc);  // feature lanes: - f_q(t+1) * (adjoint of f_q(t+1))
         }
+        if (PMS && !last) s = meas_adj(s, false);  // dJ/d(measured x_{t+1}) -> its part of dJ/dx_{t+1}
         const double xn = xb + s;  // state lanes: adjoint of x_{t+1}
         double val = fma(own, xn, gbase);
 #pragma unroll
@@ -1146,8 +1188,9 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       if (t == 0) step(0, stA);
       // adjoint of x_0
       {
-        const double s = gather();
+        double s = gather();
         glacc = fma(-fprev, s, glacc);
+        if (PMS) s = meas_adj(s, true);
         if (a.g_x0 && st_lane && valid) a.g_x0[(size_t)m * S + lane] = xb + s;
       }
     } else {
@@ -1318,11 +1361,14 @@ static int g_last_bwd_lean = 0;
 extern "C" void mcp_debug_set_bwd_lean(int v) { g_bwd_lean = v; }
 extern "C" int mcp_debug_last_bwd_lean(void) { return g_last_bwd_lean; }
 // what rollout_bwd_lat_kernel covers: the narrow class with its lane roles (states on lanes 0-7, features on 8-15, inputs on 16-17),
-// up to 256 basis functions, plain / angle policies on the true state, disjoint index lists
+// up to 256 basis functions, plain / angle policies on the true or (measurement model) the measured state, disjoint index lists
 static bool bwd_lean_applies(const mcp_model* md, const mcp_policy* pl, int T) {
   if (T < 2 || md->G < 1 || md->G > BL_GM || md->S > 8 || pl->P > 8 || pl->U > 2 || pl->B > 256 || md->U != pl->U) return false;
   if (pl->kind != MCP_POLICY_PLAIN && pl->kind != MCP_POLICY_ANGLES) return false;
-  if (pl->meas.n > 0) return false;
+  if (pl->meas.n > 4) return false;  // (measurement pairs cross lanes by uniform-index v_readlane: up to 4 pairs on 8 state lanes)
+  for (int i = 0; i < pl->meas.n; ++i)
+    for (int j = 0; j < pl->meas.n; ++j)
+      if ((i != j && (pl->meas.pos[i] == pl->meas.pos[j] || pl->meas.vel[i] == pl->meas.vel[j])) || pl->meas.pos[i] == pl->meas.vel[j]) return false;
   if (pl->kind == MCP_POLICY_PLAIN && pl->P != md->S) return false;
   if (md->n_not_angle + 2 * md->n_angle + md->U != md->D) return false;
   for (int i = 0; i < md->n_angle; ++i)
@@ -1424,10 +1470,16 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
       const int grid = (imin(M - mb, 512) + 1) / 2;
       a.m_base = mb;
       a.slab_accum = mb >= 1024;
-      if (model->G <= 2)
-        hipLaunchKernelGGL(rollout_bwd_lat_kernel<2>, dim3(grid), dim3(nt), 0, st, a);
-      else
-        hipLaunchKernelGGL(rollout_bwd_lat_kernel<BL_GM>, dim3(grid), dim3(nt), 0, st, a);
+      if (policy->meas.n > 0) {
+        if (model->G <= 2)
+          hipLaunchKernelGGL((rollout_bwd_lat_kernel<2, true>), dim3(grid), dim3(nt), 0, st, a);
+        else
+          hipLaunchKernelGGL((rollout_bwd_lat_kernel<BL_GM, true>), dim3(grid), dim3(nt), 0, st, a);
+      } else if (model->G <= 2) {
+        hipLaunchKernelGGL((rollout_bwd_lat_kernel<2, false>), dim3(grid), dim3(nt), 0, st, a);
+      } else {
+        hipLaunchKernelGGL((rollout_bwd_lat_kernel<BL_GM, false>), dim3(grid), dim3(nt), 0, st, a);
+      }
       MCP_LAUNCH_CHECK();
     }
     g_last_bwd_lean = 1;

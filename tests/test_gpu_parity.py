@@ -702,12 +702,17 @@ def test_wide_class_with_a_different_subset_size_per_gp():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", [("c1", 400, 150, 0.25, "philox"), ("c1", 37, 2, 0.25, "philox"), ("c1", 64, 9, 0.0, "philox"), ("c1", 48, 12, 0.25, "masks"),
-                                  ("c3", 96, 20, 0.25, "philox"), ("c1", 1333, 7, 0.25, "philox"), ("c1", 600, 5, 0.25, "masks")])
+                                  ("c3", 96, 20, 0.25, "philox"), ("c1", 1333, 7, 0.25, "philox"), ("c1", 600, 5, 0.25, "masks"),
+                                  ("pms_script", 400, 90, 0.25, "philox"), ("pms_script", 37, 2, 0.25, "philox"), ("pms_script", 64, 11, 0.0, "philox"),
+                                  ("pms_script", 515, 6, 0.25, "philox")])
 def test_lean_backward_sweep_matches_the_general_one(case):
     """rollout_bwd_lat_kernel (small swarms: wave 0 runs the adjoint chain from registers, the RBF waves prepare their step ahead of the
     barrier) against the general sweep on the same rollout: all three policy gradients and dJ/dx0 to 1e-11 relative (different
     summation order only), with in-kernel dropout bits, with mask buffers, without dropout, at T = 2, at the headline size, and beyond 512
-    particles, where 256 workgroups walk several particles per slot (an uneven number of rounds at M = 1333 and 600)."""
+    particles, where 256 workgroups walk several particles per slot (an uneven number of rounds at M = 1333 and 600).  Round 4: the same
+    with the measurement model of MC_PILCO4PMS between particles and policy (the filter's adjoint recursion carried in the chain's
+    registers) at the launch script's size (M = 400, T = 90), at T = 2 (only the t = 0 special case and one filtered step), without
+    dropout, and beyond one round."""
     from gpu_helpers import dev
     from mc_pilco_amd import hipabi, ops, workloads
 
@@ -729,7 +734,7 @@ def test_lean_backward_sweep_matches_the_general_one(case):
             for q in w.params:
                 q.grad = None
             x0.grad = None
-            st, inp, status = ops.rollout(w.model, w.policy, nz, x0, w.T, w.p_drop)
+            st, inp, status = ops.rollout(w.model, w.policy, nz, x0, w.T, w.p_drop, meas=w.meas)
             c, s = ops.expected_cost(w.cost, st)
             (c + 0.3 * s + 1e-3 * (inp ** 2).sum()).backward()  # (a cost on the inputs too: dJ/du_t enters the chain)
             assert L.mcp_debug_last_bwd_lean() == lean
