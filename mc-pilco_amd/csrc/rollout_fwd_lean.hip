@@ -41,7 +41,9 @@ using namespace mcp;
 //     of the model of the same degree.  With p1_j = w1_D + sum_d w1_d z_d X_jd, A_j = sum_d w20_d z_d X_jd, B_j = sum_d w21_d z_d X_jd:
 //     k_j = kse_j + p1_j + A_j B_j.  The three bilinear forms ride in the policy + K(state) pass (one product z_d X_jd per dimension
 //     feeds all of them), phase V is unchanged (its operand is the total k), and phase J takes NW = 4 / 6 weight columns per particle
-//     instead of 2:  [kse alpha | kse v | v | k v]  and, degree 2,  [.. | v B | v A]  (in that order, slot-major: W[j][s P + p]) --
+//     instead of 2, one 16-byte-aligned record per (training point, particle), W[j][p NW + s]:  [kse alpha | kse v | v | k v]  (degree 1),
+//     [kse alpha | kse v | v B | v A | v | k v]  (degree 2): phase K fills the slots that do not need v with vector stores, the tail of
+//     phase V multiplies by v in place and appends the rest, each with at most three LDS instructions per side --
 //     the alpha-weighted polynomial sums need no column at all: they are launch constants contracted with z
 //     (sum_j alpha_j, sum_j alpha_j X_jd, sum_j alpha_j X_jc X_je), formed by an otherwise idle wave while the others finish phase K.
 //   * PMS -- the measurement model of MC_PILCO4PMS.apply_policy (policy_learning/MC_PILCO.py:808-906, mcp_meas): phase S also produces
@@ -53,6 +55,9 @@ using namespace mcp;
 #define RL_PFM 6  // policy features, zero padded
 #ifndef RL_NRES
 #define RL_NRES 2  // register buffers kept resident: RL_NRES or RL_NRES + 1, whichever leaves an even number to stream
+#endif
+#ifndef RL_NRES_CUT2
+#define RL_NRES_CUT2 0  // resident buffers the degree-2 / 4-particle instantiation gives up (experiment switch)
 #endif
 #ifndef RL_PRE
 #define RL_PRE 0  // register buffers of the Kinv stream issued ahead of the barrier that ends phase K (0, 1, 2): measured equal
@@ -226,9 +231,9 @@ __device__ __forceinline__ void kt_use(const v2d (&A)[KT_NL], const v2d (&K)[3],
 // the barrier).  The steady-state loop issues its reloads UNCONDITIONALLY (nb - nres is even and >= 2, kt_resident_count): with a
 // test around the reloads the compiler must assume at every use that no younger loads are outstanding and waits for vmcnt(5..0) --
 // for the OTHER buffer's loads as well, i.e. no double buffering at all (seen in the ISA).
-template <int P>
+template <int P, int NRES>
 __device__ __forceinline__ void kt_stream(gptr2_t p, int nrt, int njg, const double* kb, int lane, double (&acc3)[2][3], double (&acc2)[2][2],
-                                          const v2d (&res)[RL_NRES + 1][KT_NL], int nres, v2d (&bufA)[KT_NL], v2d (&bufB)[KT_NL],
+                                          const v2d (&res)[NRES + 1][KT_NL], int nres, v2d (&bufA)[KT_NL], v2d (&bufB)[KT_NL],
                                           int npre) {
   const int nb = (nrt * njg + KT_NL - 1) / KT_NL;
   const int gpb = nrt == 3 ? 2 : 3;  // column groups per buffer
@@ -240,7 +245,7 @@ __device__ __forceinline__ void kt_stream(gptr2_t p, int nrt, int njg, const dou
   if (npre < 2) kt_load(bufB, p, b + 1);
   kt_readk<P>(kB, ka, (b + 1) * gpb);
 #pragma unroll
-  for (int r = 0; r < RL_NRES + 1; ++r) {
+  for (int r = 0; r < NRES + 1; ++r) {
     if (r < nres) {  // wave-uniform
       v2d kR[3];
       kt_readk<P>(kR, ka, r * gpb);
@@ -260,16 +265,16 @@ __device__ __forceinline__ void kt_stream(gptr2_t p, int nrt, int njg, const dou
 }
 // how many of a wave's nb register buffers stay resident: at most RL_NRES, leaving an even number >= 2 to stream (the double-buffered
 // loop then needs no test around its reloads)
-__device__ __forceinline__ int kt_resident_count(int nb) {
-  int nres = imin(RL_NRES, nb - 2);
+__device__ __forceinline__ int kt_resident_count(int nb, int maxres) {
+  int nres = imin(maxres, nb - 2);
   if (nres < 0) nres = 0;
   if ((nb - nres) & 1) nres += (nb - nres >= 3) ? 1 : -1;  // (the register array has RL_NRES + 1 slots; nb >= 2 always)
   return nres;
 }
 // the tail of phase V: v is complete in this wave, so it forms the two phase-J weights of its rows on the spot,
 //   W[j][2p] = kse_j alpha_j,  W[j][2p+1] = kse_j v_j     (D lane = 16 i + 4 blk + p: row 16 rt + 4 blk + i, particle p)
-// Polynomial kernels (MAXDEG > 0): phase K left  W[j][0 P + p] = kse alpha (final),  [1 P + p] = kse,  [4 P + p] = B,  [5 P + p] = A  and the
-// total k in kb; the tail turns them into  [1] kse v,  [2] v,  [3] k v,  [4] v B,  [5] v A.
+// Polynomial kernels (MAXDEG > 0): phase K left the record  W[j][p NW + .] = [kse alpha (final) | kse | B | A]  (degree 1: the first two) and the
+// total k in kb; the tail turns it into  [kse alpha | kse v | v B | v A | v | k v]  (degree 1: [kse alpha | kse v | v | k v]).
 template <int P, int MAXDEG>
 __device__ __forceinline__ void kt_tail(double (&acc3)[2][3], double (&acc2)[2][2], int rt0, int nrt, const double* kb, const double* al_l,
                                         double* vb, int lane) {
@@ -287,19 +292,21 @@ __device__ __forceinline__ void kt_tail(double (&acc3)[2][3], double (&acc2)[2][
         w.y = kse * v;
         *reinterpret_cast<v2d*>(__builtin_assume_aligned(vb + 2 * (row * P + p), 16)) = w;
       } else {
-        double* w = vb + row * (P * lat_nw(MAXDEG)) + p;
-        const double kt = kb[row * P + p], kse = w[P];
-        double pb_ = 0.0, pa_ = 0.0;
+        double* w = vb + (row * P + p) * lat_nw(MAXDEG);  // (records of 4 or 6 doubles: 16-byte aligned)
+        const double kt = kb[row * P + p], kse = w[1];
+        v2d vk;
+        vk.x = v;
+        vk.y = kt * v;
         if (MAXDEG >= 2) {
-          pb_ = w[4 * P];
-          pa_ = w[5 * P];
-        }
-        w[P] = kse * v;
-        w[2 * P] = v;
-        w[3 * P] = kt * v;
-        if (MAXDEG >= 2) {
-          w[4 * P] = v * pb_;
-          w[5 * P] = v * pa_;
+          v2d ba = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(w + 2, 16));
+          ba.x *= v;
+          ba.y *= v;
+          w[1] = kse * v;
+          *reinterpret_cast<v2d*>(__builtin_assume_aligned(w + 2, 16)) = ba;
+          *reinterpret_cast<v2d*>(__builtin_assume_aligned(w + 4, 16)) = vk;
+        } else {
+          w[1] = kse * v;
+          *reinterpret_cast<v2d*>(__builtin_assume_aligned(w + 2, 16)) = vk;
         }
       }
     }
@@ -366,8 +373,8 @@ __device__ __forceinline__ void lean_j(const double* xe, const double* vb, doubl
 }
 
 // The same with NCG > 1 column groups of 8 (polynomial kernels: NW P = 16 or 24 columns at P = 4): the A operand of a step is shared by
-// the groups, each group keeps its own accumulator pair; partial tiles to red[wave][group][8][8].  W is [j][NCOL] (slot-major columns
-// s P + p); the last group may reach up to 7 columns past NCOL -- into the next row, finite values whose output columns nobody reads.
+// the groups, each group keeps its own accumulator pair; partial tiles to red[wave][group][8][8].  W is [j][NCOL] (columns p NW + s);
+// the last group may reach up to 7 columns past NCOL -- into the next row, finite values whose output columns nobody reads.
 template <int NCOL, int NCG>
 __device__ __forceinline__ void lean_j_groups(const double* xe, const double* vb, double* red, int Npad, int j0, int nu, int wv, int lane) {
   const int kq = lane >> 4, blk = (lane >> 2) & 3, e = lane & 3;
@@ -725,12 +732,16 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   }
   const gptr2_t vp = (gptr2_t)(a.kt + (size_t)myg * a.kt_stride + (size_t)vrt0 * vnjg * 128) + (tid0 & 63);
   const int vnt = vnrt * vnjg;  // tiles in this wave's stream
-  v2d vres[RL_NRES + 1][KT_NL];  // (+ 1: a wave whose buffer count has the other parity keeps one more or one fewer)
+  // (degree-2 polynomial kernels at 4 particles: one resident buffer fewer -- the two halves of phase K carry six values per item
+  //  across the barrier in between, and with three resident buffers the allocator spilled one of them to scratch: its reload in
+  //  phase V waits with vmcnt(0), i.e. for the whole stream in flight: +1-2 k cycles per wave and step)
+  constexpr int NRES = (MAXDEG >= 2 && P == 4) ? (RL_NRES > 1 ? RL_NRES - RL_NRES_CUT2 : RL_NRES) : RL_NRES;
+  v2d vres[NRES + 1][KT_NL];  // (+ 1: a wave whose buffer count has the other parity keeps one more or one fewer)
   int nres = 0;
   if (vnrt > 0) {
-    nres = kt_resident_count((vnt + KT_NL - 1) / KT_NL);
+    nres = kt_resident_count((vnt + KT_NL - 1) / KT_NL, NRES);
 #pragma unroll
-    for (int r = 0; r < RL_NRES + 1; ++r)
+    for (int r = 0; r < NRES + 1; ++r)
       if (r < nres) kt_load(vres[r], vp, r);
   }
   unsigned long long last_stamp = clock64(), sub_stamp = last_stamp;
@@ -823,84 +834,105 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
       for (int q = 0; q < RL_PFM; ++q) sfr[q] = sf[pP * RL_PFM + q];
 #pragma unroll
       for (int d = 0; d < RL_DSM; ++d) zr[d] = zs[pK * RL_ZD + d];
-      if (t < T - 1) {
+      auto k_state = [&]() {
+        if (t < T - 1) {
 #pragma unroll
-        for (int r = 0; r < KR; ++r) {
-          // (the last round holds N P - (KR - 1) 512 items: at N = 300, P = 4 three of the eight waves; the others skip it -- wave-uniform)
-          if (r == KR - 1 && r > 0 && ((wv * 64 + r * RF_NT) >> LP) >= Npad) {
-            ds[r] = 0.0;
+          for (int r = 0; r < KR; ++r) {
+            // (the last round holds N P - (KR - 1) 512 items: at N = 300, P = 4 three of the eight waves; the others skip it -- wave-uniform)
+            if (r == KR - 1 && r > 0 && ((wv * 64 + r * RF_NT) >> LP) >= Npad) {
+              ds[r] = 0.0;
+              if (MAXDEG < 2) {
 #pragma unroll
-            for (int k = 0; k < RL_UM; ++k) xin[r][k] = 0.0;
-            if (MAXDEG >= 1) p1s[r] = 0.0;
-            if (MAXDEG >= 2) pAs[r] = pBs[r] = 0.0;
-            continue;
-          }
-          const int j = imin((tid + r * RF_NT) >> LP, Npad - 1);
-          double xv[RL_DSM];
+                for (int k = 0; k < RL_UM; ++k) xin[r][k] = 0.0;
+              }
+              if (MAXDEG >= 1) p1s[r] = 0.0;
+              if (MAXDEG >= 2) pAs[r] = pBs[r] = 0.0;
+              continue;
+            }
+            const int j = imin((tid + r * RF_NT) >> LP, Npad - 1);
+            double xv[RL_DSM];
 #pragma unroll
-          for (int d = 0; d < RL_DSM; ++d) xv[d] = xq[d * Npad + j];
+            for (int d = 0; d < RL_DSM; ++d) xv[d] = xq[d * Npad + j];
+            if (MAXDEG < 2) {
 #pragma unroll
-          for (int k = 0; k < RL_UM; ++k) xin[r][k] = xq[(RL_DSM + k) * Npad + j];
-          double acc = 0.0;
-#pragma unroll
-          for (int d = 0; d < RL_DSM; ++d) {
-            const double rr = zr[d] - xv[d];
-            acc = fma(rr, rr, acc);
-          }
-          ds[r] = acc;
-          if (MAXDEG >= 1) {
-            // p1 = w1_D + sum_d w1_d z_d X_jd,  A = sum_d w20_d z_d X_jd,  B = sum_d w21_d z_d X_jd  on the scaled operands: one product
-            // per dimension feeds the three forms (weights w l^2 from the constants table; padded dimensions carry weight zero)
-            double q1 = pc[24], qa = 0.0, qb = 0.0;
+              for (int k = 0; k < RL_UM; ++k) xin[r][k] = xq[(RL_DSM + k) * Npad + j];
+            }
+            double acc = 0.0;
 #pragma unroll
             for (int d = 0; d < RL_DSM; ++d) {
-              const double zx = zr[d] * xv[d];
-              q1 = fma(pc[d], zx, q1);
+              const double rr = zr[d] - xv[d];
+              acc = fma(rr, rr, acc);
+            }
+            ds[r] = acc;
+            if (MAXDEG >= 1) {
+              // p1 = w1_D + sum_d w1_d z_d X_jd,  A = sum_d w20_d z_d X_jd,  B = sum_d w21_d z_d X_jd  on the scaled operands: one product
+              // per dimension feeds the three forms (weights w l^2 from the constants table; padded dimensions carry weight zero)
+              // (a padded dimension costs four instructions here, not two as in the distance: the last two state dimensions and the
+              //  second input sit behind a uniform test)
+              double q1 = pc[24], qa = 0.0, qb = 0.0;
+#pragma unroll
+              for (int d = 0; d < RL_DSM; ++d) {
+                if (d < RL_DSM - 2 || d < DS) {
+                  const double zx = zr[d] * xv[d];
+                  q1 = fma(pc[d], zx, q1);
+                  if (MAXDEG >= 2) {
+                    qa = fma(pc[8 + d], zx, qa);
+                    qb = fma(pc[16 + d], zx, qb);
+                  }
+                }
+              }
+              p1s[r] = q1;
               if (MAXDEG >= 2) {
-                qa = fma(pc[8 + d], zx, qa);
-                qb = fma(pc[16 + d], zx, qb);
+                pAs[r] = qa;
+                pBs[r] = qb;
               }
             }
-            p1s[r] = q1;
-            if (MAXDEG >= 2) {
-              pAs[r] = qa;
-              pBs[r] = qb;
+          }
+        }
+      };
+      auto policy_pass = [&]() {
+        const int NPR = NG << LP;  // (basis group, particle) pairs, particle fastest
+        for (int pr0 = 0; pr0 < NPR; pr0 += 32) {
+          const int pr = pr0 + row;
+          const int g = pr >> LP;
+          const int b = imin(g, NG - 1) * 16 + e16;
+          double cv[RL_PFM], wv_[RL_UM];
+#pragma unroll
+          for (int q = 0; q < RL_PFM; ++q) cv[q] = cen[q * Bp + b];
+#pragma unroll
+          for (int k = 0; k < RL_UM; ++k) wv_[k] = wgt[k * Bp + b];
+          int kbits = 0;
+          if (drop) {
+            if (a.nz.masks)
+              kbits = (b < B && a.nz.masks[((size_t)t * M + imin(m0 + pP, Mend - 1)) * B + b] != 0) ? 1 : 0;
+            else
+              kbits = (mk[pP * BQ + imin(b >> 2, BQ - 1)] >> (b & 3)) & 1;  // (b >= B: weight 0, whatever the bit)
+          }
+          double dist = 0.0;
+#pragma unroll
+          for (int q = 0; q < RL_PFM; ++q) {
+            const double rr = sfr[q] - cv[q];
+            dist = fma(rr, rr, dist);
+          }
+          double phi = exp(-dist);
+          if (drop) phi = kbits ? phi * keep_scale : 0.0;
+#pragma unroll
+          for (int k = 0; k < RL_UM; ++k) {
+            if (k < U) {  // uniform
+              const double sgrp = row16_sum(wv_[k] * phi);
+              if (e16 == 15 && pr < NPR) gs[(k * P + pP) * NGP + g] = sgrp;
             }
           }
         }
-      }
-      const int NPR = NG << LP;  // (basis group, particle) pairs, particle fastest
-      for (int pr0 = 0; pr0 < NPR; pr0 += 32) {
-        const int pr = pr0 + row;
-        const int g = pr >> LP;
-        const int b = imin(g, NG - 1) * 16 + e16;
-        double cv[RL_PFM], wv_[RL_UM];
-#pragma unroll
-        for (int q = 0; q < RL_PFM; ++q) cv[q] = cen[q * Bp + b];
-#pragma unroll
-        for (int k = 0; k < RL_UM; ++k) wv_[k] = wgt[k * Bp + b];
-        int kbits = 0;
-        if (drop) {
-          if (a.nz.masks)
-            kbits = (b < B && a.nz.masks[((size_t)t * M + imin(m0 + pP, Mend - 1)) * B + b] != 0) ? 1 : 0;
-          else
-            kbits = (mk[pP * BQ + imin(b >> 2, BQ - 1)] >> (b & 3)) & 1;  // (b >= B: weight 0, whatever the bit)
-        }
-        double dist = 0.0;
-#pragma unroll
-        for (int q = 0; q < RL_PFM; ++q) {
-          const double rr = sfr[q] - cv[q];
-          dist = fma(rr, rr, dist);
-        }
-        double phi = exp(-dist);
-        if (drop) phi = kbits ? phi * keep_scale : 0.0;
-#pragma unroll
-        for (int k = 0; k < RL_UM; ++k) {
-          if (k < U) {  // uniform
-            const double sgrp = row16_sum(wv_[k] * phi);
-            if (e16 == 15 && pr < NPR) gs[(k * P + pP) * NGP + g] = sgrp;
-          }
-        }
+      };
+      // (polynomial kernels: the policy pass first -- the six values per item that phase K carries to its second half are then not live
+      //  beside the policy pass's operands; in the other order the degree-2 instantiation spilled a resident Kinv buffer to scratch)
+      if (MAXDEG >= 2) {
+        policy_pass();
+        k_state();
+      } else {
+        k_state();
+        policy_pass();
       }
     }
     lds_barrier();  // B1
@@ -951,6 +983,10 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
         const int it = tid + r * RF_NT;
         const int j = it >> LP;
         double dd = ds[r];
+        if (MAXDEG >= 2) {  // (re-read, not carried across the barrier: registers -- see the resident buffers of phase V)
+#pragma unroll
+          for (int k = 0; k < RL_UM; ++k) xin[r][k] = xq[(RL_DSM + k) * Npad + imin(j, Npad - 1)];
+        }
 #pragma unroll
         for (int k = 0; k < RL_UM; ++k) {
           const double rr = ur[k] - xin[r][k];
@@ -960,8 +996,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
         if (MAXDEG == 0) {
           if (j < Npad) kb[it] = kv;
         } else {
-          // k = kse + p1 + A B (Sparse_GP.py:625-646, GP_prior.py:314-335); the phase-J slots of (j, p) that do not need v: kse alpha (final),
-          // kse, B, A (multiplied by v in the tail of phase V).  Rows j >= N carry zeros in every slot.
+          // k = kse + p1 + A B (Sparse_GP.py:625-646, GP_prior.py:314-335); the slots of (j, p)'s phase-J record that do not need v: kse alpha
+          // (final), kse, B, A (multiplied by v in the tail of phase V).  Rows j >= N carry zeros in every slot.
           double q1 = p1s[r], qa = 0.0, qb = 0.0;
           if (MAXDEG >= 2) {
             qa = pAs[r];
@@ -969,24 +1005,31 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
           }
 #pragma unroll
           for (int k = 0; k < RL_UM; ++k) {
-            const double zx = ur[k] * xin[r][k];
-            q1 = fma(pc[RL_DSM + k], zx, q1);
-            if (MAXDEG >= 2) {
-              qa = fma(pc[8 + RL_DSM + k], zx, qa);
-              qb = fma(pc[16 + RL_DSM + k], zx, qb);
+            if (k == 0 || k < U) {
+              const double zx = ur[k] * xin[r][k];
+              q1 = fma(pc[RL_DSM + k], zx, q1);
+              if (MAXDEG >= 2) {
+                qa = fma(pc[8 + RL_DSM + k], zx, qa);
+                qb = fma(pc[16 + RL_DSM + k], zx, qb);
+              }
             }
           }
-          const bool real = j < Nown;
+          // (rows N <= j < Npad need no masking beyond kse: their alpha and their v are zero -- Kinv and alpha are zero padded -- so every
+          //  phase-J weight of such a row vanishes whatever its k, B, A; and k_j itself only meets zero columns of Kinv in phase V)
           double kt = kv + q1;
           if (MAXDEG >= 2) kt = fma(qa, qb, kt);
           if (j < Npad) {
-            kb[it] = real ? kt : 0.0;
-            double* w = vb + j * NCOL + pK;
-            w[0] = kv * al_l[j];
-            w[P] = kv;
+            kb[it] = kt;
+            double* w = vb + it * NWC;  // the record of (j, p): it = j P + p
+            v2d w01;
+            w01.x = kv * al_l[j];
+            w01.y = kv;
+            *reinterpret_cast<v2d*>(__builtin_assume_aligned(w, 16)) = w01;
             if (MAXDEG >= 2) {
-              w[4 * P] = real ? qb : 0.0;
-              w[5 * P] = real ? qa : 0.0;
+              v2d w23;
+              w23.x = qb;
+              w23.y = qa;
+              *reinterpret_cast<v2d*>(__builtin_assume_aligned(w + 2, 16)) = w23;
             }
           }
         }
@@ -1004,7 +1047,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
       for (int r = 0; r < 3; ++r) acc3[0][r] = acc3[1][r] = 0.0;
 #pragma unroll
       for (int r = 0; r < 2; ++r) acc2[0][r] = acc2[1][r] = 0.0;
-      kt_stream<P>(vp, vnrt, vnjg, kb, lane, acc3, acc2, vres, nres, bufA, bufB, RL_PRE);
+      kt_stream<P, NRES>(vp, vnrt, vnjg, kb, lane, acc3, acc2, vres, nres, bufA, bufB, RL_PRE);
       kt_tail<P, MAXDEG>(acc3, acc2, vrt0, vnrt, kb, al_l, vb, lane);
       if (stamping && lane == 0) stl[16 + wv] += clock64() - tv0_;  // this wave's own phase V
       // ---- phase J over the rows this wave has just finished (wave-level ordering only) ----
@@ -1047,11 +1090,12 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
         const GpL& gp = gpl[0];
         const double vscale = gp.var_scale;
         // SE only: R[D][2p] = sum_j k_j alpha_j,  R[D][2p+1] = k^T Kinv k;  R[c][.] the same sums weighted by X_jc.
-        // Polynomial kernels: column s P + p of R, slots s = 0 kse alpha, 1 kse v, 2 v, 3 k v, 4 v B, 5 v A (GP_prior.py:137-155 with
-        // the kernel of GP_prior.py:314-335; the alpha-weighted polynomial sums and k(z, z) come from lean_prefz).
+        // Polynomial kernels: column p NW + s of R, slots s = 0 kse alpha, 1 kse v, then [v, k v] (degree 1) or [v B, v A, v, k v] (degree 2)
+        // (GP_prior.py:137-155 with the kernel of GP_prior.py:314-335; the alpha-weighted polynomial sums and k(z, z): lean_prefz).
         const int cc = imin(c, D - 1);
+        constexpr int SV = MAXDEG >= 2 ? 4 : 2, SKV = SV + 1;  // slots of v and k v
         auto Rp = [&](int row, int slot) {
-          const int col = slot * P + p;
+          const int col = p * NWC + slot;
           return rtot[(col >> 3) * 64 + row * 8 + (col & 7)];
         };
         v2d RD, RC;
@@ -1067,7 +1111,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
           RC.x = Rp(cc, 0);
           RC.y = Rp(cc, 1);
           mu = gp.mean + (RD.x + fz[p * 4 + 0]);
-          var = (fz[p * 4 + 1] - Rp(D, 3)) * vscale;
+          var = (fz[p * 4 + 1] - Rp(D, SKV)) * vscale;
         }
         double eps = 0.0, wj = 0.0, sd = 0.0;
         if (a.particle_pred) {
@@ -1094,12 +1138,12 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
           if (MAXDEG >= 1) {
             const double w1c = kpar[KP_W1(D) + c];
             Jmu = fma(w1c, kpar[KP_AX(D) + c], Jmu);
-            Jvar += 2.0 * w1c * (zc - Rp(c, 2));
+            Jvar += 2.0 * w1c * (zc - Rp(c, SV));
             if (MAXDEG >= 2) {
               const double a_ = kpar[KP_W20(D) + c], b_ = kpar[KP_W21(D) + c];
               const double qB = fz[P * 4 + (p * 8 + c) * 2], qA = fz[P * 4 + (p * 8 + c) * 2 + 1];
               Jmu += a_ * qB + b_ * qA;
-              Jvar += 2.0 * zc * (a_ * fz[p * 4 + 3] + b_ * fz[p * 4 + 2]) - 2.0 * (a_ * Rp(c, 4) + b_ * Rp(c, 5));
+              Jvar += 2.0 * zc * (a_ * fz[p * 4 + 3] + b_ * fz[p * 4 + 2]) - 2.0 * (a_ * Rp(c, 2) + b_ * Rp(c, 3));
             }
           }
           a.jac[(((size_t)t * M + m0 + p) * G + myg) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
