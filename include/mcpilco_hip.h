@@ -189,6 +189,36 @@ int mcp_sod_select(const mcp_kernel* kern, int N, const double* X, double thresh
 size_t mcp_nll_workspace_bytes(int N, int D);
 int mcp_nll_grad(const mcp_kernel* kern, int N, const double* X, const double* Kinv, int ldk, const double* alpha, double* grad,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* One epoch of hyper-parameter training for the G GPs of a model at once, from the optimizer's RAW parameters to their gradients and the
+ * loss, without a host round trip -- what GP_prior.fit_model does per epoch through forward + Marginal_log_likelihood + autograd
+ * (GP_prior.py:91-115,179-230; Gaussian_likelihood.py:15-24; Model_learning.train_gp_likelihood, Model_learning.py:398-421).  The GPs of
+ * a model are independent (the reference trains them one after the other, Model_learning.py:149-161): every stage -- Gram, Cholesky,
+ * U^-1, K^-1, alpha, gradient -- is ONE launch whose grid carries the GP index.  All GPs share the inputs X [N][D] and the kernel
+ * structure: one squared-exponential term (lengthscales per dimension or, ard == 0, one shared) plus poly_deg = 0 / 1 / 2 Volterra
+ * terms (MPK_1 with the offset feature, MPK_2 without), noise from the squared-exponential term.  mcp_nll_gp: device pointers to the
+ * raw parameters as the reference stores them (log_lengthscales_par, log_lambda_par, sigma_n_log, mean_par, MPK Sigma_pos_par) and to
+ * the gradient buffers (NULL: not wanted -- a frozen parameter).  16 < N <= 1152.  status: one word, OR of MCP_STATUS_NOT_SPD. */
+typedef struct mcp_nll_gp {
+  const double* log_ls;       /* [D], or [1] when ard == 0                                        */
+  const double* log_lambda;   /* [1]                                                              */
+  const double* sigma_n_log;  /* [1] or NULL: no noise parameter                                  */
+  const double* mean;         /* [1] or NULL: zero prior mean                                     */
+  const double* mpk1;         /* [D+1] MPK_1 Sigma_pos_par (log), or NULL                         */
+  const double* mpk2;         /* [2D]  MPK_2 Sigma_pos_par (log): factor 0 | factor 1, or NULL    */
+  const double* Y;            /* [N] targets                                                      */
+  double y_scale;             /* the targets enter as Y * y_scale (1 / norm_list[g])              */
+  double sigma_n_num2;        /* sigma_n_num^2                                                    */
+  double* g_log_ls;           /* gradients w.r.t. the raw parameters, same shapes (NULL: skip)    */
+  double* g_log_lambda;
+  double* g_sigma_n_log;
+  double* g_mean;
+  double* g_mpk1;
+  double* g_mpk2;
+  double* loss;               /* [1]  1/2 ((Y-m)^T K^-1 (Y-m) + logdet K), or NULL                */
+} mcp_nll_gp;
+size_t mcp_nll_epoch_workspace_bytes(int G, int N, int D);
+int mcp_nll_epoch(int G, const mcp_nll_gp* gps, int N, int D, int poly_deg, int ard, const double* X, uint32_t* status, void* workspace,
+                  size_t workspace_bytes, void* stream);
 /* Packs pretrain outputs into the mcp_gp layout (padding, transposes, aX). */
 int mcp_gp_pack(int N, int D, const double* X, const double* alpha, const double* Kinv, int ldk, int Npad, double* Xt_out,
                 double* X_out, double* alpha_out, double* Kinv_out, double* aX_out, void* stream);
@@ -280,7 +310,7 @@ int mcp_cost_finalize_sums(int T, int64_t n_total, const double* sums, const dou
  * mcp_opt_state lives in device memory, zero-initialised (+ cost_prev = the warm-up cost, :462) by the caller; the caller resets
  * it (memset on the stream) when it builds a new optimizer or re-initialises the policy. */
 #define MCP_OPT_MAX_ATTEMPTS 10
-#define MCP_OPT_MAX_TENSORS 8
+#define MCP_OPT_MAX_TENSORS 32
 #define MCP_OPT_RECORD_DOUBLES 12
 typedef struct mcp_opt_state {
   int64_t step;           /* optimizer steps taken since the last (re-)initialisation = next index of cost_list            */
@@ -292,13 +322,14 @@ typedef struct mcp_opt_state {
   double cost_prev;       /* cost_tm1                                                                                     */
 } mcp_opt_state;
 /* torch.optim.Adam's update (weight_decay 0, no amsgrad) of up to MCP_OPT_MAX_TENSORS parameter tensors in ONE launch, applied only
- * when the attempt counts (state == NULL: always).  params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors device pointers,
+ * when the attempt counts (state == NULL: always, as step number `step` >= 1 of the optimizer -- GP training, where the host knows it;
+ * with a state the step number is state->adam_t + 1).  params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors device pointers,
  * numel their sizes; a NULL grad skips that tensor.  Must be enqueued BEFORE mcp_policy_step_commit of the same attempt (it reads
  * the state that call advances).  Replaces optimizer.step(), MC_PILCO.py:525. */
 int mcp_adam_step_guarded(int n_tensors, double* const* params, const double* const* grads, double* const* exp_avg,
                           double* const* exp_avg_sq, const int64_t* numel, double lr, double beta1, double beta2, double eps,
-                          const mcp_opt_state* state, int n_steps, const double* cost, const double* flags, const uint32_t* status,
-                          void* stream);
+                          const mcp_opt_state* state, int64_t step, int n_steps, const double* cost, const double* flags,
+                          const uint32_t* status, void* stream);
 /* The loop's decisions for one attempt.  cost / std_cost: device scalars of the attempt; flags: optional device [3] doubles (> 0 =
  * NaN cost, hand-off time-out, non-positive variance -- the all-reduced form of a particle-sharded step), status: optional device
  * status word of the rollout (either or both may be NULL; a NaN cost always fails).  cost_list / std_list [n_steps], es1 / ratio

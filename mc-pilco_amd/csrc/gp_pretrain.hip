@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void tri_inverse_wave_kernel(int N, const doub
 // (the LDS form above spends ~13 k cycles per block in volatile round trips; this one ~5 k).
 // Measured at N = 300 (tools/time_fit_model.py, rocprofv3): see DESIGN.md 4.5.
 // ---------------------------------------------------------------------------------------
-#define CM_NT 512
+#define CM_NT 512  // (1024 threads = 128 registers: the in-register diagonal block of wave 0 spills 26 of them)
 #define CM_NW (CM_NT / 64)
 typedef double v4d_p __attribute__((ext_vector_type(4)));
 
@@ -271,8 +271,10 @@ __device__ __forceinline__ void tri16_inverse(const double (&x)[16], const doubl
 }
 
 __global__ __launch_bounds__(CM_NT) void chol_factor_mfma_kernel(int N, double* __restrict__ A, int lda, double* __restrict__ logdet,
-                                                                 uint32_t* __restrict__ status) {
+                                                                 uint32_t* __restrict__ status, size_t a_stride, size_t ld_stride) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  A += (size_t)blockIdx.x * a_stride;  // (one workgroup per matrix of a batch: the G GPs of a training epoch, mcp_nll_epoch)
+  logdet += (size_t)blockIdx.x * ld_stride;
   double* ui = smem;        // [16][16]  U_kk^-1 (row m, column r at ui[m * 16 + r])
   double* pn = smem + 256;  // [16][ncp] the row panel of this block row
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, li = lane & 15;
@@ -342,21 +344,40 @@ __global__ __launch_bounds__(CM_NT) void chol_factor_mfma_kernel(int N, double* 
     }
     __syncthreads();
     // (3) trailing update, blocks (I, J), I <= J, of the upper triangle:  T[i][j] -= sum_m P[m][16 I + i] P[m][16 J + j]
+    // (round 4: the tiles of a wave are independent, but each one was load -> MFMA -> store with the matrix in global memory: a memory
+    //  round trip per tile on every wave, 38 of them in a row in the first block step at N = 400.  Now the NEXT tile's accumulator
+    //  loads are in flight while the current one is multiplied and stored.)
     const int nblk = nct * (nct + 1) / 2;
-    for (int bidx = wv; bidx < nblk; bidx += CM_NW) {
-      int I = 0, rem = bidx;
+    auto tile_of = [&](int bidx, int& I, int& J) {
+      I = 0;
+      int rem = bidx;
       while (rem >= nct - I) {
         rem -= nct - I;
         ++I;
       }
-      const int J = I + rem;
+      J = I + rem;
+    };
+    auto load_acc = [&](int I, int J, v4d_p& acc) {
       const int col = j0 + 16 * J + li;
-      v4d_p acc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = j0 + 16 * I + kq + 4 * r;
         acc[r] = (row < N && col < N) ? A[(size_t)row * lda + col] : 0.0;
       }
+    };
+    int I = 0, J = 0, In = 0, Jn = 0;
+    v4d_p acc = {0.0, 0.0, 0.0, 0.0}, accn = {0.0, 0.0, 0.0, 0.0};
+    if (wv < nblk) {
+      tile_of(wv, I, J);
+      load_acc(I, J, acc);
+    }
+    for (int bidx = wv; bidx < nblk; bidx += CM_NW) {
+      const bool more = bidx + CM_NW < nblk;
+      if (more) {
+        tile_of(bidx + CM_NW, In, Jn);
+        load_acc(In, Jn, accn);
+      }
+      const int col = j0 + 16 * J + li;
       double av[4], bv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -370,6 +391,9 @@ __global__ __launch_bounds__(CM_NT) void chol_factor_mfma_kernel(int N, double* 
         const int row = j0 + 16 * I + kq + 4 * r;
         if (row < N && col < N) A[(size_t)row * lda + col] = acc[r];
       }
+      I = In;
+      J = Jn;
+      acc = accn;
     }
     __syncthreads();
   }
@@ -388,7 +412,10 @@ __global__ __launch_bounds__(CM_NT) void chol_factor_mfma_kernel(int N, double* 
 
 // Uinv = U^-1 by 16x16 blocks, one workgroup: the diagonal blocks W_I = U_II^-1 in registers (one wave each), then block diagonal
 // d = 1, 2, ...:  Uinv[I][J] = - W_I sum_{K = I+1..J} U[I][K] Uinv[K][J],  J = I + d  (every term was finished in an earlier stage).
-__global__ __launch_bounds__(CM_NT) void tri_inverse_block_kernel(int N, const double* __restrict__ U, int ldu, double* __restrict__ Ui, int ldi) {
+__global__ __launch_bounds__(CM_NT) void tri_inverse_block_kernel(int N, const double* __restrict__ U, int ldu, double* __restrict__ Ui, int ldi,
+                                                                  size_t u_stride, size_t ui_stride) {
+  U += (size_t)blockIdx.x * u_stride;
+  Ui += (size_t)blockIdx.x * ui_stride;
   const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, li = lane & 15;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NBK = (N + 15) >> 4;
@@ -448,8 +475,156 @@ __global__ __launch_bounds__(CM_NT) void tri_inverse_block_kernel(int N, const d
   }
 }
 
+// Round 4: U^-1 by BLOCK COLUMNS.  Column J of X = U^-1 depends on U alone:  X[J][J] = W_J = U_JJ^-1,  X[I][J] = - W_I sum_{K = I+1..J} U[I][K]
+// X[K][J]  for I = J-1 .. 0 -- a serial chain over I inside a column, no dependence between columns.  So: one launch inverts the
+// diagonal blocks (one wave each), a second one gives every block column its own one-wave workgroup, which keeps the column's finished
+// blocks in LDS (the B operands of its later products): no workgroup barrier anywhere, NBK x G workgroups in flight instead of one
+// (the block-diagonal sweep above: NBK stages of at most NBK / 8 tile products per wave behind a barrier each -- 0.52 ms at N = 400).
+__global__ __launch_bounds__(64) void tri_diag_inverse_kernel(int N, const double* __restrict__ U, int ldu, double* __restrict__ Ui, int ldi,
+                                                              size_t u_stride, size_t ui_stride) {
+  U += (size_t)blockIdx.y * u_stride;
+  Ui += (size_t)blockIdx.y * ui_stride;
+  const int lane = threadIdx.x, c = lane & 15, kb = (int)blockIdx.x << 4, nb = min(16, N - kb);
+  double x[16], inv_d[16], w[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) x[r] = (r <= c && c < nb) ? U[(size_t)(kb + r) * ldu + kb + c] : (r == c ? 1.0 : 0.0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) inv_d[r] = 1.0 / lane_get(x[r], r);
+  tri16_inverse(x, inv_d, c, w);
+  if (lane < 16 && c < nb) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (r < nb) Ui[(size_t)(kb + r) * ldi + kb + c] = r <= c ? w[r] : 0.0;
+  }
+}
+__global__ __launch_bounds__(64) void tri_inverse_cols_kernel(int N, const double* __restrict__ U, int ldu, double* __restrict__ Ui, int ldi,
+                                                              size_t u_stride, size_t ui_stride) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];  // [J + 1][16][16]: the finished blocks of this column
+  U += (size_t)blockIdx.y * u_stride;
+  Ui += (size_t)blockIdx.y * ui_stride;
+  const int NBK = (N + 15) >> 4;
+  const int J = NBK - 1 - (int)blockIdx.x;  // (the longest columns start first)
+  const int lane = threadIdx.x, kq = lane >> 4, li = lane & 15;
+  const int col = 16 * J + li;
+  // zeros below the diagonal block of this block column
+  for (int row = 16 * (J + 1) + kq; row < N; row += 4)
+    if (col < N) Ui[(size_t)row * ldi + col] = 0.0;
+  // X[J][J] = W_J (written by tri_diag_inverse_kernel)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * J + kq + 4 * r;
+    xs[J * 256 + (kq + 4 * r) * 16 + li] = (row < N && col < N) ? Ui[(size_t)row * ldi + col] : 0.0;
+  }
+  // The products of the column, flattened: pair (I, K), I = J-1 .. 0, K = I+1 .. J.  The A operands (blocks of U, global memory) do not
+  // depend on the chain, so they are loaded TC_PF pairs ahead -- across the step boundaries -- into a ring of register sets; the diagonal
+  // inverse W_I of a step is loaded one step ahead.  (With the operand of pair q+1 requested only while pair q multiplied, every pair paid
+  // most of an L2 round trip: 163 us at N = 400 for a chain whose MFMAs take 32 us.)
+  constexpr int TC_PF = 6;
+  int Ic = J - 1, Kc = J, Il = J - 1, Kl = J;
+  double buf[TC_PF][4];
+  auto issue = [&](double (&dst)[4]) {
+    if (Il >= 0) {  // (wave-uniform)
+      const double* urow = U + (size_t)(16 * Il + li) * ldu + kq;  // A[i = li][k]: U[16 I + i][16 K + k]   (rows 16 I + i < N: I < J)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ac = 16 * Kl + 4 * u + kq;
+        dst[u] = ac < N ? urow[16 * Kl + 4 * u] : 0.0;
+      }
+      if (++Kl > J) {
+        --Il;
+        Kl = Il + 1;
+      }
+    }
+  };
+  auto load_w = [&](int I, double (&wa)[4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wa[u] = I >= 0 ? -Ui[(size_t)(16 * I + li) * ldi + 16 * I + 4 * u + kq] : 0.0;
+  };
+#pragma unroll
+  for (int q = 0; q < TC_PF; ++q) issue(buf[q]);
+  double wa[4], wn[4];
+  load_w(J - 1, wa);
+  load_w(J - 2, wn);
+  v4d_p acc = {0.0, 0.0, 0.0, 0.0};
+  while (Ic >= 0) {
+#pragma unroll
+    for (int q = 0; q < TC_PF; ++q) {
+      if (Ic >= 0) {  // (wave-uniform)
+        double bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bv[u] = xs[Kc * 256 + (4 * u + kq) * 16 + li];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[q][u], bv[u], acc, 0, 0, 0);
+        issue(buf[q]);  // this register set: the pair TC_PF further on
+        if (Kc == J) {  // the last product of step Ic:  X[I][J] = - W_I S  (register u of the accumulator is row 4 u + kq of S: the B operand of step u)
+          v4d_p out = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) out = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[u], acc[u], out, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * Ic + kq + 4 * r;
+            xs[Ic * 256 + (kq + 4 * r) * 16 + li] = col < N ? out[r] : 0.0;
+            if (col < N) Ui[(size_t)row * ldi + col] = out[r];
+          }
+          acc = (v4d_p){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) wa[u] = wn[u];
+          load_w(Ic - 2, wn);
+          --Ic;
+          Kc = Ic + 1;
+        } else {
+          ++Kc;
+        }
+      }
+    }
+  }
+}
+// Kinv = Uinv Uinv^T by 16x16 tiles on the matrix cores, one wave per tile (I <= J) of the upper triangle, mirrored into the lower:
+//   Kinv[I][J] = sum_{K >= J} Uinv[I][K] Uinv[J][K]^T      (both operands read rows of Uinv: A[i][k] = Ui[16 I + i][16 K + k], B[k][j] = Ui[16 J + j][16 K + k])
+__global__ __launch_bounds__(256) void kinv_tiles_kernel(int N, const double* __restrict__ Ui, int ldi, double* __restrict__ Kinv, int ldk,
+                                                         size_t ui_stride, size_t k_stride) {
+  Ui += (size_t)blockIdx.y * ui_stride;
+  Kinv += (size_t)blockIdx.y * k_stride;
+  const int NBK = (N + 15) >> 4, nt = NBK * (NBK + 1) / 2;
+  const int lane = threadIdx.x & 63, kq = lane >> 4, li = lane & 15;
+  const int t = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (t >= nt) return;
+  int I = 0, rem = t;
+  while (rem >= NBK - I) {
+    rem -= NBK - I;
+    ++I;
+  }
+  const int J = I + rem;
+  const bool ra = 16 * I + li < N, rb = 16 * J + li < N;
+  const double* pa = Ui + (size_t)(ra ? 16 * I + li : 0) * ldi + kq;
+  const double* pb = Ui + (size_t)(rb ? 16 * J + li : 0) * ldi + kq;
+  v4d_p acc = {0.0, 0.0, 0.0, 0.0};
+  for (int K = J; K < NBK; ++K) {
+    double av[4], bv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = 16 * K + 4 * u + kq;
+      av[u] = (ra && c < N) ? pa[16 * K + 4 * u] : 0.0;
+      bv[u] = (rb && c < N) ? pb[16 * K + 4 * u] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * I + kq + 4 * r, col = 16 * J + li;
+    if (row < N && col < N) {
+      Kinv[(size_t)row * ldk + col] = acc[r];
+      if (I != J) Kinv[(size_t)col * ldk + row] = acc[r];
+    }
+  }
+}
+
 // Kinv[i][j] = sum_{m >= max(i,j)} Ui[i][m] Ui[j][m]
-__global__ void kinv_from_uinv_kernel(int N, const double* __restrict__ Ui, int ldi, double* __restrict__ Kinv, int ldk) {
+__global__ void kinv_from_uinv_kernel(int N, const double* __restrict__ Ui, int ldi, double* __restrict__ Kinv, int ldk, size_t ui_stride,
+                                      size_t k_stride) {
+  Ui += (size_t)blockIdx.z * ui_stride;
+  Kinv += (size_t)blockIdx.z * k_stride;
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   int i = blockIdx.y;
   if (i >= N || j >= N) return;
@@ -562,8 +737,8 @@ __global__ __launch_bounds__(MCP_WAVE) void sod_select_kernel(mcp_kernel kn, int
 // Parameter layout (NP = 4D+3): [0,D) log lengthscales | D log lambda | D+1 noise (1/2 tr Wm) | [D+2,2D+3) MPK_1 (D+1)
 //                               | [2D+3,3D+3) MPK_2 factor 0 | [3D+3,4D+3) MPK_2 factor 1
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void nll_grad_kernel(mcp_kernel kn, int N, const double* __restrict__ X, const double* __restrict__ Kinv,
-                                                       int ldk, const double* __restrict__ alpha, double* __restrict__ slab) {
+__device__ __forceinline__ void nll_grad_row(const mcp_kernel& kn, int N, const double* __restrict__ X, const double* __restrict__ Kinv, int ldk,
+                                             const double* __restrict__ alpha, double* __restrict__ slab) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* wm = sm;          // [N] Wm_ij
   double* wk = sm + N;      // [N] Wm_ij * kse_ij
@@ -627,6 +802,10 @@ __global__ __launch_bounds__(256) void nll_grad_kernel(mcp_kernel kn, int N, con
     slab[(size_t)i * NP + p] = 0.5 * s;
   }
 }
+__global__ __launch_bounds__(256) void nll_grad_kernel(mcp_kernel kn, int N, const double* __restrict__ X, const double* __restrict__ Kinv,
+                                                       int ldk, const double* __restrict__ alpha, double* __restrict__ slab) {
+  nll_grad_row(kn, N, X, Kinv, ldk, alpha, slab);
+}
 
 __global__ void nll_colsum_kernel(int rows, int cols, const double* __restrict__ slab, double* __restrict__ out) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -667,7 +846,22 @@ extern "C" int mcp_cov_diag(const mcp_kernel* kern, int N, const double* X, int 
   return MCP_OK;
 }
 
-static int g_chol_mfma = 1;  // test hook: 0 = the round-1/2 kernels (scalar trailing update, one wave per column of the inverse)
+// U^-1 and K^-1 = U^-1 U^-T of `batch` matrices (strides in doubles): diagonal blocks, block columns, tiles -- three launches
+static int launch_inverse_mfma(int N, const double* U, int ldu, double* Ui, int ldi, double* Kinv, int ldk, int batch, size_t u_stride,
+                               size_t ui_stride, size_t k_stride, hipStream_t st) {
+  const int NBK = (N + 15) >> 4, nt = NBK * (NBK + 1) / 2;
+  hipLaunchKernelGGL(tri_diag_inverse_kernel, dim3(NBK, batch), dim3(64), 0, st, N, U, ldu, Ui, ldi, u_stride, ui_stride);
+  MCP_LAUNCH_CHECK();
+  MCP_ENSURE_MAX_LDS(tri_inverse_cols_kernel);
+  hipLaunchKernelGGL(tri_inverse_cols_kernel, dim3(NBK, batch), dim3(64), sizeof(double) * 256 * (size_t)NBK, st, N, U, ldu, Ui, ldi, u_stride,
+                     ui_stride);
+  MCP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(kinv_tiles_kernel, dim3((nt + 3) / 4, batch), dim3(256), 0, st, N, Ui, ldi, Kinv, ldk, ui_stride, k_stride);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+static int g_chol_mfma = 1;  // test hook: 0 = the round-1/2 kernels (scalar trailing update, one wave per column of the inverse); 2 = the round-3 inverse
 extern "C" void mcp_debug_set_chol_mfma(int on) { g_chol_mfma = on; }
 
 extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32_t* status, void* stream) {
@@ -676,7 +870,7 @@ extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32
   if (g_chol_mfma && N > 16) {
     const size_t lds = sizeof(double) * (256 + (size_t)16 * (N + 16));
     MCP_ENSURE_MAX_LDS(chol_factor_mfma_kernel);
-    hipLaunchKernelGGL(chol_factor_mfma_kernel, dim3(1), dim3(CM_NT), lds, (hipStream_t)stream, N, A, lda, logdet, status);
+    hipLaunchKernelGGL(chol_factor_mfma_kernel, dim3(1), dim3(CM_NT), lds, (hipStream_t)stream, N, A, lda, logdet, status, (size_t)0, (size_t)0);
     MCP_LAUNCH_CHECK();
     return MCP_OK;
   }
@@ -690,8 +884,10 @@ extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32
 extern "C" int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream) {
   if (!U || !Uinv || !Kinv || N <= 0 || ldu < N || ldi < N || ldk < N) return MCP_ERR_ARG;
   if (N > 16384) return MCP_ERR_LIMIT;
-  if (g_chol_mfma && N > 16 && N <= 1152)
-    hipLaunchKernelGGL(tri_inverse_block_kernel, dim3(1), dim3(CM_NT), 0, (hipStream_t)stream, N, U, ldu, Uinv, ldi);
+  if (g_chol_mfma == 1 && N > 16 && N <= 1152)
+    return launch_inverse_mfma(N, U, ldu, Uinv, ldi, Kinv, ldk, 1, 0, 0, 0, (hipStream_t)stream);
+  if (g_chol_mfma && N > 16 && N <= 1152)  // (2: the round-3 block-diagonal sweep of one workgroup, kept as a comparison form)
+    hipLaunchKernelGGL(tri_inverse_block_kernel, dim3(1), dim3(CM_NT), 0, (hipStream_t)stream, N, U, ldu, Uinv, ldi, (size_t)0, (size_t)0);
   else if (N <= 64 * TW_KM)
     hipLaunchKernelGGL(tri_inverse_wave_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, U, ldu, Uinv, ldi);
   else
@@ -699,7 +895,7 @@ extern "C" int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, i
                        ldu, Uinv, ldi);
   MCP_LAUNCH_CHECK();
   dim3 grid((N + 255) / 256, N);
-  hipLaunchKernelGGL(kinv_from_uinv_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, Uinv, ldi, Kinv, ldk);
+  hipLaunchKernelGGL(kinv_from_uinv_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, Uinv, ldi, Kinv, ldk, (size_t)0, (size_t)0);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }
@@ -750,6 +946,225 @@ extern "C" int mcp_nll_grad(const mcp_kernel* kern, int N, const double* X, cons
                      slab);
   MCP_LAUNCH_CHECK();
   hipLaunchKernelGGL(nll_colsum_kernel, dim3((NP + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, NP, slab, grad);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// One epoch of GP hyper-parameter training for the G GPs of a model at once (mcp_nll_epoch): what GP_prior.fit_model does per epoch
+// through forward + Marginal_log_likelihood + autograd (gpr_lib/GP_prior/GP_prior.py:91-115,179-230; Gaussian_likelihood.py:15-24;
+// Model_learning.train_gp_likelihood, model_learning/Model_learning.py:398-421), from the optimizer's RAW parameters to their gradients
+// without a host round trip: the GPs are independent, so every stage is ONE launch whose grid carries the GP index.
+// Workspace, per GP (doubles): K -> U [N N] | Uinv [N N] | Kinv [N N] | alpha [N] | r [N] | slab [N NP] | grad [NP] | inv_ls [D] |
+// w1 [D+1] | w20 [D] | w21 [D] | scal [3] | logdet [1]; in front of all of them the G mcp_kernel descriptors the stages read.
+// ---------------------------------------------------------------------------------------
+struct NllBatch {
+  mcp_nll_gp gp[MCP_MAX_GP];
+};
+struct NllWs {
+  size_t kn, K, Ui, Kinv, alpha, r, slab, grad, invls, w1, w20, w21, scal, logdet, per_gp, total;  // offsets in doubles
+};
+static inline NllWs nll_ws_layout(int G, int N, int D) {
+  NllWs w;
+  const size_t NP = 4 * (size_t)D + 3, NN = (size_t)N * N;
+  size_t o = 0;
+  auto take = [&](size_t n) {
+    size_t r = o;
+    o += (n + 1) & ~(size_t)1;
+    return r;
+  };
+  w.K = take(NN);
+  w.Ui = take(NN);
+  w.Kinv = take(NN);
+  w.alpha = take(N);
+  w.r = take(N);
+  w.slab = take((size_t)N * NP);
+  w.grad = take(NP);
+  w.invls = take(D);
+  w.w1 = take(D + 1);
+  w.w20 = take(D);
+  w.w21 = take(D);
+  w.scal = take(4);
+  w.logdet = take(2);
+  w.per_gp = o;
+  w.kn = 0;  // the descriptors come first
+  const size_t knd = ((size_t)G * sizeof(mcp_kernel) + 15) / 16 * 2;
+  w.total = knd + (size_t)G * w.per_gp;
+  return w;
+}
+__device__ __forceinline__ double* nll_gp_base(double* ws, int G, size_t per_gp, int g) {
+  const size_t knd = ((size_t)G * sizeof(mcp_kernel) + 15) / 16 * 2;
+  return ws + knd + (size_t)g * per_gp;
+}
+
+// raw parameters -> the kernels' operands: 1 / l, lambda = exp(log_lambda), sigma_n^2 = exp(sigma_n_log)^2 + sigma_n_num^2, the MPK weights
+// s^2 with s_d = (k - d) exp(par_d) (Sparse_GP.py:613-623: the reference's get_Sigma), and the mcp_kernel descriptor that points at them
+__global__ void nll_prep_kernel(NllBatch b, int G, int N, int D, int deg, int ard, double* __restrict__ ws, NllWs L) {
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const mcp_nll_gp& gp = b.gp[g];
+  double* base = nll_gp_base(ws, G, L.per_gp, g);
+  double *invls = base + L.invls, *w1 = base + L.w1, *w20 = base + L.w20, *w21 = base + L.w21, *scal = base + L.scal;
+  for (int d = tid; d < D; d += blockDim.x) {
+    invls[d] = exp(-gp.log_ls[ard ? d : 0]);
+    if (deg >= 2) {
+      const double s0 = 2.0 * exp(gp.mpk2[d]), s1 = exp(gp.mpk2[D + d]);
+      w20[d] = s0 * s0;
+      w21[d] = s1 * s1;
+    }
+  }
+  if (deg >= 1)
+    for (int d = tid; d <= D; d += blockDim.x) {
+      const double s = gp.mpk1 ? exp(gp.mpk1[d]) : 0.0;  // (a degree-2 term without a degree-1 term: zero weights)
+      w1[d] = s * s;
+    }
+  if (tid == 0) {
+    scal[0] = gp.log_lambda ? exp(gp.log_lambda[0]) : 0.0;
+    const double sn = gp.sigma_n_log ? exp(gp.sigma_n_log[0]) : 0.0;
+    scal[1] = sn * sn + gp.sigma_n_num2;
+    scal[2] = gp.mean ? gp.mean[0] : 0.0;
+    mcp_kernel kn;
+    kn.D = D;
+    kn.poly_deg = deg;
+    kn.lambda = kn.sigma_n2 = kn.mean = 0.0;
+    kn.inv_ls = invls;
+    kn.w1 = deg >= 1 ? w1 : nullptr;
+    kn.w20 = deg >= 2 ? w20 : nullptr;
+    kn.w21 = deg >= 2 ? w21 : nullptr;
+    kn.scal = scal;
+    reinterpret_cast<mcp_kernel*>(ws)[g] = kn;
+  }
+}
+__global__ void cov_build_batch_kernel(const mcp_kernel* __restrict__ kns, int N, const double* __restrict__ X, double* __restrict__ ws, int G,
+                                       NllWs L) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, g = blockIdx.z;
+  if (i >= N || j >= N) return;
+  const mcp_kernel kn = kns[g];
+  double k = kern_eval(kn, X + (size_t)i * kn.D, 1, X + (size_t)j * kn.D, 1);
+  if (i == j) k += kern_sigma_n2(kn);
+  (nll_gp_base(ws, G, L.per_gp, g) + L.K)[(size_t)i * N + j] = k;
+}
+// r = Y y_scale - mean;  alpha = Kinv r  (one wave per row)
+__global__ void nll_alpha_batch_kernel(NllBatch b, int G, int N, double* __restrict__ ws, NllWs L) {
+  const int g = blockIdx.y, row = blockIdx.x * (blockDim.x / MCP_WAVE) + (threadIdx.x / MCP_WAVE), lane = threadIdx.x % MCP_WAVE;
+  if (row >= N) return;
+  const mcp_nll_gp& gp = b.gp[g];
+  double* base = nll_gp_base(ws, G, L.per_gp, g);
+  const double* Kinv = base + L.Kinv;
+  const double mean = base[L.scal + 2];
+  double s = 0.0;
+  for (int m = lane; m < N; m += MCP_WAVE) s = fma(Kinv[(size_t)row * N + m], gp.Y[m] * gp.y_scale - mean, s);
+  s = wave_sum(s);
+  if (lane == 0) {
+    base[L.alpha + row] = s;
+    base[L.r + row] = gp.Y[row] * gp.y_scale - mean;
+  }
+}
+__global__ __launch_bounds__(256) void nll_grad_batch_kernel(const mcp_kernel* __restrict__ kns, int N, const double* __restrict__ X,
+                                                             double* __restrict__ ws, int G, NllWs L) {
+  const int g = blockIdx.y;
+  double* base = nll_gp_base(ws, G, L.per_gp, g);
+  nll_grad_row(kns[g], N, X, base + L.Kinv, N, base + L.alpha, base + L.slab);
+}
+// column sums of the slab (fixed order), the loss, and the chain rule back to the optimizer's raw parameters (mc_pilco_amd/nll.py)
+__global__ __launch_bounds__(256) void nll_finish_kernel(NllBatch b, int G, int N, int D, int deg, int ard, double* __restrict__ ws, NllWs L) {
+  __shared__ double sh[4 * MCP_MAX_GPDIM + 3];
+  __shared__ double red[4];
+  const int g = blockIdx.x, tid = threadIdx.x, NP = 4 * D + 3;
+  const mcp_nll_gp& gp = b.gp[g];
+  double* base = nll_gp_base(ws, G, L.per_gp, g);
+  const double* slab = base + L.slab;
+  for (int c = tid; c < NP; c += 256) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int r = 0;
+    for (; r + 3 < N; r += 4) {
+      s0 += slab[(size_t)r * NP + c];
+      s1 += slab[(size_t)(r + 1) * NP + c];
+      s2 += slab[(size_t)(r + 2) * NP + c];
+      s3 += slab[(size_t)(r + 3) * NP + c];
+    }
+    for (; r < N; ++r) s0 += slab[(size_t)r * NP + c];
+    sh[c] = (s0 + s1) + (s2 + s3);
+  }
+  // r . alpha and sum alpha
+  double ra = 0.0, sa = 0.0;
+  for (int j = tid; j < N; j += 256) {
+    const double a = base[L.alpha + j];
+    ra = fma(base[L.r + j], a, ra);
+    sa += a;
+  }
+  ra = wave_sum(ra);
+  sa = wave_sum(sa);
+  if ((tid & 63) == 0) red[tid >> 6] = ra;
+  __syncthreads();
+  const double rdot = ((red[0] + red[1]) + red[2]) + red[3];
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = sa;
+  __syncthreads();
+  const double asum = ((red[0] + red[1]) + red[2]) + red[3];
+  if (tid == 0 && gp.loss) gp.loss[0] = 0.5 * (rdot + base[L.logdet]);
+  if (gp.g_log_ls) {
+    if (ard) {
+      for (int d = tid; d < D; d += 256) gp.g_log_ls[d] = sh[d];
+    } else if (tid == 0) {
+      double s = 0.0;
+      for (int d = 0; d < D; ++d) s += sh[d];
+      gp.g_log_ls[0] = s;
+    }
+  }
+  if (tid == 0) {
+    if (gp.g_log_lambda) gp.g_log_lambda[0] = sh[D];
+    if (gp.g_sigma_n_log && gp.sigma_n_log) gp.g_sigma_n_log[0] = sh[D + 1] * 2.0 * exp(2.0 * gp.sigma_n_log[0]);
+    if (gp.g_mean) gp.g_mean[0] = -asum;
+  }
+  if (gp.g_mpk1 && deg >= 1)
+    for (int e = tid; e <= D; e += 256) gp.g_mpk1[e] = sh[D + 2 + e];
+  if (gp.g_mpk2 && deg >= 2)
+    for (int e = tid; e < 2 * D; e += 256) gp.g_mpk2[e] = sh[2 * D + 3 + e];
+}
+
+extern "C" size_t mcp_nll_epoch_workspace_bytes(int G, int N, int D) {
+  if (G <= 0 || G > MCP_MAX_GP || N <= 0 || D <= 0 || D > MCP_MAX_GPDIM) return 0;
+  return sizeof(double) * nll_ws_layout(G, N, D).total;
+}
+
+extern "C" int mcp_nll_epoch(int G, const mcp_nll_gp* gps, int N, int D, int poly_deg, int ard, const double* X, uint32_t* status,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  if (!gps || !X || !status || !workspace || G <= 0 || N <= 0 || D <= 0) return MCP_ERR_ARG;
+  if (G > MCP_MAX_GP || D > MCP_MAX_GPDIM || N > 1152 || N <= 16) return MCP_ERR_LIMIT;  // (the MFMA-blocked factorisations: 16 < N, row panel in LDS)
+  if (poly_deg < 0 || poly_deg > 2) return MCP_ERR_ARG;
+  const NllWs L = nll_ws_layout(G, N, D);
+  if (workspace_bytes < sizeof(double) * L.total) return MCP_ERR_WORKSPACE;
+  NllBatch b;
+  for (int g = 0; g < MCP_MAX_GP; ++g) b.gp[g] = gps[g < G ? g : 0];
+  for (int g = 0; g < G; ++g) {
+    if (!gps[g].log_ls || !gps[g].log_lambda || !gps[g].Y) return MCP_ERR_ARG;
+    if (poly_deg >= 2 && !gps[g].mpk2) return MCP_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  double* ws = (double*)workspace;
+  const mcp_kernel* kns = (const mcp_kernel*)workspace;
+  const size_t knd = ((size_t)G * sizeof(mcp_kernel) + 15) / 16 * 2;
+  double* g0 = ws + knd;
+  hipLaunchKernelGGL(nll_prep_kernel, dim3(G), dim3(64), 0, st, b, G, N, D, poly_deg, ard, ws, L);
+  MCP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(cov_build_batch_kernel, dim3((N + 255) / 256, N, G), dim3(256), 0, st, kns, N, X, ws, G, L);
+  MCP_LAUNCH_CHECK();
+  {
+    const size_t lds = sizeof(double) * (256 + (size_t)16 * (N + 16));
+    MCP_ENSURE_MAX_LDS(chol_factor_mfma_kernel);
+    hipLaunchKernelGGL(chol_factor_mfma_kernel, dim3(G), dim3(CM_NT), lds, st, N, g0 + L.K, N, g0 + L.logdet, status, L.per_gp, L.per_gp);
+    MCP_LAUNCH_CHECK();
+  }
+  {
+    const int rc = launch_inverse_mfma(N, g0 + L.K, N, g0 + L.Ui, N, g0 + L.Kinv, N, G, L.per_gp, L.per_gp, L.per_gp, st);
+    if (rc != MCP_OK) return rc;
+  }
+  hipLaunchKernelGGL(nll_alpha_batch_kernel, dim3((N + 3) / 4, G), dim3(256), 0, st, b, G, N, ws, L);
+  MCP_LAUNCH_CHECK();
+  MCP_ENSURE_MAX_LDS(nll_grad_batch_kernel);
+  hipLaunchKernelGGL(nll_grad_batch_kernel, dim3(N, G), dim3(256), sizeof(double) * 4 * (size_t)N, st, kns, N, X, ws, G, L);
+  MCP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(nll_finish_kernel, dim3(G), dim3(256), 0, st, b, G, N, D, poly_deg, ard, ws, L);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }

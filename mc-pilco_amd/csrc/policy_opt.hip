@@ -41,15 +41,15 @@ struct AdamSegs {
 // torch.optim.Adam (weight_decay = 0, amsgrad = False, maximize = False), one thread per element, in torch's order of operations:
 //   exp_avg.lerp_(grad, 1 - beta1);  exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
 //   denom = exp_avg_sq.sqrt() / sqrt(1 - beta2^t) + eps;  param.addcdiv_(exp_avg, denom, value = -lr / (1 - beta1^t))
-__global__ void adam_guarded_kernel(AdamSegs s, double lr, double beta1, double beta2, double eps, const mcp_opt_state* st, int n_steps,
-                                    const double* cost, const double* flags, const uint32_t* status) {
+__global__ void adam_guarded_kernel(AdamSegs s, double lr, double beta1, double beta2, double eps, const mcp_opt_state* st, long long step,
+                                    int n_steps, const double* cost, const double* flags, const uint32_t* status) {
   if (st && (loop_frozen(st, n_steps) || attempt_failed(cost, flags, status))) return;  // (uniform over the grid)
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= s.end[s.n - 1]) return;
   int k = 0;
   while (i >= s.end[k]) ++k;
   const long long e = i - (k ? s.end[k - 1] : 0);
-  const double t = (double)((st ? st->adam_t : 0) + 1);
+  const double t = st ? (double)(st->adam_t + 1) : (double)step;
   const double g = s.g[k][e];
   double m = s.m[k][e], v = s.v[k][e];
   m = m + (1.0 - beta1) * (g - m);
@@ -96,11 +96,12 @@ __global__ void step_commit_kernel(mcp_opt_state* st, int n_steps, const double*
     const double r = alpha * ratio[k] + (1.0 - alpha) * (e1 / sqrt(st->es2));
     ratio[k + 1] = r;
     rabs = fabs(r);
-    if ((double)k > min_step) {  // :540-547  (the window reaches back num_min_diff_cost entries; k > min_step >= that many by construction
-      long long cnt = 0;         //  of the reference's settings -- a shorter history counts what there is, like the reference's slice)
+    if ((double)k > min_step) {  // :540-547: the last num_min_diff_cost ratios BEFORE this step's (ratio[k + 1 - n .. k]) all below the bound
+      long long cnt = 0;         // (a window that would reach before the start cannot hold n entries: the condition never fires there)
       const long long lo = k + 1 - num_min_diff_cost;
-      for (long long j = lo < 0 ? 0 : lo; j <= k; ++j) cnt += fabs(ratio[j]) < min_diff ? 1 : 0;
-      if (cnt >= num_min_diff_cost) st->pending = 1;
+      if (lo >= 0)
+        for (long long j = lo; j <= k; ++j) cnt += fabs(ratio[j]) < min_diff ? 1 : 0;
+      if (lo >= 0 && cnt >= num_min_diff_cost) st->pending = 1;
     }
     st->step = k + 1;
     st->attempt = 0;
@@ -127,11 +128,12 @@ __global__ void step_commit_kernel(mcp_opt_state* st, int n_steps, const double*
 
 extern "C" int mcp_adam_step_guarded(int n_tensors, double* const* params, const double* const* grads, double* const* exp_avg,
                                      double* const* exp_avg_sq, const int64_t* numel, double lr, double beta1, double beta2, double eps,
-                                     const mcp_opt_state* state, int n_steps, const double* cost, const double* flags, const uint32_t* status,
-                                     void* stream) {
+                                     const mcp_opt_state* state, int64_t step, int n_steps, const double* cost, const double* flags,
+                                     const uint32_t* status, void* stream) {
   if (n_tensors <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !numel) return MCP_ERR_ARG;
   if (n_tensors > MCP_OPT_MAX_TENSORS) return MCP_ERR_LIMIT;
   if (state && !cost) return MCP_ERR_ARG;
+  if (!state && step < 1) return MCP_ERR_ARG;
   AdamSegs s;
   long long tot = 0;
   s.n = 0;
@@ -154,7 +156,7 @@ extern "C" int mcp_adam_step_guarded(int n_tensors, double* const* params, const
     s.end[i] = tot;
   }
   hipLaunchKernelGGL(adam_guarded_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s, lr, beta1, beta2, eps, state,
-                     n_steps, cost, flags, status);
+                     (long long)step, n_steps, cost, flags, status);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }

@@ -184,11 +184,19 @@ class GP_prior(torch.nn.Module):
 
         if not isinstance(criterion, Marginal_log_likelihood):
             raise NotImplementedError("fit_model on the HIP path supports the Marginal_log_likelihood criterion")
+        from mc_pilco_amd import nll
+
+        # one full batch, the textbook Adam, a squared-exponential (+ Volterra) kernel: the whole epoch is two C calls (mcp_nll_epoch +
+        # mcp_adam_step_guarded), no torch op and no host sync in between (mc_pilco_amd/nll.py: BatchedFit, here with one GP)
+        batches = list(trainloader) if (f_saving_model is None and f_print is None and isinstance(trainloader, (list, tuple))) else None
+        if batches is not None and len(batches) == 1:
+            fit = nll.BatchedFit([self], batches[0][0], [batches[0][1]], [1.0], [optimizer], N_epoch, N_epoch_print)
+            if fit.eligible:
+                print(fit.run()[0], end="")
+                return
         print("\nInitial parameters:")
         self.print_model()
         t0 = time.time()
-        from mc_pilco_amd import nll
-
         for epoch in range(N_epoch):
             running, nb = None, 0  # the loss stays on the device: one host sync per epoch (the kernel descriptor's scalars), not three
             for inputs, labels in trainloader:

@@ -64,7 +64,13 @@ class OptState(C.Structure):
                 ("es2", C.c_double), ("cost_prev", C.c_double)]
 
 
-OPT_MAX_ATTEMPTS, OPT_MAX_TENSORS, OPT_RECORD_DOUBLES = 10, 8, 12
+OPT_MAX_ATTEMPTS, OPT_MAX_TENSORS, OPT_RECORD_DOUBLES = 10, 32, 12
+
+
+class NllGP(C.Structure):
+    _fields_ = [("log_ls", dptr), ("log_lambda", dptr), ("sigma_n_log", dptr), ("mean", dptr), ("mpk1", dptr), ("mpk2", dptr), ("Y", dptr),
+                ("y_scale", C.c_double), ("sigma_n_num2", C.c_double), ("g_log_ls", dptr), ("g_log_lambda", dptr), ("g_sigma_n_log", dptr),
+                ("g_mean", dptr), ("g_mpk1", dptr), ("g_mpk2", dptr), ("loss", dptr)]
 
 
 class Cost(C.Structure):
@@ -99,7 +105,9 @@ _SIGS = {
     "mcp_cost_sums": (C.c_int, [C.c_int, C.c_int, dptr, dptr, dptr, dptr]),
     "mcp_cost_finalize_sums": (C.c_int, [C.c_int, C.c_int64, dptr, dptr, dptr, dptr, dptr]),
     "mcp_adam_step_guarded": (C.c_int, [C.c_int, C.POINTER(dptr), C.POINTER(dptr), C.POINTER(dptr), C.POINTER(dptr), C.POINTER(C.c_int64), C.c_double,
-                                        C.c_double, C.c_double, C.c_double, dptr, C.c_int, dptr, dptr, dptr, dptr]),
+                                        C.c_double, C.c_double, C.c_double, dptr, C.c_int64, C.c_int, dptr, dptr, dptr, dptr]),
+    "mcp_nll_epoch_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "mcp_nll_epoch": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, dptr, dptr, dptr, C.c_size_t, dptr]),
     "mcp_policy_step_commit": (C.c_int, [dptr, C.c_int, dptr, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.c_double, C.c_double, C.c_double, C.c_int,
                                          dptr, dptr]),
     "mcp_comm_unique_id": (C.c_int, [C.c_char_p]),

@@ -121,10 +121,45 @@ class Model_learning(torch.nn.Module):
     # ---- training / pretraining ---------------------------------------------------------------------------------
     def reinforce_model(self, optimization_opt_list=None):
         self.init_gp_models()
+        texts = self._train_all_gps_at_once(optimization_opt_list)
+        if texts is not None:
+            for i in range(self.num_gp):  # (the sequential run's output order: GP i's training text, then its pretrain)
+                print(texts[i], end="")
+                with torch.no_grad():
+                    self.pretrain_gp(gp_index=i)
+            return
         for i in range(self.num_gp):
             self.train_gp(gp_index=i, optimization_opt_dict=optimization_opt_list[i])
             with torch.no_grad():
                 self.pretrain_gp(gp_index=i)
+
+    def _train_all_gps_at_once(self, optimization_opt_list):
+        """The GPs of a model are independent (the reference trains them one after the other, Model_learning.py:149-161): when they
+        share kernel structure, training options and the plain Adam, every epoch of ALL of them is one batched launch sequence
+        (mcp_nll_epoch: the grid carries the GP index) + one Adam launch.  Returns the text the sequential run prints, per GP, or
+        None: not applicable -- the caller trains them one by one."""
+        from mc_pilco_amd import nll
+
+        if type(self).train_gp is not Model_learning.train_gp or type(self).train_gp_likelihood is not Model_learning.train_gp_likelihood:
+            return None  # (a subclass with its own training)
+        opts = list(optimization_opt_list[:self.num_gp])
+        if len(opts) < self.num_gp or self.num_gp < 1:
+            return None
+        o0 = opts[0]
+        from mc_pilco_amd.gpr_lib.Likelihood.Gaussian_likelihood import Marginal_log_likelihood
+
+        for o in opts:
+            if (o.get("f_optimizer") != o0.get("f_optimizer") or o.get("N_epoch") != o0.get("N_epoch") or o.get("N_epoch_print") != o0.get("N_epoch_print")
+                    or o.get("criterion") is not Marginal_log_likelihood or o.get("train_mode", "likelihood") != "likelihood"):
+                return None
+        if self.flg_norm:
+            for i in range(self.num_gp):
+                self.norm_list[i] = torch.max(torch.abs(self.gp_output_list[i]))
+        f_optim = eval(o0["f_optimizer"])  # same optimizer strings as the reference
+        optims = [f_optim(gp.parameters()) for gp in self.gp_list]
+        fit = nll.BatchedFit(self.gp_list, self.gp_inputs, self.gp_output_list, [1.0 / float(self.norm_list[i]) for i in range(self.num_gp)], optims,
+                             o0["N_epoch"], o0["N_epoch_print"])
+        return fit.run() if fit.eligible else None
 
     def train_gp(self, gp_index, optimization_opt_dict):
         self.train_gp_likelihood(gp_index, optimization_opt_dict)

@@ -79,3 +79,169 @@ def check_status(gp):
     gp._nll_status = None
     if st is not None and ops.status_flags(st)["not_spd"]:
         raise RuntimeError("cholesky: the covariance matrix is not positive-definite")
+
+
+# --------------------------------------------------------------------------------------------------------------------------------
+# batched training: the G GPs of a model, epoch by epoch, two C calls per epoch (mcp_nll_epoch + mcp_adam_step_guarded)
+# --------------------------------------------------------------------------------------------------------------------------------
+def plain_adam_options(opt):
+    """(lr, beta1, beta2, eps) when ``opt`` is a torch.optim.Adam whose update is the textbook one (what every launch script builds:
+    "lambda p : torch.optim.Adam(p, lr=0.01)"); None for anything else."""
+    if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+        return None
+    g = opt.param_groups[0]
+    if (g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False) or g.get("differentiable", False)
+            or g.get("decoupled_weight_decay", False) or isinstance(g["lr"], torch.Tensor)):
+        return None
+    return float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])
+
+
+def _structure(gp):
+    """(rbf, mpk1, mpk2, degree) when ``gp`` is one squared-exponential term (+ MPK_1 with the offset feature (+ MPK_2 without)) whose
+    noise comes from the squared-exponential term alone -- every model the launch scripts build; None otherwise."""
+    from .gpr_lib.GP_prior import Sparse_GP, Stationary_GP
+
+    leaves = _leaves(gp)
+    if not leaves or not isinstance(leaves[0], Stationary_GP.RBF):
+        return None
+    rbf, mpk1, mpk2 = leaves[0], None, None
+    for leaf in leaves[1:]:
+        if not isinstance(leaf, Sparse_GP.MPK_GP) or leaf.GP_with_noise:
+            return None
+        if leaf.poly_deg == 1 and leaf.flg_offset and mpk1 is None:
+            mpk1 = leaf
+        elif leaf.poly_deg == 2 and not leaf.flg_offset and mpk2 is None:
+            mpk2 = leaf
+        else:
+            return None
+    if mpk2 is not None and mpk1 is None:
+        return None
+    for leaf in leaves:
+        ad = leaf._active()
+        if ad is None or not bool((ad.detach().cpu() == torch.arange(ad.numel())).all()) or ad.numel() != rbf.num_features:
+            return None
+    return rbf, mpk1, mpk2, (0 if mpk1 is None else (1 if mpk2 is None else 2))
+
+
+class BatchedFit:
+    """Epoch-synchronous training of G structurally identical GPs on shared inputs (they are independent: the result is what training
+    them one after the other gives, Model_learning.py:149-161).  ``eligible`` says whether the batched path applies; ``run`` trains
+    and returns, per GP, the text ``GP_prior.fit_model`` would have printed."""
+
+    def __init__(self, gps, X, Ys, y_scales, optimizers, N_epoch, N_epoch_print):
+        self.gps, self.N_epoch, self.N_epoch_print = list(gps), int(N_epoch), int(N_epoch_print)
+        self.eligible = False
+        st = [_structure(g) for g in self.gps]
+        ad = [plain_adam_options(o) for o in optimizers]
+        if any(v is None for v in st) or any(a is None or a != ad[0] for a in ad) or len(self.gps) > abi.MAX_GP:
+            return
+        rbf0 = st[0][0]
+        if any(v[3] != st[0][3] or v[0].flg_ARD != rbf0.flg_ARD or v[0].num_features != rbf0.num_features for v in st):
+            return
+        dev = rbf0.device
+        Xc = self.gps[0]._cols(X)
+        N, D = Xc.shape
+        if not (16 < N <= 1152) or dev.type != "cuda":
+            return
+        self.adam, self.dev, self.X, self.N, self.D, self.deg, self.ard = ad[0], dev, Xc, N, D, st[0][3], int(rbf0.flg_ARD)
+        self.Ys = [Y.to(dev).to(DT).reshape(-1).contiguous() for Y in Ys]
+        self.loss = torch.zeros(len(self.gps), dtype=DT, device=dev)
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        desc = (abi.NllGP * len(self.gps))()
+        self.params, self.grads = [], []
+
+        def slot(p):
+            """(data pointer, gradient buffer pointer or None) of parameter ``p``; trainable ones join the optimizer's list."""
+            if p is None:
+                return None, None
+            if p.dtype != DT or not p.is_cuda or not p.is_contiguous():
+                raise RuntimeError("GP hyper-parameters must be contiguous float64 GPU tensors")
+            if not p.requires_grad:
+                return p.data_ptr(), None
+            g = torch.zeros_like(p)
+            self.params.append(p)
+            self.grads.append(g)
+            return p.data_ptr(), g.data_ptr()
+
+        for i, (gp, (rbf, m1, m2, _)) in enumerate(zip(self.gps, st)):
+            d = desc[i]
+            d.log_ls, d.g_log_ls = slot(rbf.log_lengthscales_par)
+            d.log_lambda, d.g_log_lambda = slot(rbf.log_lambda_par)
+            d.sigma_n_log, d.g_sigma_n_log = slot(rbf.sigma_n_log if rbf.GP_with_noise else None)
+            d.mean, d.g_mean = slot(rbf.mean_par)
+            d.mpk1, d.g_mpk1 = slot(None if m1 is None else m1.Sigma_pos_par)
+            d.mpk2, d.g_mpk2 = slot(None if m2 is None else m2.Sigma_pos_par)
+            d.Y = self.Ys[i].data_ptr()
+            d.y_scale = float(y_scales[i])
+            d.sigma_n_num2 = float(rbf.sigma_n_num) ** 2 if rbf.GP_with_noise else 0.0
+            d.loss = self.loss[i:i + 1].data_ptr()
+        self.desc = desc
+        nbytes = abi.lib().mcp_nll_epoch_workspace_bytes(len(self.gps), N, D)
+        self.ws, self.nbytes = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev), nbytes
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self.eligible = True
+
+    def run(self):
+        import io
+        import time
+
+        lib, n = abi.lib(), len(self.params)
+        # Adam over all trainable tensors of all GPs, at most OPT_MAX_TENSORS per launch
+        chunks = []
+        for a in range(0, n, abi.OPT_MAX_TENSORS):
+            b = min(n, a + abi.OPT_MAX_TENSORS)
+            arr = lambda ts: (abi.dptr * (b - a))(*[t.data_ptr() for t in ts[a:b]])
+            chunks.append((b - a, arr([p.data for p in self.params]), arr(self.grads), arr(self.m), arr(self.v),
+                           (C.c_int64 * (b - a))(*[p.numel() for p in self.params[a:b]])))
+        lr, b1, b2, eps = self.adam
+        snaps = []  # (epoch, [state_dict clones per GP], losses clone, wall time) at the print epochs
+
+        def snapshot(epoch):
+            snaps.append((epoch, [{k: v.detach().clone() for k, v in gp.named_parameters()} for gp in self.gps], self.loss.clone(), time.time()))
+
+        snapshot(-1)  # the initial parameters
+        for epoch in range(self.N_epoch):
+            abi.check(lib.mcp_nll_epoch(len(self.gps), C.cast(self.desc, C.c_void_p), self.N, self.D, self.deg, self.ard, abi.ptr(self.X),
+                                        abi.ptr(self.status), abi.ptr(self.ws), self.nbytes, abi.stream()), "mcp_nll_epoch")
+            for cnt, ps, gs, ms, vs, ne in chunks:
+                abi.check(lib.mcp_adam_step_guarded(cnt, ps, gs, ms, vs, ne, lr, b1, b2, eps, None, epoch + 1, 0, None, None, None, abi.stream()),
+                          "mcp_adam_step_guarded")
+            if epoch % self.N_epoch_print == 0:
+                snapshot(epoch)
+        snapshot(self.N_epoch)  # the final parameters
+        if ops.status_flags(self.status)["not_spd"]:  # (the one host sync of the training)
+            raise RuntimeError("cholesky: the covariance matrix is not positive-definite")
+        for p, g in zip(self.params, self.grads):
+            p.grad = g  # (what the last epoch left, as after the reference's last backward)
+        # the text GP_prior.fit_model prints, GP by GP
+        texts = []
+        for i, gp in enumerate(self.gps):
+            out = io.StringIO()
+
+            def show(params):
+                saved = {k: v.detach().clone() for k, v in gp.named_parameters()}
+                with torch.no_grad():
+                    for k, v in gp.named_parameters():
+                        v.copy_(params[k])
+                import contextlib
+
+                with contextlib.redirect_stdout(out):
+                    gp.print_model()
+                with torch.no_grad():
+                    for k, v in gp.named_parameters():
+                        v.copy_(saved[k])
+
+            out.write("\nInitial parameters:\n")
+            show(snaps[0][1][i])
+            t_prev = snaps[0][3]
+            for epoch, pars, losses, tm in snaps[1:-1]:
+                out.write("\nEPOCH: %d\n" % epoch)
+                show(pars[i])
+                out.write("Running loss: %s\n" % float(losses[i]))
+                out.write("Time elapsed: %s\n" % (tm - t_prev))
+                t_prev = tm
+            out.write("\nFinal parameters:\n")
+            show(snaps[-1][1][i])
+            texts.append(out.getvalue())
+        return texts

@@ -262,7 +262,7 @@ class MC_PILCO(torch.nn.Module):
                 or g.get("decoupled_weight_decay", False) or isinstance(g["lr"], torch.Tensor)):
             return None
         ps = [q for q in g["params"] if q.requires_grad]
-        if not ps or len(ps) > 8 or any(q.dtype != torch.float64 or not q.is_cuda or not q.is_contiguous() for q in ps):
+        if not ps or len(ps) > 32 or any(q.dtype != torch.float64 or not q.is_cuda or not q.is_contiguous() for q in ps):
             return None
         return float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])
 
@@ -357,7 +357,7 @@ class MC_PILCO(torch.nn.Module):
             if adam is not None:
                 grads = (abi.dptr * len(ad["ps"]))(*[None if q.grad is None else q.grad.data_ptr() for q in ad["ps"]])
                 abi.check(lib.mcp_adam_step_guarded(len(ad["ps"]), ad["c_ps"], grads, ad["c_m"], ad["c_v"], ad["numel"], float(hs["lr"]), adam[1],
-                                                    adam[2], adam[3], abi.ptr(st), n_steps, cptr, abi.ptr(flags), abi.ptr(status), abi.stream()),
+                                                    adam[2], adam[3], abi.ptr(st), 0, n_steps, cptr, abi.ptr(flags), abi.ptr(status), abi.stream()),
                           "mcp_adam_step_guarded")
             slot = seq[0] % (depth + 2)
             seq[0] += 1

@@ -889,3 +889,64 @@ def test_optimizer_loop_with_another_optimizer_updates_through_its_own_step(gold
     assert costs.shape == (4,) and np.all(np.isfinite(costs)) and obj._rollout_calls == 1 + 4 + 1
     w1 = obj.control_policy.f_linear.weight.detach()
     assert bool(torch.isfinite(w1).all()) and float((w1 - w0).abs().max()) > 0
+
+
+# ---- round 4: GP hyper-parameter training of all GPs of a model at once ---------------------------------------------------------------
+@pytest.mark.parametrize("deg", [0, 2])
+def test_batched_gp_training_equals_training_the_gps_one_by_one(golden, deg):
+    """Model_learning.reinforce_model trains the G GPs of a model epoch-synchronously (mcp_nll_epoch: every stage one launch whose grid
+    carries the GP index, one Adam launch for all parameters) where the reference trains them one after the other
+    (Model_learning.py:149-161).  The GPs are independent: the batched run must leave exactly the hyper-parameters, the cached alpha and
+    K^-1 of the sequential one (each GP through GP_prior.fit_model on its own) -- bit for bit -- and print the same text."""
+    import re
+
+    from mc_pilco_amd.gpr_lib.Likelihood import Gaussian_likelihood as Likelihood
+
+    fx = golden("rollout_se_poly2" if deg else "rollout_se")
+    opt = dict(f_optimizer="lambda p : torch.optim.Adam(p, lr=0.01)", criterion=Likelihood.Marginal_log_likelihood, N_epoch=12, N_epoch_print=5)
+    res = {}
+    for mode in ("batched", "one_by_one"):
+        ml = build_cartpole(fx, deg, False)
+        ml.set_training_mode()
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            if mode == "batched":
+                ml.reinforce_model([opt, opt])
+            else:
+                ml.init_gp_models()
+                for i in range(ml.num_gp):
+                    ml.train_gp(gp_index=i, optimization_opt_dict=opt)  # (GP_prior.fit_model of ONE GP)
+                    with torch.no_grad():
+                        ml.pretrain_gp(gp_index=i)
+        res[mode] = dict(par=[{k: v.detach().cpu().numpy().copy() for k, v in gp.named_parameters()} for gp in ml.gp_list],
+                         alpha=[a.detach().cpu().numpy().copy() for a in ml.alpha_list], kinv=[k.detach().cpu().numpy().copy() for k in ml.K_X_inv_list],
+                         txt=re.sub(r"Time elapsed: [0-9.e+-]+", "Time elapsed", buf.getvalue()))
+    a, b = res["batched"], res["one_by_one"]
+    for pa, pb in zip(a["par"], b["par"]):
+        assert pa.keys() == pb.keys()
+        for k in pa:
+            assert np.array_equal(pa[k], pb[k]), k
+    for x, y in zip(a["alpha"] + a["kinv"], b["alpha"] + b["kinv"]):
+        assert np.array_equal(x, y)
+    assert a["txt"] == b["txt"] and a["txt"].count("EPOCH:") == 2 * 3 and a["txt"].count("Final parameters") == 2
+    # and training moved the parameters
+    ml0 = build_cartpole(fx, deg, False)
+    moved = max(float(np.abs(pa[k] - v.detach().cpu().numpy()).max()) for pa, gp in zip(a["par"], ml0.gp_list) for k, v in gp.named_parameters()
+                if v.requires_grad or True)
+    assert moved > 1e-3
+
+
+def test_gp_training_with_another_optimizer_keeps_the_callers_step():
+    """fit_model with anything but the textbook Adam runs the caller's optimizer on the analytic gradient (the legacy path)."""
+    from mc_pilco_amd.gpr_lib.GP_prior import Stationary_GP
+    from mc_pilco_amd.gpr_lib.Likelihood import Gaussian_likelihood as Likelihood
+
+    rng = np.random.RandomState(0)
+    X = T(rng.randn(40, 6))
+    Y = T(np.sin(rng.randn(40, 1)))
+    with quiet():
+        gp = Stationary_GP.RBF(**rbf_dict(6, np.ones(6), 0.3))
+        p0 = gp.log_lengthscales_par.detach().clone()
+        gp.fit_model(trainloader=[(X, Y)], optimizer=torch.optim.SGD(gp.parameters(), lr=1e-3), criterion=Likelihood.Marginal_log_likelihood(),
+                     N_epoch=3, N_epoch_print=10)
+    assert float((gp.log_lengthscales_par.detach() - p0).abs().max()) > 0 and bool(torch.isfinite(gp.log_lengthscales_par).all())
