@@ -1021,6 +1021,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
           if (j < Npad) {
             kb[it] = kt;
             double* w = vb + it * NWC;  // the record of (j, p): it = j P + p
+#ifndef RLX_NOWREC  // (experiment switch: timing without the phase-J records of phase K)
             v2d w01;
             w01.x = kv * al_l[j];
             w01.y = kv;
@@ -1031,11 +1032,10 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
               w23.y = qa;
               *reinterpret_cast<v2d*>(__builtin_assume_aligned(w + 2, 16)) = w23;
             }
+#endif
           }
         }
       }
-      // the z-only polynomial terms of this step, by wave 7 (no item in the last round of phase K at the headline shape): u is known
-      if (MAXDEG > 0 && wv == RF_NW - 1) lean_prefz<P, MAXDEG>(z, kpar, pc, fz, lambda, D, lane);
     }
     lds_barrier();  // B2
     RL_STAMP(3);
@@ -1060,6 +1060,10 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
       else
         lean_j_groups<NCOL, NCG>(xe, vb, red, Npad, 16 * vrt0, 4 * vnrt, wv, lane);
       if (stamping && tid == 0) stl[12] += clock64() - tj0_;
+      // the z-only polynomial terms of this step (2.3 k cycles of one wave: LDS round trips in series), by wave 0 behind its own phase J --
+      // it owns the fewest rows of Kinv and would wait ~4 k cycles at the barrier below; phase F (wave 0 itself) reads the result.
+      // (At the end of phase K on a wave without an item in the last round it lengthened that phase by 0.9 k: profiles/r04_lean_variants.txt.)
+      if (MAXDEG > 0 && wv == 0) lean_prefz<P, MAXDEG>(z, kpar, pc, fz, gpl[0].lambda, D, lane);
     } else {
 #pragma unroll
       for (int g = 0; g < NCG; ++g) red[(wv * NCG + g) * 64 + lane] = 0.0;  // (a wave without rows)
