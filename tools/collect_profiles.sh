@@ -15,6 +15,14 @@ run() { echo "[$(date +%T)] $1"; shift; "$@" || exit 1; }
 run "c1 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c1_stats" -o c1 -- $B --steps 20 --warmup 3 > "$OUT/c1_stats.log" 2>&1
 run "c3 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c3_stats" -o c3 -- $B --workload c3 --steps 5 --warmup 2 > "$OUT/c3_stats.log" 2>&1
 run "c5 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5_stats" -o c5 -- $B --workload c5 --steps 3 --warmup 1 > "$OUT/c5_stats.log" 2>&1
+# the reference's own small-swarm launch scripts' shapes (round 4)
+for w in c1_script c2_script pms_script ur5_script; do
+  run "$w stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/${w}_stats" -o $w -- $B --workload $w --steps 20 --warmup 3 > "$OUT/${w}_stats.log" 2>&1
+done
+# phase stamps (tools/phase_stamps.py) of the same shapes
+for w in c1 c1_script c2_script pms_script ur5_script c3 c5; do
+  run "$w stamps" python3 $R/tools/phase_stamps.py $w > "$OUT/${w}_stamps.txt" 2>&1
+done
 for w in c1 c3 c5; do
   st=4; [ $w = c5 ] && st=2
   run "$w fetch" rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/${w}_fetch" -o $w -- $B --workload $w --steps $st --warmup 1 > "$OUT/${w}_fetch.log" 2>&1

@@ -20,10 +20,10 @@ if ppw >= 100:  # 101 / 102 / 104 (general kernel), 201 / 202 / 204 (lean kernel
 elif ppw:
     hipabi.lib().mcp_debug_set_gp_sharding(0)
 for i in range(2):
-    ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=i), x0, w.T, w.p_drop)
+    ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=i), x0, w.T, w.p_drop, meas=w.meas)
 hipabi.lib().mcp_debug_set_stamp_block(int(os.environ.get("MCP_STAMP_BLOCK", "0")))  # which workgroup is stamped
 hipabi.lib().mcp_debug_set_stamp_buffer(buf.data_ptr())
-ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=9), x0, w.T, w.p_drop)
+ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=9), x0, w.T, w.p_drop, meas=w.meas)
 torch.cuda.synchronize()
 hipabi.lib().mcp_debug_set_stamp_buffer(None)
 v = buf.cpu().tolist()
@@ -33,7 +33,7 @@ if hipabi.lib().mcp_debug_last_fwd_lean():  # the lean kernel's five barrier int
 tot = sum(v[:8])
 # backward stamps
 w.params[0].grad = None
-st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=10), x0, w.T, w.p_drop)
+st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=1, call=10), x0, w.T, w.p_drop, meas=w.meas)
 c, sd = ops.expected_cost(w.cost, st)
 buf2 = torch.zeros(16, dtype=torch.int64, device=dev)
 buf2[1] = buf2[2] = 1 << 62

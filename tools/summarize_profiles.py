@@ -17,10 +17,13 @@ src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 SHAPES = {"c1": (400, 150, 112), "c3": (4000, 150, 112), "c5": (2000, 300, 384)}  # M, T, algorithmic HBM bytes per particle-step
 
-for cfg in SHAPES:
+for cfg in list(SHAPES) + ["c1_script", "c2_script", "pms_script", "ur5_script"]:
     f = os.path.join(src, cfg + "_stats", cfg + "_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, cfg)))
+    f = os.path.join(src, cfg + "_stamps.txt")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, "%s_%s_stamps.txt" % (rnd, cfg)))
 
 out = {"_note": "forward rollout kernel, HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (gfx950 "
                 "FETCH_SIZE correction x2, MI355X_MICROARCH.md), mean over the steady-state launches; *_alg = algorithmic bytes per launch "
