@@ -25,6 +25,7 @@ CONFIGS = {
     "c2_script": ("cartpole", 2, 300, 400, 60),   # test_mcpilco_cartpole.py:51-53,101,199: SE + polynomial(2), M=400, T=3.0/0.05
     "pms_script": ("cartpole", 0, 300, 400, 90),  # test_mcpilco4pms_cartpole.py:51-53,155-157,171: SE, M=400, T=3.0/(1/30), measured states
     "ur5_script": ("ur5", 1, 400, 200, 200),      # test_mcpilco_ur5_mujoco.py:58-59,102,195: 6 GPs, D=24, SE + polynomial(1), M=200, T=4.0/0.02
+    "c2p1_script": ("cartpole", 1, 300, 400, 60),  # the same with a degree-1 Volterra term (tests: the lean kernel's MAXDEG = 1 instantiations)
     "tiny": ("cartpole", 0, 48, 16, 6),
     "tiny_ur5": ("ur5", 1, 40, 8, 5),
 }

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 Tt = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
 
-REAL = {"se300": ("c1", 48, 8), "sep2_300": ("c3", 48, 8), "ur5_400": ("c5", 40, 6), "se300_long": ("c1", 32, 150)}
+REAL = {"se300": ("c1", 48, 8), "sep2_300": ("c3", 48, 8), "ur5_400": ("c5", 40, 6), "se300_long": ("c1", 32, 150), "sep1_300": ("c2p1_script", 48, 8)}
 
 
 @functools.lru_cache(maxsize=None)
@@ -93,7 +93,7 @@ ACHIEVED = {}
 
 @pytest.mark.parametrize("pb", [1, 2, 4])
 @pytest.mark.parametrize("code", [1, 2, 4, 16, 101, 102, 104, 116, 201, 202, 204])
-@pytest.mark.parametrize("key", ["se300", "sep2_300", "ur5_400"])
+@pytest.mark.parametrize("key", ["se300", "sep2_300", "ur5_400", "sep1_300"])
 def test_rollout_kernels_alone_against_the_oracle_at_real_sizes(key, code, pb):
     """with each side factorising K itself, the real-size comparison could only hold 1e-7 (the conditioning of K).
     Here the HIP rollout runs on the oracle's OWN Kinv / alpha (N = 300, 300 + poly(2), 400 / D = 24): what differs is the rollout and
@@ -113,7 +113,7 @@ def test_rollout_kernels_alone_against_the_oracle_at_real_sizes(key, code, pb):
         st, inp, status = ops.rollout(w.model, w.policy, nz, o["x0"].to(dev()), w.T, o["p"])
         c, s = ops.expected_cost(w.cost, st)
         c.backward()
-        fv.check(sharding_optional=(key == "ur5_400"), lean_expected=(key in ("se300", "sep2_300")) if code >= 200 else None)
+        fv.check(sharding_optional=(key == "ur5_400"), lean_expected=(key in ("se300", "sep2_300", "sep1_300")) if code >= 200 else None)
     assert int(status.item()) == 0
     es = float((st.detach().cpu() - o["states"]).abs().max())
     eu = float((inp.detach().cpu() - o["inputs"]).abs().max())
@@ -160,17 +160,23 @@ def test_long_horizon_against_the_oracle_at_n300(code):
         assert float((q.grad.cpu().reshape(g.shape) - g).abs().max()) < 1e-6 * float(g.abs().max()), k
 
 
-@pytest.mark.parametrize("name", ["c1", "c2_script", "pms_script"])
+@pytest.mark.parametrize("name", ["c1", "c2_script", "pms_script", "c2p1_script", "c2_script+pms", "c2p1_script+pms"])
 def test_lean_kernel_draws_the_same_dropout_bits_and_noise_as_the_general_one(name):
     """Philox mode (what every benchmark number runs in): the lean kernel's dropout decisions, process noise and (measurement model)
     position noise are the general kernels' -- identical counters, so the trajectories agree to rounding (different summation
     orders), far below what one flipped keep bit or a different normal would cause.  SE, SE + polynomial(2) and the measurement
-    model of MC_PILCO4PMS (every instantiation family of the lean kernel); 1 and 4 particles per workgroup bit for bit."""
+    model of MC_PILCO4PMS, and their combinations (every instantiation family of the lean kernel: degree 0 / 1 / 2 x with / without the
+    measurement model x 1 / 2 / 4 particles per workgroup); the cluster sizes reproduce each other bit for bit."""
     from gpu_helpers import dev, forced_variant
     from mc_pilco_amd import hipabi, ops, workloads
 
-    w = workloads.build(name, device=dev(), M=96, T=10)
-    assert (w.meas is not None) == (name == "pms_script")
+    w = workloads.build(name.split("+")[0], device=dev(), M=96, T=10)
+    if name.endswith("+pms"):  # (polynomial kernel AND measurement model: the <., ., 1 / 2, true> instantiations)
+        from scipy import signal
+
+        bb, aa = signal.butter(1, 0.5)
+        w.meas = ops.MeasSpec(pos=[0, 2], vel=[1, 3], std_pos=[3e-3, 3e-3], b=bb, a=aa)
+    assert (w.meas is not None) == ("pms" in name)
     torch.manual_seed(4)
     x0 = w.sample_x0()
     outs = {}
