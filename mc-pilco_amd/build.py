@@ -88,6 +88,9 @@ if __name__ == "__main__":
     elif "--variant-lean" in sys.argv:  # the same, recompiling rollout_fwd_lean.hip only
         i = sys.argv.index("--variant-lean")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], only=["rollout_fwd_lean.hip"]))
+    elif "--variant-gp" in sys.argv:  # the same, recompiling gp_pretrain.hip only
+        i = sys.argv.index("--variant-gp")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], only=["gp_pretrain.hip"]))
     elif "--variant-bwd" in sys.argv:  # the same, recompiling rollout_bwd.hip only
         i = sys.argv.index("--variant-bwd")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], only=["rollout_bwd.hip"]))

@@ -4,6 +4,8 @@
 // Sparse_GP.py:426-441,625-646, GP_prior.py:314-335).  These run once per GP per trial
 // (Model_learning.pretrain_gp), so they are written for clarity and fp64 accuracy; the
 // per-step hot path is rollout.hip.
+#include <type_traits>
+
 #include "mcp_device.h"
 
 using namespace mcp;
@@ -250,11 +252,80 @@ __global__ __launch_bounds__(256) void tri_inverse_wave_kernel(int N, const doub
 #define CM_NT 512  // (1024 threads = 128 registers: the in-register diagonal block of wave 0 spills 26 of them)
 #define CM_NW (CM_NT / 64)
 typedef double v4d_p __attribute__((ext_vector_type(4)));
+typedef double __attribute__((address_space(1))) * gdp_t;         // explicit global pointers: a noinline device function would otherwise
+typedef const double __attribute__((address_space(1))) * gcdp_t;  // address its pointer arguments as flat (64-bit address per lane and load)
+// arguments of a non-kernel function arrive in vector registers even when they are uniform: back to scalars
+__device__ __forceinline__ int uniform_int(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ gdp_t uniform_ptr(gdp_t p) {
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (gdp_t)(((unsigned long long)hi << 32) | lo);
+}
 
 __device__ __forceinline__ double lane_get(double v, int l) {  // l: a compile-time constant after unrolling
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
   return __hiloint2double(hi, lo);
 }
+
+// the value of lane R of each 16-lane row, in every lane of that row (DPP row_newbcast: stays in the vector registers -- the 136
+// scalars a 16x16 block needs through v_readlane overflowed the scalar file into v_writelane / v_readlane spill pairs)
+template <int R>
+__device__ __forceinline__ double row_get(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + R, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + R, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// Column steps k = K..15 of the in-register Cholesky of a 16x16 block (lane c: column c in x[]; rows below the diagonal are scratch)
+// with the inverse riding along: after step k row k of U is final, which is all that row k of L^-1 = U^-T needs,
+//   Linv[k][c] = (delta_kc - sum_{m < k} U[m][k] Linv[m][c]) / U[k][k]          (lane c: v[m] = Linv[m][c] = Uinv[c][m]),
+// k independent FMAs that fill the stalls of the step's dependent chain (rsq, Newton steps, the pivot row) instead of a second
+// serial pass of sixteen rows after it.
+template <int K>
+struct Chol16Col {
+  template <int Rr>
+  static __device__ __forceinline__ void update(double uk, double (&x)[16]) {
+    if constexpr (Rr < 16) {
+      x[Rr] = fma(-row_get<Rr>(uk), uk, x[Rr]);
+      update<Rr + 1>(uk, x);
+    }
+  }
+  template <int M>
+  static __device__ __forceinline__ void dotl(const double (&x)[16], const double (&v)[16], double& s0, double& s1) {
+    if constexpr (M < K) {
+      if constexpr (M & 1)
+        s1 = fma(-row_get<K>(x[M]), v[M], s1);
+      else
+        s0 = fma(-row_get<K>(x[M]), v[M], s0);
+      dotl<M + 1>(x, v, s0, s1);
+    }
+  }
+  static __device__ __forceinline__ void run(double (&x)[16], double (&v)[16], int c, uint32_t& bad) {
+    const double dk = row_get<K>(x[K]);
+    if (!(dk > 0.0)) bad |= MCP_STATUS_NOT_SPD;
+    // sqrt(dk) and 1 / sqrt(dk) together (v_rsq_f64 seed, coupled Goldschmidt step, two Newton steps each): the pivots of a Gram
+    // matrix are far from the denormal / overflow ranges the library forms rescale for, and a pivot <= 0 or NaN still gives NaN
+    const double y = __builtin_amdgcn_rsq(dk);
+    double g = dk * y, h = 0.5 * y;
+    const double r0 = fma(-h, g, 0.5);
+    g = fma(g, r0, g);
+    h = fma(h, r0, h);
+    g = fma(fma(-g, g, dk), h, g);
+    g = fma(fma(-g, g, dk), h, g);
+    double is = h + h;
+    is = fma(is, fma(-g, is, 1.0), is);
+    is = fma(is, fma(-g, is, 1.0), is);
+    const double uk = c == K ? g : (c > K ? x[K] * is : 0.0);
+    x[K] = uk;
+    update<K + 1>(uk, x);
+    double s0 = c == K ? 1.0 : 0.0, s1 = 0.0;
+    dotl<0>(x, v, s0, s1);
+    double vk = (s0 + s1) * is;
+    asm volatile("" : "+v"(vk));  // (pins the step's work before the scheduling fence below)
+    v[K] = vk;
+    __builtin_amdgcn_sched_barrier(0);  // (or the scheduler hoists every broadcast of every step to the top and spills a hundred registers)
+    if constexpr (K < 15) Chol16Col<K + 1>::run(x, v, c, bad);
+  }
+};
 
 // lane c (= lane & 15; the four 16-lane rows of the wave work redundantly) holds column c of an upper-triangular 16x16 block in
 // x[0..15] (x[r] = U[r][c], 0 below the diagonal).  Returns column c of U^-1 in w[].  inv_d[r] = 1 / U[r][r].
@@ -408,6 +479,404 @@ __global__ __launch_bounds__(CM_NT) void chol_factor_mfma_kernel(int N, double* 
     if (lane == 0) *logdet = 2.0 * tot;
   }
   if (bad) atomicOr(status, bad);
+}
+
+// The same factorization LEFT-looking (round 4): block row I of U is finished in one go,
+//   T_IJ = A_IJ - sum_{k < I} U_kI^T U_kJ,   U_II = chol(T_II),   U_IJ = U_II^-T T_IJ   (J > I),
+// so every 16x16 tile of the matrix is written ONCE (the right-looking kernel above reads, updates and writes every trailing tile in
+// every block step: a store -> barrier -> load chain per step that its MFMAs wait behind), the sums over k stream finished, read-only
+// rows with their loads two k-steps ahead, and the one serial chain -- factoring and inverting the diagonal block, wave 0 -- runs
+// BESIDE the other waves' sums, which do not need it until their last four MFMAs:
+//   wave 0:       T_II = P_I - U_(I-1)I^T U_(I-1)I  (P_I and the tile both wait in LDS, see below) -> columns in registers -> U_II, W_I = U_II^-1
+//   tile waves:   tiles J = I + 1 + hw + 6 s, up to CL_GS at a time in the same k loop (their loads overlap), T_IJ kept in registers
+//   wave 1 also:  P_(I+1) = A_(I+1)(I+1) - sum_{k < I} U_k(I+1)^T U_k(I+1): all of the NEXT diagonal block's sum that can be had
+//                 before this row is finished; both of its MFMA operands are the B operand of the wave's tile J = I + 1 -- no loads
+//                 (in the last block rows, where some waves have no tile, the first of those does it instead)
+//   barrier;  U_IJ = W_I^T T_IJ (register u of T IS the B operand of step u), wave 1 leaves U_I(I+1) in LDS for the next row;  barrier.
+// The chain per block row is then: 4 MFMAs, two LDS round trips, the 16 column steps, the inverse, two barriers and one tile product.
+// CL_MAXS tile slots per tile wave, up to CL_GS of them in one k loop (registers).
+#ifdef CLX_STAMPS  // experiment build only (build.py --variant-gp): cycle stamps of wave 0 / wave 1 per block row
+__device__ unsigned long long g_clx[16 * 128];
+#define CLX_T(w, slot) do { if (blockIdx.x == 0 && wv == (w) && lane == 0 && I < 128) g_clx[I * 16 + (slot)] = clock64(); } while (0)
+extern "C" int mcp_debug_read_chol_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clx), sizeof(g_clx)); }
+#else
+#define CLX_T(w, slot) do { } while (0)
+#endif
+// the role of wave 0 (a function of its own: its registers are then allocated apart from the tile role's)
+__device__ __noinline__ void chol_left_diag_role(int N_, gdp_t A_, int lda_, double* __restrict__ logdet, uint32_t* __restrict__ status,
+                                                 double* ui, double* dg, double (*dgp)[256], double* nt) {
+  const int N = uniform_int(N_), lda = uniform_int(lda_);
+  const gdp_t A = uniform_ptr(A_);
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, li = lane & 15;
+  const int NBK = (N + 15) >> 4;
+  const int wv = 0;
+  (void)wv;
+  {
+    double ld_acc = 0.0;
+    uint32_t bad = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // P_0 = A_00 (identity beyond N), no tile above it
+      const int row = kq + 4 * r;
+      dgp[0][row * 16 + li] = (row < N && li < N) ? A[(size_t)row * lda + li] : (row == li ? 1.0 : 0.0);
+      nt[row * 16 + li] = 0.0;
+    }
+    for (int I = 0; I < NBK; ++I) {
+      int kb = I << 4;
+      asm volatile("" : "+s"(kb));  // (or the sixteen store addresses of the block become 64-bit induction variables, spilled and reloaded every row)
+      const int nb = min(16, N - kb);
+      CLX_T(0, 0);
+      v4d_p acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = dgp[I & 1][(kq + 4 * r) * 16 + li];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const double av = nt[(4 * u + kq) * 16 + li];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, av, acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dg[(kq + 4 * r) * 16 + li] = acc[r];
+      __builtin_amdgcn_wave_barrier();
+      int c = li;
+      asm volatile("" : "+v"(c));  // (or sixty loop-invariant masks and constants of c are hoisted out of the row loop and spilled)
+      double x[16], w[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const double v = dg[r * 16 + c];
+        x[r] = r <= c ? v : 0.0;
+      }
+      CLX_T(0, 1);
+      Chol16Col<0>::run(x, w, c, bad);  // w[m] = Uinv[c][m]
+      if (lane < 16 && c < nb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (r < nb) A[(size_t)(kb + r) * lda + kb + c] = r <= c ? x[r] : 0.0;  // (zeros below the diagonal, as torch.cholesky(upper=True) returns)
+        double dcc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dcc = r == c ? x[r] : dcc;
+        ld_acc += log(dcc);
+      }
+      CLX_T(0, 2);
+      if (lane < 16) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) ui[c * 16 + m] = w[m];
+      }
+      CLX_T(0, 3);
+      __syncthreads();
+      CLX_T(0, 4);
+      __syncthreads();
+      CLX_T(0, 5);
+    }
+    const double tot = wave_sum(lane < 16 ? ld_acc : 0.0);
+    if (lane == 0) *logdet = 2.0 * tot;
+    if (bad) atomicOr(status, bad);
+  }
+}
+
+// the k loop of NA tiles of one wave:  acc[q] = sum_{k < I} U_kI^T U_kJq.  The loads are unconditional (a lane beyond column N reads a
+// valid address of no consequence: its sums reach only outputs that are never stored; rows are always inside, off-diagonal tiles
+// exist only in full block rows).  Operands of NS consecutive k-steps wait in NS register sets that take turns: the loads of a set are
+// issued right after its MFMAs, NS k-steps before they are needed.
+// WITH_P: tile 0 of the group is J = I + 1, whose B operand U_k(I+1) is both operands of the next diagonal block's sum
+// accp = sum_{k < I} U_k(I+1)^T U_k(I+1)  (four more MFMAs per k-step, no more loads; okc: this lane's column of that block is inside N).
+template <int NA, bool WITH_P, bool PANEL>
+__device__ __forceinline__ void chol_left_sums(gcdp_t A, int lda, int I, unsigned aoff, const double* panel, const unsigned (&off)[NA], v4d_p (&acc)[NA],
+                                               v4d_p& accp, bool okc) {
+  // register sets in flight (a wave with one tile has only its loads to wait for; deeper measured slower: every row starts with NS
+  // sets of loads whether it has that many k-steps or not)
+  constexpr int NS = NA == 1 ? 6 : (NA == 2 ? 4 : 3);
+  const int kmax = max(I - 1, 0);
+  double av[PANEL ? 1 : NS][4], bv[NS][NA][4];
+  auto fetch = [&](int set, int k) {
+    gcdp_t rp = A + (size_t)(16 * min(k, kmax)) * lda;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if constexpr (!PANEL) av[set][u] = (rp + (size_t)(4 * u) * lda)[aoff];
+#pragma unroll
+      for (int q = 0; q < NA; ++q) bv[set][q][u] = (rp + (size_t)(4 * u) * lda)[off[q]];
+    }
+  };
+  auto mult = [&](int set, int k) {
+    if constexpr (PANEL) {  // the A operand of the whole row waits in LDS (aoff: this lane's element of a 4-row slab there)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) av[0][u] = panel[(16 * k + 4 * u) * 16 + aoff];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double a = av[PANEL ? 0 : set][u];
+#pragma unroll
+      for (int q = 0; q < NA; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[set][q][u], acc[q], 0, 0, 0);
+      if constexpr (WITH_P) {
+        const double v = okc ? bv[set][0][u] : 0.0;
+        accp = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, accp, 0, 0, 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < NA; ++q) acc[q] = (v4d_p){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int st = 0; st < NS; ++st) fetch(st, st);
+  // whole rounds without a branch (a conditional step would make the number of loads in flight unknown to the compiler's wait-count
+  // bookkeeping, which then waits for all of them: one memory latency per k-step), then the last I % NS steps
+  int k = 0;
+  for (; k + NS <= I; k += NS) {
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      mult(st, k + st);
+      fetch(st, k + st + NS);
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st)
+    if (k + st < I) mult(st, k + st);  // (uniform)
+}
+
+// the same sum for a wave that has no tile in the row (the last five block rows): accp = sum_{k < I} U_k(I+1)^T U_k(I+1), own loads
+__device__ __forceinline__ void chol_left_psum(gcdp_t A, int lda, int I, unsigned offn, bool okc, v4d_p& accp) {
+  constexpr int NS = 6;
+  const int kmax = max(I - 1, 0);
+  double pv[NS][4];
+  auto fetch = [&](int set, int k) {
+    gcdp_t rp = A + (size_t)(16 * min(k, kmax)) * lda;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pv[set][u] = (rp + (size_t)(4 * u) * lda)[offn];
+  };
+  auto mult = [&](int set) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const double v = okc ? pv[set][u] : 0.0;
+      accp = __builtin_amdgcn_mfma_f64_16x16x4f64(v, v, accp, 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int st = 0; st < NS; ++st) fetch(st, st);
+  int k = 0;
+  for (; k + NS <= I; k += NS) {
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      mult(st);
+      fetch(st, k + st + NS);
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st)
+    if (k + st < I) mult(st);  // (uniform)
+}
+
+// tile t (J = I + t) of slot s of tile wave hw: the first six tiles go round once, then wave hw = 0 -- which carries the next diagonal
+// block's sum with its first tile -- sits out one turn:  hw 0: 1, 12, 18, ...;  hw 1..5: 1 + hw, 6 + hw, 12 + hw, ...
+__device__ __forceinline__ int chol_left_tile_of(int hw, int s) { return s == 0 ? 1 + hw : (hw == 0 ? 6 + 6 * s : hw + 6 * s); }
+
+// The role of the six tile waves 1, 2, 3, 5, 6, 7 (helper index hw = 0..5; wave 4 shares its SIMD with wave 0, whose double-precision
+// FMAs wait behind any MFMA issued there -- fp64 MFMA and VALU share the DP units -- so it only keeps the barriers company):
+// slots s in groups of CL_GS, each group's k loop instantiated for the number of tiles it really has.
+template <int CL_MAXS, int CL_GS, bool PANEL>
+__device__ __noinline__ void chol_left_tile_role(int N_, gdp_t A_, int lda_, int wv_, const double* ui, double (*dgp)[256], double* nt, double* panels) {
+  const int N = uniform_int(N_), lda = uniform_int(lda_), wv = uniform_int(wv_);
+  const gdp_t A = uniform_ptr(A_);
+  static_assert(CL_MAXS % CL_GS == 0 && CL_GS <= 4, "slots come in whole groups");
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, li = lane & 15;
+  const int NBK = (N + 15) >> 4;
+  const int hw = wv < 4 ? wv - 1 : wv - 2;
+  const unsigned lrow = (unsigned)(kq * lda);
+  const int pstride = 16 * (NBK << 4);  // doubles per LDS panel
+  v4d_p T[CL_MAXS];
+  // the original entries A_IJ of this wave's tiles of block row I: loaded a row ahead (behind the previous row's stores, in front of
+  // its second barrier), so that their latency is not part of the row
+  auto load_tiles = [&](int I) {
+    const int kb = I << 4, ntile = NBK - I;
+#pragma unroll
+    for (int s = 0; s < CL_MAXS; ++s) {
+      const int t = chol_left_tile_of(hw, s);
+      if (t < ntile) {  // (uniform)
+        const unsigned o = lrow + (unsigned)min(kb + 16 * t + li, N - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[s][r] = (A + (size_t)(kb + 4 * r) * lda)[o];
+      }
+    }
+  };
+  if (wv != 4) load_tiles(0);
+  for (int I = 0; I < NBK; ++I) {
+    int kb = I << 4;
+    asm volatile("" : "+s"(kb));  // (keeps the per-slot addresses from becoming spilled 64-bit induction variables of the row loop)
+    const int ntile = NBK - I;
+    CLX_T(1, 8);
+    if (wv != 4) {
+      // the mirror tiles below the diagonal: zeros, as torch.cholesky(upper=True) returns (nothing reads them; stored here, the stores
+      // drain behind the k loops instead of in front of the row's second barrier)
+#pragma unroll
+      for (int s = 0; s < CL_MAXS; ++s) {
+        const int t = chol_left_tile_of(hw, s);
+        if (t < ntile) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int mrow = kb + 16 * t + kq + 4 * r;
+#ifndef CLX_NOMIRROR
+            if (mrow < N) A[(size_t)mrow * lda + kb + li] = 0.0;
+#endif
+          }
+        }
+      }
+      CLX_T(1, 11);
+      const unsigned aoff = PANEL ? (unsigned)(kq * 16 + li) : lrow + (unsigned)min(kb + li, N - 1);
+      const double* panel = panels + (I & 1) * pstride;
+      // P_(I+1): with six or more tiles in the row every wave has one, and the sum rides in wave hw = 0's first k loop on the operand
+      // that is there anyway; with fewer, the first wave WITHOUT a tile takes it as a job of its own
+      const bool okc = kb + 16 + li < N;
+      const int p_owner = ntile - 1 >= 6 ? 0 : ntile - 1;  // (the last row, ntile = 1, has no next block: owner 0 finds no tile)
+      double an[4] = {0.0, 0.0, 0.0, 0.0};
+      if (hw == p_owner && ntile > 1) {
+        const int cn = kb + 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = kq + 4 * r, rown = kb + 16 + row;
+          an[r] = (cn < N && rown < N) ? A[(size_t)rown * lda + cn] : (row == li ? 1.0 : 0.0);  // identity beyond N
+        }
+      }
+      if (hw == p_owner && p_owner > 0) {
+        v4d_p accp = {0.0, 0.0, 0.0, 0.0};
+        chol_left_psum(A, lda, I, lrow + (unsigned)(okc ? kb + 16 + li : 0), okc, accp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dgp[(I + 1) & 1][(kq + 4 * r) * 16 + li] = an[r] - accp[r];
+      }
+#pragma unroll
+      for (int g0 = 0; g0 < CL_MAXS; g0 += CL_GS) {
+        int na = 0;  // (uniform) tiles of this group
+#pragma unroll
+        for (int q = 0; q < CL_GS; ++q) na += chol_left_tile_of(hw, g0 + q) < ntile ? 1 : 0;
+        if (na > 0) {
+          unsigned off[CL_GS];
+#pragma unroll
+          for (int q = 0; q < CL_GS; ++q) {
+            const int t = chol_left_tile_of(hw, g0 + q);
+            off[q] = lrow + (unsigned)min(kb + 16 * (t < ntile ? t : 0) + li, N - 1);
+          }
+          v4d_p accp = {0.0, 0.0, 0.0, 0.0};
+          const bool with_p = g0 == 0 && hw == 0 && p_owner == 0;  // (this group holds tile 1)
+          auto run = [&](auto na_c) {
+            constexpr int NA = decltype(na_c)::value;
+            unsigned o[NA];
+            v4d_p acc[NA];
+#pragma unroll
+            for (int q = 0; q < NA; ++q) o[q] = off[q];
+            if (with_p)
+              chol_left_sums<NA, true, PANEL>(A, lda, I, aoff, panel, o, acc, accp, okc);
+            else
+              chol_left_sums<NA, false, PANEL>(A, lda, I, aoff, panel, o, acc, accp, okc);
+#pragma unroll
+            for (int q = 0; q < NA; ++q) T[g0 + q] -= acc[q];
+          };
+          if (na == 1) run(std::integral_constant<int, 1>());
+          if constexpr (CL_GS >= 2) {
+            if (na == 2) run(std::integral_constant<int, 2>());
+          }
+          if constexpr (CL_GS >= 3) {
+            if (na == 3) run(std::integral_constant<int, 3>());
+          }
+          if constexpr (CL_GS >= 4) {
+            if (na == 4) run(std::integral_constant<int, 4>());
+          }
+          if (with_p) {  // P_(I+1)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dgp[(I + 1) & 1][(kq + 4 * r) * 16 + li] = an[r] - accp[r];
+          }
+        }
+      }
+    }
+    if constexpr (PANEL) {
+      // the column panel U[0 : 16 I][block column I + 1], the A operand of every tile of the NEXT row, into the other LDS buffer (these rows
+      // are final; the last sixteen, U_I(I+1), follow from wave 1 below): one pass by the seven waves here while the chain finishes
+      if (I + 1 < NBK) {
+        double* pn = panels + ((I + 1) & 1) * pstride;
+        const int cnt = kb * 16, c0 = kb + 16;
+        for (int base = (wv - 1) * 64 + lane; base < cnt; base += 8 * 448) {
+          double v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int idx = base + e * 448, r = idx >> 4, c = c0 + (idx & 15);
+            v[e] = (idx < cnt && c < N) ? A[(size_t)r * lda + c] : 0.0;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int idx = base + e * 448;
+            if (idx < cnt) pn[idx] = v[e];
+          }
+        }
+      }
+    }
+    CLX_T(1, 9);
+    __syncthreads();
+    if (wv != 4) {
+      double wa[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wa[u] = ui[(4 * u + kq) * 16 + li];
+#pragma unroll
+      for (int s = 0; s < CL_MAXS; ++s) {
+        const int t = chol_left_tile_of(hw, s);
+        if (t < ntile) {  // (uniform)
+          const int col = kb + 16 * t + li;
+          v4d_p o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) o = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[u], T[s][u], o, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = kb + kq + 4 * r;
+            if (col < N) A[(size_t)row * lda + col] = o[r];
+            if (t == 1) {
+              nt[(kq + 4 * r) * 16 + li] = col < N ? o[r] : 0.0;
+              if constexpr (PANEL) (panels + ((I + 1) & 1) * pstride)[(kb + kq + 4 * r) * 16 + li] = col < N ? o[r] : 0.0;
+            }
+          }
+        }
+      }
+      if (I + 1 < NBK) load_tiles(I + 1);
+    }
+    CLX_T(1, 10);
+    __syncthreads();
+  }
+}
+
+#define CL_LDS_FIXED 1280  // doubles
+template <int CL_MAXS, int CL_GS, bool PANEL>
+__global__ __launch_bounds__(CM_NT) void chol_left_mfma_kernel(int N, double* __restrict__ A, int lda, double* __restrict__ logdet,
+                                                               uint32_t* __restrict__ status, size_t a_stride, size_t ld_stride) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* ui = smem;                                   // [256]    W_I (row m, column r at ui[m * 16 + r])
+  double* dg = smem + 256;                             // [256]    T_II on its way from accumulator layout to one column per lane
+  double(*dgp)[256] = (double(*)[256])(smem + 512);    // [2][256] P_I (row I & 1), accumulator layout unfolded: [row][column]
+  double* nt = smem + 1024;                            // [256]    U_(I-1)I
+  double* panels = smem + CL_LDS_FIXED;                // PANEL: two column panels [16 NBK][16] (this row's and the next one's)
+  A += (size_t)blockIdx.x * a_stride;
+  logdet += (size_t)blockIdx.x * ld_stride;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // two roles with the same two barriers per block row
+  if (wv == 0)
+    chol_left_diag_role(N, (gdp_t)A, lda, logdet, status, ui, dg, dgp, nt);
+  else
+    chol_left_tile_role<CL_MAXS, CL_GS, PANEL>(N, (gdp_t)A, lda, wv, ui, dgp, nt, panels);
+}
+
+static int launch_chol_mfma(int form, int N, double* A, int lda, double* logdet, uint32_t* status, int batch, size_t a_stride, size_t ld_stride,
+                             hipStream_t st) {
+  if (form == 1) {
+    const size_t fixed_lds = sizeof(double) * CL_LDS_FIXED, panel_lds = fixed_lds + sizeof(double) * 2 * 16 * (size_t)(((N + 15) >> 4) << 4);
+    if (N <= 400) {  // 1 + 6 * 4 tiles in the first block row
+      MCP_ENSURE_MAX_LDS((chol_left_mfma_kernel<4, 4, true>));
+      hipLaunchKernelGGL((chol_left_mfma_kernel<4, 4, true>), dim3(batch), dim3(CM_NT), panel_lds, st, N, A, lda, logdet, status, a_stride, ld_stride);
+    } else if (N <= 576) {  // (two panels of 16 x 576 doubles: 144 KiB, + 10 KiB, of the 160)
+      MCP_ENSURE_MAX_LDS((chol_left_mfma_kernel<8, 2, true>));
+      hipLaunchKernelGGL((chol_left_mfma_kernel<8, 2, true>), dim3(batch), dim3(CM_NT), panel_lds, st, N, A, lda, logdet, status, a_stride, ld_stride);
+    } else if (N <= 784) {  // 1 + 6 * 8
+      hipLaunchKernelGGL((chol_left_mfma_kernel<8, 2, false>), dim3(batch), dim3(CM_NT), fixed_lds, st, N, A, lda, logdet, status, a_stride, ld_stride);
+    } else {  // 1 + 6 * 12 >= 72 (N <= 1152)
+      hipLaunchKernelGGL((chol_left_mfma_kernel<12, 2, false>), dim3(batch), dim3(CM_NT), fixed_lds, st, N, A, lda, logdet, status, a_stride, ld_stride);
+    }
+  } else {
+    const size_t lds = sizeof(double) * (256 + (size_t)16 * (N + 16));
+    MCP_ENSURE_MAX_LDS(chol_factor_mfma_kernel);
+    hipLaunchKernelGGL(chol_factor_mfma_kernel, dim3(batch), dim3(CM_NT), lds, st, N, A, lda, logdet, status, a_stride, ld_stride);
+  }
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
 }
 
 // Uinv = U^-1 by 16x16 blocks, one workgroup: the diagonal blocks W_I = U_II^-1 in registers (one wave each), then block diagonal
@@ -861,18 +1330,15 @@ static int launch_inverse_mfma(int N, const double* U, int ldu, double* Ui, int 
   return MCP_OK;
 }
 
-static int g_chol_mfma = 1;  // test hook: 0 = the round-1/2 kernels (scalar trailing update, one wave per column of the inverse); 2 = the round-3 inverse
+static int g_chol_mfma = 1;  // test hook: 0 = the round-1/2 kernels (scalar trailing update, one wave per column of the inverse); 2 = the round-3 forms
+                             // (right-looking factorization, block-diagonal sweep of the inverse)
 extern "C" void mcp_debug_set_chol_mfma(int on) { g_chol_mfma = on; }
 
 extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32_t* status, void* stream) {
   if (!A || !logdet || !status || N <= 0 || lda < N) return MCP_ERR_ARG;
   if (N > 1152) return MCP_ERR_LIMIT;  // row panel [16][N] must fit the 160 KiB LDS
   if (g_chol_mfma && N > 16) {
-    const size_t lds = sizeof(double) * (256 + (size_t)16 * (N + 16));
-    MCP_ENSURE_MAX_LDS(chol_factor_mfma_kernel);
-    hipLaunchKernelGGL(chol_factor_mfma_kernel, dim3(1), dim3(CM_NT), lds, (hipStream_t)stream, N, A, lda, logdet, status, (size_t)0, (size_t)0);
-    MCP_LAUNCH_CHECK();
-    return MCP_OK;
+    return launch_chol_mfma(g_chol_mfma, N, A, lda, logdet, status, 1, 0, 0, (hipStream_t)stream);
   }
   size_t lds = sizeof(double) * ((size_t)CH_NB * (CH_NB + 1) + (size_t)CH_NB * N);
   MCP_ENSURE_MAX_LDS(chol_factor_kernel);
@@ -1150,10 +1616,8 @@ extern "C" int mcp_nll_epoch(int G, const mcp_nll_gp* gps, int N, int D, int pol
   hipLaunchKernelGGL(cov_build_batch_kernel, dim3((N + 255) / 256, N, G), dim3(256), 0, st, kns, N, X, ws, G, L);
   MCP_LAUNCH_CHECK();
   {
-    const size_t lds = sizeof(double) * (256 + (size_t)16 * (N + 16));
-    MCP_ENSURE_MAX_LDS(chol_factor_mfma_kernel);
-    hipLaunchKernelGGL(chol_factor_mfma_kernel, dim3(G), dim3(CM_NT), lds, st, N, g0 + L.K, N, g0 + L.logdet, status, L.per_gp, L.per_gp);
-    MCP_LAUNCH_CHECK();
+    const int rc = launch_chol_mfma(g_chol_mfma ? g_chol_mfma : 1, N, g0 + L.K, N, g0 + L.logdet, status, G, L.per_gp, L.per_gp, st);
+    if (rc != MCP_OK) return rc;
   }
   {
     const int rc = launch_inverse_mfma(N, g0 + L.K, N, g0 + L.Ui, N, g0 + L.Kinv, N, G, L.per_gp, L.per_gp, L.per_gp, st);

@@ -86,9 +86,10 @@ def test_cholesky_sizes():
         assert abs(float(logdet) - np.linalg.slogdet(K)[1]) < 1e-10 * max(1.0, abs(np.linalg.slogdet(K)[1]))
 
 
-@pytest.mark.parametrize("mfma", [1, 0])
+@pytest.mark.parametrize("mfma", [1, 2, 0])
 def test_cholesky_and_inverse_kernels_both_forms(mfma):
-    """The MFMA-blocked Cholesky / triangular inverse of round 3 and the round-1/2 forms behind them (mcp_debug_set_chol_mfma), at
+    """The MFMA-blocked Cholesky / triangular inverse (1: the left-looking factorization and column-parallel inverse of round 4, 2: the
+    right-looking / block-diagonal forms of round 3) and the round-1/2 forms behind them (mcp_debug_set_chol_mfma), at
     sizes around every block edge (16-wide blocks, partial last block, one block only), at the benchmark's N = 300, the UR5 model's
     N = 400 and near the limit; a Gram-like ill-conditioned matrix (cond ~1e6) as the GP training sees it; upper-triangular outputs
     (zeros below the diagonal, as torch.cholesky(upper=True) / torch.inverse(U) return them); the not-SPD flag from a late pivot."""
@@ -98,7 +99,7 @@ def test_cholesky_and_inverse_kernels_both_forms(mfma):
     hipabi.lib().mcp_debug_set_chol_mfma(mfma)
     try:
         rs = np.random.RandomState(1)
-        for N in (17, 31, 32, 33, 47, 48, 100, 300, 400, 1000):
+        for N in (17, 31, 32, 33, 47, 48, 100, 129, 300, 400, 401, 500, 576, 577, 784, 785, 1000, 1152):
             A = rs.randn(N, N + 3)
             K = A @ A.T / (N + 3) + 0.1 * np.eye(N)
             U, logdet, status = ops.chol_factor(G(K))
