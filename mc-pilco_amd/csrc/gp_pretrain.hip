@@ -975,78 +975,76 @@ __global__ __launch_bounds__(64) void tri_inverse_cols_kernel(int N, const doubl
   const int J = NBK - 1 - (int)blockIdx.x;  // (the longest columns start first)
   const int lane = threadIdx.x, kq = lane >> 4, li = lane & 15;
   const int col = 16 * J + li;
-  // zeros below the diagonal block of this block column
-  for (int row = 16 * (J + 1) + kq; row < N; row += 4)
-    if (col < N) Ui[(size_t)row * ldi + col] = 0.0;
   // X[J][J] = W_J (written by tri_diag_inverse_kernel)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = 16 * J + kq + 4 * r;
     xs[J * 256 + (kq + 4 * r) * 16 + li] = (row < N && col < N) ? Ui[(size_t)row * ldi + col] : 0.0;
   }
-  // The products of the column, flattened: pair (I, K), I = J-1 .. 0, K = I+1 .. J.  The A operands (blocks of U, global memory) do not
-  // depend on the chain, so they are loaded TC_PF pairs ahead -- across the step boundaries -- into a ring of register sets; the diagonal
-  // inverse W_I of a step is loaded one step ahead.  (With the operand of pair q+1 requested only while pair q multiplied, every pair paid
-  // most of an L2 round trip: 163 us at N = 400 for a chain whose MFMAs take 32 us.)
+  // The chain of the column as one stream of ITEMS: for I = J-1 .. 0 the products S += U[I][K] X[K][J], K = I+1 .. J, then the item that
+  // closes the step, X[I][J] = -W_I S.  Every item is one 16x16 A operand from global memory (a block of U, or the diagonal inverse W_I)
+  // that does not depend on the chain: they are loaded TC_PF items ahead into a ring of register sets.  The loop body has no memory
+  // operation under a branch -- results stay in LDS until the end -- so the compiler can count the loads in flight.  (Round 4 first form:
+  // the prefetch sat under wave-uniform branches together with the stores of the results, the wait-count bookkeeping gave up and every
+  // item paid an L2 round trip: 78 us at N = 300 for a chain whose MFMAs take 18.)
   constexpr int TC_PF = 6;
-  int Ic = J - 1, Kc = J, Il = J - 1, Kl = J;
+  const gcdp_t Ug = (gcdp_t)U, Wg = (gcdp_t)Ui;
+  int If = J - 1, Kf = J, Ip = J - 1, Kp = J;  // fetch and process positions; K = J + 1 stands for the closing item of the step
   double buf[TC_PF][4];
-  auto issue = [&](double (&dst)[4]) {
-    if (Il >= 0) {  // (wave-uniform)
-      const double* urow = U + (size_t)(16 * Il + li) * ldu + kq;  // A[i = li][k]: U[16 I + i][16 K + k]   (rows 16 I + i < N: I < J)
+  auto fetch = [&](double (&dst)[4]) {
+    const bool live = If >= 0;                 // (past the end of the stream: block (0, 0) of U, never used)
+    const int I = live ? If : 0;
+    const bool closing = live && Kf > J;
+    const gcdp_t base = closing ? Wg : Ug;     // (uniform)
+    const int ld = closing ? ldi : ldu, kc = live ? (closing ? I : Kf) : 0;
+    const unsigned rowoff = (unsigned)((16 * I + li) * ld);  // A[i = li][k]: block row 16 I + i (< N: I < J)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int ac = 16 * Kl + 4 * u + kq;
-        dst[u] = ac < N ? urow[16 * Kl + 4 * u] : 0.0;
-      }
-      if (++Kl > J) {
-        --Il;
-        Kl = Il + 1;
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int ac = 16 * kc + 4 * u + kq;
+      const double v = base[rowoff + (unsigned)min(ac, N - 1)];
+      dst[u] = ac < N ? v : 0.0;
+    }
+    if (live && ++Kf > J + 1) {  // (scalar bookkeeping)
+      --If;
+      Kf = If + 1;
     }
   };
-  auto load_w = [&](int I, double (&wa)[4]) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) wa[u] = I >= 0 ? -Ui[(size_t)(16 * I + li) * ldi + 16 * I + 4 * u + kq] : 0.0;
-  };
-#pragma unroll
-  for (int q = 0; q < TC_PF; ++q) issue(buf[q]);
-  double wa[4], wn[4];
-  load_w(J - 1, wa);
-  load_w(J - 2, wn);
+  for (int q = 0; q < TC_PF; ++q) fetch(buf[q]);
   v4d_p acc = {0.0, 0.0, 0.0, 0.0};
-  while (Ic >= 0) {
+  const int items = J * (J + 1) / 2 + J;
+  for (int q0 = 0; q0 < items; q0 += TC_PF) {
 #pragma unroll
     for (int q = 0; q < TC_PF; ++q) {
-      if (Ic >= 0) {  // (wave-uniform)
-        double bv[4];
+      if (Ip >= 0) {  // (wave-uniform; MFMAs and LDS only)
+        if (Kp <= J) {
+          double bv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bv[u] = xs[Kc * 256 + (4 * u + kq) * 16 + li];
+          for (int u = 0; u < 4; ++u) bv[u] = xs[Kp * 256 + (4 * u + kq) * 16 + li];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[q][u], bv[u], acc, 0, 0, 0);
-        issue(buf[q]);  // this register set: the pair TC_PF further on
-        if (Kc == J) {  // the last product of step Ic:  X[I][J] = - W_I S  (register u of the accumulator is row 4 u + kq of S: the B operand of step u)
+          for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[q][u], bv[u], acc, 0, 0, 0);
+          ++Kp;
+        } else {  // X[I][J] = - W_I S  (register u of the accumulator is row 4 u + kq of S: the B operand of step u)
           v4d_p out = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int u = 0; u < 4; ++u) out = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[u], acc[u], out, 0, 0, 0);
+          for (int u = 0; u < 4; ++u) out = __builtin_amdgcn_mfma_f64_16x16x4f64(-buf[q][u], acc[u], out, 0, 0, 0);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * Ic + kq + 4 * r;
-            xs[Ic * 256 + (kq + 4 * r) * 16 + li] = col < N ? out[r] : 0.0;
-            if (col < N) Ui[(size_t)row * ldi + col] = out[r];
-          }
+          for (int r = 0; r < 4; ++r) xs[Ip * 256 + (kq + 4 * r) * 16 + li] = col < N ? out[r] : 0.0;
           acc = (v4d_p){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int u = 0; u < 4; ++u) wa[u] = wn[u];
-          load_w(Ic - 2, wn);
-          --Ic;
-          Kc = Ic + 1;
-        } else {
-          ++Kc;
+          --Ip;
+          Kp = Ip + 1;
         }
       }
+      fetch(buf[q]);  // this register set: the item TC_PF further on
     }
   }
+  // the column, from LDS: blocks 0 .. J-1 (block J is already there), zeros below
+  for (int idx = lane; idx < 16 * J * 16; idx += 64) {
+    const int row = idx >> 4, c = 16 * J + (idx & 15);
+    if (c < N) Ui[(size_t)row * ldi + c] = xs[idx];
+  }
+  for (int row = 16 * (J + 1) + kq; row < N; row += 4)
+    if (col < N) Ui[(size_t)row * ldi + col] = 0.0;
 }
 // Kinv = Uinv Uinv^T by 16x16 tiles on the matrix cores, one wave per tile (I <= J) of the upper triangle, mirrored into the lower:
 //   Kinv[I][J] = sum_{K >= J} Uinv[I][K] Uinv[J][K]^T      (both operands read rows of Uinv: A[i][k] = Ui[16 I + i][16 K + k], B[k][j] = Ui[16 J + j][16 K + k])
