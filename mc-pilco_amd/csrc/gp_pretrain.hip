@@ -1233,33 +1233,91 @@ __device__ __forceinline__ void nll_grad_row(const mcp_kernel& kn, int N, const 
     fb[j] = Bv;
   }
   __syncthreads();
+  // (2) the sums over j, one per hyper-parameter: the 256 threads as nseg segments of NPpad >= NP lanes, segment s taking j = s, s + nseg, ...
+  // (one thread per parameter left 157 of the 256 idle at D = 24 and walked 400 dependent global loads each); partial sums meet in LDS
+  // and are added in segment order
   const int NP = 4 * D + 3;
-  for (int p = tid; p < NP; p += 256) {
-    double s = 0.0;
+  double* red = sm + 4 * N;  // [256]
+  int NPpad = 32;
+  while (NPpad < NP) NPpad <<= 1;
+  if (NPpad <= 256) {
+    const int nseg = 256 / NPpad, p = tid % NPpad, seg = tid / NPpad;
+    double s0 = 0.0, s1 = 0.0;
+    auto over_j = [&](auto term) {  // two accumulators: consecutive loads do not wait for each other's FMA
+      int j = seg;
+      for (; j + nseg < N; j += 2 * nseg) {
+        s0 += term(j);
+        s1 += term(j + nseg);
+      }
+      if (j < N) s0 += term(j);
+    };
     if (p < D) {  // d/d log l_p :  kse * 2 (dx/l)^2
+      const double il2 = kn.inv_ls[p] * kn.inv_ls[p], xip = xi[p];
+      over_j([&](int j) {
+        const double dx = xip - X[(size_t)j * D + p];
+        return wk[j] * (2.0 * dx * dx * il2);
+      });
+    } else if (p == D) {  // d/d log lambda
+      over_j([&](int j) { return wk[j]; });
+    } else if (p == D + 1) {  // 1/2 tr Wm (the caller multiplies by d sigma_n^2 / d sigma_n_log)
+      s0 = seg == 0 ? wm[i] : 0.0;
+    } else if (p < 2 * D + 3) {  // MPK_1, feature e (e == D: the offset feature)
+      const int e = p - (D + 2);
+      if (kn.poly_deg >= 1) {
+        const double c = 2.0 * kn.w1[e] * (e < D ? xi[e] : 1.0);
+        if (e < D)
+          over_j([&](int j) { return wm[j] * (c * X[(size_t)j * D + e]); });
+        else
+          over_j([&](int j) { return wm[j] * c; });
+      }
+    } else if (p < 3 * D + 3) {  // MPK_2 factor 0 parameter e: 2 w20_e x_ie x_je * B_ij
+      const int e = p - (2 * D + 3);
+      if (kn.poly_deg >= 2) {
+        const double c = 2.0 * kn.w20[e] * xi[e];
+        over_j([&](int j) { return (wm[j] * fb[j]) * (c * X[(size_t)j * D + e]); });
+      }
+    } else if (p < NP) {  // MPK_2 factor 1 parameter e: 2 w21_e x_ie x_je * A_ij
+      const int e = p - (3 * D + 3);
+      if (kn.poly_deg >= 2) {
+        const double c = 2.0 * kn.w21[e] * xi[e];
+        over_j([&](int j) { return (wm[j] * fa[j]) * (c * X[(size_t)j * D + e]); });
+      }
+    }
+    red[tid] = s0 + s1;
+    __syncthreads();
+    if (tid < NP) {
+      double s = 0.0;
+      for (int sg = 0; sg < nseg; ++sg) s += red[sg * NPpad + tid];
+      slab[(size_t)i * NP + tid] = 0.5 * s;
+    }
+    return;
+  }
+  for (int p = tid; p < NP; p += 256) {  // (more than 256 hyper-parameters: D > 63 -- beyond MCP_MAX_GPDIM today)
+    double s = 0.0;
+    if (p < D) {
       const double il2 = kn.inv_ls[p] * kn.inv_ls[p];
       for (int j = 0; j < N; ++j) {
         double dx = xi[p] - X[(size_t)j * D + p];
         s = fma(wk[j], 2.0 * dx * dx * il2, s);
       }
-    } else if (p == D) {  // d/d log lambda
+    } else if (p == D) {
       for (int j = 0; j < N; ++j) s += wk[j];
-    } else if (p == D + 1) {  // 1/2 tr Wm (the caller multiplies by d sigma_n^2 / d sigma_n_log)
+    } else if (p == D + 1) {
       s = wm[i];
-    } else if (p < 2 * D + 3) {  // MPK_1, feature e (e == D: the offset feature)
+    } else if (p < 2 * D + 3) {
       const int e = p - (D + 2);
       if (kn.poly_deg >= 1) {
         const double we = 2.0 * kn.w1[e];
         const double pie = e < D ? xi[e] : 1.0;
         for (int j = 0; j < N; ++j) s = fma(wm[j], we * pie * (e < D ? X[(size_t)j * D + e] : 1.0), s);
       }
-    } else if (p < 3 * D + 3) {  // MPK_2 factor 0 parameter e: 2 w20_e x_ie x_je * B_ij
+    } else if (p < 3 * D + 3) {
       const int e = p - (2 * D + 3);
       if (kn.poly_deg >= 2) {
         const double we = 2.0 * kn.w20[e] * xi[e];
         for (int j = 0; j < N; ++j) s = fma(wm[j] * fb[j], we * X[(size_t)j * D + e], s);
       }
-    } else {  // MPK_2 factor 1 parameter e: 2 w21_e x_ie x_je * A_ij
+    } else {
       const int e = p - (3 * D + 3);
       if (kn.poly_deg >= 2) {
         const double we = 2.0 * kn.w21[e] * xi[e];
@@ -1406,7 +1464,7 @@ extern "C" int mcp_nll_grad(const mcp_kernel* kern, int N, const double* X, cons
   MCP_ENSURE_MAX_LDS(nll_grad_kernel);
   const int NP = 4 * kern->D + 3;
   double* slab = (double*)workspace;
-  hipLaunchKernelGGL(nll_grad_kernel, dim3(N), dim3(256), sizeof(double) * 4 * (size_t)N, (hipStream_t)stream, *kern, N, X, Kinv, ldk, alpha,
+  hipLaunchKernelGGL(nll_grad_kernel, dim3(N), dim3(256), sizeof(double) * (4 * (size_t)N + 256), (hipStream_t)stream, *kern, N, X, Kinv, ldk, alpha,
                      slab);
   MCP_LAUNCH_CHECK();
   hipLaunchKernelGGL(nll_colsum_kernel, dim3((NP + 127) / 128), dim3(128), 0, (hipStream_t)stream, N, NP, slab, grad);
@@ -1498,15 +1556,64 @@ __global__ void nll_prep_kernel(NllBatch b, int G, int N, int D, int deg, int ar
     reinterpret_cast<mcp_kernel*>(ws)[g] = kn;
   }
 }
-__global__ void cov_build_batch_kernel(const mcp_kernel* __restrict__ kns, int N, const double* __restrict__ X, double* __restrict__ ws, int G,
-                                       NllWs L) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y, g = blockIdx.z;
-  if (i >= N || j >= N) return;
+// 16 rows x 256 columns of one GP's Gram matrix per workgroup.  The 256 inputs x_j of the columns (transposed: xj[d][j], lanes read
+// consecutive addresses), the 16 inputs x_i of the rows and the kernel's weights are staged in LDS once, so a thread's D-long loops run
+// on LDS instead of on strided global loads whose latency they could not hide (one thread per entry with both inputs in global memory:
+// 124 us for the six 400 x 400, D = 24 matrices of the UR5 model).  The arithmetic is kern_eval's, operation for operation.
+#define CB_ROWS 16
+__global__ __launch_bounds__(256) void cov_build_batch_kernel(const mcp_kernel* __restrict__ kns, int N, const double* __restrict__ X,
+                                                              double* __restrict__ ws, int G, NllWs L) {
+  extern __shared__ __attribute__((aligned(16))) double cb[];
+  const int g = blockIdx.z, i0 = blockIdx.y * CB_ROWS, j0 = blockIdx.x * 256, tid = threadIdx.x;
   const mcp_kernel kn = kns[g];
-  double k = kern_eval(kn, X + (size_t)i * kn.D, 1, X + (size_t)j * kn.D, 1);
-  if (i == j) k += kern_sigma_n2(kn);
-  (nll_gp_base(ws, G, L.per_gp, g) + L.K)[(size_t)i * N + j] = k;
+  const int D = kn.D, deg = kn.poly_deg;
+  double* xj = cb;                       // [D][257]
+  double* xi = xj + 257 * D;             // [CB_ROWS][D]
+  double* par = xi + CB_ROWS * D;        // inv_ls[D] | w1[D + 1] | w20[D] | w21[D]
+  const int nj = min(256, N - j0), ni = min(CB_ROWS, N - i0);
+  for (int e = tid; e < nj * D; e += 256) {
+    const int r = e / D, d = e - r * D;
+    xj[d * 257 + r] = X[(size_t)j0 * D + e];
+  }
+  for (int e = tid; e < ni * D; e += 256) xi[e] = X[(size_t)i0 * D + e];
+  for (int d = tid; d < D; d += 256) {
+    par[d] = kn.inv_ls[d];
+    par[2 * D + 1 + d] = deg >= 2 ? kn.w20[d] : 0.0;
+    par[3 * D + 1 + d] = deg >= 2 ? kn.w21[d] : 0.0;
+  }
+  for (int d = tid; d <= D; d += 256) par[D + d] = deg >= 1 ? kn.w1[d] : 0.0;
+  __syncthreads();
+  if (tid >= nj) return;
+  const double *inv_ls = par, *w1 = par + D, *w20 = par + 2 * D + 1, *w21 = par + 3 * D + 1;
+  double* Kg = nll_gp_base(ws, G, L.per_gp, g) + L.K;
+  const double sn2 = kern_sigma_n2(kn), lam = kern_lambda(kn);
+  for (int r = 0; r < ni; ++r) {
+    const double* a = xi + r * D;
+    double dist = 0.0;
+    for (int d = 0; d < D; ++d) {
+      const double q = (a[d] - xj[d * 257 + tid]) * inv_ls[d];
+      dist = fma(q, q, dist);
+    }
+    double k = lam * exp(-dist);
+    if (deg >= 1) {
+      double p1 = w1[D];
+      for (int d = 0; d < D; ++d) p1 = fma(w1[d] * a[d], xj[d * 257 + tid], p1);
+      k += p1;
+      if (deg >= 2) {
+        double pa = 0.0, pb = 0.0;
+        for (int d = 0; d < D; ++d) {
+          const double ab = a[d] * xj[d * 257 + tid];
+          pa = fma(w20[d], ab, pa);
+          pb = fma(w21[d], ab, pb);
+        }
+        k = fma(pa, pb, k);
+      }
+    }
+    if (i0 + r == j0 + tid) k += sn2;
+    Kg[(size_t)(i0 + r) * N + j0 + tid] = k;
+  }
 }
+static inline size_t cov_build_batch_lds(int D) { return sizeof(double) * ((size_t)257 * D + (size_t)CB_ROWS * D + 4 * (size_t)D + 2); }
 // r = Y y_scale - mean;  alpha = Kinv r  (one wave per row)
 __global__ void nll_alpha_batch_kernel(NllBatch b, int G, int N, double* __restrict__ ws, NllWs L) {
   const int g = blockIdx.y, row = blockIdx.x * (blockDim.x / MCP_WAVE) + (threadIdx.x / MCP_WAVE), lane = threadIdx.x % MCP_WAVE;
@@ -1529,8 +1636,121 @@ __global__ __launch_bounds__(256) void nll_grad_batch_kernel(const mcp_kernel* _
   double* base = nll_gp_base(ws, G, L.per_gp, g);
   nll_grad_row(kns[g], N, X, base + L.Kinv, N, base + L.alpha, base + L.slab);
 }
-// column sums of the slab (fixed order), the loss, and the chain rule back to the optimizer's raw parameters (mc_pilco_amd/nll.py)
-__global__ __launch_bounds__(256) void nll_finish_kernel(NllBatch b, int G, int N, int D, int deg, int ard, double* __restrict__ ws, NllWs L) {
+// The same rows by a workgroup of 16 waves that takes `rows` consecutive rows i, with the inputs staged in LDS once, TRANSPOSED
+// (xs[d][j], odd pitch: lanes j read consecutive addresses), and the kernel's weights beside them.
+//   (1) thread j:  Wm_ij, Wm_ij kse_ij, A_ij, B_ij                          (the D-long loops run on LDS)
+//   (2) wave w:    hyper-parameters p = w, w + 16, ...  -- one parameter at a time, the SAME for all lanes (no divergence between the
+//                  parameter classes), lanes over j, one wave reduction per parameter; summed over the workgroup's rows in registers:
+//                  slab[workgroup][p], added up by nll_finish_kernel in workgroup order.
+// The row kernel above walks D- and N-long loops of global loads per thread (strided, or one element per iteration, with one thread per
+// parameter and the classes diverging inside a wave): 128 us per epoch at the UR5 shape (six GPs, N = 400, D = 24), where the
+// arithmetic is a few microseconds.
+#define NG_NT 1024
+#define NG_KMAX ((4 * MCP_MAX_GPDIM + 3 + NG_NT / 64 - 1) / (NG_NT / 64))  // parameters per wave
+__global__ __launch_bounds__(NG_NT) void nll_grad_rows_kernel(const mcp_kernel* __restrict__ kns, int N, const double* __restrict__ X,
+                                                              double* __restrict__ ws, int G, NllWs L, int rows) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i0 = blockIdx.x * rows;
+  const mcp_kernel kn = kns[g];
+  const int D = kn.D, NP = 4 * D + 3, deg = kn.poly_deg, Np = N | 1;
+  double* wm = sm;               // [N] Wm_ij
+  double* wk = sm + N;           // [N] Wm_ij * kse_ij
+  double* fa = sm + 2 * N;       // [N] Wm_ij * A_ij   (MPK_2 factors)
+  double* fb = sm + 3 * N;       // [N] Wm_ij * B_ij
+  double* par = sm + 4 * N;      // inv_ls[D] | w1[D + 1] | w20[D] | w21[D]
+  double* xs = par + 4 * D + 2;  // [D][Np]
+  const double* base = nll_gp_base(ws, G, L.per_gp, g);
+  const double *Kinv = base + L.Kinv, *alpha = base + L.alpha;
+  double* slab = nll_gp_base(ws, G, L.per_gp, g) + L.slab;
+  for (int e = tid; e < N * D; e += NG_NT) {
+    const int r = e / D, d = e - r * D;
+    xs[d * Np + r] = X[e];
+  }
+  for (int d = tid; d < D; d += NG_NT) {
+    par[d] = kn.inv_ls[d];
+    par[2 * D + 1 + d] = deg >= 2 ? kn.w20[d] : 0.0;
+    par[3 * D + 1 + d] = deg >= 2 ? kn.w21[d] : 0.0;
+  }
+  for (int d = tid; d <= D; d += NG_NT) par[D + d] = deg >= 1 ? kn.w1[d] : 0.0;
+  const double lam = kern_lambda(kn);
+  const double *inv_ls = par, *w1 = par + D, *w20 = par + 2 * D + 1, *w21 = par + 3 * D + 1;
+  double tot[NG_KMAX];  // this wave's parameters, summed over the workgroup's rows
+#pragma unroll
+  for (int kx = 0; kx < NG_KMAX; ++kx) tot[kx] = 0.0;
+  __syncthreads();
+  for (int i = i0; i < min(i0 + rows, N); ++i) {
+    const double ai = alpha[i];
+    for (int j = tid; j < N; j += NG_NT) {
+      double dist = 0.0, A = 0.0, Bv = 0.0;
+      for (int d = 0; d < D; ++d) {
+        const double xid = xs[d * Np + i], xjd = xs[d * Np + j];
+        double r = (xid - xjd) * inv_ls[d];
+        dist = fma(r, r, dist);
+        if (deg >= 2) {
+          double xx = xid * xjd;
+          A = fma(w20[d], xx, A);
+          Bv = fma(w21[d], xx, Bv);
+        }
+      }
+      double w = Kinv[(size_t)i * N + j] - ai * alpha[j];
+      wm[j] = w;
+      wk[j] = w * lam * exp(-dist);
+      fa[j] = w * A;
+      fb[j] = w * Bv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kx = 0; kx < NG_KMAX; ++kx) {
+      const int p = wv + kx * (NG_NT / 64);  // (wave-uniform)
+      if (p >= NP) break;
+      double s = 0.0;
+      if (p < D) {  // d/d log l_p :  kse * 2 (dx/l)^2
+        const double il2 = inv_ls[p] * inv_ls[p], xip = xs[p * Np + i];
+        for (int j = lane; j < N; j += 64) {
+          const double dx = xip - xs[p * Np + j];
+          s = fma(wk[j], 2.0 * dx * dx * il2, s);
+        }
+      } else if (p == D) {  // d/d log lambda
+        for (int j = lane; j < N; j += 64) s += wk[j];
+      } else if (p == D + 1) {  // 1/2 tr Wm (the caller multiplies by d sigma_n^2 / d sigma_n_log)
+        s = lane == 0 ? wm[i] : 0.0;
+      } else if (p < 2 * D + 3) {  // MPK_1, feature e (e == D: the offset feature)
+        const int e = p - (D + 2);
+        if (deg >= 1) {
+          const double c = 2.0 * w1[e] * (e < D ? xs[e * Np + i] : 1.0);
+          if (e < D)
+            for (int j = lane; j < N; j += 64) s = fma(wm[j], c * xs[e * Np + j], s);
+          else
+            for (int j = lane; j < N; j += 64) s = fma(wm[j], c, s);
+        }
+      } else if (p < 3 * D + 3) {  // MPK_2 factor 0 parameter e: 2 w20_e x_ie x_je * B_ij
+        const int e = p - (2 * D + 3);
+        if (deg >= 2) {
+          const double c = 2.0 * w20[e] * xs[e * Np + i];
+          for (int j = lane; j < N; j += 64) s = fma(fb[j], c * xs[e * Np + j], s);
+        }
+      } else {  // MPK_2 factor 1 parameter e: 2 w21_e x_ie x_je * A_ij
+        const int e = p - (3 * D + 3);
+        if (deg >= 2) {
+          const double c = 2.0 * w21[e] * xs[e * Np + i];
+          for (int j = lane; j < N; j += 64) s = fma(fa[j], c * xs[e * Np + j], s);
+        }
+      }
+      tot[kx] += 0.5 * wave_sum(s);  // (rows in order: the sum does not depend on how many GPs share the launch)
+    }
+    __syncthreads();  // (wm .. fb are rewritten by the next row)
+  }
+#pragma unroll
+  for (int kx = 0; kx < NG_KMAX; ++kx) {
+    const int p = wv + kx * (NG_NT / 64);
+    if (p < NP && lane == 0) slab[(size_t)blockIdx.x * NP + p] = tot[kx];
+  }
+}
+// rows per workgroup: a function of N alone, so that a GP's sums are the same whether it is trained alone or in a batch
+static inline int nll_grad_rows_per_wg(int N) { return (N + 127) / 128; }
+static inline size_t nll_grad_rows_lds(int N, int D) { return sizeof(double) * (4 * (size_t)N + 4 * (size_t)D + 2 + (size_t)D * (N | 1)); }
+__global__ __launch_bounds__(256) void nll_finish_kernel(NllBatch b, int G, int N, int D, int deg, int ard, double* __restrict__ ws, NllWs L,
+                                                         int slab_rows) {
   __shared__ double sh[4 * MCP_MAX_GPDIM + 3];
   __shared__ double red[4];
   const int g = blockIdx.x, tid = threadIdx.x, NP = 4 * D + 3;
@@ -1540,13 +1760,13 @@ __global__ __launch_bounds__(256) void nll_finish_kernel(NllBatch b, int G, int 
   for (int c = tid; c < NP; c += 256) {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int r = 0;
-    for (; r + 3 < N; r += 4) {
+    for (; r + 3 < slab_rows; r += 4) {  // (slab: one row per row of K, or per workgroup of nll_grad_rows_kernel)
       s0 += slab[(size_t)r * NP + c];
       s1 += slab[(size_t)(r + 1) * NP + c];
       s2 += slab[(size_t)(r + 2) * NP + c];
       s3 += slab[(size_t)(r + 3) * NP + c];
     }
-    for (; r < N; ++r) s0 += slab[(size_t)r * NP + c];
+    for (; r < slab_rows; ++r) s0 += slab[(size_t)r * NP + c];
     sh[c] = (s0 + s1) + (s2 + s3);
   }
   // r . alpha and sum alpha
@@ -1611,7 +1831,10 @@ extern "C" int mcp_nll_epoch(int G, const mcp_nll_gp* gps, int N, int D, int pol
   double* g0 = ws + knd;
   hipLaunchKernelGGL(nll_prep_kernel, dim3(G), dim3(64), 0, st, b, G, N, D, poly_deg, ard, ws, L);
   MCP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(cov_build_batch_kernel, dim3((N + 255) / 256, N, G), dim3(256), 0, st, kns, N, X, ws, G, L);
+  if (cov_build_batch_lds(D) > 150 * 1024) return MCP_ERR_LIMIT;
+  MCP_ENSURE_MAX_LDS(cov_build_batch_kernel);
+  hipLaunchKernelGGL(cov_build_batch_kernel, dim3((N + 255) / 256, (N + CB_ROWS - 1) / CB_ROWS, G), dim3(256), cov_build_batch_lds(D), st, kns, N, X,
+                     ws, G, L);
   MCP_LAUNCH_CHECK();
   {
     const int rc = launch_chol_mfma(g_chol_mfma ? g_chol_mfma : 1, N, g0 + L.K, N, g0 + L.logdet, status, G, L.per_gp, L.per_gp, st);
@@ -1623,10 +1846,18 @@ extern "C" int mcp_nll_epoch(int G, const mcp_nll_gp* gps, int N, int D, int pol
   }
   hipLaunchKernelGGL(nll_alpha_batch_kernel, dim3((N + 3) / 4, G), dim3(256), 0, st, b, G, N, ws, L);
   MCP_LAUNCH_CHECK();
-  MCP_ENSURE_MAX_LDS(nll_grad_batch_kernel);
-  hipLaunchKernelGGL(nll_grad_batch_kernel, dim3(N, G), dim3(256), sizeof(double) * 4 * (size_t)N, st, kns, N, X, ws, G, L);
+  int slab_rows = N;
+  if (nll_grad_rows_lds(N, D) <= 150 * 1024) {
+    const int rows = nll_grad_rows_per_wg(N);
+    slab_rows = (N + rows - 1) / rows;
+    MCP_ENSURE_MAX_LDS(nll_grad_rows_kernel);
+    hipLaunchKernelGGL(nll_grad_rows_kernel, dim3(slab_rows, G), dim3(NG_NT), nll_grad_rows_lds(N, D), st, kns, N, X, ws, G, L, rows);
+  } else {
+    MCP_ENSURE_MAX_LDS(nll_grad_batch_kernel);
+    hipLaunchKernelGGL(nll_grad_batch_kernel, dim3(N, G), dim3(256), sizeof(double) * (4 * (size_t)N + 256), st, kns, N, X, ws, G, L);
+  }
   MCP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(nll_finish_kernel, dim3(G), dim3(256), 0, st, b, G, N, D, poly_deg, ard, ws, L);
+  hipLaunchKernelGGL(nll_finish_kernel, dim3(G), dim3(256), 0, st, b, G, N, D, poly_deg, ard, ws, L, slab_rows);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }
