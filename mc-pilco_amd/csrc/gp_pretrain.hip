@@ -1048,6 +1048,161 @@ __global__ __launch_bounds__(64) void tri_inverse_cols_kernel(int N, const doubl
 }
 // Kinv = Uinv Uinv^T by 16x16 tiles on the matrix cores, one wave per tile (I <= J) of the upper triangle, mirrored into the lower:
 //   Kinv[I][J] = sum_{K >= J} Uinv[I][K] Uinv[J][K]^T      (both operands read rows of Uinv: A[i][k] = Ui[16 I + i][16 K + k], B[k][j] = Ui[16 J + j][16 K + k])
+// The same column by FOUR waves (round 4, second form).  Step I of the chain is a sum of J - I block products followed by one closing
+// product: the products of a step are dealt to the four waves (item m = J - K of the step to wave m mod 4, oldest blocks first, so that the
+// one product that needs the block finished in the previous step, K = I + 1, is the last of its wave), partial sums meet in LDS, wave 0
+// adds them and closes the step while the others are already in the next one.  Per step two LDS-only barriers (s_waitcnt lgkmcnt(0) +
+// s_barrier: the prefetched global operands stay in flight across them; __syncthreads would drain them twice per step).
+// The chain of the last column, 171 products at N = 300, becomes 18 steps of ceil(n / 4) products + close.
+#define TC4_PF 4
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__global__ __launch_bounds__(256) void tri_inverse_cols4_kernel(int N, const double* __restrict__ U, int ldu, double* __restrict__ Ui, int ldi,
+                                                                size_t u_stride, size_t ui_stride) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];  // [J + 1][256] finished blocks | [3][256] partial sums of waves 1..3
+  U += (size_t)blockIdx.y * u_stride;
+  Ui += (size_t)blockIdx.y * ui_stride;
+  const int NBK = (N + 15) >> 4;
+  const int J = NBK - 1 - (int)blockIdx.x;  // (the longest columns start first)
+  const int tid = threadIdx.x, lane = tid & 63, kq = lane >> 4, li = lane & 15;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = 16 * J + li;
+  double* part = xs + (J + 1) * 256;
+  if (w == 0) {  // X[J][J] = W_J (written by tri_diag_inverse_kernel)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * J + kq + 4 * r;
+      xs[J * 256 + (kq + 4 * r) * 16 + li] = (row < N && col < N) ? Ui[(size_t)row * ldi + col] : 0.0;
+    }
+  }
+  const gcdp_t Ug = (gcdp_t)U, Wg = (gcdp_t)Ui;
+  // this wave's stream of items: per step I = J-1 .. 0 the products m = w, w + 4, ... < n = J - I (block K = J - m), then, wave 0 only, the
+  // closing item (m = -1 stands for it).  Steps in which the wave has no product (n <= w) have no item.
+  int If = J - 1, mf = w;  // fetch position
+  auto skip_empty = [&](int& I, int& m) {
+    while (I >= 0 && m >= 0 && m >= J - I) {  // no (more) product of mine in step I
+      if (w == 0) {
+        m = -1;  // the closing item comes next
+        return;
+      }
+      --I;
+      m = w;
+    }
+  };
+  skip_empty(If, mf);
+  double buf[TC4_PF][4];
+  auto fetch = [&](double (&dst)[4]) {
+    const bool live = If >= 0;  // (past the end of the stream: block (0, 0) of U, never used)
+    const int I = live ? If : 0;
+    const bool closing = live && mf < 0;
+    const gcdp_t base = closing ? Wg : Ug;  // (uniform)
+    const int ld = closing ? ldi : ldu, kc = live ? (closing ? I : J - mf) : 0;
+    const unsigned rowoff = (unsigned)((16 * I + li) * ld);  // A[i = li][k]: block row 16 I + i (< N: I < J)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ac = 16 * kc + 4 * u + kq;
+      const double v = base[rowoff + (unsigned)min(ac, N - 1)];
+      dst[u] = ac < N ? v : 0.0;
+    }
+    if (live) {  // (scalar bookkeeping)
+      if (mf < 0) {
+        --If;
+        mf = w;
+      } else {
+        mf += 4;
+      }
+      skip_empty(If, mf);
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < TC4_PF; ++q) fetch(buf[q]);
+  lds_barrier();  // X[J][J] is in LDS
+  v4d_p acc = {0.0, 0.0, 0.0, 0.0};
+  int Ip = J - 1, mp = w;   // process position
+  bool newest_seen = false;  // this step's barrier B passed
+  // the end of a wave's products of step I: barrier B if it has not passed it yet, partial sum to LDS (waves 1..3), barrier A
+  auto end_products = [&]() {
+    if (!newest_seen) lds_barrier();  // B: the block of the previous step is in LDS (this wave did not need it)
+    if (w > 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(w - 1) * 256 + (kq + 4 * r) * 16 + li] = acc[r];
+      acc = (v4d_p){0.0, 0.0, 0.0, 0.0};
+    }
+    lds_barrier();  // A: the partial sums of the step are in LDS
+    newest_seen = false;
+  };
+  // steps without a product of this wave: their two barriers
+  auto idle_steps = [&]() {
+    while (Ip >= 0 && mp >= 0 && mp >= J - Ip) {
+      if (w == 0) {
+        end_products();
+        mp = -1;
+        return;
+      }
+      end_products();
+      --Ip;
+      mp = w;
+    }
+  };
+  idle_steps();
+  while (Ip >= 0) {
+#pragma unroll
+    for (int q = 0; q < TC4_PF; ++q) {
+      if (Ip >= 0) {  // (wave-uniform; MFMAs, LDS and barriers only)
+        if (mp >= 0) {
+          const int n = J - Ip, K = J - mp;
+          if (mp == n - 1) {  // the product on the block of the previous step
+            lds_barrier();    // B
+            newest_seen = true;
+          }
+          double bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) bv[u] = xs[K * 256 + (4 * u + kq) * 16 + li];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(buf[q][u], bv[u], acc, 0, 0, 0);
+          mp += 4;
+          if (mp >= n) {
+            end_products();
+            if (w == 0) {
+              mp = -1;
+            } else {
+              --Ip;
+              mp = w;
+              idle_steps();
+            }
+          }
+        } else {  // wave 0: S = sum of the partial sums;  X[I][J] = - W_I S  (register u of S is the B operand of step u)
+          const int n = J - Ip;
+#pragma unroll
+          for (int pw = 1; pw < 4; ++pw) {
+            if (pw < n) {  // (waves beyond the step's products wrote zeros: skip the read)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[r] += part[(pw - 1) * 256 + (kq + 4 * r) * 16 + li];
+            }
+          }
+          v4d_p out = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) out = __builtin_amdgcn_mfma_f64_16x16x4f64(-buf[q][u], acc[u], out, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xs[Ip * 256 + (kq + 4 * r) * 16 + li] = col < N ? out[r] : 0.0;
+          acc = (v4d_p){0.0, 0.0, 0.0, 0.0};
+          --Ip;
+          mp = 0;
+          idle_steps();
+        }
+      }
+      fetch(buf[q]);  // this register set: the item TC4_PF further on
+    }
+  }
+  lds_barrier();  // the last block of the column is in LDS
+  // the column, from LDS: blocks 0 .. J-1 (block J is already there), zeros below
+  for (int idx = tid; idx < 16 * J * 16; idx += 256) {
+    const int row = idx >> 4, c = 16 * J + (idx & 15);
+    if (c < N) Ui[(size_t)row * ldi + c] = xs[idx];
+  }
+  for (int row = 16 * (J + 1) + (tid >> 4); row < N; row += 16)
+    if (col < N) Ui[(size_t)row * ldi + col] = 0.0;
+}
+
 __global__ __launch_bounds__(256) void kinv_tiles_kernel(int N, const double* __restrict__ Ui, int ldi, double* __restrict__ Kinv, int ldk,
                                                          size_t ui_stride, size_t k_stride) {
   Ui += (size_t)blockIdx.y * ui_stride;
@@ -1373,13 +1528,19 @@ extern "C" int mcp_cov_diag(const mcp_kernel* kern, int N, const double* X, int 
 
 // U^-1 and K^-1 = U^-1 U^-T of `batch` matrices (strides in doubles): diagonal blocks, block columns, tiles -- three launches
 static int launch_inverse_mfma(int N, const double* U, int ldu, double* Ui, int ldi, double* Kinv, int ldk, int batch, size_t u_stride,
-                               size_t ui_stride, size_t k_stride, hipStream_t st) {
+                               size_t ui_stride, size_t k_stride, hipStream_t st, bool one_wave_columns = false) {
   const int NBK = (N + 15) >> 4, nt = NBK * (NBK + 1) / 2;
   hipLaunchKernelGGL(tri_diag_inverse_kernel, dim3(NBK, batch), dim3(64), 0, st, N, U, ldu, Ui, ldi, u_stride, ui_stride);
   MCP_LAUNCH_CHECK();
-  MCP_ENSURE_MAX_LDS(tri_inverse_cols_kernel);
-  hipLaunchKernelGGL(tri_inverse_cols_kernel, dim3(NBK, batch), dim3(64), sizeof(double) * 256 * (size_t)NBK, st, N, U, ldu, Ui, ldi, u_stride,
-                     ui_stride);
+  if (one_wave_columns) {
+    MCP_ENSURE_MAX_LDS(tri_inverse_cols_kernel);
+    hipLaunchKernelGGL(tri_inverse_cols_kernel, dim3(NBK, batch), dim3(64), sizeof(double) * 256 * (size_t)NBK, st, N, U, ldu, Ui, ldi, u_stride,
+                       ui_stride);
+  } else {
+    MCP_ENSURE_MAX_LDS(tri_inverse_cols4_kernel);
+    hipLaunchKernelGGL(tri_inverse_cols4_kernel, dim3(NBK, batch), dim3(256), sizeof(double) * 256 * (size_t)(NBK + 3), st, N, U, ldu, Ui, ldi,
+                       u_stride, ui_stride);
+  }
   MCP_LAUNCH_CHECK();
   hipLaunchKernelGGL(kinv_tiles_kernel, dim3((nt + 3) / 4, batch), dim3(256), 0, st, N, Ui, ldi, Kinv, ldk, ui_stride, k_stride);
   MCP_LAUNCH_CHECK();
@@ -1394,7 +1555,7 @@ extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32
   if (!A || !logdet || !status || N <= 0 || lda < N) return MCP_ERR_ARG;
   if (N > 1152) return MCP_ERR_LIMIT;  // row panel [16][N] must fit the 160 KiB LDS
   if (g_chol_mfma && N > 16) {
-    return launch_chol_mfma(g_chol_mfma, N, A, lda, logdet, status, 1, 0, 0, (hipStream_t)stream);
+    return launch_chol_mfma(g_chol_mfma == 3 ? 1 : g_chol_mfma, N, A, lda, logdet, status, 1, 0, 0, (hipStream_t)stream);
   }
   size_t lds = sizeof(double) * ((size_t)CH_NB * (CH_NB + 1) + (size_t)CH_NB * N);
   MCP_ENSURE_MAX_LDS(chol_factor_kernel);
@@ -1406,8 +1567,8 @@ extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32
 extern "C" int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream) {
   if (!U || !Uinv || !Kinv || N <= 0 || ldu < N || ldi < N || ldk < N) return MCP_ERR_ARG;
   if (N > 16384) return MCP_ERR_LIMIT;
-  if (g_chol_mfma == 1 && N > 16 && N <= 1152)
-    return launch_inverse_mfma(N, U, ldu, Uinv, ldi, Kinv, ldk, 1, 0, 0, 0, (hipStream_t)stream);
+  if ((g_chol_mfma == 1 || g_chol_mfma == 3) && N > 16 && N <= 1152)  // (3: the one-wave-per-column form of the inverse)
+    return launch_inverse_mfma(N, U, ldu, Uinv, ldi, Kinv, ldk, 1, 0, 0, 0, (hipStream_t)stream, g_chol_mfma == 3);
   if (g_chol_mfma && N > 16 && N <= 1152)  // (2: the round-3 block-diagonal sweep of one workgroup, kept as a comparison form)
     hipLaunchKernelGGL(tri_inverse_block_kernel, dim3(1), dim3(CM_NT), 0, (hipStream_t)stream, N, U, ldu, Uinv, ldi, (size_t)0, (size_t)0);
   else if (N <= 64 * TW_KM)
@@ -1837,7 +1998,7 @@ extern "C" int mcp_nll_epoch(int G, const mcp_nll_gp* gps, int N, int D, int pol
                      ws, G, L);
   MCP_LAUNCH_CHECK();
   {
-    const int rc = launch_chol_mfma(g_chol_mfma ? g_chol_mfma : 1, N, g0 + L.K, N, g0 + L.logdet, status, G, L.per_gp, L.per_gp, st);
+    const int rc = launch_chol_mfma(g_chol_mfma == 2 ? 2 : 1, N, g0 + L.K, N, g0 + L.logdet, status, G, L.per_gp, L.per_gp, st);
     if (rc != MCP_OK) return rc;
   }
   {

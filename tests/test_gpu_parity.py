@@ -86,7 +86,7 @@ def test_cholesky_sizes():
         assert abs(float(logdet) - np.linalg.slogdet(K)[1]) < 1e-10 * max(1.0, abs(np.linalg.slogdet(K)[1]))
 
 
-@pytest.mark.parametrize("mfma", [1, 2, 0])
+@pytest.mark.parametrize("mfma", [1, 3, 2, 0])
 def test_cholesky_and_inverse_kernels_both_forms(mfma):
     """The MFMA-blocked Cholesky / triangular inverse (1: the left-looking factorization and column-parallel inverse of round 4, 2: the
     right-looking / block-diagonal forms of round 3) and the round-1/2 forms behind them (mcp_debug_set_chol_mfma), at
