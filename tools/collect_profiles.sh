@@ -30,6 +30,16 @@ for w in c1 c3 c5; do
 done
 run "c3 mfma" rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/c3_mfma" -o c3 -- $B --workload c3 --steps 3 --warmup 1 > "$OUT/c3_mfma.log" 2>&1
 run "c5 mfma" rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/c5_mfma" -o c5 -- $B --workload c5 --steps 2 --warmup 1 > "$OUT/c5_mfma.log" 2>&1
+# GP training epoch (round 4): per-kernel statistics at the cart-pole and the UR5 shape, the factorisation kernels alone, and -- when the
+# CLX_STAMPS experiment build is there (python mc-pilco_amd/build.py --variant-gp stamps CLX_STAMPS) -- the Cholesky's cycles per block row
+run "fit c1 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/fit_c1_stats" -o fit_c1 -- python3 $R/tools/time_fit_model.py 300 100 > "$OUT/fit_c1_stats.log" 2>&1
+run "fit ur5 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/fit_ur5_stats" -o fit_ur5 -- python3 $R/tools/time_fit_ur5.py 100 > "$OUT/fit_ur5_stats.log" 2>&1
+run "chol times" python3 $R/tools/time_chol.py 300 400 500 600 1000 > "$OUT/chol_times.txt" 2>&1
+if [ -f $R/mc-pilco_amd/libmcpilco_hip_stamps.so ]; then
+  for n in 300 400; do
+    MCPILCO_HIP_LIB=$R/mc-pilco_amd/libmcpilco_hip_stamps.so python3 $R/tools/chol_stamps.py $n > "$OUT/chol_stamps_n$n.txt" 2>&1 || exit 1
+  done
+fi
 # keep what is cited: the per-kernel statistics, and of the counter passes only the rollout kernels' rows
 for f in $(find "$OUT" -name "*counter_collection.csv"); do
   head -1 "$f" > "$f.rollout" && grep "rollout_" "$f" >> "$f.rollout"; rm -f "$f"

@@ -25,6 +25,15 @@ for cfg in list(SHAPES) + ["c1_script", "c2_script", "pms_script", "ur5_script"]
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_%s_stamps.txt" % (rnd, cfg)))
 
+for cfg in ("fit_c1", "fit_ur5"):  # GP training epochs (round 4)
+    f = os.path.join(src, cfg + "_stats", cfg + "_kernel_stats.csv")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, cfg)))
+for name in ("chol_times.txt", "chol_stamps_n300.txt", "chol_stamps_n400.txt"):
+    f = os.path.join(src, name)
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, "%s_%s" % (rnd, name)))
+
 out = {"_note": "forward rollout kernel, HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (gfx950 "
                 "FETCH_SIZE correction x2, MI355X_MICROARCH.md), mean over the steady-state launches; *_alg = algorithmic bytes per launch "
                 "(16*(S+U+G) B per particle-step x M x T, SURVEY 8d)"}
