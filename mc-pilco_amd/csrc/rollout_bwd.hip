@@ -12,7 +12,7 @@
 // policy features) are wave64 DPP sums meeting in LDS.  Workgroup partial gradients go to a slab
 // that grad_reduce_kernel sums in a fixed order (deterministic, no atomics).
 //
-// Two kernels:  rollout_bwd_kernel<PFM, UM, MAXNT, WPE, PB, PMS>  -- the general sweep (any class, 1 / 2 / 4 particles per workgroup, measurement
+// Two kernels:  rollout_bwd_kernel<PFM, UM, MAXNT, WPE, PB, PMS>  -- the general sweep (any class, 1 / 2 / 4 (wide class: 8) particles per workgroup, measurement
 // models), and  rollout_bwd_lat_kernel<GM>  -- narrow plain / angle policies on swarms up to 3072 particles: one chain wave per particle working
 // from registers beside RBF waves that prepare their step ahead of the barrier.
 #include "rollout_common.h"
@@ -607,19 +607,24 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       if (drop && !a.nz.masks) {
         const int cq = b & 3;
         const int bq = imin(b, B - 1) >> 2;
-        const u32x4 rnd = philox_draw(a.nz, imin(mbase + (cq % PB), M - 1), t, MCP_STREAM_MASK, (uint32_t)bq);
-        if (PB == 1) {
-          kw[0] = cq == 0 ? rnd.x : cq == 1 ? rnd.y : cq == 2 ? rnd.z : rnd.w;
-        } else {
+        // (PB = 8: two rounds, slots cq and cq + 4)
+        constexpr int PQ = PB < 4 ? PB : 4;  // slots served by one round of the quad
 #pragma unroll
-          for (int k4 = 0; k4 < 4; ++k4) {
-            const int ws = (cq + k4) & 3;
-            const uint32_t snd = ws == 0 ? rnd.x : ws == 1 ? rnd.y : ws == 2 ? rnd.z : rnd.w;
-            const int src = (cq - k4) & 3;  // lane of the quad that drew for slot src % PB; it sends word[cq]
-            const uint32_t rcv = quad_from_back(snd, k4);
+        for (int rd = 0; rd < (PB + 3) / 4; ++rd) {
+          const u32x4 rnd = philox_draw(a.nz, imin(mbase + 4 * rd + (cq % PQ), M - 1), t, MCP_STREAM_MASK, (uint32_t)bq);
+          if (PB == 1) {
+            kw[0] = cq == 0 ? rnd.x : cq == 1 ? rnd.y : cq == 2 ? rnd.z : rnd.w;
+          } else {
 #pragma unroll
-            for (int p = 0; p < PB; ++p)
-              if ((src % PB) == p) kw[p] = rcv;
+            for (int k4 = 0; k4 < 4; ++k4) {
+              const int ws = (cq + k4) & 3;
+              const uint32_t snd = ws == 0 ? rnd.x : ws == 1 ? rnd.y : ws == 2 ? rnd.z : rnd.w;
+              const int src = (cq - k4) & 3;  // lane of the quad that drew for slot 4 rd + src % PQ; it sends word[cq]
+              const uint32_t rcv = quad_from_back(snd, k4);
+#pragma unroll
+              for (int p = 0; p < PQ; ++p)
+                if ((src % PQ) == p) kw[4 * rd + p] = rcv;
+            }
           }
         }
       }
@@ -1456,10 +1461,17 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   // (two 256-thread workgroups per CU are resident: one particle per workgroup while M of them fit in one round, then 2, then 4;
   //  measured, tools/sweep_bwd_particles.py: M=800 1.74 / 1.34 / 1.92 ms, M=2000 3.24 / 2.51 / 2.07 ms for 1 / 2 / 4)
   int PB = g_force_bwd_pb ? g_force_bwd_pb : (M > 2816 ? 4 : (M > 512 ? 2 : 1));  // (round 3, after the RBF stage's diet: 2 particles win up to ~2800, tools/sweep_bwd_particles.py)
-  if (!g_force_bwd_pb && (PF > 16 || U > 4)) PB = M > 1024 ? 4 : 1;  // wide policies: four particles per sweep on large swarms where the
+  if (!g_force_bwd_pb && (PF > 16 || U > 4)) {
+    PB = M > 1024 ? 4 : 1;
+    // eight per sweep (round 4) where that saves resident rounds: a 512-thread workgroup of this class has a CU to itself (256 per round), and a
+    // step of eight particles costs 1.86 x a step of four (tools/phase_stamps.py c5: 64.7 k vs 34.7 k cycles -- the RBF stage is per particle) --
+    // M = 2000: one round instead of two, 8.74 -> 8.1 ms; M = 3072: two instead of three, slower (16.8 vs 13.6 ms)
+    const int r4 = (((M + 3) / 4) + 255) / 256, r8 = (((M + 7) / 8) + 255) / 256;
+    if (PB == 4 && bwd_threads(policy->B) > 256 && 1.86 * r8 < (double)r4) PB = 8;  // (the 512-thread instantiation: > 256 basis functions)
+  }  // wide policies: eight (round 4; four before) particles per sweep on large swarms where the
                                                                       // instantiation exists (> 256 basis functions), else two
                                                                       // (tools/time_bwd.py, UR5 shape, M = 2000, T = 300: 18.1 / 15.5 / 14.5 ms for 1 / 2 / 4)
-  if (PB != 1 && PB != 2 && PB != 4) return MCP_ERR_ARG;
+  if (PB != 1 && PB != 2 && PB != 4 && PB != 8) return MCP_ERR_ARG;
   int NT = imax(bwd_threads(policy->B), 64 * PB);
   int rc = MCP_ERR_LIMIT;
   g_last_bwd_lean = 0;
@@ -1503,7 +1515,11 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
       if (NT <= 256)
         rc = PB == 2 ? launch_bwd<24, 6, 256, BW_WPE_A, 2>(a, NT, st) : PB == 1 ? launch_bwd<24, 6, 256, BW_WPE_A, 1>(a, NT, st) : MCP_ERR_LIMIT;
       else
-        rc = PB == 4 ? launch_bwd<24, 6, 512, 2, 4>(a, NT, st) : PB == 2 ? launch_bwd<24, 6, 512, 2, 2>(a, NT, st) : PB == 1 ? launch_bwd<24, 6, 512, 2, 1>(a, NT, st) : MCP_ERR_LIMIT;
+        rc = PB == 8   ? launch_bwd<24, 6, 512, 2, 8>(a, NT, st)
+             : PB == 4 ? launch_bwd<24, 6, 512, 2, 4>(a, NT, st)
+             : PB == 2 ? launch_bwd<24, 6, 512, 2, 2>(a, NT, st)
+             : PB == 1 ? launch_bwd<24, 6, 512, 2, 1>(a, NT, st)
+                       : MCP_ERR_LIMIT;
     } else {
       if (NT <= 256)
         rc = PB == 2 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 256, BW_WPE_A, 2>(a, NT, st)

@@ -220,6 +220,39 @@ def test_every_variant_against_the_oracle_at_real_training_set_sizes(key, code, 
         assert float((q.grad.cpu().reshape(g.shape) - g).abs().max()) < 1e-6 * float(g.abs().max()), k
 
 
+@pytest.mark.parametrize("mode", ["masks", "philox"])
+def test_eight_particles_per_backward_sweep_on_the_wide_class(mode):
+    """Round 4: `rollout_bwd_kernel<24, 6, 512, 2, 8>` -- the UR5 class sweeps EIGHT particles per workgroup on large swarms (250 workgroups
+    for C5's 2000 particles: one resident round instead of two).  With recorded masks the gradients are the oracle's (1e-9, as for the other
+    widths); with Philox noise -- where the four lanes of a quad now draw twice per step and pass the words round -- they are those of the
+    one-particle sweep on the same forward pass (a wrong keep bit anywhere changes them in the first digits)."""
+    from gpu_helpers import dev, forced_variant
+    from mc_pilco_amd import hipabi, ops
+
+    o = oracle_answer("ur5_400")
+    w = hip_workload_on_oracle_operands("ur5_400")
+    if mode == "masks":
+        nz = ops.NoiseSpec(eps=o["eps"].to(dev()).contiguous(), masks=o["masks"].to(torch.uint8).to(dev()).contiguous())
+    else:
+        nz = ops.NoiseSpec(seed=5, call=3)
+    grads = {}
+    for pb in (1, 8):
+        for q in w.params:
+            q.grad = None
+        with forced_variant(16, bwd_particles=pb):
+            st, inp, status = ops.rollout(w.model, w.policy, nz, o["x0"].to(dev()), w.T, o["p"])
+            c, s = ops.expected_cost(w.cost, st)
+            c.backward()
+        assert int(status.item()) == 0
+        grads[pb] = [q.grad.detach().cpu().clone() for q in w.params]
+    for a, b in zip(grads[1], grads[8]):
+        assert float((a - b).abs().max()) < 1e-11 * float(a.abs().max())
+    if mode == "masks":
+        for g8, k in zip(grads[8], ["log_ls", "centers", "weight"]):
+            ref = o["grads"][k]
+            assert float((g8.reshape(ref.shape) - ref).abs().max()) < 1e-9 * float(ref.abs().max()), k
+
+
 # -------------------------------------------------------------------------------------------------------------------------
 # configs[4] at its stated size
 # -------------------------------------------------------------------------------------------------------------------------
