@@ -18,6 +18,9 @@ void mcp_debug_set_particles_per_wg(int p);
 int mcp_debug_last_particles_per_wg(void);
 /* GP-sharded launch forms: -1 automatic, 0 never, 1 whenever the grid fits the device */
 void mcp_debug_set_gp_sharding(int mode);
+/* the policy of the GP-sharded 16-particle kernel: -1 automatic, 0 every member of a cluster evaluates all of it, 1 split over the members
+ * whenever the shape allows it (partial sums W phi exchanged per step) */
+void mcp_debug_set_policy_split(int mode);
 /* number of GP-sharded launches the last forward call made (0 = unsharded) */
 int mcp_debug_last_gp_sharded(void);
 /* the latency-lean GP-sharded kernel of narrow SE-only models (rollout_fwd_lat_kernel): -1 / 1 wherever it applies, 0 never */

@@ -32,6 +32,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // hand-off buffer of the GP-sharded forward launch (rollout_fwd.hip): [clusters][2][G][P][2] granules of 8 bytes, clusters * P < M + 16 (a launch per chunk, each rounded up to whole clusters)
 static inline size_t rollout_xch_bytes(int M, int G) { return ((size_t)(M + 16) * 2 * G * 2 * sizeof(unsigned long long) + 15) & ~(size_t)15; }
+// partial policy sums of the GP-sharded 16-particle kernel: clusters x 2 (step parity) x members (<= G) x 16 particles x U x 2 granules
+static inline size_t rollout_uxch_bytes(int M, int G, int U) { return ((size_t)(M + 16) * 2 * G * U * 2 * sizeof(unsigned long long) + 15) & ~(size_t)15; }
 
 // Packed phase-J operands of the 16-particle kernel's wide classes (D + 1 > 16; rollout_fwd_tile.hip, tile_xj_pack_kernel): per GP two
 // variants ([X^T; 1] and its columns scaled by alpha_j) x two row tiles x (NpadMax / 8) x 64 lanes x 2 doubles, placed behind the hand-off

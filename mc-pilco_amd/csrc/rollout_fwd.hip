@@ -1203,6 +1203,9 @@ static int g_last_sharded = 0;  // test hook: number of GP-sharded launches the 
 static int g_gp_max_launches = 2;  // a swarm goes out GP-sharded when it fits this many resident grids (cart-pole shape, forward ms,
                                    // tools/sweep_fwd_swarm.py: M=1024 two launches 4.9 vs 6.5 unsharded; M=1280 three launches 7.3 vs 6.9 on the tile kernel)
 extern "C" void mcp_debug_set_gp_sharding(int mode) { g_gp_sharding = mode; }
+static int g_policy_split = -1;  // test hook: -1 automatic, 0 = every member of a cluster of the GP-sharded 16-particle kernel evaluates the whole policy
+                                 // (rounds 2-3), 1 = the split whenever the shape allows it
+extern "C" void mcp_debug_set_policy_split(int mode) { g_policy_split = mode; }
 extern "C" int mcp_debug_last_gp_sharded(void) { return g_last_sharded; }
 static int g_fwd_lean = -1;  // test hook: -1 / 1 the latency-lean GP-sharded kernel wherever it applies, 0 never (the general one)
 static int g_last_lean = 0;  // test hook: 1 when the last forward call ran the latency-lean kernel
@@ -1320,6 +1323,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   a.m_off = 0;
   a.m_cnt = M;
   a.gsh_cs = 0;
+  a.uxch = nullptr;
   hipStream_t st = (hipStream_t)stream;
   // configuration search: most particles per workgroup first, operands in LDS if they fit, all GPs per pass if they fit
   int P0 = g_force_ppw ? g_force_ppw : pick_particles_per_wg(M);
@@ -1389,6 +1393,18 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
       a.nclusters = ncl;
       a.gsh_cs = tile_sharded_cluster(model, policy, a.NpadMax, M, T);
       if (hipMemsetAsync(workspace, 0, rollout_xch_bytes(M, model->G), st) != hipSuccess) return MCP_ERR_LAUNCH;
+      {  // the policy split over the members of a cluster (every member needs a tile of 16 basis functions)
+        const size_t uoff = rollout_xch_bytes(M, model->G) + rollout_xj_bytes(model) + rollout_kt_bytes(model);
+        const size_t ub = (size_t)ncl * 2 * a.gsh_cs * 16 * model->U * 2 * sizeof(unsigned long long);
+        // automatic: clusters of three or more on small swarms (the UR5 launch script's M = 200: six members, the policy 1/6 of the step;
+        // ur5_script 11.2 -> 10.5 ms).  Not with two members -- the exchange costs what half a cart-pole policy does -- and not on large
+        // swarms, whose halves run another cluster size: they would no longer reproduce the whole bit for bit (tests: *_full_size_properties)
+        const bool want = g_policy_split == 1 || (g_policy_split < 0 && a.gsh_cs >= 3 && M <= 512);
+        if (want && (policy->B + 15) / 16 >= a.gsh_cs && workspace_bytes >= uoff + rollout_uxch_bytes(M, model->G, model->U)) {
+          a.uxch = (unsigned long long*)((char*)workspace + uoff);
+          if (hipMemsetAsync(a.uxch, 0, ub, st) != hipSuccess) return MCP_ERR_LAUNCH;
+        }
+      }
       const int rc = launch_fwd_tile_sharded(a, st);
       if (rc == MCP_OK) {
         g_last_ppw = 16;
@@ -1397,6 +1413,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
       }
       if (rc != MCP_ERR_LIMIT) return rc;
       a.xch = nullptr;
+      a.uxch = nullptr;
       a.nclusters = 0;
     }
   }

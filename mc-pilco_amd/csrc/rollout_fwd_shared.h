@@ -55,6 +55,10 @@ struct FwdArgs {
   unsigned long long* xch;
   int nclusters;
   int gsh_cs;        // workgroups per cluster in the GP-sharded 16-particle kernel (each takes G / gsh_cs consecutive GPs)
+  // GP-sharded 16-particle kernel, round 4: the policy's basis functions are SPLIT over the gsh_cs workgroups of a cluster instead of being
+  // evaluated by each of them; the partial pre-squash sums W phi (16 particles x U) go round through granules
+  //   uxch[cluster][t & 1][member][p * U + k][half]   (zeroed per launch; null: every member evaluates the whole policy)
+  unsigned long long* uxch;
   int m_off, m_cnt;  // the particles [m_off, m_off + m_cnt) of the swarm that this launch covers (a swarm too large for one
                      // resident GP-sharded grid goes out as a few launches back to back on the stream)
 };

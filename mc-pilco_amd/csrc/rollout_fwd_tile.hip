@@ -753,7 +753,7 @@ __device__ __forceinline__ void tile_polr_consume(const double (&cb)[NQ], const 
 }
 template <int NQ, int UM, int DM>
 __device__ __forceinline__ void tile_policy_reg(const FwdArgs& a, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* upart,
-                                            int B, int PF, int U, int t, int m0, int wv, int lane, bool drop, double keep_scale, uint32_t drop_thr) {
+                                            int B, int PF, int U, int t, int m0, int wv, int lane, bool drop, double keep_scale, uint32_t drop_thr, int tb, int te) {
   const int kk = lane >> 4, n = lane & 15;
   TilePolRConst<NQ> c;
   double sss = 0.0;
@@ -778,18 +778,18 @@ __device__ __forceinline__ void tile_policy_reg(const FwdArgs& a, const double* 
   for (int r = 0; r < 4; ++r)
 #pragma unroll
     for (int k = 0; k < UM; ++k) uacc[r][k] = 0.0;
-  const int ntile = (B + 15) >> 4;
+  const int ntile = te - tb;  // this workgroup's tiles of 16 basis functions: [tb, te)
   if (wv < ntile) {
     const int nt = (ntile - wv + RF_NW - 1) / RF_NW;
     double c0[NQ], c1[NQ], w0[UM], w1[UM];
-    tile_polr_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, wv, kk, n);
+    tile_polr_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, tb + wv, kk, n);
     for (int sI = 0; sI + 1 < nt; sI += 2) {
-      tile_polr_load<NQ, UM>(c1, w1, cen, wgt, B, PF, U, wv + RF_NW * (sI + 1), kk, n);
-      tile_polr_consume<NQ, UM, DM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, uacc);
-      tile_polr_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
-      tile_polr_consume<NQ, UM, DM>(c1, w1, c, a, B, U, t, m0, wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
+      tile_polr_load<NQ, UM>(c1, w1, cen, wgt, B, PF, U, tb + wv + RF_NW * (sI + 1), kk, n);
+      tile_polr_consume<NQ, UM, DM>(c0, w0, c, a, B, U, t, m0, tb + wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, uacc);
+      tile_polr_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, tb + wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
+      tile_polr_consume<NQ, UM, DM>(c1, w1, c, a, B, U, t, m0, tb + wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
     }
-    if (nt & 1) tile_polr_consume<NQ, UM, DM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
+    if (nt & 1) tile_polr_consume<NQ, UM, DM>(c0, w0, c, a, B, U, t, m0, tb + wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
   }
   // sum over the 16 basis lanes of each row; lane 15 of row kq holds the partial of particles kq + 4 r
 #pragma unroll
@@ -888,7 +888,7 @@ __device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const d
 template <int NQ, int DM>
 __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* ptile,
                                             double* upart, int B, int PF, int U, int t, int m0, int wv, int lane, bool drop, double keep_scale,
-                                            uint32_t drop_thr) {
+                                            uint32_t drop_thr, int tb, int te) {
   const int kk = lane >> 4, n = lane & 15;
   TilePolConst<NQ> c;
   double sss = 0.0;
@@ -909,18 +909,18 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
 #pragma unroll
   for (int r = 0; r < 4; ++r) c.ss4[r] = wslot[kk + 4 * r];
   v4d uacc = (v4d){0.0, 0.0, 0.0, 0.0};  // rows: particles kq + 4 r, column n: input k = n
-  const int ntile = (B + 15) >> 4;
+  const int ntile = te - tb;  // this workgroup's tiles of 16 basis functions: [tb, te)
   if (wv < ntile) {
     const int nt = (ntile - wv + RF_NW - 1) / RF_NW;
     double c0[NQ], c1[NQ], w0[4], w1[4];
-    tile_pol_load<NQ>(c0, w0, cen, wgt, B, PF, U, wv, kk, n);
+    tile_pol_load<NQ>(c0, w0, cen, wgt, B, PF, U, tb + wv, kk, n);
     for (int sI = 0; sI + 1 < nt; sI += 2) {
-      tile_pol_load<NQ>(c1, w1, cen, wgt, B, PF, U, wv + RF_NW * (sI + 1), kk, n);
-      tile_pol_consume<NQ, DM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
-      tile_pol_load<NQ>(c0, w0, cen, wgt, B, PF, U, wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
-      tile_pol_consume<NQ, DM>(c1, w1, c, a, B, U, t, m0, wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
+      tile_pol_load<NQ>(c1, w1, cen, wgt, B, PF, U, tb + wv + RF_NW * (sI + 1), kk, n);
+      tile_pol_consume<NQ, DM>(c0, w0, c, a, B, U, t, m0, tb + wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
+      tile_pol_load<NQ>(c0, w0, cen, wgt, B, PF, U, tb + wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
+      tile_pol_consume<NQ, DM>(c1, w1, c, a, B, U, t, m0, tb + wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
     }
-    if (nt & 1) tile_pol_consume<NQ, DM>(c0, w0, c, a, B, U, t, m0, wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
+    if (nt & 1) tile_pol_consume<NQ, DM>(c0, w0, c, a, B, U, t, m0, tb + wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
   }
   if (n < U) {
 #pragma unroll
@@ -936,7 +936,8 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
 // function made the register allocator spill the small path's long-lived values for the benefit of the big one.
 // CLS: 0 = cart-pole class (D <= 7, policy features <= 8, inputs <= 2, N <= 512), 1 = UR5 class (<= 24, <= 24, <= 6, N <= 512), 2 = any
 // PMS: the policy is evaluated on a simulated measurement (mcp_meas, MC_PILCO4PMS.apply_policy) instead of the true state
-// GSH: a.gsh_cs workgroups per 16-particle tile, each evaluates G / gsh_cs consecutive GPs (and, redundantly, the policy); they hand
+// GSH: a.gsh_cs workgroups per 16-particle tile, each evaluates G / gsh_cs consecutive GPs and (round 4, a.uxch) its share of the policy's
+// basis functions -- rounds 2-3: the whole policy, redundantly; they hand
 // each other the sampled increments once per step exactly as the small-tile kernel's GP-sharded launch does (rollout_fwd.hip).
 // XL: X^T and alpha of every GP are staged in LDS once per launch (cart-pole class, when the layout has the room): phases K and J
 // then take their small operands with LDS latency instead of an L2 round trip per tile / batch
@@ -967,10 +968,10 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   GpL* gpl = reinterpret_cast<GpL*>(smem + L.gpl);
   double* kpar = smem + L.kpar;
   int cluster = blockIdx.x, gbeg = 0, gend = G;  // the GPs [gbeg, gend) this workgroup evaluates
+  int myc = 0;                                   // ... as member myc of its cluster of CS workgroups
+  const int CS = GSH ? a.gsh_cs : 1;
   if (GSH) {  // blocks b and b + 8 share an XCD: the members of a cluster sit 8 apart (speed only)
-    const int CS = a.gsh_cs;
     const int b = blockIdx.x, grp = b / (8 * CS), r = b - grp * 8 * CS;
-    int myc;
     if (8 % CS == 0) {
       // Member c of every cluster goes to the XCDs [c * 8/CS, (c+1) * 8/CS) (blocks are dealt round-robin over the 8 XCDs), so
       // an XCD's L2 only ever holds the Kinv of ONE GP range: the UR5 shape needs 3.8 MB per range against 4 MB of L2 -- with both
@@ -987,6 +988,10 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     gend = ((myc + 1) * G) / CS;
   }
   const bool writer = !GSH || gbeg == 0;  // states / inputs are identical in the workgroups of a cluster: one of them stores
+  // the policy: member myc evaluates the tiles [ptb, pte) of 16 basis functions and the members add their partial sums (a.uxch), or everyone all of it
+  const bool psplit = GSH && a.uxch != nullptr;
+  const int pnt = (B + 15) >> 4;
+  const int ptb = psplit ? (myc * pnt) / CS : 0, pte = psplit ? ((myc + 1) * pnt) / CS : pnt;
   int* abortw = reinterpret_cast<int*>(dl + P * G);
   if (GSH && tid0 == 0) *abortw = 0;
   const int m0 = cluster * P;
@@ -1169,18 +1174,18 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       double* pt_w = smem + L.ptile + wv * 16 * TL_PHP;
       if (CLS == 0) {
         if (dm == 1)
-          tile_policy_reg<NG, 2, 1>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+          tile_policy_reg<NG, 2, 1>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
         else if (dm == 2)
-          tile_policy_reg<NG, 2, 2>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+          tile_policy_reg<NG, 2, 2>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
         else
-          tile_policy_reg<NG, 2, 0>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+          tile_policy_reg<NG, 2, 0>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
       } else {
         if (dm == 1)
-          tile_policy<NG, 1>(a, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+          tile_policy<NG, 1>(a, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
         else if (dm == 2)
-          tile_policy<NG, 2>(a, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+          tile_policy<NG, 2>(a, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
         else
-          tile_policy<NG, 0>(a, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr);
+          tile_policy<NG, 0>(a, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
       }
     }
     lds_barrier();
@@ -1192,6 +1197,40 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       double sacc = 0.0;
 #pragma unroll
       for (int w = 0; w < RF_NW; ++w) sacc += up[(w * P + p) * U + k];
+      if (psplit) {
+        // this member's partial sum goes out as two granules; the members' sums are added in member order, so every workgroup of the
+        // cluster ends up with the same bits
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(sacc);
+        gu64_t ub = (gu64_t)a.uxch + ((size_t)(cluster * 2 + (t & 1)) * CS) * (size_t)(P * U * 2);
+        gu64_t mine = ub + (size_t)myc * (P * U * 2) + 2 * tid;
+        store_granule(mine, (unsigned)t + 1u, (unsigned)bits);
+        store_granule(mine + 1, (unsigned)t + 1u, (unsigned)(bits >> 32));
+        // all partners' granules are requested together and re-read until every tag matches: one L2 round trip, not one per partner
+        unsigned lo[MCP_MAX_GP], hi[MCP_MAX_GP];
+        bool ok = false;
+        for (unsigned spins = 0; spins < RF_SPIN_LIMIT && !ok; ++spins) {
+          ok = true;
+#pragma unroll
+          for (int r = 0; r < MCP_MAX_GP; ++r) {
+            if (r < CS && r != myc) {
+              gu64_t src = ub + (size_t)r * (P * U * 2) + 2 * tid;
+              const unsigned long long x0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const unsigned long long x1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              ok = ok && (unsigned)(x0 >> 32) == (unsigned)t + 1u && (unsigned)(x1 >> 32) == (unsigned)t + 1u;
+              lo[r] = (unsigned)x0;
+              hi[r] = (unsigned)x1;
+            }
+          }
+          if (!ok) __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) *abortw = 1;
+        double tot = 0.0;
+#pragma unroll
+        for (int r = 0; r < MCP_MAX_GP; ++r) {
+          if (r < CS) tot += r == myc ? sacc : __longlong_as_double((long long)(((unsigned long long)hi[r] << 32) | lo[r]));
+        }
+        sacc = tot;
+      }
       if (pl.bias) sacc += pl.bias[k];
       const double um = pl.u_max[k];
       const double u = pl.squash ? um * fast_tanh(sacc / um) : sacc;

@@ -123,6 +123,7 @@ _SIGS = {
     "mcp_debug_set_fwd_mode": (None, [C.c_int, C.c_int]),
     "mcp_debug_set_bwd_stamp_buffer": (None, [dptr]),
     "mcp_debug_set_gp_sharding": (None, [C.c_int]),
+    "mcp_debug_set_policy_split": (None, [C.c_int]),
     "mcp_debug_last_gp_sharded": (C.c_int, []),
     "mcp_debug_set_fwd_lean": (None, [C.c_int]),
     "mcp_debug_set_chol_mfma": (None, [C.c_int]),

@@ -220,6 +220,45 @@ def test_every_variant_against_the_oracle_at_real_training_set_sizes(key, code, 
         assert float((q.grad.cpu().reshape(g.shape) - g).abs().max()) < 1e-6 * float(g.abs().max()), k
 
 
+@pytest.mark.parametrize("key", ["ur5_400", "sep2_300"])
+@pytest.mark.parametrize("mode", ["masks", "philox"])
+def test_policy_split_over_the_cluster_of_the_gp_sharded_tile_kernel(key, mode):
+    """Round 4: in the GP-sharded 16-particle kernel the members of a cluster no longer evaluate the whole policy each; member c takes its
+    share of the basis functions and the partial sums W phi go round (`FwdArgs.uxch`).  Same states / inputs / cost as with the split off
+    (`mcp_debug_set_policy_split(0)`: the round-3 form) up to the summation order of W phi, identical dropout bits in Philox
+    mode (a wrong keep bit shows in the first digits), bitwise reproducible, and against the oracle at 1e-9 with recorded masks."""
+    from gpu_helpers import dev, forced_variant
+    from mc_pilco_amd import hipabi, ops
+
+    o = oracle_answer(key)
+    w = hip_workload_on_oracle_operands(key)
+    if mode == "masks":
+        nz = ops.NoiseSpec(eps=o["eps"].to(dev()).contiguous(), masks=o["masks"].to(torch.uint8).to(dev()).contiguous())
+    else:
+        nz = ops.NoiseSpec(seed=11, call=2)
+    L = hipabi.lib()
+    out = {}
+    try:
+        for split in (1, 0, 1):
+            L.mcp_debug_set_policy_split(1 if split else 0)
+            with forced_variant(116) as fv, torch.no_grad():
+                st, inp, status = ops.rollout(w.model, w.policy, nz, o["x0"].to(dev()), w.T, o["p"])
+                assert L.mcp_debug_last_gp_sharded() == 1, "the shape was expected to run GP-sharded"
+            assert int(status.item()) == 0
+            if split in out:
+                assert torch.equal(out[split][0], st) and torch.equal(out[split][1], inp)  # bitwise reproducible
+            out[split] = (st.clone(), inp.clone())
+    finally:
+        L.mcp_debug_set_policy_split(-1)
+    # the first step differs by the summation order of W phi alone; later steps by what Kinv (condition 5e5) makes of it -- the same
+    # distance either form keeps from the oracle
+    assert float((out[1][1][0] - out[0][1][0]).abs().max()) < 1e-13
+    assert float((out[1][0] - out[0][0]).abs().max()) < 2e-9 and float((out[1][1] - out[0][1]).abs().max()) < 4e-9
+    assert not torch.equal(out[1][1], torch.zeros_like(out[1][1]))
+    if mode == "masks":
+        assert float((out[1][0].cpu() - o["states"]).abs().max()) < 1e-9 and float((out[1][1].cpu() - o["inputs"]).abs().max()) < 2e-9
+
+
 @pytest.mark.parametrize("mode", ["masks", "philox"])
 def test_eight_particles_per_backward_sweep_on_the_wide_class(mode):
     """Round 4: `rollout_bwd_kernel<24, 6, 512, 2, 8>` -- the UR5 class sweeps EIGHT particles per workgroup on large swarms (250 workgroups
