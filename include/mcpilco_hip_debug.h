@@ -29,9 +29,10 @@ void mcp_debug_set_fwd_lean(int mode);
 int mcp_debug_last_fwd_lean(void);
 /* small-tile kernel: xlds -1 automatic / 0 never stage the small operands in LDS; gb = GPs per pass (0 = as many as fit) */
 void mcp_debug_set_fwd_mode(int xlds, int gb);
-/* Cholesky / triangular inverse: 1 (default) the MFMA-blocked kernels, 0 the round-1/2 forms */
+/* Cholesky / triangular inverse: 1 (default) the round-4 MFMA kernels (left-looking factorisation, four-wave inverse columns), 3 the same with
+ * one wave per inverse column, 2 the round-3 forms (right-looking factorisation, block-diagonal sweep of the inverse), 0 the round-1/2 forms */
 void mcp_debug_set_chol_mfma(int on);
-/* backward sweep: particles per workgroup 1 / 2 / 4; 0 = automatic */
+/* backward sweep: particles per workgroup 1 / 2 / 4 (wide 512-thread class: also 8); 0 = automatic */
 void mcp_debug_set_bwd_particles(int pb);
 /* backward sweep of small swarms: -1 (default) the latency-lean kernel where it applies (automatic particle count only), 0 never;
    1 when the last mcp_rollout_bwd ran it */
