@@ -1260,6 +1260,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       const int deg = MAXDEG == 0 ? 0 : __builtin_amdgcn_readfirstlane(gp.deg);
       const double* xt_g = smem + L.xt + g * D * a.NpadMax;  // (XL only)
       const double* al_g = smem + L.al + g * a.NpadMax;
+      const bool wstamp = a.stamps && blockIdx.x == a.stamp_block;  // diagnostic: every wave's own time in phases K and V, slots 16.. / 24..
+      unsigned long long wt0 = wstamp ? clock64() : 0;
       {
         unsigned long long* kdbg = (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr;
         const bool exact = MAXDEG >= 1 && deg == MAXDEG;  // (MAXDEG == 0 has no degree tests to remove)
@@ -1275,8 +1277,10 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
             tile_phase_k<MAXDEG, NG, gptr_t, false>(gp, (gptr_t)gp.Xt, (gptr_t)gp.alpha, Npad, kp, D, z, ks, kv, scr + wv * 16, mup, wv, lane, kdbg);
         }
       }
+      if (wstamp && lane == 0) a.stamps[16 + wv] += clock64() - wt0;
       lds_barrier();
       TL_STAMP(3);
+      wt0 = wstamp ? clock64() : 0;
       // ---- phase V ---------------------------------------------------------------------------
       // Work = 32-row blocks of v x 16-row batches of the summation index.  Wave w takes blocks w, w + 8, ... in full; the
       // last (nblk mod 8) blocks are dealt as ONE contiguous run of batches cut into 8 equal shares, so a share is at most two
@@ -1349,6 +1353,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
             }
           }
         }
+        if (wstamp && lane == 0) a.stamps[24 + wv] += clock64() - wt0;
         lds_barrier();  // every wave is done reading k: v may overwrite it
         TL_STAMP(4);
 #pragma unroll

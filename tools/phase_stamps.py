@@ -51,6 +51,9 @@ else:
 print("workload", name, "T", w.T, "M", w.M, "ppw forced", ppw, "launched", hipabi.lib().mcp_debug_last_particles_per_wg(), "gp-sharded", hipabi.lib().mcp_debug_last_gp_sharded(), "lean", hipabi.lib().mcp_debug_last_fwd_lean(), "total cycles", tot, "-> per step", tot / (w.T - 1))
 print("tile kernel detail (wave 0, per step, all GPs): K setup %.0f, K tiles %.0f | J setup %.0f, J batches %.0f cyc" % tuple(v[i] / (w.T - 1) for i in (12, 13, 14, 15)))
 print("J finish (wave 0, per step, all GPs): wait for the other waves %.0f, park + barrier %.0f, add + barrier %.0f cyc" % tuple(v[i] / (w.T - 1) for i in (9, 10, 11)))
+if hipabi.lib().mcp_debug_last_particles_per_wg() == 16:
+    print("tile kernel, phase K per wave (own time, all GPs):", " ".join("%.0f" % (v[16 + i] / (w.T - 1)) for i in range(8)))
+    print("tile kernel, phase V per wave (own time to the barrier, all GPs):", " ".join("%.0f" % (v[24 + i] / (w.T - 1)) for i in range(8)))
 if hipabi.lib().mcp_debug_last_fwd_lean():
     print("lean kernel, wave 0 per step: S compute (to the barrier) %.0f | F compute (delta, granules, Jacobian stores) %.0f | hand-off poll %.0f | J (own rows) %.0f cyc"
           % tuple(v[i] / (w.T - 1) for i in (15, 9, 10, 12)))
