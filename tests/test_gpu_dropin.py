@@ -213,6 +213,45 @@ def test_marginal_likelihood_and_gradient_match_reference_autograd(golden, name,
     assert checked == (3 if deg == 0 else 3 + deg)
 
 
+@pytest.mark.parametrize("N,D,deg", [(500, 6, 0), (600, 6, 2), (1100, 24, 1)])
+def test_training_epoch_kernels_match_the_single_gp_path_at_large_n(N, D, deg):
+    """`mcp_nll_epoch` (the batched training epoch: Gram tiles, left-looking Cholesky, four-wave inverse columns, LDS-staged gradient rows or, beyond
+    their LDS budget, the row kernel) against `nll_loss_and_grad` (the one-GP path: separate entry points, the row kernel) on the same GP at sizes
+    that take the epoch's other instantiations -- N = 500 the LDS-panel Cholesky with 8 tile slots, 600 the global-operand one, 1100 twelve slots and
+    the gradient fallback: loss and every gradient to 1e-9 (two independent routes to the same numbers), and the epoch with lr = 0 leaves the
+    parameters where they were."""
+    from mc_pilco_amd import nll
+    from mc_pilco_amd.gpr_lib.GP_prior import GP_prior as GP
+    from mc_pilco_amd.gpr_lib.GP_prior import Sparse_GP, Stationary_GP
+    from mc_pilco_amd.gpr_lib.Likelihood import Gaussian_likelihood as Likelihood
+
+    rs = np.random.RandomState(N)
+    X = rs.uniform(-1.0, 1.0, size=(N, D))
+    Y = (np.sin(X[:, :2].sum(1)) + 0.05 * rs.randn(N)).reshape(-1, 1)
+    rbf = dict(rbf_dict(D, 0.8 + 0.6 * rs.rand(D) + 0.3 * D ** 0.5, 0.3), flg_train_lambda=True)
+    with quiet():
+        if deg == 0:
+            gp = Stationary_GP.RBF(**rbf)
+        else:
+            pw = [0.3 * rs.rand(D + 1) if k == 1 else 0.3 * rs.rand(2, D) for k in range(1, deg + 1)]
+            gp = GP.Sum_Independent_GP(Stationary_GP.RBF(**rbf), Sparse_GP.get_Volterra_MPK_GP(**mpk_dict(D, deg, pw)))
+    before = {n: p.detach().clone() for n, p in gp.named_parameters()}
+    loss_a = float(Likelihood.Marginal_log_likelihood().loss_and_grad(gp, T(X), T(Y)))
+    grads_a = {n: p.grad.detach().clone() for n, p in gp.named_parameters() if p.grad is not None}
+    for p in gp.parameters():
+        p.grad = None
+    fit = nll.BatchedFit([gp], T(X), [T(Y)], [1.0], [torch.optim.Adam(gp.parameters(), lr=0.0)], 1, 10 ** 9)
+    assert fit.eligible
+    with quiet():
+        fit.run()
+    assert abs(float(fit.loss[0]) - loss_a) < 1e-9 * abs(loss_a)
+    assert len(grads_a) >= 3
+    for n, p in gp.named_parameters():
+        assert torch.equal(p.detach(), before[n]), n
+        if n in grads_a:
+            assert float((p.grad - grads_a[n]).abs().max()) < 1e-9 * max(1.0, float(grads_a[n].abs().max())), n
+
+
 def test_reinforce_runs_end_to_end():
     """The whole algorithm on the drop-in: exploration on the simulated cart-pole, GP training (fit_model on the device),
     SOD pretrain, policy optimisation with the fused kernels, policy applied to the system -- two short trials."""
