@@ -1722,19 +1722,35 @@ __global__ void nll_prep_kernel(NllBatch b, int G, int N, int D, int deg, int ar
 // on LDS instead of on strided global loads whose latency they could not hide (one thread per entry with both inputs in global memory:
 // 124 us for the six 400 x 400, D = 24 matrices of the UR5 model).  The arithmetic is kern_eval's, operation for operation.
 #define CB_ROWS 16
+// (DEG: the polynomial degree as a template parameter -- as a run-time test inside the unrolled row loop it was a scalar branch behind every LDS
+//  read, each waiting for its own operand: 41 us for what takes 11 without the loop)
+template <int DEG>
 __global__ __launch_bounds__(256) void cov_build_batch_kernel(const mcp_kernel* __restrict__ kns, int N, const double* __restrict__ X,
                                                               double* __restrict__ ws, int G, NllWs L) {
   extern __shared__ __attribute__((aligned(16))) double cb[];
   const int g = blockIdx.z, i0 = blockIdx.y * CB_ROWS, j0 = blockIdx.x * 256, tid = threadIdx.x;
   const mcp_kernel kn = kns[g];
-  const int D = kn.D, deg = kn.poly_deg;
+  const int D = kn.D;
+  constexpr int deg = DEG;
   double* xj = cb;                       // [D][257]
   double* xi = xj + 257 * D;             // [CB_ROWS][D]
   double* par = xi + CB_ROWS * D;        // inv_ls[D] | w1[D + 1] | w20[D] | w21[D]
   const int nj = min(256, N - j0), ni = min(CB_ROWS, N - i0);
-  for (int e = tid; e < nj * D; e += 256) {
-    const int r = e / D, d = e - r * D;
-    xj[d * 257 + r] = X[(size_t)j0 * D + e];
+  for (int base = tid; base < nj * D; base += 8 * 256) {  // (eight loads in flight per thread: four waves alone on a CU hide nothing else)
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = base + u * 256;
+      v[u] = e < nj * D ? X[(size_t)j0 * D + e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = base + u * 256;
+      if (e < nj * D) {
+        const int r = e / D, d = e - r * D;
+        xj[d * 257 + r] = v[u];
+      }
+    }
   }
   for (int e = tid; e < ni * D; e += 256) xi[e] = X[(size_t)i0 * D + e];
   for (int d = tid; d < D; d += 256) {
@@ -1748,30 +1764,41 @@ __global__ __launch_bounds__(256) void cov_build_batch_kernel(const mcp_kernel* 
   const double *inv_ls = par, *w1 = par + D, *w20 = par + 2 * D + 1, *w21 = par + 3 * D + 1;
   double* Kg = nll_gp_base(ws, G, L.per_gp, g) + L.K;
   const double sn2 = kern_sigma_n2(kn), lam = kern_lambda(kn);
-  for (int r = 0; r < ni; ++r) {
-    const double* a = xi + r * D;
-    double dist = 0.0;
-    for (int d = 0; d < D; ++d) {
-      const double q = (a[d] - xj[d * 257 + tid]) * inv_ls[d];
-      dist = fma(q, q, dist);
-    }
-    double k = lam * exp(-dist);
-    if (deg >= 1) {
-      double p1 = w1[D];
-      for (int d = 0; d < D; ++d) p1 = fma(w1[d] * a[d], xj[d * 257 + tid], p1);
-      k += p1;
+  // feature by feature, the CB_ROWS rows side by side: this column's x_jd and the weights are read once per feature instead of once per
+  // (row, feature), and the rows' sums are CB_ROWS independent chains; every sum still runs over d in kern_eval's order
+  double dist[CB_ROWS], p1[CB_ROWS], pa[CB_ROWS], pb[CB_ROWS];
+#pragma unroll
+  for (int r = 0; r < CB_ROWS; ++r) {
+    dist[r] = 0.0;
+    p1[r] = w1[D];
+    pa[r] = pb[r] = 0.0;
+  }
+  for (int d = 0; d < D; ++d) {
+    const double xjd = xj[d * 257 + tid], il = inv_ls[d], wd = w1[d], wa = w20[d], wb = w21[d];
+#pragma unroll
+    for (int r = 0; r < CB_ROWS; ++r) {
+      const double ad = xi[(r < ni ? r : 0) * D + d];
+      const double q = (ad - xjd) * il;
+      dist[r] = fma(q, q, dist[r]);
+      if (deg >= 1) p1[r] = fma(wd * ad, xjd, p1[r]);
       if (deg >= 2) {
-        double pa = 0.0, pb = 0.0;
-        for (int d = 0; d < D; ++d) {
-          const double ab = a[d] * xj[d * 257 + tid];
-          pa = fma(w20[d], ab, pa);
-          pb = fma(w21[d], ab, pb);
-        }
-        k = fma(pa, pb, k);
+        const double ab = ad * xjd;
+        pa[r] = fma(wa, ab, pa[r]);
+        pb[r] = fma(wb, ab, pb[r]);
       }
     }
-    if (i0 + r == j0 + tid) k += sn2;
-    Kg[(size_t)(i0 + r) * N + j0 + tid] = k;
+  }
+#pragma unroll
+  for (int r = 0; r < CB_ROWS; ++r) {
+    if (r < ni) {
+      double k = lam * exp(-dist[r]);
+      if (deg >= 1) {
+        k += p1[r];
+        if (deg >= 2) k = fma(pa[r], pb[r], k);
+      }
+      if (i0 + r == j0 + tid) k += sn2;
+      Kg[(size_t)(i0 + r) * N + j0 + tid] = k;
+    }
   }
 }
 static inline size_t cov_build_batch_lds(int D) { return sizeof(double) * ((size_t)257 * D + (size_t)CB_ROWS * D + 4 * (size_t)D + 2); }
@@ -1808,12 +1835,14 @@ __global__ __launch_bounds__(256) void nll_grad_batch_kernel(const mcp_kernel* _
 // arithmetic is a few microseconds.
 #define NG_NT 1024
 #define NG_KMAX ((4 * MCP_MAX_GPDIM + 3 + NG_NT / 64 - 1) / (NG_NT / 64))  // parameters per wave
+template <int DEG>  // (the polynomial degree at compile time: no scalar branch inside the feature loops)
 __global__ __launch_bounds__(NG_NT) void nll_grad_rows_kernel(const mcp_kernel* __restrict__ kns, int N, const double* __restrict__ X,
                                                               double* __restrict__ ws, int G, NllWs L, int rows) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i0 = blockIdx.x * rows;
   const mcp_kernel kn = kns[g];
-  const int D = kn.D, NP = 4 * D + 3, deg = kn.poly_deg, Np = N | 1;
+  const int D = kn.D, NP = 4 * D + 3, Np = N | 1;
+  constexpr int deg = DEG;
   double* wm = sm;               // [N] Wm_ij
   double* wk = sm + N;           // [N] Wm_ij * kse_ij
   double* fa = sm + 2 * N;       // [N] Wm_ij * A_ij   (MPK_2 factors)
@@ -1823,9 +1852,21 @@ __global__ __launch_bounds__(NG_NT) void nll_grad_rows_kernel(const mcp_kernel* 
   const double* base = nll_gp_base(ws, G, L.per_gp, g);
   const double *Kinv = base + L.Kinv, *alpha = base + L.alpha;
   double* slab = nll_gp_base(ws, G, L.per_gp, g) + L.slab;
-  for (int e = tid; e < N * D; e += NG_NT) {
-    const int r = e / D, d = e - r * D;
-    xs[d * Np + r] = X[e];
+  for (int base = tid; base < N * D; base += 12 * NG_NT) {  // (twelve loads in flight per thread: the staging is a chain of round trips otherwise)
+    double v[12];
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int e = base + u * NG_NT;
+      v[u] = e < N * D ? X[e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      const int e = base + u * NG_NT;
+      if (e < N * D) {
+        const int r = e / D, d = e - r * D;
+        xs[d * Np + r] = v[u];
+      }
+    }
   }
   for (int d = tid; d < D; d += NG_NT) {
     par[d] = kn.inv_ls[d];
@@ -1843,6 +1884,7 @@ __global__ __launch_bounds__(NG_NT) void nll_grad_rows_kernel(const mcp_kernel* 
     const double ai = alpha[i];
     for (int j = tid; j < N; j += NG_NT) {
       double dist = 0.0, A = 0.0, Bv = 0.0;
+#pragma unroll 6
       for (int d = 0; d < D; ++d) {
         const double xid = xs[d * Np + i], xjd = xs[d * Np + j];
         double r = (xid - xjd) * inv_ls[d];
@@ -1867,11 +1909,13 @@ __global__ __launch_bounds__(NG_NT) void nll_grad_rows_kernel(const mcp_kernel* 
       double s = 0.0;
       if (p < D) {  // d/d log l_p :  kse * 2 (dx/l)^2
         const double il2 = inv_ls[p] * inv_ls[p], xip = xs[p * Np + i];
+#pragma unroll 4
         for (int j = lane; j < N; j += 64) {
           const double dx = xip - xs[p * Np + j];
           s = fma(wk[j], 2.0 * dx * dx * il2, s);
         }
       } else if (p == D) {  // d/d log lambda
+#pragma unroll 4
         for (int j = lane; j < N; j += 64) s += wk[j];
       } else if (p == D + 1) {  // 1/2 tr Wm (the caller multiplies by d sigma_n^2 / d sigma_n_log)
         s = lane == 0 ? wm[i] : 0.0;
@@ -1880,20 +1924,24 @@ __global__ __launch_bounds__(NG_NT) void nll_grad_rows_kernel(const mcp_kernel* 
         if (deg >= 1) {
           const double c = 2.0 * w1[e] * (e < D ? xs[e * Np + i] : 1.0);
           if (e < D)
-            for (int j = lane; j < N; j += 64) s = fma(wm[j], c * xs[e * Np + j], s);
+#pragma unroll 4
+          for (int j = lane; j < N; j += 64) s = fma(wm[j], c * xs[e * Np + j], s);
           else
-            for (int j = lane; j < N; j += 64) s = fma(wm[j], c, s);
+#pragma unroll 4
+          for (int j = lane; j < N; j += 64) s = fma(wm[j], c, s);
         }
       } else if (p < 3 * D + 3) {  // MPK_2 factor 0 parameter e: 2 w20_e x_ie x_je * B_ij
         const int e = p - (2 * D + 3);
         if (deg >= 2) {
           const double c = 2.0 * w20[e] * xs[e * Np + i];
+#pragma unroll 4
           for (int j = lane; j < N; j += 64) s = fma(fb[j], c * xs[e * Np + j], s);
         }
       } else {  // MPK_2 factor 1 parameter e: 2 w21_e x_ie x_je * A_ij
         const int e = p - (3 * D + 3);
         if (deg >= 2) {
           const double c = 2.0 * w21[e] * xs[e * Np + i];
+#pragma unroll 4
           for (int j = lane; j < N; j += 64) s = fma(fa[j], c * xs[e * Np + j], s);
         }
       }
@@ -1993,9 +2041,19 @@ extern "C" int mcp_nll_epoch(int G, const mcp_nll_gp* gps, int N, int D, int pol
   hipLaunchKernelGGL(nll_prep_kernel, dim3(G), dim3(64), 0, st, b, G, N, D, poly_deg, ard, ws, L);
   MCP_LAUNCH_CHECK();
   if (cov_build_batch_lds(D) > 150 * 1024) return MCP_ERR_LIMIT;
-  MCP_ENSURE_MAX_LDS(cov_build_batch_kernel);
-  hipLaunchKernelGGL(cov_build_batch_kernel, dim3((N + 255) / 256, (N + CB_ROWS - 1) / CB_ROWS, G), dim3(256), cov_build_batch_lds(D), st, kns, N, X,
-                     ws, G, L);
+  {
+    const dim3 cgrid((N + 255) / 256, (N + CB_ROWS - 1) / CB_ROWS, G);
+    if (poly_deg >= 2) {
+      MCP_ENSURE_MAX_LDS(cov_build_batch_kernel<2>);
+      hipLaunchKernelGGL(cov_build_batch_kernel<2>, cgrid, dim3(256), cov_build_batch_lds(D), st, kns, N, X, ws, G, L);
+    } else if (poly_deg == 1) {
+      MCP_ENSURE_MAX_LDS(cov_build_batch_kernel<1>);
+      hipLaunchKernelGGL(cov_build_batch_kernel<1>, cgrid, dim3(256), cov_build_batch_lds(D), st, kns, N, X, ws, G, L);
+    } else {
+      MCP_ENSURE_MAX_LDS(cov_build_batch_kernel<0>);
+      hipLaunchKernelGGL(cov_build_batch_kernel<0>, cgrid, dim3(256), cov_build_batch_lds(D), st, kns, N, X, ws, G, L);
+    }
+  }
   MCP_LAUNCH_CHECK();
   {
     const int rc = launch_chol_mfma(g_chol_mfma == 2 ? 2 : 1, N, g0 + L.K, N, g0 + L.logdet, status, G, L.per_gp, L.per_gp, st);
@@ -2011,8 +2069,16 @@ extern "C" int mcp_nll_epoch(int G, const mcp_nll_gp* gps, int N, int D, int pol
   if (nll_grad_rows_lds(N, D) <= 150 * 1024) {
     const int rows = nll_grad_rows_per_wg(N);
     slab_rows = (N + rows - 1) / rows;
-    MCP_ENSURE_MAX_LDS(nll_grad_rows_kernel);
-    hipLaunchKernelGGL(nll_grad_rows_kernel, dim3(slab_rows, G), dim3(NG_NT), nll_grad_rows_lds(N, D), st, kns, N, X, ws, G, L, rows);
+    if (poly_deg >= 2) {
+      MCP_ENSURE_MAX_LDS(nll_grad_rows_kernel<2>);
+      hipLaunchKernelGGL(nll_grad_rows_kernel<2>, dim3(slab_rows, G), dim3(NG_NT), nll_grad_rows_lds(N, D), st, kns, N, X, ws, G, L, rows);
+    } else if (poly_deg == 1) {
+      MCP_ENSURE_MAX_LDS(nll_grad_rows_kernel<1>);
+      hipLaunchKernelGGL(nll_grad_rows_kernel<1>, dim3(slab_rows, G), dim3(NG_NT), nll_grad_rows_lds(N, D), st, kns, N, X, ws, G, L, rows);
+    } else {
+      MCP_ENSURE_MAX_LDS(nll_grad_rows_kernel<0>);
+      hipLaunchKernelGGL(nll_grad_rows_kernel<0>, dim3(slab_rows, G), dim3(NG_NT), nll_grad_rows_lds(N, D), st, kns, N, X, ws, G, L, rows);
+    }
   } else {
     MCP_ENSURE_MAX_LDS(nll_grad_batch_kernel);
     hipLaunchKernelGGL(nll_grad_batch_kernel, dim3(N, G), dim3(256), sizeof(double) * (4 * (size_t)N + 256), st, kns, N, X, ws, G, L);
