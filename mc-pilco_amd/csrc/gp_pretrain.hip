@@ -1876,7 +1876,7 @@ __global__ __launch_bounds__(NG_NT) void nll_grad_rows_kernel(const mcp_kernel* 
   for (int d = tid; d <= D; d += NG_NT) par[D + d] = deg >= 1 ? kn.w1[d] : 0.0;
   const double lam = kern_lambda(kn);
   const double *inv_ls = par, *w1 = par + D, *w20 = par + 2 * D + 1, *w21 = par + 3 * D + 1;
-  double tot[NG_KMAX];  // this wave's parameters, summed over the workgroup's rows
+  double tot[NG_KMAX];  // this wave's parameters, this lane's share, summed over the workgroup's rows
 #pragma unroll
   for (int kx = 0; kx < NG_KMAX; ++kx) tot[kx] = 0.0;
   __syncthreads();
@@ -1945,14 +1945,17 @@ __global__ __launch_bounds__(NG_NT) void nll_grad_rows_kernel(const mcp_kernel* 
           for (int j = lane; j < N; j += 64) s = fma(fa[j], c * xs[e * Np + j], s);
         }
       }
-      tot[kx] += 0.5 * wave_sum(s);  // (rows in order: the sum does not depend on how many GPs share the launch)
+      tot[kx] += s;  // per lane, rows in order; the lanes meet once, below (the sum does not depend on how many GPs share the launch)
     }
     __syncthreads();  // (wm .. fb are rewritten by the next row)
   }
 #pragma unroll
   for (int kx = 0; kx < NG_KMAX; ++kx) {
     const int p = wv + kx * (NG_NT / 64);
-    if (p < NP && lane == 0) slab[(size_t)blockIdx.x * NP + p] = tot[kx];
+    if (p < NP) {  // (wave-uniform)
+      const double t = 0.5 * wave_sum(tot[kx]);
+      if (lane == 0) slab[(size_t)blockIdx.x * NP + p] = t;
+    }
   }
 }
 // rows per workgroup: a function of N alone, so that a GP's sums are the same whether it is trained alone or in a batch
