@@ -10,8 +10,9 @@ synthetic cart-pole-shaped data.  Metric: particle-steps/s = M*T / step time, wh
 
 Workload.  One GPU: BASELINE.json configs[1] (c1: 4-D state, SE kernel, N=300, M=400 particles, T=150).  N > 1 GPUs:
 configs[3] (c4: SE + polynomial(2), 4000 particles PER GPU -- 32 000 over 8 -- T=150), weak scaling; the JSON line of an
-N > 1 run carries `scaling_reference` = the same per-GPU shard timed on one GPU without the collective (so that the
-efficiency of THIS workload can be read off one line) and the latency-bound c1 shard as an extra.
+N > 1 run carries `one_gpu_same_workload` = the same per-GPU shard timed by rank 0 ALONE on one GPU before the ranks start, and
+`scaling_efficiency` = value / (N x that); the N = 1 line carries `scale_base` = that workload's one-GPU value (its extra `c3`),
+so a 1 -> N ratio is always formed on ONE workload.  The latency-bound c1 shard is an extra of the N > 1 line.
 
 `--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself as child processes -- before
 this process makes any GPU call (after building the library once, in the parent) -- relays rank 0's JSON line and WATCHES the
@@ -254,11 +255,9 @@ class Runner:
         nz = ops.NoiseSpec(eps=eps, masks=masks, seed=2026, call=i + 1, particle_offset=self.rank * M)
         for p in w.params:
             p.grad = None
-        if ev is not None:
-            ev[0].record()
+        # HIP events on the launch stream right around mcp_rollout_fwd / mcp_rollout_bwd (ops.fwd_events / ops.bwd_events)
+        ops.fwd_events, ops.bwd_events = (None, None) if ev is None else ((ev[0], ev[1]), (ev[2], ev[3]))
         states, inputs, status = ops.rollout(w.model, w.policy, nz, x0, T, w.p_drop, meas=self.meas)
-        if ev is not None:
-            ev[1].record()
         self.status_or |= status
         if sharded:
             # this rank's share of the pooled cost -> its own adjoint sweep -> ONE all-reduce of [gradient | cost sums | flags]; the
@@ -271,11 +270,12 @@ class Runner:
         else:
             cost, _std = ops.expected_cost(w.cost, states)
             cost.backward()
+        ops.fwd_events = ops.bwd_events = None
         self.opt.step()
         return cost
 
-    def barrier(self):
-        if self.world > 1:
+    def barrier(self, solo=False):
+        if self.world > 1 and not solo:
             import torch.distributed as dist
 
             dist.barrier()
@@ -291,8 +291,9 @@ class Runner:
             raise SystemExit("bench: kernel status flags were raised during the run (local %s, reduced counts %s) -- the measurement is invalid"
                              % (self.ops.status_flags(self.status_or), self.flags_sum.tolist()))
 
-    def run(self, steps, warmup, min_seconds=0.0, sharded=None):
-        """warmup untimed steps, then blocks of exactly `steps` timed ones between barriers, repeated until `min_seconds` have been
+    def run(self, steps, warmup, min_seconds=0.0, sharded=None, solo=False):
+        """``solo``: this rank alone (no barrier / time exchange with the other ranks -- they wait elsewhere).
+        warmup untimed steps, then blocks of exactly `steps` timed ones between barriers, repeated until `min_seconds` have been
         measured (the number of blocks follows from the first block's time, maximum over ranks, so every rank runs the same).
         Returns (median block seconds [max over ranks], mean forward-kernel ms from HIP events on the launch stream, last cost,
         all block seconds)."""
@@ -301,17 +302,17 @@ class Runner:
         self.rank_block_s = []
         for i in range(warmup):
             self.step(i, None, sharded)
-        blocks, fwd, cost, k, nblocks = [], [], None, warmup, 1
+        blocks, fwd, bwd, cost, k, nblocks = [], [], [], None, warmup, 1
         while len(blocks) < nblocks:
-            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-            self.barrier()
+            evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)]
+            self.barrier(solo)
             t0 = time.perf_counter()
             for i in range(steps):
                 cost = self.step(k + i, evs[i], sharded)
-            self.barrier()
+            self.barrier(solo)
             el = time.perf_counter() - t0
             k += steps
-            if self.world > 1:  # (also without the step's collective: every rank must arrive at the same number of blocks)
+            if self.world > 1 and not solo:  # (also without the step's collective: every rank must arrive at the same number of blocks)
                 import torch.distributed as dist
 
                 tmax = torch.tensor([el, -el], dtype=torch.float64, device=self.dev)
@@ -319,13 +320,15 @@ class Runner:
                 self.rank_block_s.append((-float(tmax[1].item()), float(tmax[0].item())))  # (fastest rank, slowest rank) of this block
                 el = float(tmax[0].item())
             blocks.append(el)
-            fwd.append(sum(a.elapsed_time(b) for (a, b) in evs) / len(evs))
+            fwd.append(sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs))
+            bwd.append(sum(e[2].elapsed_time(e[3]) for e in evs) / len(evs))
             if len(blocks) == 1 and min_seconds > 0:
                 nblocks = max(1, min(50, int(min_seconds / max(el, 1e-6)) + 1))
         self.check_flags()
         order = sorted(range(len(blocks)), key=lambda j: blocks[j])
         mid = order[len(order) // 2]
         self.rank_block_mid = self.rank_block_s[mid] if self.rank_block_s else None
+        self.bwd_ms = bwd[mid]
         return blocks[mid], fwd[mid], float(cost.detach()), blocks
 
     def kernel_name(self):
@@ -337,25 +340,38 @@ class Runner:
         name = "rollout_fwd_tile_kernel" if L.mcp_debug_last_particles_per_wg() == 16 else "rollout_fwd_kernel"
         return name + (" (GP-sharded)" if L.mcp_debug_last_gp_sharded() else "")
 
+    def bwd_kernel_name(self):
+        from mc_pilco_amd import hipabi
+
+        return "rollout_bwd_lat_kernel" if hipabi.lib().mcp_debug_last_bwd_lean() else "rollout_bwd_kernel"
+
     def roofline(self, fwd_ms, step_s, traffic):
-        """`frac` prices the algorithmic flops of a whole step (fwd + bwd) against the FORWARD kernel's time -- the
-        contract's per-kernel figure (the forward kernel also forms the GP Jacobians the adjoint sweep consumes); `frac_step`
-        prices the same flops against the whole step (forward + cost + adjoint + Adam [+ all-reduce])."""
+        """The dominant kernel is the forward rollout.  `frac` = ITS OWN algorithmic flops (the forward terms of SURVEY 8d's figure)
+        x M x T / its mean launch duration (HIP events on the launch stream right around mcp_rollout_fwd) / the fp64 peak -- the
+        number that follows from profiles/*_kernel_stats.csv.  `kernels` lists forward and backward the same way; `frac_step`
+        prices the whole step's flops (fwd + bwd) against ms_per_step (forward + cost + adjoint + Adam [+ all-reduce])."""
         name = self.kernel_name()
         small = not name.startswith("rollout_fwd_tile")
-        ach = self.flops * self.M * self.T / (fwd_ms * 1e-3) / 1e12
-        ach_step = self.flops * self.M * self.T / step_s / 1e12
-        ach_fwd = self.flops_fwd * self.M * self.T / (fwd_ms * 1e-3) / 1e12
-        r = {"bound": "l2-stream+latency" if small else "fp64 units (mfma)", "roof": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS,
-             "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS, "frac_fwd_only": ach_fwd / FP64_PEAK_TFLOPS,
-             "frac_step": ach_step / FP64_PEAK_TFLOPS, "traffic": traffic,
-             "alg_flops_fwd_per_particle_step": self.flops_fwd,
-             "kernel": name, "kernel_ms": fwd_ms, "alg_flops_per_particle_step": self.flops, "units_per_launch": self.M * self.T,
-             "achieved_basis": "algorithmic fwd+bwd flops per particle-step (SURVEY 8d) x M x T / the FORWARD kernel's mean launch time "
-                               "(HIP events on the launch stream); frac_fwd_only: the forward terms of that figure alone / the same time (what the "
-                               "forward kernel itself executes); frac_step: fwd+bwd flops / ms_per_step",
+        units = self.M * self.T
+        flops_bwd = self.flops - self.flops_fwd
+        ach_fwd = self.flops_fwd * units / (fwd_ms * 1e-3) / 1e12
+        ach_bwd = flops_bwd * units / (self.bwd_ms * 1e-3) / 1e12
+        ach_step = self.flops * units / step_s / 1e12
+        c = self.w.problem["cfg"]
+        alg_bytes = 16 * (c["S"] + c["U"] + c["G"]) * units  # SURVEY 8d: B_alg = 16 (S + U + G) per particle-step
+        r = {"bound": "mfma", "bound_in_practice": "l2-stream+latency" if small else "fp64 units (mfma)", "achieved": ach_fwd,
+             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach_fwd / FP64_PEAK_TFLOPS, "frac_step": ach_step / FP64_PEAK_TFLOPS,
+             "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "traffic_ratio": (traffic / alg_bytes) if traffic else None,
+             "kernel": name, "kernel_ms": fwd_ms, "alg_flops_per_particle_step": self.flops_fwd, "units_per_launch": units,
+             "alg_flops_fwd_plus_bwd_per_particle_step": self.flops,
+             "kernels": [{"name": name, "avg_ms": fwd_ms, "alg_flops_per_unit": self.flops_fwd, "frac": ach_fwd / FP64_PEAK_TFLOPS},
+                         {"name": self.bwd_kernel_name(), "avg_ms": self.bwd_ms, "alg_flops_per_unit": flops_bwd, "frac": ach_bwd / FP64_PEAK_TFLOPS,
+                          "note": "mcp_rollout_bwd: the adjoint sweep(s) + the fixed-order gradient reduction"}],
+             "achieved_basis": "the forward kernel's own algorithmic flops per particle-step (SURVEY 8d, forward terms) x M x T / its mean launch "
+                               "duration (HIP events on the launch stream around mcp_rollout_fwd; profiles/r05_*_kernel_stats.csv is the rocprofv3 "
+                               "average of the same kernel); frac_step: fwd+bwd flops / ms_per_step",
              "regime": ("T-sequential chain of 4 barrier-separated phases per step + the per-CU L2->CU stream of one Kinv per workgroup and "
-                        "step; fp64 flop roof not reachable at M=400 (DESIGN.md 4.1)") if small else
+                        "step; fp64 flop roof not reachable at M=400 (DESIGN.md 4.0)") if small else
                        "fp64 matrix pipe (MFMA 16x16x4) beside VALU exp / Philox phases"}
         if traffic:
             gbps = traffic / (fwd_ms * 1e-3) / 1e9
@@ -476,6 +492,25 @@ def main():
                 collective["us_per_call_" + other] = time_collective(torch, sharding.StepReducer(dist.group.WORLD, other), nmsg, dev)
             except Exception as e:  # noqa: BLE001  (a smoke: reported, not fatal)
                 collective["error_" + other] = repr(e)
+    one_gpu = None
+    if world > 1 and not args.no_extra:
+        # the SAME per-GPU shard on ONE GPU, alone: rank 0 times it (no collective, median of blocks) while the other ranks wait at the
+        # barrier -- N x this value is perfect weak scaling of this workload
+        if rank == 0:
+            k1 = max(3, args.steps // 2)
+            saved = [p.detach().clone() for p in w.params]  # (rank 0's solo steps must not leave it with other parameters than its peers)
+            s1, f1, _, b1 = main_run.run(k1, 2, min(args.min_seconds, 1.0), sharded=False, solo=True)
+            with torch.no_grad():
+                for p, q in zip(w.params, saved):
+                    p.copy_(q)
+            main_run.opt = torch.optim.Adam(w.params, lr=0.01, fused=True)
+            one_gpu = {"what": "the same %s shard (M=%d, T=%d) on ONE GPU without the collective, measured by rank 0 ALONE before the ranks start "
+                               "(the others wait at a barrier), median of %d block(s) of %d steps" % (args.workload, M, T, len(b1), k1),
+                       "workload": args.workload, "value": M * T / (s1 / k1), "unit": "particle-steps/s", "ms_per_step": 1e3 * s1 / k1, "kernel_ms": f1}
+            note("one GPU alone, %s: %.3f ms per step" % (args.workload, 1e3 * s1 / k1))
+        import torch.distributed as dist
+
+        dist.barrier()
     block_s, fwd_ms, last_cost, blocks = main_run.run(args.steps, args.warmup, args.min_seconds)
     if rank != 0:
         note("rank %d: timed blocks done" % rank)
@@ -525,18 +560,13 @@ def main():
             "final_cost": last_cost,
         }
     if world > 1 and not args.no_extra:
-        # (a) the SAME per-GPU shard on one GPU, no collective: value x N would be perfect weak scaling of this workload;
-        # (b) the latency-bound c1 shard (M = 400 per GPU), sharded, for comparison with the single-GPU headline.
-        # Every rank runs both (lockstep: the sharded one contains collectives).
-        k1 = max(3, args.steps // 4)
-        ref_s, _, _, ref_blocks = main_run.run(k1, 1, min(args.min_seconds, 0.5), sharded=False)
+        # the latency-bound c1 shard (M = 400 per GPU), sharded, for comparison with the single-GPU headline (lockstep on every rank:
+        # it contains collectives)
         c1 = Runner(args, "c1", dev, rank, world, reducer)
         c1_s, c1_f, _, _ = c1.run(args.steps, 2, 0.0)
         if rank == 0:
-            out["scaling_reference"] = {"what": "the same %s shard (M=%d) on ONE GPU without the collective, median of %d block(s) of %d steps (every rank "
-                                                "runs its own copy concurrently; slowest rank's clock)" % (args.workload, M, len(ref_blocks), k1),
-                                        "value_one_gpu": M * T / (ref_s / k1), "ms_per_step": 1e3 * ref_s / k1,
-                                        "efficiency_vs_it": value / (world * M * T / (ref_s / k1))}
+            out["one_gpu_same_workload"] = one_gpu
+            out["scaling_efficiency"] = value / (world * one_gpu["value"])
             out["extra_workloads"] = [{"workload": "c1 (M=%d per GPU, sharded over %d GPUs: latency bound)" % (c1.M, world), "value": world * c1.M * c1.T / (c1_s / args.steps),
                                        "unit": "particle-steps/s", "ms_per_step": 1e3 * c1_s / args.steps, "kernel": c1.kernel_name(), "kernel_ms": c1_f}]
         del c1
@@ -558,11 +588,16 @@ def main():
                               "poly_degree": r.w.problem["deg"], "measured_states": r.meas is not None,
                               "value": r.M * r.T / (e2 / k), "unit": "particle-steps/s", "ms_per_step": 1e3 * e2 / k,
                               "us_per_time_step": 1e3 * 1e3 * e2 / k / r.T, "steps": k, "warmup": 2, "blocks": len(b2),
-                              "kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"], "frac": rf["frac"], "frac_fwd_only": rf["frac_fwd_only"],
+                              "kernel": rf["kernel"], "kernel_ms": rf["kernel_ms"], "frac": rf["frac"], "frac_step": rf["frac_step"],
                               "roofline": rf, "final_cost": c2})
                 del r
                 torch.cuda.empty_cache()
             out["extra_workloads"] = extra
+            c3x = [e for e in extra if e["workload"] == "c3"][0]
+            out["scale_base"] = {"workload": "c3 (= c4's per-GPU shard: the workload `bench.py --gpus N>1` runs on every GPU)", "value": c3x["value"],
+                                 "unit": "particle-steps/s", "ms_per_step": c3x["ms_per_step"],
+                                 "what": "the one-GPU value a multi-GPU line of this bench must be divided by (its own `one_gpu_same_workload` "
+                                         "re-measures it); the headline `value` above is c1 (M=400), a different workload"}
             # the drop-in class's own loop (monitors, NaN test, printing, Adam): MC_PILCO.reinforce_policy, 100 steps, same shape
             note("MC_PILCO.reinforce_policy on the drop-in classes (100 steps)")
             from mc_pilco_amd import workloads
@@ -587,6 +622,18 @@ def main():
             out["fit_model_ur5"] = {"what": "the same for the UR5-shaped model: N=%d, D=24, SE + polynomial(1), 6 GPs, 200 epochs each (all six trained "
                                             "epoch-synchronously: mcp_nll_epoch)" % n_tr6,
                                     "ms_per_epoch_all_6_gps": 1e3 * s_ep6, "ms_per_epoch_per_gp": 1e3 * s_ep6 / 6}
+        if default_run and not args.no_extra:
+            note("pretrain_gp with SOD (cart-pole N=300, UR5 N=600)")
+            from mc_pilco_amd import workloads
+
+            pre = {}
+            for shape in ("cartpole", "ur5"):
+                pre[shape] = workloads.time_pretrain(dev, shape)
+            out["pretrain"] = {"what": "Model_learning.pretrain_gp on the drop-in classes with the launch scripts' SOD settings (cart-pole: N=300, relative "
+                                       "0.5; UR5 shape: N=600, D=24, SE+poly(1), absolute 0.001): seconds per GP for the whole call (subset selection, Gram, "
+                                       "Cholesky, inverse, alpha, pack, posterior at all rows, the MSE print's host syncs) and the device time of each stage "
+                                       "(HIP events, median of 5)", "reference_cpu_s_per_gp_n300": 0.56,
+                               "reference_cpu_source": "BASELINE.md section 2 (survey container, 1 thread)", **pre}
         if world == 1 and not args.no_cpu:
             # the cores this process may actually run on (the box gives one GPU's share of the host, not os.cpu_count())
             ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-#define MCP_ABI_VERSION 5 /* 5: mcp_kernel.scal, MCP_FWD_NO_GP_SHARDING, MCP_STATUS_NEG_VAR, mcp_nll_epoch, mcp_adam_step_guarded (round 4) */
+#define MCP_ABI_VERSION 5 /* 5: mcp_kernel.scal, MCP_FWD_NO_GP_SHARDING, MCP_STATUS_NONPOS_VAR now means a FINITE variance <= 0, mcp_nll_epoch, \
+                             mcp_adam_step_guarded, mcp_policy_step_commit (round 4) */
 
 #define MCP_OK 0
 #define MCP_ERR_ARG (-1)       /* null pointer / non-positive size                       */
@@ -325,7 +326,9 @@ typedef struct mcp_opt_state {
  * when the attempt counts (state == NULL: always, as step number `step` >= 1 of the optimizer -- GP training, where the host knows it;
  * with a state the step number is state->adam_t + 1).  params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors device pointers,
  * numel their sizes; a NULL grad skips that tensor.  Must be enqueued BEFORE mcp_policy_step_commit of the same attempt (it reads
- * the state that call advances).  Replaces optimizer.step(), MC_PILCO.py:525. */
+ * the state that call advances).  Without a state, a non-NULL `status` whose MCP_STATUS_NOT_SPD bit is set skips the update (GP
+ * training: the epoch's Cholesky failed; the bit is sticky, so the parameters stay those of the last good epoch).
+ * Replaces optimizer.step(), MC_PILCO.py:525 and GP_prior.py:209. */
 int mcp_adam_step_guarded(int n_tensors, double* const* params, const double* const* grads, double* const* exp_avg,
                           double* const* exp_avg_sq, const int64_t* numel, double lr, double beta1, double beta2, double eps,
                           const mcp_opt_state* state, int64_t step, int n_steps, const double* cost, const double* flags,

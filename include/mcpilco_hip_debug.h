@@ -38,9 +38,10 @@ void mcp_debug_set_bwd_particles(int pb);
    1 when the last mcp_rollout_bwd ran it */
 void mcp_debug_set_bwd_lean(int mode);
 int mcp_debug_last_bwd_lean(void);
-/* device buffers of 16 uint64 per-phase cycle totals of one workgroup (NULL = off); the forward kernels stamp workgroup
+/* device buffers of per-phase cycle totals (forward: 32 uint64, backward: 16) of one workgroup (NULL = off); the forward kernels stamp workgroup
    `block` (0 by default; the partner of workgroup 0 in a 2-way GP-sharded launch of the small-tile kernel is workgroup 8) */
-void mcp_debug_set_stamp_buffer(void* device_u64x16); /* (the lean small-swarm kernel writes 24 slots: pass 32) */
+void mcp_debug_set_stamp_buffer(void* device_u64x32); /* 32 uint64: every forward kernel writes per-phase totals to slots 0..15 and per-wave
+                                                         phase totals to slots 16..31 */
 void mcp_debug_set_stamp_block(int block);
 void mcp_debug_set_bwd_stamp_buffer(void* device_u64x16);
 

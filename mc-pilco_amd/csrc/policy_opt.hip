@@ -44,6 +44,10 @@ struct AdamSegs {
 __global__ void adam_guarded_kernel(AdamSegs s, double lr, double beta1, double beta2, double eps, const mcp_opt_state* st, long long step,
                                     int n_steps, const double* cost, const double* flags, const uint32_t* status) {
   if (st && (loop_frozen(st, n_steps) || attempt_failed(cost, flags, status))) return;  // (uniform over the grid)
+  // GP training (no state): an epoch whose Cholesky met a matrix that is not positive definite leaves NaN gradients behind; the flag is
+  // sticky, so this and every later epoch's update is skipped and the parameters stay those of the last good step (the reference raises
+  // at the failing epoch with them intact, GP_prior.py:106)
+  if (!st && status && (status[0] & MCP_STATUS_NOT_SPD) != 0u) return;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= s.end[s.n - 1]) return;
   int k = 0;

@@ -135,6 +135,13 @@ class BatchedFit:
         ad = [plain_adam_options(o) for o in optimizers]
         if any(v is None for v in st) or any(a is None or a != ad[0] for a in ad) or len(self.gps) > abi.MAX_GP:
             return
+        # the caller's optimizer is replaced, not driven: that is only the same thing when it holds exactly this GP's trainable
+        # parameters and has not stepped yet (a subset would train too much here, a used one would lose its moments)
+        for g, o in zip(self.gps, optimizers):
+            want = {id(p) for p in g.parameters() if p.requires_grad}
+            have = {id(p) for p in o.param_groups[0]["params"] if p.requires_grad}
+            if want != have or len(o.state) != 0:
+                return
         rbf0 = st[0][0]
         if any(v[3] != st[0][3] or v[0].flg_ARD != rbf0.flg_ARD or v[0].num_features != rbf0.num_features for v in st):
             return
@@ -205,12 +212,14 @@ class BatchedFit:
             abi.check(lib.mcp_nll_epoch(len(self.gps), C.cast(self.desc, C.c_void_p), self.N, self.D, self.deg, self.ard, abi.ptr(self.X),
                                         abi.ptr(self.status), abi.ptr(self.ws), self.nbytes, abi.stream()), "mcp_nll_epoch")
             for cnt, ps, gs, ms, vs, ne in chunks:
-                abi.check(lib.mcp_adam_step_guarded(cnt, ps, gs, ms, vs, ne, lr, b1, b2, eps, None, epoch + 1, 0, None, None, None, abi.stream()),
+                abi.check(lib.mcp_adam_step_guarded(cnt, ps, gs, ms, vs, ne, lr, b1, b2, eps, None, epoch + 1, 0, None, None, abi.ptr(self.status), abi.stream()),
                           "mcp_adam_step_guarded")
             if epoch % self.N_epoch_print == 0:
                 snapshot(epoch)
         snapshot(self.N_epoch)  # the final parameters
         if ops.status_flags(self.status)["not_spd"]:  # (the one host sync of the training)
+            # the failing epoch and every later one skipped their update on the device (mcp_adam_step_guarded reads the sticky flag): the
+            # hyper-parameters are those of the last good step, as when the reference raises from torch.cholesky (GP_prior.py:106)
             raise RuntimeError("cholesky: the covariance matrix is not positive-definite")
         for p, g in zip(self.params, self.grads):
             p.grad = g  # (what the last epoch left, as after the reference's last backward)

@@ -367,16 +367,28 @@ def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, nois
     # workspace: the hand-off granules of the GP-sharded launch (small swarms); the library zeroes what it uses
     nbytes = abi.lib().mcp_rollout_workspace_bytes(_mc(model), C.byref(pc), M, T) if (model is not None and T > 1) else 0
     ws = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev) if nbytes else None
+    ev = fwd_events
     try:
+        if ev is not None:
+            ev[0].record()
         abi.check(abi.lib().mcp_rollout_fwd(_mc(model), C.byref(pc), C.byref(nz), M, T,
                                             int(bool(particle_pred)) | (0 if gp_sharding else abi.FWD_NO_GP_SHARDING), abi.ptr(x0),
                                             abi.ptr(states), abi.ptr(inputs), abi.ptr(jac), abi.ptr(status), abi.ptr(ws), nbytes, abi.stream()),
                   "mcp_rollout_fwd")
+        if ev is not None:
+            ev[1].record()
     finally:
         _set_meas(policy, None, T, M, None)
     if meas is not None:
         return states, inputs, jac, status, meas_buf
     return states, inputs, jac, status
+
+
+# measurement hook (bench.py): a pair of torch.cuda.Event recorded on the launch stream right around mcp_rollout_bwd -- the adjoint sweep
+# runs inside autograd's backward, where the caller cannot bracket it.  None (the default) = nothing is recorded.  ``fwd_events``: the same
+# around mcp_rollout_fwd (operand packing + hand-off buffer reset + the rollout kernel, without the host's tensor allocations).
+bwd_events = None
+fwd_events = None
 
 
 def rollout_backward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseSpec, states, inputs, jac, g_states, g_inputs, p_drop,
@@ -396,10 +408,15 @@ def rollout_backward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseS
     gs = None if g_states is None else g_states.to(dtype=DT).contiguous()
     gi = None if g_inputs is None else g_inputs.to(dtype=DT).contiguous()
     _set_meas(policy, meas, T, M, meas_buf)
+    ev = bwd_events
     try:
+        if ev is not None:
+            ev[0].record()
         abi.check(abi.lib().mcp_rollout_bwd(_mc(model), C.byref(pc), C.byref(nz), M, T, abi.ptr(states), abi.ptr(inputs), abi.ptr(jac),
                                             abi.ptr(gs), abi.ptr(gi), abi.ptr(g_ls), abi.ptr(g_c), abi.ptr(g_w), abi.ptr(g_x0), abi.ptr(ws),
                                             nbytes, abi.stream()), "mcp_rollout_bwd")
+        if ev is not None:
+            ev[1].record()
     finally:
         _set_meas(policy, None, T, M, None)
         pc.g_bias = None

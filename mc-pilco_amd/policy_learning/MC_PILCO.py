@@ -316,8 +316,12 @@ class MC_PILCO(torch.nn.Module):
 
         # ---- device-side loop state (mcp_opt_state + the monitors' arrays) ------------------------------------------------------------
         lib = abi.lib()
+        if dt != torch.float64:
+            # the loop state, the cost lists and the Adam kernel are double precision on the device (mcp_opt_state, mcp_adam_step_guarded):
+            # another dtype would be read through double* -- refuse it here rather than take garbage decisions
+            raise RuntimeError("reinforce_policy on the HIP path works in torch.float64 (the kernels are fp64); got dtype %s" % dt)
         st = torch.zeros(7, dtype=torch.int64, device=dev)  # mcp_opt_state: step, attempt, pending, adam_t, total_attempts | es2, cost_prev
-        st.view(dt)[6:7].copy_(cost0.detach().reshape(1))   # cost_tm1 = the warm-up cost (MC_PILCO.py:462)
+        st[5:].view(torch.float64)[1:2].copy_(cost0.detach().reshape(1))   # cost_tm1 = the warm-up cost (MC_PILCO.py:462)
         cost_list = torch.zeros(n_steps, device=dev, dtype=dt)
         std_list = torch.zeros(n_steps, device=dev, dtype=dt)
         es1 = torch.zeros(n_steps + 1, device=dev, dtype=dt)

@@ -304,3 +304,99 @@ def time_fit_model_ur5(device, N=400, epochs=30):
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
     return el / epochs, int(ml.gp_inputs.shape[0])
+
+
+def time_pretrain(device, shape="cartpole", reps=5):
+    """``Model_learning.pretrain_gp`` (Model_learning.py:163-208: get_SOD GP_prior.py:232-257, then forward / get_alpha / get_estimate on
+    the subset) on the drop-in classes, per GP, with the launch scripts' SOD settings, and the stages on their own (HIP events on the
+    launch stream, median of ``reps``):
+      cartpole  N = 300, D = 6, SE, 2 GPs, relative threshold 0.5 (sigma_n = 0.36: SURVEY 8c's pruning case, ~264 of 300 rows stay);
+      ur5       N = 600, D = 24, SE + polynomial(1), 6 GPs, absolute threshold 0.001 (test_mcpilco_ur5_mujoco.py:82-86).
+    Returns a dict (seconds per GP for the whole call incl. its host syncs, microseconds per stage, rows kept)."""
+    import contextlib
+    import io
+    import time
+
+    from .model_learning import Model_learning as ML
+
+    quiet = lambda: contextlib.redirect_stdout(io.StringIO())
+    if shape == "cartpole":
+        c, N, G = sy.CARTPOLE, 300, 2
+        rbf = dict(active_dims=np.arange(6), lengthscales_init=np.asarray(c["lengthscales"], dtype=float), flg_train_lengthscales=True,
+                   lambda_init=np.ones(1), flg_train_lambda=False, sigma_n_init=0.36 * np.ones(1), sigma_n_num=None, flg_train_sigma_n=True, dtype=DT,
+                   device=device)
+        par = dict(num_gp=G, T_sampling=c["Ts"], angle_indeces=c["angle"], not_angle_indeces=c["not_angle"], vel_indeces=c["vel"],
+                   not_vel_indeces=c["not_vel"], dtype=DT, device=device, init_dict_list=[rbf] * G, approximation_mode="SOD",
+                   approximation_dict={"SOD_threshold_mode": "relative", "SOD_threshold": 0.5, "flg_SOD_permutation": False})
+        with quiet():
+            ml = ML.Speed_Model_learning_RBF_angle_state(**par)
+            for xs, us in sy.cartpole_rollouts(n_roll=5):
+                ml.add_data(np.asarray(xs), np.asarray(us))
+    else:
+        c, N, G = sy.UR5, 600, 6
+        D = c["D"]
+        rbf = dict(active_dims=np.arange(D), lengthscales_init=np.asarray(c["lengthscales"], dtype=float), flg_train_lengthscales=True,
+                   lambda_init=np.ones(1), flg_train_lambda=False, sigma_n_init=c["sigma_n"] * np.ones(1), sigma_n_num=None, flg_train_sigma_n=True,
+                   dtype=DT, device=device)
+        mpk = dict(active_dims=np.arange(D), poly_deg=1, Sigma_pos_par_init_list=[0.05 * np.ones(D + 1)], flg_train_Sigma_pos_par_list=[True], dtype=DT,
+                   device=device)
+        par = dict(num_gp=G, T_sampling=c["Ts"], angle_indeces=c["angle"], not_angle_indeces=c["not_angle"], vel_indeces=c["vel"],
+                   not_vel_indeces=c["not_vel"], dtype=DT, device=device, init_dict_list=[[rbf, mpk]] * G, approximation_mode="SOD",
+                   approximation_dict={"SOD_threshold_mode": "absolute", "SOD_threshold": [0.001] * G, "flg_SOD_permutation": False})
+        with quiet():
+            ml = ML.Speed_Model_learning_RBF_MPK_angle_state(**par)
+            for xs, us in sy.ur5_rollouts(n_roll=3):
+                ml.add_data(np.asarray(xs), np.asarray(us))
+    assert int(ml.gp_inputs.shape[0]) == N
+    whole = []
+    with quiet(), torch.no_grad():
+        for r in range(reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for g in range(G):
+                ml.pretrain_gp(g)
+            torch.cuda.synchronize()
+            if r:
+                whole.append((time.perf_counter() - t0) / G)
+    kept = [len(ix) for ix in ml.SOD_indices]
+    # the stages on their own (GP 0): device time between HIP events
+    gp = ml.gp_list[0]
+    X = gp._cols(ml.gp_inputs)
+    spec = gp.kernel_spec()
+    thr = float(0.5 * torch.sqrt(gp.get_sigma_n_2())) if shape == "cartpole" else 0.001
+    idx = ml.SOD_indices[0]
+    Xs, Ys = X[idx, :].contiguous(), ml.gp_output_list[0][idx, :].contiguous()
+    stages = {}
+
+    def timed(name, fn):
+        ts, out = [], None
+        for _ in range(reps + 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        stages[name] = sorted(ts[1:])[len(ts[1:]) // 2]
+        return out
+
+    import ctypes as C
+
+    from . import hipabi as abi
+
+    nb = abi.lib().mcp_sod_workspace_bytes(N)
+    ws = torch.empty((nb + 7) // 8, dtype=DT, device=device)
+    ix = torch.zeros(N, dtype=torch.int32, device=device)
+    cnt = torch.zeros(1, dtype=torch.int32, device=device)
+    kc = spec.to_c(device)
+    timed("sod_select", lambda: abi.check(abi.lib().mcp_sod_select(C.byref(kc), N, abi.ptr(X), thr, abi.ptr(ix), abi.ptr(cnt), abi.ptr(ws), nb,
+                                                                   abi.stream()), "mcp_sod_select"))
+    K = timed("gram", lambda: ops.cov_build(spec, Xs, None, noise=True))
+    U, _, _ = timed("cholesky", lambda: ops.chol_factor(K))
+    _, Kinv = timed("inverse", lambda: ops.chol_inverse(U))
+    alpha = timed("alpha", lambda: ops.gp_alpha(Kinv, Ys, 0.0))
+    timed("pack", lambda: ops.PackedGP(spec, Xs, alpha, Kinv))
+    timed("posterior_all_rows", lambda: ops.posterior(ops.PackedGP(spec, Xs, alpha, Kinv), X))
+    whole.sort()
+    return {"N": N, "gps": G, "rows_kept": kept, "s_per_gp": whole[len(whole) // 2], "stage_us": stages,
+            "stage_us_total": sum(stages.values())}
