@@ -1302,53 +1302,164 @@ __global__ void gp_pack_kernel(int N, int D, const double* __restrict__ X, const
 }
 
 // ---------------------------------------------------------------------------------------
-// Greedy subset-of-data selection (GP_prior.get_SOD): one wave, incremental Cholesky.
-// Keeps U (upper, K_S + sigma_n^2 I = U^T U) of the current subset in the workspace; a candidate
-// x_i is tested with  var = k(x_i,x_i) - ||w||^2,  U^T w = k_S(x_i)  (== k_S^T (K_S+s I)^-1 k_S),
-// and appended (new column w, new pivot sqrt(k_ii + sigma_n^2 - ||w||^2)) when sqrt(var) > thr.
-// The reference refactors the subset from scratch for every candidate; the decisions are the
-// same comparisons in exact arithmetic and the fixtures record the smallest margin.
+// Greedy subset-of-data selection (GP_prior.get_SOD, GP_prior.py:232-257): incremental Cholesky, parallel over the CANDIDATES.
+// The reference refactors the subset from scratch for every candidate; the decisions are the same comparisons in exact arithmetic
+// (the fixtures record the smallest margin).  A candidate x_c is tested with  var = k(x_c,x_c) - ||w_c||^2,  L w_c = k_S(x_c),
+// L L^T = K_S + sigma_n^2 I.  Forward substitution row by row gives  w_c[j] = (k(x_c, x_pj) - sum_{i<j} w_c[i] w_pj[i]) / d_j  with
+// w_pj the vector of the j-th accepted point itself and d_j its pivot sqrt(k_pp + sigma_n^2 - ||w_p||^2): component j of EVERY later
+// candidate can be formed the moment point j is accepted -- one dot product per candidate, all candidates at once (round 4 walked the
+// substitution of one candidate with one wave: 23 ms at N = 300, 162 ms at N = 600, 99 % of pretrain_gp).  One 1024-thread workgroup:
+//   W [n][N] (workspace): W[j][c] = w_c[j], coalesced over c;  nrm[c] = ||w_c||^2 so far, kd[c] = k(x_c, x_c)  (workspace tail);
+//   per accepted point p: publish w_p (LDS) and its pivot; thread (g, c), c > p: partial dot over the g-th share of j (N <= 1024: the
+//   1024 threads are JS = 1024 / roundup64(N) groups of candidates; larger N: one group, several candidates per thread); group 0 adds
+//   the shares in group order, appends w_c[n], updates nrm[c] and -- the same thread, the value still in a register -- tests the
+//   candidate: the smallest accepted index (LDS atomicMin) is the next point; everything in between was rejected against the subset
+//   it was tested with, as in the sequential scan.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MCP_WAVE) void sod_select_kernel(mcp_kernel kn, int N, const double* __restrict__ X, double thr,
-                                                              int32_t* __restrict__ idx_out, int32_t* __restrict__ n_out,
-                                                              double* __restrict__ Uw) {
-  // Uw: [N][N] row-major upper factor of the subset Gram; kv (LDS): right-hand side, then w
+constexpr int SOD_NT = 1024;
+#define SOD_PIN16(v)                                                                                                                      \
+  asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), \
+               "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]))
+__global__ __launch_bounds__(SOD_NT) void sod_select_kernel(mcp_kernel kn, int N, const double* __restrict__ X, double thr,
+                                                            int32_t* __restrict__ idx_out, int32_t* __restrict__ n_out,
+                                                            double* __restrict__ W) {
   extern __shared__ __attribute__((aligned(16))) double sod_smem[];
-  volatile double* kv = sod_smem;
-  const int lane = threadIdx.x;
-  int n = 1;
-  if (lane == 0) {
-    idx_out[0] = 0;
-    Uw[0] = sqrt(kern_diag(kn, X, 1) + kern_sigma_n2(kn));
+  double* piv = sod_smem;               // [2] 1 / pivot of the accepted point, pivot = sqrt(k_pp + sigma_n^2 - ||w_p||^2)
+  double* wp = sod_smem + 2;            // [N] the accepted point's own vector
+  double* part = wp + N;                // [SOD_NT] partial dot products of groups 1..JS-1
+  int* s_next = (int*)(part + SOD_NT);  // [3] smallest accepted candidate; round k uses slot k % 3
+  double* nrm = W + (size_t)N * N;
+  double* kd = nrm + N;
+  const int tid = threadIdx.x, D = kn.D;
+  const int C = (N + MCP_WAVE - 1) / MCP_WAVE * MCP_WAVE;
+  const int JS = C <= SOD_NT ? SOD_NT / C : 1;                  // groups that share the j range of a dot product
+  const int CPT = C <= SOD_NT ? 1 : (N + SOD_NT - 1) / SOD_NT;  // candidates per thread (JS == 1 then)
+  const int grp = C <= SOD_NT ? tid / C : 0, c0 = C <= SOD_NT ? tid % C : tid;
+  const double s2 = kern_sigma_n2(kn);
+  double kd0 = 0.0, nrm0 = 0.0;  // k(x_c, x_c) and ||w_c||^2 of the thread's first candidate stay in registers; further ones in the workspace
+  for (int c = tid; c < N; c += SOD_NT) {
+    kd[c] = kern_diag(kn, X + (size_t)c * D, 1);
+    nrm[c] = 0.0;
   }
-  __threadfence_block();
-  for (int i = 1; i < N; ++i) {
-    const double* xi = X + (size_t)i * kn.D;
-    // right-hand side k_S(x_i)
-    for (int s = lane; s < n; s += MCP_WAVE) kv[s] = kern_eval(kn, xi, 1, X + (size_t)idx_out[s] * kn.D, 1);
-    __builtin_amdgcn_wave_barrier();
-    // forward substitution U^T w = kv, column-oriented: after w_s is final, eliminate it from the rest
-    double nrm = 0.0;
-    for (int s = 0; s < n; ++s) {
-      double ws = kv[s] / Uw[(size_t)s * N + s];
-      nrm = fma(ws, ws, nrm);
-      for (int r = s + 1 + lane; r < n; r += MCP_WAVE) kv[r] = fma(-Uw[(size_t)s * N + r], ws, kv[r]);
-      if (lane == 0) kv[s] = ws;
-      __builtin_amdgcn_wave_barrier();
+  if (grp == 0 && c0 < N) kd0 = kern_diag(kn, X + (size_t)c0 * D, 1);
+  if (tid == 0) s_next[0] = s_next[1] = s_next[2] = N;
+  __syncthreads();
+  // the scan: point p (the n-th of the subset) has just been accepted; every later candidate gets its component n, is tested, and the
+  // smallest index that passes is the next p
+  int n = 0, p = 0, slot = 0;
+#ifdef SOD_STAMPS
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq;
+#define SOD_STAMP(k)                                       \
+  {                                                        \
+    unsigned long long tn_ = __builtin_amdgcn_s_memtime(); \
+    st[k] += tn_ - tq;                                     \
+    tq = tn_;                                              \
+  }
+#else
+#define SOD_STAMP(k)
+#endif
+  while (true) {
+#ifdef SOD_STAMPS
+    tq = __builtin_amdgcn_s_memtime();
+#endif
+    if (tid == 0) {
+      idx_out[n] = p;
+      s_next[slot == 2 ? 0 : slot + 1] = N;  // next round's slot: last read two rounds ago
     }
-    double kii = kern_diag(kn, xi, 1);
-    double var = kii - nrm;
-    if (sqrt(var) > thr) {
-      for (int s = lane; s < n; s += MCP_WAVE) Uw[(size_t)s * N + n] = kv[s];
-      if (lane == 0) {
-        Uw[(size_t)n * N + n] = sqrt(kii + kern_sigma_n2(kn) - nrm);
-        idx_out[n] = i;
+    // the pivot's reciprocal, by the thread that holds p's sums (read by everybody behind the barrier below)
+    if (grp == 0 && (p - c0) % SOD_NT == 0 && c0 <= p) {
+      const bool first = p == c0;
+      piv[0] = 1.0 / sqrt((first ? kd0 : kd[p]) + s2 - (first ? nrm0 : nrm[p]));
+    }
+    for (int j = tid; j < n; j += SOD_NT) wp[j] = W[(size_t)j * N + p];
+    // k(x_c, x_p) of the thread's first candidate needs nothing of the above: its loads travel with the gather's
+    const double* xp = X + (size_t)p * D;
+    const bool own0 = grp == 0 && c0 < N && c0 > p;
+    double kcp0 = 0.0;
+    if (own0) kcp0 = kern_eval(kn, X + (size_t)c0 * D, 1, xp, 1);
+    SOD_STAMP(0)
+    __syncthreads();
+    SOD_STAMP(1)
+    const double rd = piv[0];
+    const int per = (n + JS - 1) / JS, j0 = grp * per, j1 = min(n, j0 + per);
+    for (int q = 0; q < CPT; ++q) {
+      const int c = c0 + q * SOD_NT;
+      const bool live = grp < JS && c < N && c > p;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      if (live) {
+        const double* wc = W + c;
+        int j = j0;
+        // (the 16 loads of a batch are pinned in flight together: left to the compiler they go out four at a time with a full wait
+        //  behind each group -- an L2 round trip per four rows)
+        for (; j + 16 <= j1; j += 16) {
+          double v[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) v[t] = wc[(size_t)(j + t) * N];
+          SOD_PIN16(v);
+#pragma unroll
+          for (int t = 0; t < 16; t += 4) {
+            a0 = fma(v[t], wp[j + t], a0);
+            a1 = fma(v[t + 1], wp[j + t + 1], a1);
+            a2 = fma(v[t + 2], wp[j + t + 2], a2);
+            a3 = fma(v[t + 3], wp[j + t + 3], a3);
+          }
+        }
+        if (j < j1) {
+          double v[16];
+#pragma unroll
+          for (int t = 0; t < 16; ++t) v[t] = wc[(size_t)min(j + t, j1 - 1) * N];
+          SOD_PIN16(v);
+#pragma unroll
+          for (int t = 0; t < 16; t += 4) {
+            a0 = fma(j + t < j1 ? v[t] : 0.0, wp[min(j + t, j1 - 1)], a0);
+            a1 = fma(j + t + 1 < j1 ? v[t + 1] : 0.0, wp[min(j + t + 1, j1 - 1)], a1);
+            a2 = fma(j + t + 2 < j1 ? v[t + 2] : 0.0, wp[min(j + t + 2, j1 - 1)], a2);
+            a3 = fma(j + t + 3 < j1 ? v[t + 3] : 0.0, wp[min(j + t + 3, j1 - 1)], a3);
+          }
+        }
       }
-      n += 1;
-      __threadfence_block();
+      double dot = (a0 + a1) + (a2 + a3);
+      SOD_STAMP(2)
+      if (JS > 1) {
+        if (grp > 0) part[tid] = dot;
+        __syncthreads();
+        SOD_STAMP(3)
+        if (grp == 0)
+          for (int g = 1; g < JS; ++g) dot += part[g * C + c0];
+      }
+      bool pass = false;
+      if (live && grp == 0) {
+        const double kcp = q == 0 ? kcp0 : kern_eval(kn, X + (size_t)c * D, 1, xp, 1);
+        const double w = (kcp - dot) * rd;
+        W[(size_t)n * N + c] = w;
+        const double nc = fma(w, w, q == 0 ? nrm0 : nrm[c]), kc = q == 0 ? kd0 : kd[c];
+        if (q == 0)
+          nrm0 = nc;
+        else
+          nrm[c] = nc;
+        pass = sqrt(kc - nc) > thr;
+      }
+      // candidates grow with the lane: the wave's first lane that passed speaks for it (one LDS atomic per wave, not one per lane)
+      const unsigned long long bal = __ballot(pass);
+      if (pass && (bal & ((1ull << (tid & 63)) - 1ull)) == 0ull) atomicMin(&s_next[slot], c);
     }
+    SOD_STAMP(4)
+    __syncthreads();
+    SOD_STAMP(5)
+    n += 1;
+    p = s_next[slot];
+    slot = slot == 2 ? 0 : slot + 1;
+    if (p >= N) break;
   }
-  if (lane == 0) *n_out = n;
+  if (tid == 0) *n_out = n;
+#ifdef SOD_STAMPS
+  if (tid == 256 || tid == 0 || tid == 256 + C) {  // into the unused tail rows of W (n < N rows are written when anything was rejected)
+    unsigned long long* o = (unsigned long long*)(W + (size_t)(N - 1) * N) + (tid == 0 ? 0 : (tid == 256 ? 8 : 16));
+    for (int k = 0; k < 6; ++k) o[k] = st[k];
+    o[6] = (unsigned long long)n;
+    o[7] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1600,17 +1711,17 @@ extern "C" int mcp_gp_pack(int N, int D, const double* X, const double* alpha, c
   return MCP_OK;
 }
 
-extern "C" size_t mcp_sod_workspace_bytes(int N) { return N > 0 ? sizeof(double) * (size_t)N * N : 0; }
+extern "C" size_t mcp_sod_workspace_bytes(int N) { return N > 0 ? sizeof(double) * ((size_t)N * N + 2 * (size_t)N) : 0; }
 
 extern "C" int mcp_sod_select(const mcp_kernel* kern, int N, const double* X, double threshold, int32_t* idx_out, int32_t* n_out,
                               void* workspace, size_t workspace_bytes, void* stream) {
   if (!kernel_ok(kern) || !X || !idx_out || !n_out || !workspace || N <= 0) return MCP_ERR_ARG;
   if (workspace_bytes < mcp_sod_workspace_bytes(N)) return MCP_ERR_WORKSPACE;
-  if (N > 16384) return MCP_ERR_LIMIT;  // kv [N] lives in LDS
+  if (N > 16384) return MCP_ERR_LIMIT;  // the accepted point's vector [N] lives in LDS
   double* Uw = (double*)workspace;
   MCP_ENSURE_MAX_LDS(sod_select_kernel);
-  hipLaunchKernelGGL(sod_select_kernel, dim3(1), dim3(MCP_WAVE), sizeof(double) * N, (hipStream_t)stream, *kern, N, X, threshold,
-                     idx_out, n_out, Uw);
+  hipLaunchKernelGGL(sod_select_kernel, dim3(1), dim3(SOD_NT), sizeof(double) * ((size_t)N + SOD_NT + 4), (hipStream_t)stream, *kern, N, X,
+                     threshold, idx_out, n_out, Uw);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }
