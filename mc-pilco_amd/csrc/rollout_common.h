@@ -52,7 +52,7 @@ static inline size_t rollout_kt_bytes(const mcp_model* m) {
   if (!m || m->D > RL_MAXD_ || m->G < 2) return 0;
   int npad = 0;
   for (int g = 0; g < m->G; ++g) npad = m->gp[g].Npad > npad ? m->gp[g].Npad : npad;
-  if (npad > 384) return 0;
+  if (npad > 640) return 0;
   return sizeof(double) * ((size_t)m->G * npad * npad + 6 * 128);  // (+ one register buffer of slack: the last stream may be read past its end)
 }
 

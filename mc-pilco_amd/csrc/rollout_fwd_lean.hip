@@ -76,8 +76,8 @@ struct LatFixed {
   static constexpr int eps = dl + 4 * MCP_MAX_GP + 2;          // [2][P] process noise of this workgroup's GP, by step parity
   static constexpr int red = eps + 2 * 4;                      // [RF_NW][NCG <= 3][8][8] phase-J partial tiles
   static constexpr int rt = red + RF_NW * 3 * 64;              // [NCG][8][8] their sum (phase F)
-  static constexpr int pc = rt + 3 * 64;                       // polynomial constants: kc1 | kcA | kcB [8 each, by xq row] | w1_D | sum alpha | AXX [8][8]
-  static constexpr int fz = pc + 24 + 4 + 64;                  // per step, z-only polynomial terms: [P][4] mpoly, kzz, Sa, Sb | [P][8][2] qB_c, qA_c
+  static constexpr int pc = rt + 3 * 64;                       // polynomial constants: kc1 | kcA | kcB [8 each, by xq row] | w1_D | sum alpha | AXX [8][8] | lengthscale by dimension [8]
+  static constexpr int fz = pc + 24 + 4 + 64 + 8;              // per step, z-only polynomial terms: [P][4] mpoly, kzz, Sa, Sb | [P][8][2] qB_c, qA_c
   static constexpr int pn = fz + 4 * 4 + 4 * 8 * 2;            // [2][32] position measurement noise by step parity (PMS)
   static constexpr int gpl = pn + 2 * 32;
   static constexpr int kpar = gpl + GPL_DOUBLES;
@@ -90,7 +90,7 @@ struct LatFixed {
 static_assert(LatFixed::pc % 2 == 0 && LatFixed::fz % 2 == 0 && LatFixed::gpl % 2 == 0, "16-byte alignment");
 static_assert(LatFixed::red % 2 == 0 && LatFixed::rt % 2 == 0 && LatFixed::zs % 2 == 0 && LatFixed::role % 2 == 0 && LatFixed::sro % 2 == 0 && LatFixed::end % 2 == 0, "16-byte alignment of the v2d regions");
 struct LatLayout {
-  int gs, kb, vb, xe, xq, al, cen, wgt, mk, total;  // offsets in doubles
+  int gs, kb, vb, xq, al, cen, wgt, mk, total;  // offsets in doubles
 };
 __host__ __device__ inline int lat_ng(int B) { return (B + 15) >> 4; }                 // groups of 16 basis functions
 __host__ __device__ inline int lat_ngp(int B) { return ((lat_ng(B) + 7) >> 3) << 3; }  // padded to whole chunks of 8 (zeros)
@@ -109,8 +109,8 @@ __host__ __device__ inline LatLayout lat_layout(int P, int B, int Npad, int maxd
   L.gs = take(RL_UM * P * lat_ngp(B));
   L.kb = take((Npad + 32) * P);   // (+ KT_ZROWS zero rows)
   L.vb = take(Npad * P * lat_nw(maxdeg) + 8);  // phase-J weights: W[j][2p + a] (SE only), W[j][s P + p] (polynomial); + the last column group's overhang
-  L.xe = take(8 * Npad);          // [X^T; 1; 0] (phase J's A operand)
-  L.xq = take(RL_ZD * Npad);
+  L.xq = take(RL_ZD * Npad);      // X^T / l by row (RL_DSM state-derived dimensions, RL_UM inputs, zero padded) with ONES in the first padded row:
+                                  // phase K's operand and phase J's A operand [X^T / l; 1] (round 4 kept a second, unscaled copy: 8 Npad doubles)
   L.al = take(Npad);
   L.cen = take(RL_PFM * Bp);
   L.wgt = take(RL_UM * Bp);
@@ -118,8 +118,13 @@ __host__ __device__ inline LatLayout lat_layout(int P, int B, int Npad, int maxd
   L.total = o;
   return L;
 }
+// rows of xq: GP-input dimension d sits in row d (state-derived, d < DS) or RL_DSM + (d - DS) (inputs); the first padded row carries ones
+// (there is one whenever D <= 7: lean_applies) -- phase J's unweighted sums; phase K sees z = 1 there: a zero distance term
+__host__ __device__ inline int lat_row_of(int d, int DS) { return d < DS ? d : RL_DSM + (d - DS); }
+__host__ __device__ inline int lat_ones_row(int DS, int U) { return DS < RL_DSM ? DS : RL_DSM + U; }
+#define LAT_PC_LS 92  // pc[LAT_PC_LS + d]: lengthscale of dimension d
 // role table entries (ints) of a thread of wave 0
-enum { RO_OP, RO_OS, RO_ZPLAIN, RO_ZANG, RO_PPLAIN, RO_PANG, RO_GVEL, RO_GPOS, RO_VELOFPOS, RO_PMPOS, RO_PMVEL, RO_PMPAIR, RO_FP, RO_FC, RO_OM, RO_N };
+enum { RO_OP, RO_OS, RO_ZPLAIN, RO_ZANG, RO_PPLAIN, RO_PANG, RO_GVEL, RO_GPOS, RO_VELOFPOS, RO_PMPOS, RO_PMVEL, RO_PMPAIR, RO_FP, RO_FC, RO_OM, RO_FROW };
 
 // ---- Kinv as MFMA operand tiles (lean kernel, phase V) ----------------------------------------------------------------
 // v = Kinv k for P <= 4 particles is [N x N] x [N x 4]: v_mfma_f64_4x4x4_4b_f64 -- four independent 4x4x4 products per
@@ -136,12 +141,21 @@ enum { RO_OP, RO_OS, RO_ZPLAIN, RO_ZANG, RO_PPLAIN, RO_PANG, RO_GVEL, RO_GPOS, R
 // i.e. 32 <= Npad <= 384): a register buffer is then always 6 CONSECUTIVE tiles of the wave's stream -- two column groups x 3 row
 // tiles or three groups x 2 -- so the loads, the double buffering and the resident buffers are one code path; only the wiring of
 // the 12 MFMAs of a buffer (which accumulator, which k operand) differs.
+// Round 5: beyond 24 row tiles (Npad > 384, up to 48 = Npad 768) the parts of 2 or 3 go to up to 16 VIRTUAL waves; a real wave then
+// streams two segments one after the other (its own, w, and 8 + order[w]) through the same code, each with fresh accumulators, its own
+// tail and its own share of phase J.  order = {3, 2, 1, 0, 7, 6, 5, 4}: the first four extra segments go one to each SIMD (waves w and
+// w + 4 share one), wave 0 -- the serial section's -- last among them.
 #define KT_NL 6
-__host__ __device__ inline int kt_waves(int nrtt) { return nrtt >= 2 * RF_NW ? RF_NW : (nrtt >= 2 ? nrtt / 2 : 1); }
+#define KT_MAX_RT 48
+__host__ __device__ inline int kt_waves(int nrtt) {
+  if (nrtt > 3 * RF_NW) return nrtt / 2 < 2 * RF_NW ? nrtt / 2 : 2 * RF_NW;
+  return nrtt >= 2 * RF_NW ? RF_NW : (nrtt >= 2 ? nrtt / 2 : 1);
+}
 __host__ __device__ inline int kt_rt0(int nrtt, int w) {
   const int nw = kt_waves(nrtt);
   return w >= nw ? nrtt : (nrtt * w) / nw;
 }
+__host__ __device__ inline int kt_second_segment(int w) { return RF_NW + (w < 4 ? 3 - w : 11 - w); }
 __global__ void kt_pack_kernel(mcp_model md, double* __restrict__ kt, int stride) {
   const mcp_gp& gp = md.gp[blockIdx.y];
   const int Npad = gp.Npad, nrtt = Npad >> 4, njg = Npad >> 3;
@@ -151,7 +165,7 @@ __global__ void kt_pack_kernel(mcp_model md, double* __restrict__ kt, int stride
     const int h = idx & 1, l = (idx >> 1) & 63, tile = idx >> 7;
     const int rt = tile / njg, jg = tile - rt * njg;
     int w = 0;
-    while (w + 1 < RF_NW && kt_rt0(nrtt, w + 1) <= rt) ++w;
+    while (w + 1 < 2 * RF_NW && kt_rt0(nrtt, w + 1) <= rt) ++w;  // (virtual wave that owns row tile rt)
     const int r0 = kt_rt0(nrtt, w), nrt = kt_rt0(nrtt, w + 1) - r0;
     const int row = 16 * rt + 4 * ((l >> 2) & 3) + (l & 3), col = 8 * jg + 4 * h + (l >> 4);
     out[((size_t)r0 * njg + (size_t)jg * nrt + (rt - r0)) * 128 + 2 * l + h] = gp.Kinv[(size_t)row * Npad + col];
@@ -233,8 +247,9 @@ __device__ __forceinline__ void kt_use(const v2d (&A)[KT_NL], const v2d (&K)[3],
 // for the OTHER buffer's loads as well, i.e. no double buffering at all (seen in the ISA).
 template <int P, int NRES>
 __device__ __forceinline__ void kt_stream(gptr2_t p, int nrt, int njg, const double* kb, int lane, double (&acc3)[2][3], double (&acc2)[2][2],
-                                          const v2d (&res)[NRES + 1][KT_NL], int nres, v2d (&bufA)[KT_NL], v2d (&bufB)[KT_NL],
+                                          const v2d (&res)[NRES + 1][KT_NL], int rlo, int nres, v2d (&bufA)[KT_NL], v2d (&bufB)[KT_NL],
                                           int npre) {
+  // (the stream's first nres buffers are resident in res[rlo .. rlo + nres))
   const int nb = (nrt * njg + KT_NL - 1) / KT_NL;
   const int gpb = nrt == 3 ? 2 : 3;  // column groups per buffer
   const double* ka = kb + (lane >> 4) * P + ((lane & 3) < P ? (lane & 3) : 0);
@@ -246,9 +261,9 @@ __device__ __forceinline__ void kt_stream(gptr2_t p, int nrt, int njg, const dou
   kt_readk<P>(kB, ka, (b + 1) * gpb);
 #pragma unroll
   for (int r = 0; r < NRES + 1; ++r) {
-    if (r < nres) {  // wave-uniform
+    if (r >= rlo && r < rlo + nres) {  // wave-uniform
       v2d kR[3];
-      kt_readk<P>(kR, ka, r * gpb);
+      kt_readk<P>(kR, ka, (r - rlo) * gpb);
       kt_use(res[r], kR, nrt, acc3, acc2);
     }
   }
@@ -350,11 +365,10 @@ struct LatLog2 {
 // produced in phase V (its own row tiles: 32 or 48 training points) -- no workgroup barrier between the two phases -- and stores
 // its partial tile to red[wave][8][8], ONE unconditional store per lane.
 template <int P>
-__device__ __forceinline__ void lean_j(const double* xe, const double* vb, double* red, int Npad, int j0, int nu, int wv, int lane) {
+__device__ __forceinline__ void lean_j(const double* xe, const double* vb, int Npad, int j0, int nu, int lane, double& acc0, double& acc1) {
   const int kq = lane >> 4, blk = (lane >> 2) & 3, e = lane & 3;
   const double* ap = xe + (4 * (blk >> 1) + e) * Npad + j0 + kq;
   const double* bp = vb + (j0 + kq) * (2 * P) + 4 * (blk & 1) + e;  // (P < 4: columns >= 2P read a neighbour's weights; those output columns are never used)
-  double acc0 = 0.0, acc1 = 0.0;
   for (int u0 = 0; u0 < nu; u0 += 4) {  // nu = 8 or 12
     double av[4], bw[4];
 #pragma unroll
@@ -368,21 +382,18 @@ __device__ __forceinline__ void lean_j(const double* xe, const double* vb, doubl
     mfma4(acc0, av[2], bw[2]);
     mfma4(acc1, av[3], bw[3]);
   }
-  // D lane = 16 i + 4 blk + j: row 4 (blk >> 1) + i, column 4 (blk & 1) + j
-  red[wv * 64 + (4 * (blk >> 1) + kq) * 8 + 4 * (blk & 1) + e] = acc0 + acc1;
 }
+// D lane = 16 i + 4 blk + j: row 4 (blk >> 1) + i, column 4 (blk & 1) + j
+__device__ __forceinline__ int lean_j_slot(int lane) { return (4 * ((lane >> 3) & 1) + (lane >> 4)) * 8 + 4 * ((lane >> 2) & 1) + (lane & 3); }
 
 // The same with NCG > 1 column groups of 8 (polynomial kernels: NW P = 16 or 24 columns at P = 4): the A operand of a step is shared by
 // the groups, each group keeps its own accumulator pair; partial tiles to red[wave][group][8][8].  W is [j][NCOL] (columns p NW + s);
 // the last group may reach up to 7 columns past NCOL -- into the next row, finite values whose output columns nobody reads.
 template <int NCOL, int NCG>
-__device__ __forceinline__ void lean_j_groups(const double* xe, const double* vb, double* red, int Npad, int j0, int nu, int wv, int lane) {
+__device__ __forceinline__ void lean_j_groups(const double* xe, const double* vb, int Npad, int j0, int nu, int lane, double (&acc)[NCG][2]) {
   const int kq = lane >> 4, blk = (lane >> 2) & 3, e = lane & 3;
   const double* ap = xe + (4 * (blk >> 1) + e) * Npad + j0 + kq;
   const double* bp = vb + (j0 + kq) * NCOL + 4 * (blk & 1) + e;
-  double acc[NCG][2];
-#pragma unroll
-  for (int g = 0; g < NCG; ++g) acc[g][0] = acc[g][1] = 0.0;
   for (int u0 = 0; u0 < nu; u0 += 4) {  // nu = 8 or 12
     double av[4], bw[NCG][4];
 #pragma unroll
@@ -399,8 +410,6 @@ __device__ __forceinline__ void lean_j_groups(const double* xe, const double* vb
 #pragma unroll
       for (int g = 0; g < NCG; ++g) mfma4(acc[g][u & 1], av[u], bw[g][u]);
   }
-#pragma unroll
-  for (int g = 0; g < NCG; ++g) red[(wv * NCG + g) * 64 + (4 * (blk >> 1) + kq) * 8 + 4 * (blk & 1) + e] = acc[g][0] + acc[g][1];
 }
 
 // The z-only part of a polynomial kernel's posterior (MAXDEG > 0), per particle and step, by ONE otherwise idle wave between u and
@@ -468,6 +477,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   const int tid0 = threadIdx.x;
   const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
   const int DS = D - U;
+  const int ROW1 = lat_ones_row(DS, U);  // the row of xq that carries ones (phase J's unweighted sums)
   const int Npad = a.NpadMax;
   const int NG = lat_ng(B), NGP = lat_ngp(B), Bp = NG * 16, BQ = (B + 3) >> 2;
   const LatLayout L = lat_layout(P, B, Npad, MAXDEG);
@@ -494,7 +504,6 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   double* gs = smem + L.gs;
   double* kb = smem + L.kb;
   double* vb = smem + L.vb;
-  double* xe = smem + L.xe;
   double* xq = smem + L.xq;
   double* al_l = smem + L.al;
   double* cen = smem + L.cen;
@@ -534,10 +543,6 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   stage_gp_tables(gps_l, md.var_scale + myg, 1, D, gpl, kpar, tid0);
   {
     const mcp_gp& gp = gps_l[0];
-    for (int it = tid0; it < 8 * Npad; it += RF_NT) {  // [X^T; 1; 0]
-      const int d = it / Npad, j = it - d * Npad;
-      xe[it] = d < D ? (j < gp.Npad ? gp.Xt[(size_t)d * gp.Npad + j] : 0.0) : (d == D ? 1.0 : 0.0);
-    }
     for (int it = tid0; it < Npad; it += RF_NT) al_l[it] = it < gp.Npad ? gp.alpha[it] : 0.0;
     for (int it = tid0; it < Npad * NCOL + 8; it += RF_NT) vb[it] = 0.0;
   }
@@ -547,8 +552,12 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   }
   for (int it = tid0; it < RL_UM * P * NGP; it += RF_NT) gs[it] = 0.0;  // (the padding groups stay zero)
   for (int it = tid0; it < KT_ZROWS * P; it += RF_NT) kb[gps_l[0].Npad * P + it] = 0.0;  // (zero rows behind THIS GP's k: phase V's out-of-range operands)
-  for (int it = tid0; it < P * RL_ZD; it += RF_NT) zs[it] = 0.0;
+  for (int it = tid0; it < P * RL_ZD; it += RF_NT) zs[it] = (it % RL_ZD) == ROW1 ? 1.0 : 0.0;  // (the ones row meets z = 1: no distance term)
   for (int it = tid0; it < P * RL_PFM; it += RF_NT) sf[it] = 0.0;
+  // (before the barrier below: wave 1 writes step 1's position noise into this table in draw_step(0), behind it -- zeroed any later, a slow
+  //  wave 0 could wipe what wave 1 had just drawn)
+  if (PMS)
+    for (int it = tid0; it < 2 * 32; it += RF_NT) pnz[it] = 0.0;
   // roles of the threads of wave 0 in the serial section (read back from LDS every step: values derived from the thread id would
   // otherwise be hoisted out of the time loop and held in registers across every phase).  Thread (p, s) = p * S + s owns state
   // component s of particle p; thread (p, c) = p * (D + 1) + c evaluates column c of phase F for particle p.
@@ -605,7 +614,10 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     ro[RO_FP] = tid0 / (D + 1);
     ro[RO_FC] = tid0 % (D + 1);
     ro[RO_OM] = imin(m0 + op, Mend - 1);
-    ro[RO_N] = 0;
+    {  // row of xq that belongs to column c of phase F (c == D: the ones row)
+      const int c = tid0 % (D + 1);
+      ro[RO_FROW] = c < D ? lat_row_of(c, DS) : ROW1;
+    }
   }
   lds_barrier();
   // phase S as a table: thread (p, s) writes x, sin x or cos x to at most two GP-input slots (raw and divided by the lengthscale) and two
@@ -649,12 +661,17 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     const int q = it / Bp, b = it - q * Bp;
     cen[it] = (q < PF && b < B) ? pl.centers[(size_t)b * PF + q] * pol[q] : 0.0;
   }
-  for (int it = tid0; it < RL_ZD * Npad; it += RF_NT) {
-    const int r = it / Npad, j = it - r * Npad;
-    const int d = r < RL_DSM ? (r < DS ? r : -1) : (r - RL_DSM < U ? DS + r - RL_DSM : -1);
-    xq[it] = (d >= 0) ? xe[d * Npad + j] * kpar[KP_INVLS(D) + d] : 0.0;
+  {
+    const mcp_gp& gp = gps_l[0];
+    for (int it = tid0; it < RL_ZD * Npad; it += RF_NT) {
+      const int r = it / Npad, j = it - r * Npad;
+      const int d = r < RL_DSM ? (r < DS ? r : -1) : (r - RL_DSM < U ? DS + r - RL_DSM : -1);
+      xq[it] = (d >= 0) ? (j < gp.Npad ? gp.Xt[(size_t)d * gp.Npad + j] * kpar[KP_INVLS(D) + d] : 0.0) : (r == ROW1 ? 1.0 : 0.0);
+    }
   }
+  if (tid0 < RL_MAXD) pc[LAT_PC_LS + tid0] = tid0 < D ? 1.0 / kpar[KP_INVLS(D) + tid0] : 0.0;
   if (MAXDEG > 0) {
+    lds_barrier();  // (xq and the lengthscales, read below)
     // launch constants of the polynomial terms.  The bilinear forms are evaluated on SCALED operands (z_d / l_d)(X_jd / l_d), the tables
     // the SE distance already reads: their weights carry l_d^2.  Rows of xq: r < RL_DSM a state-derived dimension, RL_DSM + k an input.
     if (tid0 < RL_ZD) {
@@ -678,14 +695,16 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     if (tid0 >= 128 && tid0 < 192) {  // AXX[c][e] = sum_j alpha_j X_jc X_je (rows / columns >= D: zero)
       const int c = (tid0 - 128) >> 3, e = tid0 & 7;
       double sx = 0.0;
-      if (MAXDEG >= 2 && c < D && e < D)
-        for (int j = 0; j < Npad; ++j) sx = fma(al_l[j] * xe[c * Npad + j], xe[e * Npad + j], sx);
+      if (MAXDEG >= 2 && c < D && e < D) {
+        const double* xc_ = xq + lat_row_of(c, DS) * Npad;
+        const double* xe_ = xq + lat_row_of(e, DS) * Npad;
+        for (int j = 0; j < Npad; ++j) sx = fma(al_l[j] * xc_[j], xe_[j], sx);
+        sx *= pc[LAT_PC_LS + c] * pc[LAT_PC_LS + e];  // (xq holds X / l)
+      }
       pc[28 + c * 8 + e] = sx;
     }
     for (int it = tid0; it < 4 * 4 + 4 * 8 * 2; it += RF_NT) fz[it] = 0.0;
   }
-  if (PMS)
-    for (int it = tid0; it < 2 * 32; it += RF_NT) pnz[it] = 0.0;
   int cur = 0;
 
   // the random numbers of step `ts`: process noise of this workgroup's GP by wave 1, dropout decisions (one Philox block per 4 basis
@@ -724,25 +743,34 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   // this wave's share of Kinv: the row tiles [vrt0, vrt0 + vnrt) of its GP, as MFMA operand tiles in streaming order; the first
   // RL_NRES register buffers of the stream stay in registers for the whole rollout
   const int vnpad = __builtin_amdgcn_readfirstlane(gpl[0].Npad), vnjg = vnpad >> 3;
-  int vrt0, vnrt;
+  int vrt0, vnrt, vrt0b, vnrtb;  // first / second segment: row tiles [vrt0, vrt0 + vnrt), [vrt0b, vrt0b + vnrtb) (vnrtb = 0: none)
   {
-    const int w = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(tid0 >> 6), w2 = kt_second_segment(w);
     vrt0 = kt_rt0(vnpad >> 4, w);
     vnrt = kt_rt0(vnpad >> 4, w + 1) - vrt0;
+    vrt0b = kt_rt0(vnpad >> 4, w2);
+    vnrtb = kt_rt0(vnpad >> 4, w2 + 1) - vrt0b;
   }
   const gptr2_t vp = (gptr2_t)(a.kt + (size_t)myg * a.kt_stride + (size_t)vrt0 * vnjg * 128) + (tid0 & 63);
-  const int vnt = vnrt * vnjg;  // tiles in this wave's stream
+  const gptr2_t vpb = (gptr2_t)(a.kt + (size_t)myg * a.kt_stride + (size_t)vrt0b * vnjg * 128) + (tid0 & 63);
+  const int vnt = vnrt * vnjg;  // tiles in this wave's (first) stream
   // (degree-2 polynomial kernels at 4 particles: one resident buffer fewer -- the two halves of phase K carry six values per item
   //  across the barrier in between, and with three resident buffers the allocator spilled one of them to scratch: its reload in
   //  phase V waits with vmcnt(0), i.e. for the whole stream in flight: +1-2 k cycles per wave and step)
   constexpr int NRES = (MAXDEG >= 2 && P == 4) ? (RL_NRES > 1 ? RL_NRES - RL_NRES_CUT2 : RL_NRES) : RL_NRES;
   v2d vres[NRES + 1][KT_NL];  // (+ 1: a wave whose buffer count has the other parity keeps one more or one fewer)
+  // the second segment streams an even number of buffers as well: with an odd count its first buffer takes the register array's last slot
+  // (the first segment then keeps at most NRES)
   int nres = 0;
+  const int nresb = (vnrtb > 0 && (((vnrtb * vnjg + KT_NL - 1) / KT_NL) & 1)) ? 1 : 0;
   if (vnrt > 0) {
     nres = kt_resident_count((vnt + KT_NL - 1) / KT_NL, NRES);
+    if (nresb && nres > NRES) nres -= 2;  // (the parity rule had taken the spare slot)
 #pragma unroll
-    for (int r = 0; r < NRES + 1; ++r)
+    for (int r = 0; r < NRES + 1; ++r) {
       if (r < nres) kt_load(vres[r], vp, r);
+      if (r == NRES && nresb) kt_load(vres[r], vpb, 0);
+    }
   }
   unsigned long long last_stamp = clock64(), sub_stamp = last_stamp;
   double pm_prev_np = 0.0, pm_prev_nv = 0.0, pm_prev_mv = 0.0;  // PMS: previous noisy position / noisy velocity / filtered velocity of this lane's pair
@@ -941,7 +969,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     double ur[RL_UM];
 #pragma unroll
     for (int k = 0; k < RL_UM; ++k) {
-      ur[k] = 0.0;
+      ur[k] = (RL_DSM + k == ROW1) ? 1.0 : 0.0;  // (a padded input row that carries the ones: z = 1 there)
       if (k < U) {  // uniform
         const double* gk = gs + (k * P + pK) * NGP;
         double s = 0.0;
@@ -1042,24 +1070,31 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     // ---- phase V, second half: v = Kinv k on the 4x4x4 MFMA, then the phase-J weights of this wave's rows ----
     const unsigned long long tv0_ = stamping ? clock64() : 0;
     if (vnrt > 0) {
-      double acc3[2][3], acc2[2][2];
+      double jacc[NCG][2];  // this wave's partial tile of phase J (both segments)
 #pragma unroll
-      for (int r = 0; r < 3; ++r) acc3[0][r] = acc3[1][r] = 0.0;
+      for (int g = 0; g < NCG; ++g) jacc[g][0] = jacc[g][1] = 0.0;
+      const int nseg = vnrtb > 0 ? 2 : 1;  // wave-uniform
+      for (int sg = 0; sg < nseg; ++sg) {
+        const int rt0 = sg ? vrt0b : vrt0, nrt = sg ? vnrtb : vnrt;
+        double acc3[2][3], acc2[2][2];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) acc2[0][r] = acc2[1][r] = 0.0;
-      kt_stream<P, NRES>(vp, vnrt, vnjg, kb, lane, acc3, acc2, vres, nres, bufA, bufB, RL_PRE);
-      kt_tail<P, MAXDEG>(acc3, acc2, vrt0, vnrt, kb, al_l, vb, lane);
-      if (stamping && lane == 0) stl[16 + wv] += clock64() - tv0_;  // this wave's own phase V
-      // ---- phase J over the rows this wave has just finished (wave-level ordering only) ----
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const unsigned long long tj0_ = (stamping && wv == 0) ? clock64() : 0;
-      if (MAXDEG == 0)
-        lean_j<P>(xe, vb, red, Npad, 16 * vrt0, 4 * vnrt, wv, lane);
-      else
-        lean_j_groups<NCOL, NCG>(xe, vb, red, Npad, 16 * vrt0, 4 * vnrt, wv, lane);
-      if (stamping && tid == 0) stl[12] += clock64() - tj0_;
+        for (int r = 0; r < 3; ++r) acc3[0][r] = acc3[1][r] = 0.0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) acc2[0][r] = acc2[1][r] = 0.0;
+        kt_stream<P, NRES>(sg ? vpb : vp, nrt, vnjg, kb, lane, acc3, acc2, vres, sg ? NRES : 0, sg ? nresb : nres, bufA, bufB, sg ? 0 : RL_PRE);
+        kt_tail<P, MAXDEG>(acc3, acc2, rt0, nrt, kb, al_l, vb, lane);
+        if (stamping && lane == 0 && sg == nseg - 1) stl[16 + wv] += clock64() - tv0_;  // this wave's own phase V
+        // ---- phase J over the rows this wave has just finished (wave-level ordering only) ----
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (MAXDEG == 0)
+          lean_j<P>(xq, vb, Npad, 16 * rt0, 4 * nrt, lane, jacc[0][0], jacc[0][1]);
+        else
+          lean_j_groups<NCOL, NCG>(xq, vb, Npad, 16 * rt0, 4 * nrt, lane, jacc);
+      }
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) red[(wv * NCG + g) * 64 + lean_j_slot(lane)] = jacc[g][0] + jacc[g][1];
       // the z-only polynomial terms of this step (2.3 k cycles of one wave: LDS round trips in series), by wave 0 behind its own phase J --
       // it owns the fewest rows of Kinv and would wait ~4 k cycles at the barrier below; phase F (wave 0 itself) reads the result.
       // (At the end of phase K on a wave without an item in the last round it lengthened that phase by 0.9 k: profiles/r04_lean_variants.txt.)
@@ -1090,13 +1125,14 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       if (lane < P * (D + 1)) {
-        const int p = r3.x, c = r3.y;
+        const int p = r3.x, c = r3.y, crow = r3.w;  // (crow: the row of R that belongs to column c -- the sums come out in xq's row order)
         const GpL& gp = gpl[0];
         const double vscale = gp.var_scale;
         // SE only: R[D][2p] = sum_j k_j alpha_j,  R[D][2p+1] = k^T Kinv k;  R[c][.] the same sums weighted by X_jc.
         // Polynomial kernels: column p NW + s of R, slots s = 0 kse alpha, 1 kse v, then [v, k v] (degree 1) or [v B, v A, v, k v] (degree 2)
         // (GP_prior.py:137-155 with the kernel of GP_prior.py:314-335; the alpha-weighted polynomial sums and k(z, z): lean_prefz).
         const int cc = imin(c, D - 1);
+        const double lc = pc[LAT_PC_LS + cc];  // (phase J summed against X / l: R[c][.] = l_c x the row of its result)
         constexpr int SV = MAXDEG >= 2 ? 4 : 2, SKV = SV + 1;  // slots of v and k v
         auto Rp = [&](int row, int slot) {
           const int col = p * NWC + slot;
@@ -1105,17 +1141,19 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
         v2d RD, RC;
         double mu, var;
         if (MAXDEG == 0) {
-          RD = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(rtot + D * 8 + 2 * p, 16));
-          RC = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(rtot + cc * 8 + 2 * p, 16));
+          RD = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(rtot + ROW1 * 8 + 2 * p, 16));
+          RC = *reinterpret_cast<const v2d*>(__builtin_assume_aligned(rtot + crow * 8 + 2 * p, 16));
+          RC.x *= lc;
+          RC.y *= lc;
           mu = gp.mean + RD.x;
           var = (gp.lambda - RD.y) * vscale;  // k(z,z) = lambda: Stationary_GP.py:172-181
         } else {
-          RD.x = Rp(D, 0);
-          RD.y = Rp(D, 1);
-          RC.x = Rp(cc, 0);
-          RC.y = Rp(cc, 1);
+          RD.x = Rp(ROW1, 0);
+          RD.y = Rp(ROW1, 1);
+          RC.x = Rp(crow, 0) * lc;
+          RC.y = Rp(crow, 1) * lc;
           mu = gp.mean + (RD.x + fz[p * 4 + 0]);
-          var = (fz[p * 4 + 1] - Rp(D, SKV)) * vscale;
+          var = (fz[p * 4 + 1] - Rp(ROW1, SKV)) * vscale;
         }
         double eps = 0.0, wj = 0.0, sd = 0.0;
         if (a.particle_pred) {
@@ -1142,12 +1180,12 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
           if (MAXDEG >= 1) {
             const double w1c = kpar[KP_W1(D) + c];
             Jmu = fma(w1c, kpar[KP_AX(D) + c], Jmu);
-            Jvar += 2.0 * w1c * (zc - Rp(c, SV));
+            Jvar += 2.0 * w1c * (zc - Rp(crow, SV) * lc);
             if (MAXDEG >= 2) {
               const double a_ = kpar[KP_W20(D) + c], b_ = kpar[KP_W21(D) + c];
               const double qB = fz[P * 4 + (p * 8 + c) * 2], qA = fz[P * 4 + (p * 8 + c) * 2 + 1];
               Jmu += a_ * qB + b_ * qA;
-              Jvar += 2.0 * zc * (a_ * fz[p * 4 + 3] + b_ * fz[p * 4 + 2]) - 2.0 * (a_ * Rp(c, 2) + b_ * Rp(c, 3));
+              Jvar += 2.0 * zc * (a_ * fz[p * 4 + 3] + b_ * fz[p * 4 + 2]) - 2.0 * lc * (a_ * Rp(crow, 2) + b_ * Rp(crow, 3));
             }
           }
           a.jac[(((size_t)t * M + m0 + p) * G + myg) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
@@ -1219,16 +1257,25 @@ static int launch_fwd_lean_i(const FwdArgs& a, size_t lds, hipStream_t st) {
   MCP_LAUNCH_CHECK();
   return MCP_OK;
 }
-template <int P, int KR>
+// MAXDEGS: the polynomial degrees this (P, KR) pair is instantiated for (0 .. MAXDEGS)
+template <int P, int KR, int MAXDEGS>
 static int launch_fwd_lean_kr(const FwdArgs& a, size_t lds, hipStream_t st) {
   const bool pms = a.pol.meas.n > 0;
   if (a.maxdeg == 0) return pms ? launch_fwd_lean_i<P, KR, 0, true>(a, lds, st) : launch_fwd_lean_i<P, KR, 0, false>(a, lds, st);
-  if (a.maxdeg == 1) return pms ? launch_fwd_lean_i<P, KR, 1, true>(a, lds, st) : launch_fwd_lean_i<P, KR, 1, false>(a, lds, st);
-  return pms ? launch_fwd_lean_i<P, KR, 2, true>(a, lds, st) : launch_fwd_lean_i<P, KR, 2, false>(a, lds, st);
+  if constexpr (MAXDEGS >= 1)
+    if (a.maxdeg == 1) return pms ? launch_fwd_lean_i<P, KR, 1, true>(a, lds, st) : launch_fwd_lean_i<P, KR, 1, false>(a, lds, st);
+  if constexpr (MAXDEGS >= 2)
+    if (a.maxdeg == 2) return pms ? launch_fwd_lean_i<P, KR, 2, true>(a, lds, st) : launch_fwd_lean_i<P, KR, 2, false>(a, lds, st);
+  return MCP_ERR_LIMIT;
 }
-static int lean_items_per_thread(int P, int NpadMax) {  // 0: the shape has no instantiation
-  if (NpadMax < 32 || NpadMax > 384) return 0;  // phase V deals 2 .. 24 row tiles of 16 to the waves in parts of 2 or 3
-  return P == 4 ? 3 : (P == 2 ? 2 : 1);         // Npad * P <= KR * RF_NT
+// phase-K items per thread (Npad * P <= KR * RF_NT) among the instantiations of P; 0: the shape has none.  Round 5: Npad up to 640
+// (KR = 4, 5 at four particles) -- the training sets the launch scripts grow to without a subset (test_mcpilco4pms_cartpole.py: N = 450).
+static int lean_items_per_thread(int P, int NpadMax, int maxdeg) {
+  if (NpadMax < 32 || NpadMax > 640 || (NpadMax >> 4) > KT_MAX_RT) return 0;  // phase V deals 2 .. 48 row tiles of 16 in parts of 2 or 3
+  const int need = (NpadMax * P + RF_NT - 1) / RF_NT;
+  if (P == 4) return need <= 3 ? 3 : (need == 4 && maxdeg <= 1 ? 4 : (need == 5 && maxdeg == 0 ? 5 : 0));
+  if (P == 2) return need <= 2 ? 2 : (need == 3 && maxdeg == 0 ? 3 : 0);
+  return need <= 1 ? 1 : (need == 2 && maxdeg == 0 ? 2 : 0);
 }
 static bool lean_applies(const mcp_model* m, const mcp_policy* p, int P, int NpadMax, int maxdeg) {
   if (maxdeg < 0 || maxdeg > 2 || m->G < 2) return false;
@@ -1251,14 +1298,16 @@ static bool lean_applies(const mcp_model* m, const mcp_policy* p, int P, int Npa
   for (int g = 0; g < m->G; ++g)
     if (m->gp[g].Npad < 32) return false;  // (every GP needs two row tiles at least)
   if (m->D - m->U > RL_DSM || m->U > RL_UM || p->P > RL_PFM) return false;
+  if (m->D >= RL_ZD) return false;  // (the ones row of phase J's operand takes a padded row of X^T / l)
   if (P * m->S > 64 || P * (m->D + 1) > 64 || (m->G - 1) * P * 2 > 64 || m->D > RL_MAXD) return false;  // wave 0 carries the serial section
-  return lean_items_per_thread(P, NpadMax) > 0;
+  return lean_items_per_thread(P, NpadMax, maxdeg) > 0;
 }
 namespace mcp {
 int launch_fwd_lean(const FwdArgs& a, int P, size_t lds, hipStream_t st) {
-  if (P == 4) return launch_fwd_lean_kr<4, 3>(a, lds, st);
-  if (P == 2) return launch_fwd_lean_kr<2, 2>(a, lds, st);
-  return launch_fwd_lean_kr<1, 1>(a, lds, st);
+  const int kr = lean_items_per_thread(P, a.NpadMax, a.maxdeg);
+  if (P == 4) return kr == 3 ? launch_fwd_lean_kr<4, 3, 2>(a, lds, st) : (kr == 4 ? launch_fwd_lean_kr<4, 4, 1>(a, lds, st) : launch_fwd_lean_kr<4, 5, 0>(a, lds, st));
+  if (P == 2) return kr == 2 ? launch_fwd_lean_kr<2, 2, 2>(a, lds, st) : launch_fwd_lean_kr<2, 3, 0>(a, lds, st);
+  return kr == 1 ? launch_fwd_lean_kr<1, 1, 2>(a, lds, st) : launch_fwd_lean_kr<1, 2, 0>(a, lds, st);
 }
 // dynamic LDS of the lean kernel for this shape at P particles per workgroup; 0: the kernel does not take the shape
 size_t fwd_lean_lds_bytes(const mcp_model* m, const mcp_policy* p, int P, int NpadMax, int maxdeg) {

@@ -761,7 +761,7 @@ def test_lean_kernels_on_models_with_three_and_four_gps(G_, angles):
     angle = [0] if angles else []
     not_angle = [i for i in range(S) if i not in angle]
     D = len(not_angle) + 2 * len(angle) + U
-    fwd_lean_ok = D <= 8 and D - U <= 6  # (the forward kernel's lane roles; the backward one takes all three shapes)
+    fwd_lean_ok = D <= 7 and D - U <= 6  # (the forward kernel's lane roles and the ones row of its phase-J operand; the backward one takes all three shapes)
     Z = rng.randn(N, D) * 0.8
     gps = []
     for g in range(G_):

@@ -21,7 +21,15 @@ pytestmark = pytest.mark.gpu
 
 Tt = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
 
-REAL = {"se300": ("c1", 48, 8), "sep2_300": ("c3", 48, 8), "ur5_400": ("c5", 40, 6), "se300_long": ("c1", 32, 150), "sep1_300": ("c2p1_script", 48, 8)}
+REAL = {"se300": ("c1", 48, 8), "sep2_300": ("c3", 48, 8), "ur5_400": ("c5", 40, 6), "se300_long": ("c1", 32, 150), "sep1_300": ("c2p1_script", 48, 8),
+        # round 5: the training sets the launch scripts grow to (4th entry: N) -- the lean kernel beyond Npad = 384
+        "se360": ("c1", 48, 8, 360), "sep2_360": ("c3", 48, 8, 360), "se450": ("c1", 48, 8, 450), "sep1_500": ("c2p1_script", 48, 8, 500),
+        "se620": ("c1", 48, 8, 620)}
+
+
+def _real(key):
+    v = REAL[key]
+    return v if len(v) == 4 else v + (None,)
 
 
 @functools.lru_cache(maxsize=None)
@@ -29,8 +37,8 @@ def oracle_answer(key):
     """(cost, std, grads, states, inputs, x0, eps, masks) of the CPU oracle at the real N, small M and T, its own pretrain."""
     from mc_pilco_amd import workloads
 
-    name, M, Tn = REAL[key]
-    pb = workloads.numpy_problem(name)
+    name, M, Tn, Ntr = _real(key)
+    pb = workloads.numpy_problem(name, N=Ntr)
     c = pb["cfg"]
     if pb["target_traj"] is not None:
         from mc_pilco_amd import synthetic as sy
@@ -64,8 +72,8 @@ def hip_workload(key):
     from gpu_helpers import dev
     from mc_pilco_amd import workloads
 
-    name, M, Tn = REAL[key]
-    return workloads.build(name, device=dev(), M=M, T=Tn)  # pretrain (Gram -> Cholesky -> inverse -> alpha) on the device
+    name, M, Tn, Ntr = _real(key)
+    return workloads.build(name, device=dev(), M=M, T=Tn, N=Ntr)  # pretrain (Gram -> Cholesky -> inverse -> alpha) on the device
 
 
 @functools.lru_cache(maxsize=None)
@@ -75,9 +83,9 @@ def hip_workload_on_oracle_operands(key):
     from gpu_helpers import G, dev
     from mc_pilco_amd import ops, workloads
 
-    name, M, Tn = REAL[key]
+    name, M, Tn, Ntr = _real(key)
     o = oracle_answer(key)
-    w = workloads.build(name, device=dev(), M=M, T=Tn)
+    w = workloads.build(name, device=dev(), M=M, T=Tn, N=Ntr)
     pb, c = o["problem"], o["problem"]["cfg"]
     gps = []
     for g in range(c["G"]):
@@ -125,6 +133,40 @@ def test_rollout_kernels_alone_against_the_oracle_at_real_sizes(key, code, pb):
     assert es < 1e-9 and eu < 2e-9
     assert ec < 1e-11
     assert eg < 1e-9
+
+
+@pytest.mark.parametrize("code", [201, 202, 204, 4])
+@pytest.mark.parametrize("key", ["se360", "sep2_360", "se450", "sep1_500", "se620"])
+def test_lean_kernel_beyond_npad_384_against_the_oracle(key, code):
+    """Round 5: `rollout_fwd_lat_kernel` takes Npad up to 640 (SE; SE + polynomial(1) to 512, (2) to 384): beyond 24 row tiles a wave streams
+    two segments of Kinv, phase K takes 4 or 5 items per thread, and the second copy of X^T in LDS is gone (phase J sums against X^T / l
+    with a ones row).  N = 360 (SE, SE + poly(2): where the cart-pole scripts end), 450 (test_mcpilco4pms_cartpole.py's last trial), 500
+    (degree 1, KR = 4), 620 (KR = 5, 39 row tiles) on the oracle's own operands: states abs 3e-9, inputs 6e-9 (|u| <= 10), cost rel 1e-11,
+    gradients rel 1e-9.  Measured: lean 8.6e-10 .. 2.0e-9 / 2.7e-9 .. 4.6e-9, the general kernel (code 4, another summation order) 9.4e-10 ..
+    1.4e-9 / 2.4e-9 .. 4.0e-9 on the same cases -- Kinv of 450 - 620 points of a smooth trajectory is worse conditioned than at N = 300,
+    where 1e-9 / 2e-9 hold; cost and gradients sit at 1e-12 / 1e-10 as there."""
+    from gpu_helpers import dev, forced_variant
+    from mc_pilco_amd import ops
+
+    o = oracle_answer(key)
+    w = hip_workload_on_oracle_operands(key)
+    assert w.model.gps[0].N == _real(key)[3]
+    nz = ops.NoiseSpec(eps=o["eps"].to(dev()).contiguous(), masks=o["masks"].to(torch.uint8).to(dev()).contiguous())
+    for q in w.params:
+        q.grad = None
+    with forced_variant(code) as fv:
+        st, inp, status = ops.rollout(w.model, w.policy, nz, o["x0"].to(dev()), w.T, o["p"])
+        c, s = ops.expected_cost(w.cost, st)
+        c.backward()
+        fv.check(lean_expected=True if code >= 200 else None)
+    assert int(status.item()) == 0
+    es = float((st.detach().cpu() - o["states"]).abs().max())
+    eu = float((inp.detach().cpu() - o["inputs"]).abs().max())
+    ec = abs(float(c) - o["cost"]) / abs(o["cost"])
+    eg = max(float((q.grad.cpu().reshape(o["grads"][k].shape) - o["grads"][k]).abs().max()) / float(o["grads"][k].abs().max())
+             for q, k in zip(w.params, ["log_ls", "centers", "weight"]))
+    print("beyond 384: %s code %d: states %.2e inputs %.2e cost rel %.2e grad rel %.2e" % (key, code, es, eu, ec, eg))
+    assert es < 3e-9 and eu < 6e-9 and ec < 1e-11 and eg < 1e-9
 
 
 @pytest.mark.parametrize("code", [0, 16])

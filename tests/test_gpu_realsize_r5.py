@@ -183,14 +183,15 @@ def test_training_epoch_at_real_sizes_vs_oracle_autograd(N, D, deg):
 # (b) the measurement model at N = 300 against the oracle
 # ----------------------------------------------------------------------------------------------------------------------------------
 @functools.lru_cache(maxsize=None)
-def _pms300():
-    """orc.apply_policy_pms + cost + autograd at the `pms_script` shape (N = 300, Ts = 1/30, SE), M = 48, T = 8, its own pretrain and
-    noise; and the HIP workload packed from the ORACLE's operands (what differs is the rollout / adjoint kernels alone)."""
+def _pms300(N=300):
+    """orc.apply_policy_pms + cost + autograd at the `pms_script` shape (N = 300 -- or 450, where the script's last trial ends --, Ts = 1/30,
+    SE), M = 48, T = 8, its own pretrain and noise; and the HIP workload packed from the ORACLE's operands (what differs is the rollout /
+    adjoint kernels alone)."""
     from gpu_helpers import G, dev
     from mc_pilco_amd import ops, workloads
 
     M, Tn, p = 48, 8, 0.25
-    pb = workloads.numpy_problem("pms_script")
+    pb = workloads.numpy_problem("pms_script", N=N)
     c, q = pb["cfg"], pb["pms"]
     hyp = [orc.GPHyper(torch.log(Tt(c["lengthscales"])), torch.log(Tt([c["lam"]])), torch.log(Tt([c["sigma_n"]]))) for _ in range(c["G"])]
     caches = [orc.pretrain_gp(hyp[g], Tt(pb["Z"]), Tt(pb["Ys"][g])) for g in range(c["G"])]
@@ -209,16 +210,17 @@ def _pms300():
     cost, std = orc.expected_cost(orc.cart_pole_cost(st, Tt(c["cost_target"]), Tt(c["cost_ls"]), c["cost_angle_index"], c["cost_pos_index"]))
     cost.backward()
     grads = [t.grad.clone() for t in prm]
-    w = workloads.build("pms_script", device=dev(), M=M, T=Tn)
-    assert w.model.gps[0].N == 300 and abs(w.model.c.Ts - 1.0 / 30.0) < 1e-15
+    w = workloads.build("pms_script", device=dev(), M=M, T=Tn, N=N)
+    assert w.model.gps[0].N == N and abs(w.model.c.Ts - 1.0 / 30.0) < 1e-15
     gps = [ops.PackedGP(workloads.spec_for(c, c["sigma_n"], None), G(ch.X.numpy()), G(ch.alpha.numpy()), G(ch.Kinv.numpy())) for ch in caches]
     w.model = ops.PackedModel(gps, c["S"], c["U"], c["Ts"], c["angle"], c["not_angle"], c["vel"], c["not_vel"])
     w.meas.pos_noise = pos_noise.to(dev()).contiguous()
     return dict(states=st.detach(), inputs=inp.detach(), cost=float(cost), grads=grads, x0=x0, eps=eps, masks=masks, p=p, w=w)
 
 
+@pytest.mark.parametrize("N", [300, 450])
 @pytest.mark.parametrize("code", [201, 202, 204, 4, 104, 16])
-def test_measurement_model_kernels_against_the_oracle_at_n300(code):
+def test_measurement_model_kernels_against_the_oracle_at_n300(code, N):
     """`pms300`: codes 201 / 202 / 204 = `rollout_fwd_lat_kernel<P, KR, 0, true>` + `rollout_bwd_lat_kernel<., true>` (what `pms_script`
     runs), 4 / 104 the general small-tile kernel, 16 the tile kernel, against orc.apply_policy_pms (MC_PILCO.py:808-906) at N = 300: states
     abs 3e-9, inputs abs 5e-9 (|u| <= 10), cost rel 1e-11, gradients rel 1e-9.  Measured (round 5): every variant -- three different summation
@@ -228,7 +230,7 @@ def test_measurement_model_kernels_against_the_oracle_at_n300(code):
     from gpu_helpers import dev, forced_variant
     from mc_pilco_amd import ops
 
-    o = _pms300()
+    o = _pms300(N)
     w = o["w"]
     nz = ops.NoiseSpec(eps=o["eps"].to(dev()).contiguous(), masks=o["masks"].to(torch.uint8).to(dev()).contiguous())
     for q in w.params:
@@ -243,7 +245,7 @@ def test_measurement_model_kernels_against_the_oracle_at_n300(code):
     eu = float((inp.detach().cpu() - o["inputs"]).abs().max())
     ec = abs(float(c) - o["cost"]) / abs(o["cost"])
     eg = max(float((q.grad.cpu().reshape(g.shape) - g).abs().max()) / float(g.abs().max()) for q, g in zip(w.params, o["grads"]))
-    print("pms300 code %d: states %.2e inputs %.2e cost rel %.2e grad rel %.2e" % (code, es, eu, ec, eg))
+    print("pms N=%d code %d: states %.2e inputs %.2e cost rel %.2e grad rel %.2e" % (N, code, es, eu, ec, eg))
     assert es < 3e-9 and eu < 5e-9 and ec < 1e-11 and eg < 1e-9
 
 
