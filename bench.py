@@ -4,7 +4,7 @@ MC_PILCO.reinforce_policy (policy_learning/MC_PILCO.py:484-525) -- fused particl
 expected cost, reverse-time adjoint, [one all-reduce of gradient + cost sums], Adam update -- on
 synthetic cart-pole-shaped data.  Metric: particle-steps/s = M*T / step time, whole job.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c1_script|c2_script|pms_script|ur5_script|c3|c4|c5] [--no-cpu] [--no-extra]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c1|c1_script|c2_script|pms_script|pms_script_n450|c1_script_n360|c2_script_n360|ur5_script|c3|c4|c5] [--no-cpu] [--no-extra]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -577,7 +577,8 @@ def main():
             # SURVEY 8d), c3 (SE+poly(2), M=4000) and c5 (UR5, 6 GPs, D=24, N=400, M=2000, T=300) -- same step definition, fewer steps
             extra = []
             # (same rule as the headline: blocks of exactly k steps, repeated until >= min-seconds have been measured, median block)
-            for name, k in (("c1_script", 20), ("c2_script", 20), ("pms_script", 20), ("ur5_script", 10), ("c3", 5), ("c5", 3)):
+            for name, k in (("c1_script", 20), ("c2_script", 20), ("pms_script", 20), ("pms_script_n450", 20), ("c1_script_n360", 20), ("c2_script_n360", 20),
+                            ("ur5_script", 10), ("c3", 5), ("c5", 3)):
                 note("extra workload %s" % name)
                 r = Runner(args, name, dev, rank, world, reducer)
                 e2, f2, c2, b2 = r.run(k, 2, args.min_seconds)

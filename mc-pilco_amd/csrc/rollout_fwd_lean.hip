@@ -471,6 +471,9 @@ template <int P, int KR, int MAXDEG, bool PMS>
 __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   constexpr int LP = LatLog2<P>::v;
+  // two segments of Kinv per wave only beyond 24 row tiles (Npad > 384), i.e. in the instantiations with more phase-K items per thread than
+  // the base ones (lean_items_per_thread): the base instantiations carry no second stream pointer, no segment loop
+  constexpr bool SEG2 = KR > (P == 4 ? 3 : (P == 2 ? 2 : 1));
   constexpr int NWC = lat_nw(MAXDEG), NCOL = P * NWC, NCG = lat_ncg(P, MAXDEG);  // phase-J weight columns: per particle, in all, groups of 8
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
@@ -748,8 +751,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid0 >> 6), w2 = kt_second_segment(w);
     vrt0 = kt_rt0(vnpad >> 4, w);
     vnrt = kt_rt0(vnpad >> 4, w + 1) - vrt0;
-    vrt0b = kt_rt0(vnpad >> 4, w2);
-    vnrtb = kt_rt0(vnpad >> 4, w2 + 1) - vrt0b;
+    vrt0b = SEG2 ? kt_rt0(vnpad >> 4, w2) : 0;
+    vnrtb = SEG2 ? kt_rt0(vnpad >> 4, w2 + 1) - vrt0b : 0;
   }
   const gptr2_t vp = (gptr2_t)(a.kt + (size_t)myg * a.kt_stride + (size_t)vrt0 * vnjg * 128) + (tid0 & 63);
   const gptr2_t vpb = (gptr2_t)(a.kt + (size_t)myg * a.kt_stride + (size_t)vrt0b * vnjg * 128) + (tid0 & 63);
@@ -762,7 +765,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   // the second segment streams an even number of buffers as well: with an odd count its first buffer takes the register array's last slot
   // (the first segment then keeps at most NRES)
   int nres = 0;
-  const int nresb = (vnrtb > 0 && (((vnrtb * vnjg + KT_NL - 1) / KT_NL) & 1)) ? 1 : 0;
+  const int nresb = (SEG2 && vnrtb > 0 && (((vnrtb * vnjg + KT_NL - 1) / KT_NL) & 1)) ? 1 : 0;
   if (vnrt > 0) {
     nres = kt_resident_count((vnt + KT_NL - 1) / KT_NL, NRES);
     if (nresb && nres > NRES) nres -= 2;  // (the parity rule had taken the spare slot)
@@ -1073,7 +1076,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
       double jacc[NCG][2];  // this wave's partial tile of phase J (both segments)
 #pragma unroll
       for (int g = 0; g < NCG; ++g) jacc[g][0] = jacc[g][1] = 0.0;
-      const int nseg = vnrtb > 0 ? 2 : 1;  // wave-uniform
+      const int nseg = (SEG2 && vnrtb > 0) ? 2 : 1;  // wave-uniform
       for (int sg = 0; sg < nseg; ++sg) {
         const int rt0 = sg ? vrt0b : vrt0, nrt = sg ? vnrtb : vnrt;
         double acc3[2][3], acc2[2][2];
@@ -1272,10 +1275,11 @@ static int launch_fwd_lean_kr(const FwdArgs& a, size_t lds, hipStream_t st) {
 // (KR = 4, 5 at four particles) -- the training sets the launch scripts grow to without a subset (test_mcpilco4pms_cartpole.py: N = 450).
 static int lean_items_per_thread(int P, int NpadMax, int maxdeg) {
   if (NpadMax < 32 || NpadMax > 640 || (NpadMax >> 4) > KT_MAX_RT) return 0;  // phase V deals 2 .. 48 row tiles of 16 in parts of 2 or 3
+  if (NpadMax <= 384) return P == 4 ? 3 : (P == 2 ? 2 : 1);  // the base instantiations: one segment of Kinv per wave, every degree
+  if (maxdeg > 1) return 0;                                  // beyond: two segments; SE and SE + polynomial(1) (the LDS takes no more)
   const int need = (NpadMax * P + RF_NT - 1) / RF_NT;
-  if (P == 4) return need <= 3 ? 3 : (need == 4 && maxdeg <= 1 ? 4 : (need == 5 && maxdeg == 0 ? 5 : 0));
-  if (P == 2) return need <= 2 ? 2 : (need == 3 && maxdeg == 0 ? 3 : 0);
-  return need <= 1 ? 1 : (need == 2 && maxdeg == 0 ? 2 : 0);
+  if (P == 4) return need <= 4 ? 4 : (maxdeg == 0 ? 5 : 0);
+  return P == 2 ? 3 : 2;
 }
 static bool lean_applies(const mcp_model* m, const mcp_policy* p, int P, int NpadMax, int maxdeg) {
   if (maxdeg < 0 || maxdeg > 2 || m->G < 2) return false;
@@ -1306,8 +1310,8 @@ namespace mcp {
 int launch_fwd_lean(const FwdArgs& a, int P, size_t lds, hipStream_t st) {
   const int kr = lean_items_per_thread(P, a.NpadMax, a.maxdeg);
   if (P == 4) return kr == 3 ? launch_fwd_lean_kr<4, 3, 2>(a, lds, st) : (kr == 4 ? launch_fwd_lean_kr<4, 4, 1>(a, lds, st) : launch_fwd_lean_kr<4, 5, 0>(a, lds, st));
-  if (P == 2) return kr == 2 ? launch_fwd_lean_kr<2, 2, 2>(a, lds, st) : launch_fwd_lean_kr<2, 3, 0>(a, lds, st);
-  return kr == 1 ? launch_fwd_lean_kr<1, 1, 2>(a, lds, st) : launch_fwd_lean_kr<1, 2, 0>(a, lds, st);
+  if (P == 2) return kr == 2 ? launch_fwd_lean_kr<2, 2, 2>(a, lds, st) : launch_fwd_lean_kr<2, 3, 1>(a, lds, st);
+  return kr == 1 ? launch_fwd_lean_kr<1, 1, 2>(a, lds, st) : launch_fwd_lean_kr<1, 2, 1>(a, lds, st);
 }
 // dynamic LDS of the lean kernel for this shape at P particles per workgroup; 0: the kernel does not take the shape
 size_t fwd_lean_lds_bytes(const mcp_model* m, const mcp_policy* p, int P, int NpadMax, int maxdeg) {

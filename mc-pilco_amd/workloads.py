@@ -25,6 +25,9 @@ CONFIGS = {
     "c2_script": ("cartpole", 2, 300, 400, 60),   # test_mcpilco_cartpole.py:51-53,101,199: SE + polynomial(2), M=400, T=3.0/0.05
     "pms_script": ("cartpole", 0, 300, 400, 90),  # test_mcpilco4pms_cartpole.py:51-53,155-157,171: SE, M=400, T=3.0/(1/30), measured states
     "ur5_script": ("ur5", 1, 400, 200, 200),      # test_mcpilco_ur5_mujoco.py:58-59,102,195: 6 GPs, D=24, SE + polynomial(1), M=200, T=4.0/0.02
+    "pms_script_n450": ("cartpole", 0, 450, 400, 90),  # the same script's LAST trial: exact GP, 90 samples per trial, no subset (:50-53,64-88) -> N = 450
+    "c1_script_n360": ("cartpole", 0, 360, 400, 60),   # the cart-pole scripts' last trial without a subset: 60 + 5 x 60 samples
+    "c2_script_n360": ("cartpole", 2, 360, 400, 60),
     "c2p1_script": ("cartpole", 1, 300, 400, 60),  # the same with a degree-1 Volterra term (tests: the lean kernel's MAXDEG = 1 instantiations)
     "tiny": ("cartpole", 0, 48, 16, 6),
     "tiny_ur5": ("ur5", 1, 40, 8, 5),
@@ -32,6 +35,7 @@ CONFIGS = {
 # per-workload overrides: sampling time of the data / model, measurement model of MC_PILCO4PMS (pos, vel, noise std, filter cutoff)
 OPTIONS = {
     "pms_script": dict(Ts=1.0 / 30.0, pms=dict(pos=[0, 2], vel=[1, 3], std=3e-3, fc=0.5)),
+    "pms_script_n450": dict(Ts=1.0 / 30.0, pms=dict(pos=[0, 2], vel=[1, 3], std=3e-3, fc=0.5)),
 }
 
 
