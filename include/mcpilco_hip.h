@@ -50,7 +50,7 @@ extern "C" {
 #define MCP_MAX_GPDIM 32   /* D  : GP input dimension                                   */
 #define MCP_MAX_PFEAT 32   /* P  : policy feature dimension                             */
 #define MCP_MAX_BASIS 1024 /* B  : policy basis functions                               */
-#define MCP_MAX_TRAIN 1024 /* N  : training points kept per GP (fused rollout kernels)  */
+#define MCP_MAX_TRAIN 4096 /* N  : training points kept per GP (fused rollout kernels; round 5: was 1024) */
 
 /* Kernel hyper-parameters of one GP: squared-exponential (+ Volterra polynomial of degree
  * 0, 1 or 2) -- gpr_lib/GP_prior/Stationary_GP.py:112-181 (RBF), gpr_lib/GP_prior/Sparse_GP.py:
