@@ -1658,13 +1658,157 @@ static int launch_inverse_mfma(int N, const double* U, int ldu, double* Ui, int 
   return MCP_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Factorisation across workgroups (round 5; N >= CHB_MIN): right-looking by panels of CHB_NB rows.  Per panel k
+//   1. U_kk = chol(A_kk)                     the one-workgroup left-looking kernel above on the diagonal block
+//   2. W = U_kk^-1                           tri_diag_inverse + tri_inverse_cols4 on that block (8 block columns)
+//   3. U_kj = W^T A_kj   (j > k, in place)   chol_panel_solve_kernel:  one wave per 16 columns, the whole 128-row column slab in registers
+//   4. A_ij -= U_ki^T U_kj  (k < i <= j)     chol_trailing_update_kernel: one wave per 32 x 32 tile, 64 x 64 per workgroup, upper tiles only
+// Every product is  C[m][n] = sum_k P[k][m] Q[k][n]  on v_mfma_f64_16x16x4_f64 (A operand lane (kq, li) = P[k0 + kq][m0 + li], B likewise from Q,
+// result register r = C[m0 + kq + 4 r][n0 + li]), operands straight from L2.  The one-workgroup kernel (chain-bound: 8.2 k cycles per 16 rows,
+// one CU) took 3.1 ms at N = 1000 and stopped at 1152 rows; the panels' chain is 8 block rows each and the O(N^3) part runs on the whole chip.
+// Scratch: mcp_chol_factor takes no workspace, but the strictly-lower triangle of A is output-zero by contract -- W_k lives in block (k, 0) of it
+// ((1, 0) for k = 0), the panels' logdet terms in its last row; chol_finish_kernel sums those and zeroes the triangle.
+// ---------------------------------------------------------------------------------------
+#define CHB_NB 128
+#define CHB_MIN 600
+__global__ __launch_bounds__(256) void chol_panel_solve_kernel(int R, const double* __restrict__ W, int ldw, double* __restrict__ B, int ldb) {
+  const int lane = threadIdx.x & 63, kq = lane >> 4, li = lane & 15;
+  const int col = ((int)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + li;
+  const bool ok = col < R;
+  double b[CHB_NB / 4];
+#pragma unroll
+  for (int s = 0; s < CHB_NB / 4; ++s) b[s] = ok ? B[(size_t)(4 * s + kq) * ldb + col] : 0.0;
+  v4d_p out[CHB_NB / 16];
+#pragma unroll
+  for (int mt = 0; mt < CHB_NB / 16; ++mt) {
+    v4d_p acc = {0.0, 0.0, 0.0, 0.0};
+    // (W is upper triangular: rows k > 16 mt + 15 of its columns [16 mt, 16 mt + 16) are zero -- and were never written)
+#pragma unroll
+    for (int s = 0; s < 4 * (mt + 1); ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(W[(size_t)(4 * s + kq) * ldw + 16 * mt + li], b[s], acc, 0, 0, 0);
+    out[mt] = acc;
+  }
+  if (ok) {
+#pragma unroll
+    for (int mt = 0; mt < CHB_NB / 16; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) B[(size_t)(16 * mt + kq + 4 * r) * ldb + col] = out[mt][r];
+  }
+}
+
+__global__ __launch_bounds__(256) void chol_trailing_update_kernel(int R, const double* __restrict__ Up, int ldu, double* __restrict__ C, int ldc) {
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (ti > tj) return;  // (the upper tiles only)
+  const int lane = threadIdx.x & 63, kq = lane >> 4, li = lane & 15, w = threadIdx.x >> 6;
+  const int m0 = 64 * ti + 32 * (w >> 1), n0 = 64 * tj + 32 * (w & 1);
+  if (m0 >= R || n0 >= R) return;
+  const int ma = min(m0 + li, R - 1), mb = min(m0 + 16 + li, R - 1), na = min(n0 + li, R - 1), nb = min(n0 + 16 + li, R - 1);  // (clamped: such columns are not stored)
+  v4d_p acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = v4d_p{0.0, 0.0, 0.0, 0.0};
+  for (int s0 = 0; s0 < CHB_NB / 4; s0 += 8) {  // 8 k-steps per batch: 32 loads in flight, then 32 MFMAs
+    double a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const double* row = Up + (size_t)(4 * (s0 + u) + kq) * ldu;
+      a0[u] = row[ma];
+      a1[u] = row[mb];
+      b0[u] = row[na];
+      b1[u] = row[nb];
+    }
+    asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(a0[4]), "+v"(a0[5]), "+v"(a0[6]), "+v"(a0[7]), "+v"(a1[0]), "+v"(a1[1]),
+                 "+v"(a1[2]), "+v"(a1[3]), "+v"(a1[4]), "+v"(a1[5]), "+v"(a1[6]), "+v"(a1[7]));
+    asm volatile("" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(b0[4]), "+v"(b0[5]), "+v"(b0[6]), "+v"(b0[7]), "+v"(b1[0]), "+v"(b1[1]),
+                 "+v"(b1[2]), "+v"(b1[3]), "+v"(b1[4]), "+v"(b1[5]), "+v"(b1[6]), "+v"(b1[7]));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc[1][1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * i + kq + 4 * r, col = n0 + 16 * j + li;
+        if (row < R && col < R) C[(size_t)row * ldc + col] -= acc[i][j][r];
+      }
+}
+
+// logdet = sum of the panels' terms (parked in the last row of the lower triangle), then the strictly-lower triangle back to zero
+__global__ void chol_finish_kernel(int N, double* __restrict__ A, int lda, int np, double* __restrict__ logdet) {
+  __shared__ double tot;
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int k = 0; k < np; ++k) s += A[(size_t)(N - 1) * lda + k];
+    tot = s;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) *logdet = tot;
+  __syncthreads();  // (every block has read the terms of the last row before any block zeroes it: the last row belongs to the LAST block)
+  for (int row = blockIdx.x; row < N; row += gridDim.x) {
+    if (row == N - 1 && gridDim.x > 1) continue;  // (left to the tail kernel)
+    for (int c = threadIdx.x; c < row; c += blockDim.x) A[(size_t)row * lda + c] = 0.0;
+  }
+}
+__global__ void chol_finish_tail_kernel(int N, double* __restrict__ A, int lda) {
+  for (int c = threadIdx.x; c < N - 1; c += blockDim.x) A[(size_t)(N - 1) * lda + c] = 0.0;
+}
+
+static int launch_chol_blocked(int N, double* A, int lda, double* logdet, uint32_t* status, hipStream_t st) {
+  const int NB = CHB_NB, np = (N + NB - 1) / NB;
+  if (N < 2 * NB + 1 || np > NB) return MCP_ERR_LIMIT;
+  for (int k = 0; k < np; ++k) {
+    const int k0 = k * NB, nb = N - k0 < NB ? N - k0 : NB, R = N - k0 - nb;
+    double* Akk = A + (size_t)k0 * lda + k0;
+    double* ldk = A + (size_t)(N - 1) * lda + k;
+    if (nb > 16) {
+      const int rc = launch_chol_mfma(1, nb, Akk, lda, ldk, status, 1, 0, 0, st);
+      if (rc != MCP_OK) return rc;
+    } else {
+      const size_t lds = sizeof(double) * ((size_t)CH_NB * (CH_NB + 1) + (size_t)CH_NB * nb);
+      hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(CH_NT), lds, st, nb, Akk, lda, ldk, status);
+      MCP_LAUNCH_CHECK();
+    }
+    if (R > 0) {  // (nb == NB here)
+      double* W = A + (size_t)(k == 0 ? NB : k0) * lda;
+      const int NBK = NB / 16;
+      hipLaunchKernelGGL(tri_diag_inverse_kernel, dim3(NBK, 1), dim3(64), 0, st, NB, Akk, lda, W, lda, (size_t)0, (size_t)0);
+      MCP_LAUNCH_CHECK();
+      MCP_ENSURE_MAX_LDS(tri_inverse_cols4_kernel);
+      hipLaunchKernelGGL(tri_inverse_cols4_kernel, dim3(NBK, 1), dim3(256), sizeof(double) * 256 * (size_t)(NBK + 3), st, NB, Akk, lda, W, lda,
+                         (size_t)0, (size_t)0);
+      MCP_LAUNCH_CHECK();
+      double* Akj = Akk + nb;
+      hipLaunchKernelGGL(chol_panel_solve_kernel, dim3((R + 63) / 64), dim3(256), 0, st, R, W, lda, Akj, lda);
+      MCP_LAUNCH_CHECK();
+      const int T = (R + 63) / 64;
+      hipLaunchKernelGGL(chol_trailing_update_kernel, dim3(T, T), dim3(256), 0, st, R, Akj, lda, Akk + (size_t)nb * lda + nb, lda);
+      MCP_LAUNCH_CHECK();
+    }
+  }
+  hipLaunchKernelGGL(chol_finish_kernel, dim3(256), dim3(256), 0, st, N, A, lda, np, logdet);
+  MCP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(chol_finish_tail_kernel, dim3(1), dim3(256), 0, st, N, A, lda);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
 static int g_chol_mfma = 1;  // test hook: 0 = the round-1/2 kernels (scalar trailing update, one wave per column of the inverse); 2 = the round-3 forms
                              // (right-looking factorization, block-diagonal sweep of the inverse)
 extern "C" void mcp_debug_set_chol_mfma(int on) { g_chol_mfma = on; }
 
 extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32_t* status, void* stream) {
   if (!A || !logdet || !status || N <= 0 || lda < N) return MCP_ERR_ARG;
-  if (N > 1152) return MCP_ERR_LIMIT;  // row panel [16][N] must fit the 160 KiB LDS
+  if (N > 8192) return MCP_ERR_LIMIT;
+  if (g_chol_mfma == 1 && N >= CHB_MIN) return launch_chol_blocked(N, A, lda, logdet, status, (hipStream_t)stream);  // panels across the chip
+  if (N > 1152) return MCP_ERR_LIMIT;  // (the one-workgroup forms: test hooks 0, 2, 3)
   if (g_chol_mfma && N > 16) {
     return launch_chol_mfma(g_chol_mfma == 3 ? 1 : g_chol_mfma, N, A, lda, logdet, status, 1, 0, 0, (hipStream_t)stream);
   }

@@ -135,6 +135,36 @@ def test_sod_indices_exact(golden):
     assert ops.sod_select(sp, X, float(fx["thr_abs"])) == [int(i) for i in fx["idx_abs"]]
 
 
+@pytest.mark.parametrize("N", [600, 601, 729, 1000, 1153, 1500, 2048, 4096])
+def test_blocked_cholesky_across_workgroups(N):
+    """Round 5: from 600 rows on `mcp_chol_factor` factorises by panels of 128 rows across the chip (the diagonal block by the one-workgroup
+    kernel, U_kj = W^T A_kj and the trailing update A_ij -= U_ki^T U_kj as MFMA products of one wave per tile; scratch in the lower triangle,
+    which comes back zero) -- sizes around the panel edges, beyond the old 1152-row limit, up to 4096: U^T U = K to 1e-13, upper
+    triangular, logdet against numpy to 1e-10; and the not-positive-definite flag from a pivot in a late panel."""
+    from gpu_helpers import G
+    from mc_pilco_amd import ops
+
+    rs = np.random.RandomState(N)
+    A = rs.randn(N, N + 3)
+    K = A @ A.T / (N + 3) + 0.1 * np.eye(N)
+    Kg = G(K)
+    U, logdet, status = ops.chol_factor(Kg)
+    assert int(status.item()) == 0
+    assert float(torch.tril(U, -1).abs().max()) == 0.0
+    assert float((U.t() @ U - Kg).abs().max()) < 1e-13 * float(Kg.abs().max())
+    ref = np.linalg.slogdet(K)[1]
+    assert abs(float(logdet) - ref) < 1e-10 * max(1.0, abs(ref))
+    if N <= 1500:  # (the inverse beyond 1152 rows runs the round-1 column kernels: correct, not fast)
+        Ui, Kinv = ops.chol_inverse(U)
+        assert float(torch.tril(Ui, -1).abs().max()) == 0.0
+        assert relerr(Ui @ U, np.eye(N)) < 1e-11
+        assert relerr(Kinv, np.linalg.inv(K)) < 1e-10
+    if N == 729:
+        K2 = K.copy()
+        K2[700, 700] = -5.0  # a pivot of the last panel
+        assert ops.status_flags(ops.chol_factor(G(K2))[2])["not_spd"]
+
+
 @pytest.mark.parametrize("pre,kind", [("plain", "plain"), ("ang", "angles"), ("traj", "traj")])
 def test_policy_forward(golden, pre, kind):
     """Policy.forward == the fused kernel with T=1."""
