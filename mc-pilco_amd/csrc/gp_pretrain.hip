@@ -1800,6 +1800,137 @@ static int launch_chol_blocked(int N, double* A, int lda, double* logdet, uint32
   return MCP_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// U^-1 and K^-1 beyond the one-launch forms' 1152 rows (round 5): Y = U^-T by block forward substitution, every product in the transposed-
+// left form the MFMA operands load coalesced from row-major storage,  C = +- P^T Q:
+//   W_I = U_II^-1                                     all diagonal blocks at once (tri_diag_inverse + tri_inverse_cols4, batched), into Uinv
+//   Y[I][I] = W_I^T;  T = U[0:I0, I]^T Y[0:I0, 0:I0]  (K = I0; Y lower triangular: rows above a column block are skipped)
+//   Y[I][0:I0] = - W_I^T T                            (K = 128)
+// Y is built in the Kinv buffer, T in the lower triangle of Uinv (zero at the end by contract); then Uinv = Y^T by tiles and
+// Kinv = Uinv Uinv^T (kinv_tiles_kernel) over the whole matrix.  Replaces the round-1 column kernels there: N = 2048 94 -> 1.5 ms, 4096 659 -> 6.6 ms.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tn_gemm_kernel(int M, int Nn, int K, const double* __restrict__ P, int ldp, const double* __restrict__ Q,
+                                                      int ldq, double* __restrict__ C, int ldc, double sign, int q_lower) {
+  const int lane = threadIdx.x & 63, kq = lane >> 4, li = lane & 15, w = threadIdx.x >> 6;
+  const int m0 = 64 * (int)blockIdx.y + 32 * (w >> 1), n0 = 64 * (int)blockIdx.x + 32 * (w & 1);
+  if (m0 >= M || n0 >= Nn) return;
+  const int ma = min(m0 + li, M - 1), mb = min(m0 + 16 + li, M - 1), na = min(n0 + li, Nn - 1), nb = min(n0 + 16 + li, Nn - 1);
+  v4d_p acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = v4d_p{0.0, 0.0, 0.0, 0.0};
+  for (int k0 = q_lower ? (n0 & ~31) : 0; k0 < K; k0 += 32) {  // (Q lower triangular: its rows above column n0 are zero)
+    double a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kr = min(k0 + 4 * u + kq, K - 1);
+      const double* pr = P + (size_t)kr * ldp;
+      const double* qr = Q + (size_t)kr * ldq;
+      a0[u] = pr[ma];
+      a1[u] = pr[mb];
+      b0[u] = qr[na];
+      b1[u] = qr[nb];
+    }
+    asm volatile("" : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(a0[4]), "+v"(a0[5]), "+v"(a0[6]), "+v"(a0[7]), "+v"(a1[0]), "+v"(a1[1]),
+                 "+v"(a1[2]), "+v"(a1[3]), "+v"(a1[4]), "+v"(a1[5]), "+v"(a1[6]), "+v"(a1[7]));
+    asm volatile("" : "+v"(b0[0]), "+v"(b0[1]), "+v"(b0[2]), "+v"(b0[3]), "+v"(b0[4]), "+v"(b0[5]), "+v"(b0[6]), "+v"(b0[7]), "+v"(b1[0]), "+v"(b1[1]),
+                 "+v"(b1[2]), "+v"(b1[3]), "+v"(b1[4]), "+v"(b1[5]), "+v"(b1[6]), "+v"(b1[7]));
+    if (k0 + 32 > K) {  // (the last, partial batch: the clamped rows count once)
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + 4 * u + kq >= K) a0[u] = a1[u] = 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc[1][1], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 16 * i + kq + 4 * r, col = n0 + 16 * j + li;
+        if (row < M && col < Nn) C[(size_t)row * ldc + col] = sign * acc[i][j][r];
+      }
+}
+// Y[I][I] = W_I^T for every diagonal block (W_I: the diagonal blocks of Ui)
+__global__ void diag_blocks_transpose_kernel(int N, const double* __restrict__ Ui, int ldi, double* __restrict__ Y, int ldy) {
+  const int I0 = (int)blockIdx.x * CHB_NB, nb = min(CHB_NB, N - I0);
+  for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) {
+    const int r = e / nb, c = e - r * nb;
+    Y[(size_t)(I0 + r) * ldy + I0 + c] = Ui[(size_t)(I0 + c) * ldi + I0 + r];
+  }
+}
+// Ui = Y^T outside the diagonal blocks (32 x 32 tiles through LDS), the strictly-lower blocks of Ui back to zero
+__global__ __launch_bounds__(256) void uinv_from_y_kernel(int N, const double* __restrict__ Y, int ldy, double* __restrict__ Ui, int ldi) {
+  __shared__ double tile[32][33];
+  const int br = blockIdx.y, bc = blockIdx.x;  // tile (br, bc) of Y, br >= bc
+  if (br < bc) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const bool same_block = (32 * br) / CHB_NB == (32 * bc) / CHB_NB;  // inside a diagonal block of 128: Ui holds W_I already
+  if (same_block) return;
+  for (int r = ty; r < 32; r += 8) {
+    const int row = 32 * br + r, col = 32 * bc + tx;
+    tile[r][tx] = (row < N && col < N) ? Y[(size_t)row * ldy + col] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int row = 32 * bc + r, col = 32 * br + tx;  // Ui[col of Y][row of Y]
+    if (row < N && col < N) Ui[(size_t)row * ldi + col] = tile[tx][r];
+    const int lr = 32 * br + r, lc = 32 * bc + tx;    // the mirrored (strictly-lower) tile: the scratch of T -> zero
+    if (lr < N && lc < N) Ui[(size_t)lr * ldi + lc] = 0.0;
+  }
+}
+
+static int launch_inverse_blocked(int N, const double* U, int ldu, double* Ui, int ldi, double* Kinv, int ldk, hipStream_t st) {
+  const int NB = CHB_NB, np = (N + NB - 1) / NB, nfull = N / NB, nlast = N - nfull * NB;
+  const int NBK = NB / 16;
+  MCP_ENSURE_MAX_LDS(tri_inverse_cols4_kernel);
+  if (nfull > 0) {  // W_I of the full blocks, batched over I (block I at offset I (NB ld + NB))
+    hipLaunchKernelGGL(tri_diag_inverse_kernel, dim3(NBK, nfull), dim3(64), 0, st, NB, U, ldu, Ui, ldi, (size_t)NB * ldu + NB, (size_t)NB * ldi + NB);
+    MCP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tri_inverse_cols4_kernel, dim3(NBK, nfull), dim3(256), sizeof(double) * 256 * (size_t)(NBK + 3), st, NB, U, ldu, Ui, ldi,
+                       (size_t)NB * ldu + NB, (size_t)NB * ldi + NB);
+    MCP_LAUNCH_CHECK();
+  }
+  if (nlast > 0) {
+    const size_t off_u = (size_t)nfull * ((size_t)NB * ldu + NB), off_i = (size_t)nfull * ((size_t)NB * ldi + NB);
+    const int nbk = (nlast + 15) / 16;
+    hipLaunchKernelGGL(tri_diag_inverse_kernel, dim3(nbk, 1), dim3(64), 0, st, nlast, U + off_u, ldu, Ui + off_i, ldi, (size_t)0, (size_t)0);
+    MCP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(tri_inverse_cols4_kernel, dim3(nbk, 1), dim3(256), sizeof(double) * 256 * (size_t)(nbk + 3), st, nlast, U + off_u, ldu, Ui + off_i,
+                       ldi, (size_t)0, (size_t)0);
+    MCP_LAUNCH_CHECK();
+  }
+  double* Y = Kinv;
+  hipLaunchKernelGGL(diag_blocks_transpose_kernel, dim3(np), dim3(256), 0, st, N, Ui, ldi, Y, ldk);
+  MCP_LAUNCH_CHECK();
+  for (int I = 1; I < np; ++I) {
+    const int I0 = I * NB, nb = N - I0 < NB ? N - I0 : NB;
+    double* T = Ui + (size_t)I0 * ldi;  // rows I0.., columns 0..I0 of the lower triangle
+    // T [nb x I0] = U[0:I0, I0:I0+nb]^T Y[0:I0, 0:I0]
+    hipLaunchKernelGGL(tn_gemm_kernel, dim3((I0 + 63) / 64, (nb + 63) / 64), dim3(256), 0, st, nb, I0, I0, U + I0, ldu, Y, ldk, T, ldi, 1.0, 1);
+    MCP_LAUNCH_CHECK();
+    // Y[I][0:I0] = - W_I^T T
+    hipLaunchKernelGGL(tn_gemm_kernel, dim3((I0 + 63) / 64, (nb + 63) / 64), dim3(256), 0, st, nb, I0, nb, Ui + (size_t)I0 * ldi + I0, ldi, T, ldi,
+                       Y + (size_t)I0 * ldk, ldk, -1.0, 0);
+    MCP_LAUNCH_CHECK();
+  }
+  const int nt32 = (N + 31) / 32;
+  hipLaunchKernelGGL(uinv_from_y_kernel, dim3(nt32, nt32), dim3(256), 0, st, N, Y, ldk, Ui, ldi);
+  MCP_LAUNCH_CHECK();
+  const int NBK16 = (N + 15) >> 4, nt = NBK16 * (NBK16 + 1) / 2;
+  hipLaunchKernelGGL(kinv_tiles_kernel, dim3((nt + 3) / 4, 1), dim3(256), 0, st, N, Ui, ldi, Kinv, ldk, (size_t)0, (size_t)0);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
 static int g_chol_mfma = 1;  // test hook: 0 = the round-1/2 kernels (scalar trailing update, one wave per column of the inverse); 2 = the round-3 forms
                              // (right-looking factorization, block-diagonal sweep of the inverse)
 extern "C" void mcp_debug_set_chol_mfma(int on) { g_chol_mfma = on; }
@@ -1822,6 +1953,7 @@ extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32
 extern "C" int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream) {
   if (!U || !Uinv || !Kinv || N <= 0 || ldu < N || ldi < N || ldk < N) return MCP_ERR_ARG;
   if (N > 16384) return MCP_ERR_LIMIT;
+  if (g_chol_mfma == 1 && N > 1152) return launch_inverse_blocked(N, U, ldu, Uinv, ldi, Kinv, ldk, (hipStream_t)stream);
   if ((g_chol_mfma == 1 || g_chol_mfma == 3) && N > 16 && N <= 1152)  // (3: the one-wave-per-column form of the inverse)
     return launch_inverse_mfma(N, U, ldu, Uinv, ldi, Kinv, ldk, 1, 0, 0, 0, (hipStream_t)stream, g_chol_mfma == 3);
   if (g_chol_mfma && N > 16 && N <= 1152)  // (2: the round-3 block-diagonal sweep of one workgroup, kept as a comparison form)

@@ -154,11 +154,11 @@ def test_blocked_cholesky_across_workgroups(N):
     assert float((U.t() @ U - Kg).abs().max()) < 1e-13 * float(Kg.abs().max())
     ref = np.linalg.slogdet(K)[1]
     assert abs(float(logdet) - ref) < 1e-10 * max(1.0, abs(ref))
-    if N <= 1500:  # (the inverse beyond 1152 rows runs the round-1 column kernels: correct, not fast)
-        Ui, Kinv = ops.chol_inverse(U)
-        assert float(torch.tril(Ui, -1).abs().max()) == 0.0
-        assert relerr(Ui @ U, np.eye(N)) < 1e-11
-        assert relerr(Kinv, np.linalg.inv(K)) < 1e-10
+    # (beyond 1152 rows: U^-T by block forward substitution in the Kinv buffer, U^-1 = its transpose, K^-1 = U^-1 U^-T by tiles)
+    Ui, Kinv = ops.chol_inverse(U)
+    assert float(torch.tril(Ui, -1).abs().max()) == 0.0
+    assert float((Ui @ U - torch.eye(N, dtype=U.dtype, device=U.device)).abs().max()) < 1e-11
+    assert relerr(Kinv, np.linalg.inv(K)) < 1e-10
     if N == 729:
         K2 = K.copy()
         K2[700, 700] = -5.0  # a pivot of the last panel
