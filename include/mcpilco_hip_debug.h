@@ -3,7 +3,8 @@
  * boundary (include/mcpilco_hip.h): the product path never needs them.  They exist so that the
  * parity tests can force every kernel variant the automatic dispatch of mcp_rollout_fwd /
  * mcp_rollout_bwd may choose, so that bench.py / tools can report which variant ran, and so that
- * tools/phase_stamps.py can read per-phase cycle counters.  Process-global, not thread-safe.
+ * tools/phase_stamps.py can read per-phase cycle counters.  The settings and the `last_*` answers are THREAD-LOCAL (round 5): a thread's
+ * hooks steer and describe only the calls that thread makes; a thread that never touches them gets the automatic dispatch.
  */
 #ifndef MCPILCO_HIP_DEBUG_H
 #define MCPILCO_HIP_DEBUG_H

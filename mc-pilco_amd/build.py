@@ -27,7 +27,7 @@ def _stale(target, deps):
 
 
 def build_variant(tag, defines, verbose=True, only=None):
-    """Experiment helper: a second library libmcpilco_hip_<tag>.so with extra -D defines (select it with MCPILCO_HIP_LIB).
+    """Experiment helper: a second library libmcpilco_hip_<tag>.so with extra -D defines (select it with MCPILCO_HIP_EXPERIMENT=1 MCPILCO_HIP_LIB=<path>).
     ``only``: the sources the defines concern (the others are linked from the main build's objects)."""
     objs = []
     for src in SOURCES:

@@ -1931,7 +1931,7 @@ static int launch_inverse_blocked(int N, const double* U, int ldu, double* Ui, i
   return MCP_OK;
 }
 
-static int g_chol_mfma = 1;  // test hook: 0 = the round-1/2 kernels (scalar trailing update, one wave per column of the inverse); 2 = the round-3 forms
+static thread_local int g_chol_mfma = 1;  // test hook: 0 = the round-1/2 kernels (scalar trailing update, one wave per column of the inverse); 2 = the round-3 forms
                              // (right-looking factorization, block-diagonal sweep of the inverse)
 extern "C" void mcp_debug_set_chol_mfma(int on) { g_chol_mfma = on; }
 

@@ -1357,12 +1357,12 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(int nblk, int nparam, 
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
-static unsigned long long* g_bwd_stamps = nullptr;  // diagnostic hook
+static thread_local unsigned long long* g_bwd_stamps = nullptr;  // diagnostic hook
 extern "C" void mcp_debug_set_bwd_stamp_buffer(void* p) { g_bwd_stamps = (unsigned long long*)p; }
-static int g_force_bwd_pb = 0;  // test hook: particles per workgroup of the backward sweep (0 = automatic)
+static thread_local int g_force_bwd_pb = 0;  // test hook: particles per workgroup of the backward sweep (0 = automatic)
 extern "C" void mcp_debug_set_bwd_particles(int pb) { g_force_bwd_pb = pb; }
-static int g_bwd_lean = -1;  // test hook: -1 automatic (the lean sweep where it applies), 0 never
-static int g_last_bwd_lean = 0;
+static thread_local int g_bwd_lean = -1;  // test hook: -1 automatic (the lean sweep where it applies), 0 never
+static thread_local int g_last_bwd_lean = 0;
 extern "C" void mcp_debug_set_bwd_lean(int v) { g_bwd_lean = v; }
 extern "C" int mcp_debug_last_bwd_lean(void) { return g_last_bwd_lean; }
 // what rollout_bwd_lat_kernel covers: the narrow class with its lane roles (states on lanes 0-7, features on 8-15, inputs on 16-17),

@@ -1182,33 +1182,33 @@ static int pick_particles_per_wg(int M) {
   return 16;  // falls back to 4 when the model does not fit the tile kernel
 }
 
-static int g_force_ppw = 0;   // test hook: force particles per workgroup (0 = automatic)
-static int g_force_xlds = -1; // test hook: -1 automatic, 0 never stage small operands in LDS, 1 = automatic
-static int g_force_gb = 0;    // test hook: GPs per pass (0 = as many as fit)
-static int g_last_ppw = 0;    // test hook: particles per workgroup of the last forward launch (16 = tile kernel)
+static thread_local int g_force_ppw = 0;   // test hook: force particles per workgroup (0 = automatic)
+static thread_local int g_force_xlds = -1; // test hook: -1 automatic, 0 never stage small operands in LDS, 1 = automatic
+static thread_local int g_force_gb = 0;    // test hook: GPs per pass (0 = as many as fit)
+static thread_local int g_last_ppw = 0;    // test hook: particles per workgroup of the last forward launch (16 = tile kernel)
 extern "C" void mcp_debug_set_particles_per_wg(int p) { g_force_ppw = p; }
 extern "C" int mcp_debug_last_particles_per_wg(void) { return g_last_ppw; }
 extern "C" void mcp_debug_set_fwd_mode(int xlds, int gb) {
   g_force_xlds = xlds;
   g_force_gb = gb;
 }
-static unsigned long long* g_stamps = nullptr;  // diagnostic hook: device buffer of 16 u64 phase-cycle totals
+static thread_local unsigned long long* g_stamps = nullptr;  // diagnostic hook: device buffer of 16 u64 phase-cycle totals
 extern "C" void mcp_debug_set_stamp_buffer(void* p) { g_stamps = (unsigned long long*)p; }
-static unsigned g_stamp_block = 0;
+static thread_local unsigned g_stamp_block = 0;
 extern "C" void mcp_debug_set_stamp_block(int b) { g_stamp_block = b > 0 ? (unsigned)b : 0u; }
 
 // ---- GP-sharded launch: G workgroups per particle cluster ----------------------------------------------------------
-static int g_gp_sharding = -1;  // test hook: -1 automatic, 0 never, 1 whenever the grid fits the device
-static int g_last_sharded = 0;  // test hook: number of GP-sharded launches the last forward call made (0 = not sharded)
-static int g_gp_max_launches = 2;  // a swarm goes out GP-sharded when it fits this many resident grids (cart-pole shape, forward ms,
+static thread_local int g_gp_sharding = -1;  // test hook: -1 automatic, 0 never, 1 whenever the grid fits the device
+static thread_local int g_last_sharded = 0;  // test hook: number of GP-sharded launches the last forward call made (0 = not sharded)
+static const int g_gp_max_launches = 2;  // a swarm goes out GP-sharded when it fits this many resident grids (cart-pole shape, forward ms,
                                    // tools/sweep_fwd_swarm.py: M=1024 two launches 4.9 vs 6.5 unsharded; M=1280 three launches 7.3 vs 6.9 on the tile kernel)
 extern "C" void mcp_debug_set_gp_sharding(int mode) { g_gp_sharding = mode; }
-static int g_policy_split = -1;  // test hook: -1 automatic, 0 = every member of a cluster of the GP-sharded 16-particle kernel evaluates the whole policy
+static thread_local int g_policy_split = -1;  // test hook: -1 automatic, 0 = every member of a cluster of the GP-sharded 16-particle kernel evaluates the whole policy
                                  // (rounds 2-3), 1 = the split whenever the shape allows it
 extern "C" void mcp_debug_set_policy_split(int mode) { g_policy_split = mode; }
 extern "C" int mcp_debug_last_gp_sharded(void) { return g_last_sharded; }
-static int g_fwd_lean = -1;  // test hook: -1 / 1 the latency-lean GP-sharded kernel wherever it applies, 0 never (the general one)
-static int g_last_lean = 0;  // test hook: 1 when the last forward call ran the latency-lean kernel
+static thread_local int g_fwd_lean = -1;  // test hook: -1 / 1 the latency-lean GP-sharded kernel wherever it applies, 0 never (the general one)
+static thread_local int g_last_lean = 0;  // test hook: 1 when the last forward call ran the latency-lean kernel
 extern "C" void mcp_debug_set_fwd_lean(int mode) { g_fwd_lean = mode; }
 extern "C" int mcp_debug_last_fwd_lean(void) { return g_last_lean; }
 static int gsh_grid(int nclusters, int G) { return ((nclusters + 7) / 8) * 8 * G; }

@@ -11,7 +11,11 @@ import os
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("MCPILCO_HIP_LIB") or os.path.join(HERE, "libmcpilco_hip.so")  # (the override is for kernel experiments)
+LIB_PATH = os.path.join(HERE, "libmcpilco_hip.so")
+# Kernel experiments (tools/, variant builds of mc-pilco_amd/build.py --variant*) may load another build: only when they ask for it by
+# MCPILCO_HIP_EXPERIMENT=1 next to MCPILCO_HIP_LIB -- a stray MCPILCO_HIP_LIB alone never swaps the product library.
+if os.environ.get("MCPILCO_HIP_EXPERIMENT") == "1" and os.environ.get("MCPILCO_HIP_LIB"):
+    LIB_PATH = os.environ["MCPILCO_HIP_LIB"]
 
 MAX_GP, MAX_STATE, MAX_INPUT, MAX_GPDIM, MAX_PFEAT, MAX_BASIS, MAX_TRAIN = 8, 16, 8, 32, 32, 1024, 4096
 OK = 0

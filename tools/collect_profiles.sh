@@ -37,7 +37,7 @@ run "fit ur5 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OU
 run "chol times" python3 $R/tools/time_chol.py 300 400 500 600 1000 > "$OUT/chol_times.txt" 2>&1
 if [ -f $R/mc-pilco_amd/libmcpilco_hip_stamps.so ]; then
   for n in 300 400; do
-    MCPILCO_HIP_LIB=$R/mc-pilco_amd/libmcpilco_hip_stamps.so python3 $R/tools/chol_stamps.py $n > "$OUT/chol_stamps_n$n.txt" 2>&1 || exit 1
+    MCPILCO_HIP_EXPERIMENT=1 MCPILCO_HIP_LIB=$R/mc-pilco_amd/libmcpilco_hip_stamps.so python3 $R/tools/chol_stamps.py $n > "$OUT/chol_stamps_n$n.txt" 2>&1 || exit 1
   done
 fi
 # keep what is cited: the per-kernel statistics, and of the counter passes only the rollout kernels' rows

@@ -1,5 +1,5 @@
 """Per-section cycle totals of sod_select_kernel (SOD_STAMPS build: python mc-pilco_amd/build.py --variant-gp sodst SOD_STAMPS;
-MCPILCO_HIP_LIB=.../libmcpilco_hip_sodst.so python tools/sod_stamps.py): waves 0 (dead early), 4 (group 0, live to the end), 4 of group 1."""
+MCPILCO_HIP_EXPERIMENT=1 MCPILCO_HIP_LIB=.../libmcpilco_hip_sodst.so python tools/sod_stamps.py): waves 0 (dead early), 4 (group 0, live to the end), 4 of group 1."""
 import ctypes as C
 import os
 import sys
