@@ -3,8 +3,9 @@
  * boundary (include/mcpilco_hip.h): the product path never needs them.  They exist so that the
  * parity tests can force every kernel variant the automatic dispatch of mcp_rollout_fwd /
  * mcp_rollout_bwd may choose, so that bench.py / tools can report which variant ran, and so that
- * tools/phase_stamps.py can read per-phase cycle counters.  The settings and the `last_*` answers are THREAD-LOCAL (round 5): a thread's
- * hooks steer and describe only the calls that thread makes; a thread that never touches them gets the automatic dispatch.
+ * tools/phase_stamps.py can read per-phase cycle counters.  Process-wide settings, held in atomics (round 5:
+ * no data race when another thread launches meanwhile -- PyTorch runs the adjoint sweep on its autograd thread, so a thread-local setting would not
+ * reach it); they are meant for a test driver that forces ONE variant at a time, not for concurrent use with different settings.
  */
 #ifndef MCPILCO_HIP_DEBUG_H
 #define MCPILCO_HIP_DEBUG_H

@@ -7,6 +7,7 @@
 #include <type_traits>
 
 #include "mcp_device.h"
+#include <atomic>
 
 using namespace mcp;
 
@@ -1931,7 +1932,7 @@ static int launch_inverse_blocked(int N, const double* U, int ldu, double* Ui, i
   return MCP_OK;
 }
 
-static thread_local int g_chol_mfma = 1;  // test hook: 0 = the round-1/2 kernels (scalar trailing update, one wave per column of the inverse); 2 = the round-3 forms
+static std::atomic<int> g_chol_mfma = 1;  // test hook: 0 = the round-1/2 kernels (scalar trailing update, one wave per column of the inverse); 2 = the round-3 forms
                              // (right-looking factorization, block-diagonal sweep of the inverse)
 extern "C" void mcp_debug_set_chol_mfma(int on) { g_chol_mfma = on; }
 
@@ -1941,7 +1942,7 @@ extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32
   if (g_chol_mfma == 1 && N >= CHB_MIN) return launch_chol_blocked(N, A, lda, logdet, status, (hipStream_t)stream);  // panels across the chip
   if (N > 1152) return MCP_ERR_LIMIT;  // (the one-workgroup forms: test hooks 0, 2, 3)
   if (g_chol_mfma && N > 16) {
-    return launch_chol_mfma(g_chol_mfma == 3 ? 1 : g_chol_mfma, N, A, lda, logdet, status, 1, 0, 0, (hipStream_t)stream);
+    return launch_chol_mfma(g_chol_mfma == 3 ? 1 : g_chol_mfma.load(), N, A, lda, logdet, status, 1, 0, 0, (hipStream_t)stream);
   }
   size_t lds = sizeof(double) * ((size_t)CH_NB * (CH_NB + 1) + (size_t)CH_NB * N);
   MCP_ENSURE_MAX_LDS(chol_factor_kernel);

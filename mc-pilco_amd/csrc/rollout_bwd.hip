@@ -16,6 +16,7 @@
 // models), and  rollout_bwd_lat_kernel<GM>  -- narrow plain / angle policies on swarms up to 3072 particles: one chain wave per particle working
 // from registers beside RBF waves that prepare their step ahead of the barrier.
 #include "rollout_common.h"
+#include <atomic>
 #include <type_traits>
 
 using namespace mcp;
@@ -1357,12 +1358,12 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(int nblk, int nparam, 
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
-static thread_local unsigned long long* g_bwd_stamps = nullptr;  // diagnostic hook
+static std::atomic<unsigned long long*> g_bwd_stamps = nullptr;  // diagnostic hook
 extern "C" void mcp_debug_set_bwd_stamp_buffer(void* p) { g_bwd_stamps = (unsigned long long*)p; }
-static thread_local int g_force_bwd_pb = 0;  // test hook: particles per workgroup of the backward sweep (0 = automatic)
+static std::atomic<int> g_force_bwd_pb = 0;  // test hook: particles per workgroup of the backward sweep (0 = automatic)
 extern "C" void mcp_debug_set_bwd_particles(int pb) { g_force_bwd_pb = pb; }
-static thread_local int g_bwd_lean = -1;  // test hook: -1 automatic (the lean sweep where it applies), 0 never
-static thread_local int g_last_bwd_lean = 0;
+static std::atomic<int> g_bwd_lean = -1;  // test hook: -1 automatic (the lean sweep where it applies), 0 never
+static std::atomic<int> g_last_bwd_lean = 0;
 extern "C" void mcp_debug_set_bwd_lean(int v) { g_bwd_lean = v; }
 extern "C" int mcp_debug_last_bwd_lean(void) { return g_last_bwd_lean; }
 // what rollout_bwd_lat_kernel covers: the narrow class with its lane roles (states on lanes 0-7, features on 8-15, inputs on 16-17),
@@ -1460,7 +1461,7 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   // swarms keep one particle per workgroup to spread over the CUs
   // (two 256-thread workgroups per CU are resident: one particle per workgroup while M of them fit in one round, then 2, then 4;
   //  measured, tools/sweep_bwd_particles.py: M=800 1.74 / 1.34 / 1.92 ms, M=2000 3.24 / 2.51 / 2.07 ms for 1 / 2 / 4)
-  int PB = g_force_bwd_pb ? g_force_bwd_pb : (M > 2816 ? 4 : (M > 512 ? 2 : 1));  // (round 3, after the RBF stage's diet: 2 particles win up to ~2800, tools/sweep_bwd_particles.py)
+  int PB = g_force_bwd_pb ? g_force_bwd_pb.load() : (M > 2816 ? 4 : (M > 512 ? 2 : 1));  // (round 3, after the RBF stage's diet: 2 particles win up to ~2800, tools/sweep_bwd_particles.py)
   if (!g_force_bwd_pb && (PF > 16 || U > 4)) {
     PB = M > 1024 ? 4 : 1;
     // eight per sweep (round 4) where that saves resident rounds: a 512-thread workgroup of this class has a CU to itself (256 per round), and a

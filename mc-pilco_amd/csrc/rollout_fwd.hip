@@ -28,6 +28,7 @@
 // measurable systems, MC_PILCO.py:808-906) phase S also produces what the policy sees: noisy
 // positions, backward-difference velocities, first-order filter, three carried values per pair.
 #include "rollout_fwd_shared.h"
+#include <atomic>
 
 using namespace mcp;
 
@@ -1182,33 +1183,33 @@ static int pick_particles_per_wg(int M) {
   return 16;  // falls back to 4 when the model does not fit the tile kernel
 }
 
-static thread_local int g_force_ppw = 0;   // test hook: force particles per workgroup (0 = automatic)
-static thread_local int g_force_xlds = -1; // test hook: -1 automatic, 0 never stage small operands in LDS, 1 = automatic
-static thread_local int g_force_gb = 0;    // test hook: GPs per pass (0 = as many as fit)
-static thread_local int g_last_ppw = 0;    // test hook: particles per workgroup of the last forward launch (16 = tile kernel)
+static std::atomic<int> g_force_ppw = 0;   // test hook: force particles per workgroup (0 = automatic)
+static std::atomic<int> g_force_xlds = -1; // test hook: -1 automatic, 0 never stage small operands in LDS, 1 = automatic
+static std::atomic<int> g_force_gb = 0;    // test hook: GPs per pass (0 = as many as fit)
+static std::atomic<int> g_last_ppw = 0;    // test hook: particles per workgroup of the last forward launch (16 = tile kernel)
 extern "C" void mcp_debug_set_particles_per_wg(int p) { g_force_ppw = p; }
 extern "C" int mcp_debug_last_particles_per_wg(void) { return g_last_ppw; }
 extern "C" void mcp_debug_set_fwd_mode(int xlds, int gb) {
   g_force_xlds = xlds;
   g_force_gb = gb;
 }
-static thread_local unsigned long long* g_stamps = nullptr;  // diagnostic hook: device buffer of 16 u64 phase-cycle totals
+static std::atomic<unsigned long long*> g_stamps = nullptr;  // diagnostic hook: device buffer of 16 u64 phase-cycle totals
 extern "C" void mcp_debug_set_stamp_buffer(void* p) { g_stamps = (unsigned long long*)p; }
-static thread_local unsigned g_stamp_block = 0;
+static std::atomic<unsigned> g_stamp_block = 0;
 extern "C" void mcp_debug_set_stamp_block(int b) { g_stamp_block = b > 0 ? (unsigned)b : 0u; }
 
 // ---- GP-sharded launch: G workgroups per particle cluster ----------------------------------------------------------
-static thread_local int g_gp_sharding = -1;  // test hook: -1 automatic, 0 never, 1 whenever the grid fits the device
-static thread_local int g_last_sharded = 0;  // test hook: number of GP-sharded launches the last forward call made (0 = not sharded)
+static std::atomic<int> g_gp_sharding = -1;  // test hook: -1 automatic, 0 never, 1 whenever the grid fits the device
+static std::atomic<int> g_last_sharded = 0;  // test hook: number of GP-sharded launches the last forward call made (0 = not sharded)
 static const int g_gp_max_launches = 2;  // a swarm goes out GP-sharded when it fits this many resident grids (cart-pole shape, forward ms,
                                    // tools/sweep_fwd_swarm.py: M=1024 two launches 4.9 vs 6.5 unsharded; M=1280 three launches 7.3 vs 6.9 on the tile kernel)
 extern "C" void mcp_debug_set_gp_sharding(int mode) { g_gp_sharding = mode; }
-static thread_local int g_policy_split = -1;  // test hook: -1 automatic, 0 = every member of a cluster of the GP-sharded 16-particle kernel evaluates the whole policy
+static std::atomic<int> g_policy_split = -1;  // test hook: -1 automatic, 0 = every member of a cluster of the GP-sharded 16-particle kernel evaluates the whole policy
                                  // (rounds 2-3), 1 = the split whenever the shape allows it
 extern "C" void mcp_debug_set_policy_split(int mode) { g_policy_split = mode; }
 extern "C" int mcp_debug_last_gp_sharded(void) { return g_last_sharded; }
-static thread_local int g_fwd_lean = -1;  // test hook: -1 / 1 the latency-lean GP-sharded kernel wherever it applies, 0 never (the general one)
-static thread_local int g_last_lean = 0;  // test hook: 1 when the last forward call ran the latency-lean kernel
+static std::atomic<int> g_fwd_lean = -1;  // test hook: -1 / 1 the latency-lean GP-sharded kernel wherever it applies, 0 never (the general one)
+static std::atomic<int> g_last_lean = 0;  // test hook: 1 when the last forward call ran the latency-lean kernel
 extern "C" void mcp_debug_set_fwd_lean(int mode) { g_fwd_lean = mode; }
 extern "C" int mcp_debug_last_fwd_lean(void) { return g_last_lean; }
 static int gsh_grid(int nclusters, int G) { return ((nclusters + 7) / 8) * 8 * G; }
@@ -1326,7 +1327,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   a.uxch = nullptr;
   hipStream_t st = (hipStream_t)stream;
   // configuration search: most particles per workgroup first, operands in LDS if they fit, all GPs per pass if they fit
-  int P0 = g_force_ppw ? g_force_ppw : pick_particles_per_wg(M);
+  int P0 = g_force_ppw ? g_force_ppw.load() : pick_particles_per_wg(M);
   if (P0 != 1 && P0 != 2 && P0 != 4 && P0 != 16) return MCP_ERR_ARG;
   if (policy->meas.n > 0 && !policy->meas.meas) return MCP_ERR_ARG;
   // small swarms: shard the GPs of a particle cluster over G workgroups (each streams one Kinv) when the whole grid is
@@ -1343,7 +1344,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
     a.xch = (unsigned long long*)workspace;
     a.GB = 1;
     a.NCmax = NC1;
-    for (int P = forced ? g_force_ppw : 1; P <= (forced ? g_force_ppw : 4) && NC1 <= RF_MAX_CHUNKS; P <<= 1) {
+    for (int P = forced ? g_force_ppw.load() : 1; P <= (forced ? g_force_ppw.load() : 4) && NC1 <= RF_MAX_CHUNKS; P <<= 1) {
       // particles one resident grid takes at this cluster size (whole groups of 8 clusters, G workgroups each)
       const int cap = (cus / (8 * model->G)) * 8 * P;
       if (cap <= 0) break;
@@ -1473,7 +1474,7 @@ extern "C" int mcp_posterior_fwd(const mcp_gp* gp, int M, const double* Z, doubl
   a.Jmu = Jmu;
   a.Jvar = Jvar;
   a.status = status;
-  int P0 = g_force_ppw ? g_force_ppw : pick_particles_per_wg(M);
+  int P0 = g_force_ppw ? g_force_ppw.load() : pick_particles_per_wg(M);
   if (P0 == 16) P0 = 4;  // (the single-step operator has no 16-particle form: more than 1024 test points run 4 per workgroup)
   if (P0 != 1 && P0 != 2 && P0 != 4) return MCP_ERR_ARG;
   for (int P = P0; P >= 1; P >>= 1) {

@@ -141,21 +141,34 @@ enum { RO_OP, RO_OS, RO_ZPLAIN, RO_ZANG, RO_PPLAIN, RO_PANG, RO_GVEL, RO_GPOS, R
 // i.e. 32 <= Npad <= 384): a register buffer is then always 6 CONSECUTIVE tiles of the wave's stream -- two column groups x 3 row
 // tiles or three groups x 2 -- so the loads, the double buffering and the resident buffers are one code path; only the wiring of
 // the 12 MFMAs of a buffer (which accumulator, which k operand) differs.
-// Round 5: beyond 24 row tiles (Npad > 384, up to 48 = Npad 768) the parts of 2 or 3 go to up to 16 VIRTUAL waves; a real wave then
-// streams two segments one after the other (its own, w, and 8 + order[w]) through the same code, each with fresh accumulators, its own
-// tail and its own share of phase J.  order = {3, 2, 1, 0, 7, 6, 5, 4}: the first four extra segments go one to each SIMD (waves w and
-// w + 4 share one), wave 0 -- the serial section's -- last among them.
+// Round 5: beyond 24 row tiles (Npad > 384, up to 48 = Npad 768) a wave streams TWO segments of 2 or 3 row tiles one after the other through
+// the same code, each with fresh accumulators, its own tail and its own share of phase J.  The phase is bound per SIMD (waves w and w + 4 share
+// one's issue port and matrix pipe), so the tiles are dealt per SIMD first -- nrtt / 4 each, the remainder to the last SIMDs (SIMD 0 hosts the
+// serial section's wave) --, a SIMD's share goes to its two waves (the older one gets the smaller half), and a wave's 4 / 5 / 6 tiles become
+// segments of (2, 2) / (3, 2) / (3, 3); 2 or 3 tiles: one segment.  (Dealing nrtt / 14 .. 16 "virtual waves" round the real ones left the SIMDs
+// with 6 / 6 / 9 / 8 tiles at N = 450: phase V of the slowest wave 33.5 k cycles against 18.2 k of the fastest.)
+// Segment (w, seg) = virtual wave seg * 8 + w; tiles are stored virtual wave by virtual wave.
 #define KT_NL 6
 #define KT_MAX_RT 48
-__host__ __device__ inline int kt_waves(int nrtt) {
-  if (nrtt > 3 * RF_NW) return nrtt / 2 < 2 * RF_NW ? nrtt / 2 : 2 * RF_NW;
-  return nrtt >= 2 * RF_NW ? RF_NW : (nrtt >= 2 ? nrtt / 2 : 1);
+__host__ __device__ inline int kt_waves(int nrtt) { return nrtt >= 2 * RF_NW ? RF_NW : (nrtt >= 2 ? nrtt / 2 : 1); }
+// row tiles of virtual wave vw (0 .. 15): count
+__host__ __device__ inline int kt_vcount(int nrtt, int vw) {
+  const int w = vw & (RF_NW - 1), seg = vw >> 3;
+  if (nrtt <= 3 * RF_NW) {  // one segment per wave, floor distribution
+    if (seg) return 0;
+    const int nw = kt_waves(nrtt);
+    return w >= nw ? 0 : (nrtt * (w + 1)) / nw - (nrtt * w) / nw;
+  }
+  const int s = w & 3, q = nrtt / 4 + (s >= 4 - (nrtt & 3) ? 1 : 0);  // this SIMD's share
+  const int c = w < 4 ? q / 2 : q - q / 2;                            // this wave's
+  if (c <= 3) return seg ? 0 : c;
+  return seg ? c / 2 : c - c / 2;
 }
-__host__ __device__ inline int kt_rt0(int nrtt, int w) {
-  const int nw = kt_waves(nrtt);
-  return w >= nw ? nrtt : (nrtt * w) / nw;
+__host__ __device__ inline int kt_vrt0(int nrtt, int vw) {
+  int r = 0;
+  for (int v = 0; v < vw; ++v) r += kt_vcount(nrtt, v);
+  return r;
 }
-__host__ __device__ inline int kt_second_segment(int w) { return RF_NW + (w < 4 ? 3 - w : 11 - w); }
 __global__ void kt_pack_kernel(mcp_model md, double* __restrict__ kt, int stride) {
   const mcp_gp& gp = md.gp[blockIdx.y];
   const int Npad = gp.Npad, nrtt = Npad >> 4, njg = Npad >> 3;
@@ -164,9 +177,12 @@ __global__ void kt_pack_kernel(mcp_model md, double* __restrict__ kt, int stride
     // idx = ((rt * njg + jg) * 64 + l) * 2 + h  in "row tile major" numbering; the destination re-orders the tiles per wave
     const int h = idx & 1, l = (idx >> 1) & 63, tile = idx >> 7;
     const int rt = tile / njg, jg = tile - rt * njg;
-    int w = 0;
-    while (w + 1 < 2 * RF_NW && kt_rt0(nrtt, w + 1) <= rt) ++w;  // (virtual wave that owns row tile rt)
-    const int r0 = kt_rt0(nrtt, w), nrt = kt_rt0(nrtt, w + 1) - r0;
+    int w = 0, r0 = 0;
+    while (w + 1 < 2 * RF_NW && r0 + kt_vcount(nrtt, w) <= rt) {  // (virtual wave that owns row tile rt)
+      r0 += kt_vcount(nrtt, w);
+      ++w;
+    }
+    const int nrt = kt_vcount(nrtt, w);
     const int row = 16 * rt + 4 * ((l >> 2) & 3) + (l & 3), col = 8 * jg + 4 * h + (l >> 4);
     out[((size_t)r0 * njg + (size_t)jg * nrt + (rt - r0)) * 128 + 2 * l + h] = gp.Kinv[(size_t)row * Npad + col];
   }
@@ -748,11 +764,11 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   const int vnpad = __builtin_amdgcn_readfirstlane(gpl[0].Npad), vnjg = vnpad >> 3;
   int vrt0, vnrt, vrt0b, vnrtb;  // first / second segment: row tiles [vrt0, vrt0 + vnrt), [vrt0b, vrt0b + vnrtb) (vnrtb = 0: none)
   {
-    const int w = __builtin_amdgcn_readfirstlane(tid0 >> 6), w2 = kt_second_segment(w);
-    vrt0 = kt_rt0(vnpad >> 4, w);
-    vnrt = kt_rt0(vnpad >> 4, w + 1) - vrt0;
-    vrt0b = SEG2 ? kt_rt0(vnpad >> 4, w2) : 0;
-    vnrtb = SEG2 ? kt_rt0(vnpad >> 4, w2 + 1) - vrt0b : 0;
+    const int w = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    vrt0 = kt_vrt0(vnpad >> 4, w);
+    vnrt = kt_vcount(vnpad >> 4, w);
+    vrt0b = SEG2 ? kt_vrt0(vnpad >> 4, RF_NW + w) : 0;
+    vnrtb = SEG2 ? kt_vcount(vnpad >> 4, RF_NW + w) : 0;
   }
   const gptr2_t vp = (gptr2_t)(a.kt + (size_t)myg * a.kt_stride + (size_t)vrt0 * vnjg * 128) + (tid0 & 63);
   const gptr2_t vpb = (gptr2_t)(a.kt + (size_t)myg * a.kt_stride + (size_t)vrt0b * vnjg * 128) + (tid0 & 63);

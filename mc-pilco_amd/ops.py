@@ -347,6 +347,23 @@ def _mc(model):
     return None if model is None else C.byref(model.c)
 
 
+def _workspace(model, policy, pc, M, T, which):
+    """(bytes, tensor) of the rollout workspace for this (model, policy shape, M, T), kept on the model object: the forward and the
+    backward call each have their own (a step's backward runs after its forward on the same stream, and the next forward after that)."""
+    if model is None:  # (policy-only evaluation: nothing to keep it on)
+        nbytes = abi.lib().mcp_rollout_workspace_bytes(None, C.byref(pc), M, T)
+        return nbytes, (torch.empty((nbytes + 7) // 8, dtype=DT, device=policy.device) if nbytes else None)
+    cache = model.__dict__.setdefault("_ws_cache", {})
+    key = (which, int(M), int(T), policy.kind, policy.B, policy.P, policy.U, policy.c.meas.n)
+    hit = cache.get(key)
+    if hit is None:
+        nbytes = abi.lib().mcp_rollout_workspace_bytes(_mc(model), C.byref(pc), M, T)
+        if len(cache) >= 8:  # (a few shapes per model at most: the warm-up rollout, the optimisation, an evaluation)
+            cache.clear()
+        hit = cache[key] = (nbytes, torch.empty((nbytes + 7) // 8, dtype=DT, device=model.device) if nbytes else None)
+    return hit
+
+
 def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, noise: NoiseSpec, x0, T, p_drop, particle_pred=True, need_jac=True,
                         meas: Optional[MeasSpec] = None, gp_sharding=True):
     """model None (only with T == 1) evaluates the policy alone.  gp_sharding False: the library never launches GP-sharded (the
@@ -364,9 +381,10 @@ def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, nois
     nz = noise.to_c()
     meas_buf = torch.empty(T, M, policy.S, dtype=DT, device=dev) if meas is not None else None
     _set_meas(policy, meas, T, M, meas_buf)
-    # workspace: the hand-off granules of the GP-sharded launch (small swarms); the library zeroes what it uses
-    nbytes = abi.lib().mcp_rollout_workspace_bytes(_mc(model), C.byref(pc), M, T) if (model is not None and T > 1) else 0
-    ws = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev) if nbytes else None
+    # workspace: the hand-off granules of the GP-sharded launch (small swarms) and the kernels' packed operand copies; the library zeroes /
+    # rebuilds what it uses on the stream, so ONE buffer per (model, shape) serves every step of an optimisation (no size query, no
+    # allocation per step)
+    nbytes, ws = _workspace(model, policy, pc, M, T, "fwd") if (model is not None and T > 1) else (0, None)
     ev = fwd_events
     try:
         if ev is not None:
@@ -397,8 +415,7 @@ def rollout_backward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseS
     T, M = states.shape[0], states.shape[1]
     pc = policy.bind(p_drop)
     nz = noise.to_c()
-    nbytes = abi.lib().mcp_rollout_workspace_bytes(_mc(model), C.byref(pc), M, T)
-    ws = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev)
+    nbytes, ws = _workspace(model, policy, pc, M, T, "bwd")
     g_ls = torch.empty(1, policy.P, dtype=DT, device=dev)
     g_c = torch.empty(policy.B, policy.P, dtype=DT, device=dev)
     g_w = torch.empty(policy.U, policy.B, dtype=DT, device=dev)

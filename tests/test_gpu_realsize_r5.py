@@ -226,7 +226,8 @@ def test_measurement_model_kernels_against_the_oracle_at_n300(code, N):
     abs 3e-9, inputs abs 5e-9 (|u| <= 10), cost rel 1e-11, gradients rel 1e-9.  Measured (round 5): every variant -- three different summation
     orders -- sits at states 1.1-1.25e-9, inputs 1.6-2.5e-9, cost 1e-12, gradients 2.5-3.9e-11: the data sampled at Ts = 1/30 are denser than
     the Ts = 0.05 sets (Kinv is worse conditioned), and the backward-difference velocity the policy sees multiplies a position difference by
-    2 / Ts = 60 -- hence 3x the bounds of the `se300` cases, not a property of one kernel."""
+    2 / Ts = 60 -- hence 3x the bounds of the `se300` cases, not a property of one kernel.  N = 450 (Kinv worse conditioned again): 5e-9 / 1e-8;
+    measured 2.2e-9 / 5.4e-9 on the lean kernel, the general ones alike."""
     from gpu_helpers import dev, forced_variant
     from mc_pilco_amd import ops
 
@@ -246,7 +247,7 @@ def test_measurement_model_kernels_against_the_oracle_at_n300(code, N):
     ec = abs(float(c) - o["cost"]) / abs(o["cost"])
     eg = max(float((q.grad.cpu().reshape(g.shape) - g).abs().max()) / float(g.abs().max()) for q, g in zip(w.params, o["grads"]))
     print("pms N=%d code %d: states %.2e inputs %.2e cost rel %.2e grad rel %.2e" % (N, code, es, eu, ec, eg))
-    assert es < 3e-9 and eu < 5e-9 and ec < 1e-11 and eg < 1e-9
+    assert es < (3e-9 if N <= 300 else 5e-9) and eu < (5e-9 if N <= 300 else 1e-8) and ec < 1e-11 and eg < 1e-9
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------
