@@ -16,11 +16,11 @@ run "c1 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c1_
 run "c3 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c3_stats" -o c3 -- $B --workload c3 --steps 5 --warmup 2 > "$OUT/c3_stats.log" 2>&1
 run "c5 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/c5_stats" -o c5 -- $B --workload c5 --steps 3 --warmup 1 > "$OUT/c5_stats.log" 2>&1
 # the reference's own small-swarm launch scripts' shapes (round 4)
-for w in c1_script c2_script pms_script ur5_script; do
+for w in c1_script c2_script pms_script pms_script_n450 c2_script_n360 ur5_script; do
   run "$w stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/${w}_stats" -o $w -- $B --workload $w --steps 20 --warmup 3 > "$OUT/${w}_stats.log" 2>&1
 done
 # phase stamps (tools/phase_stamps.py) of the same shapes
-for w in c1 c1_script c2_script pms_script ur5_script c3 c5; do
+for w in c1 c1_script c2_script pms_script pms_script_n450 ur5_script c3 c5; do
   run "$w stamps" python3 $R/tools/phase_stamps.py $w > "$OUT/${w}_stamps.txt" 2>&1
 done
 for w in c1 c3 c5; do
@@ -34,7 +34,10 @@ run "c5 mfma" rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_
 # CLX_STAMPS experiment build is there (python mc-pilco_amd/build.py --variant-gp stamps CLX_STAMPS) -- the Cholesky's cycles per block row
 run "fit c1 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/fit_c1_stats" -o fit_c1 -- python3 $R/tools/time_fit_model.py 300 100 > "$OUT/fit_c1_stats.log" 2>&1
 run "fit ur5 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/fit_ur5_stats" -o fit_ur5 -- python3 $R/tools/time_fit_ur5.py 100 > "$OUT/fit_ur5_stats.log" 2>&1
-run "chol times" python3 $R/tools/time_chol.py 300 400 500 600 1000 > "$OUT/chol_times.txt" 2>&1
+run "chol times" python3 $R/tools/time_chol.py 300 400 500 600 1000 1153 2048 4096 > "$OUT/chol_times.txt" 2>&1
+run "pretrain times" python3 $R/tools/time_pretrain.py > "$OUT/pretrain_times.txt" 2>&1
+# the symmetric phase-V experiment of round 5 (measured and dropped) beside the full stream it would replace
+( hipcc --offload-arch=gfx950 -O3 -w -o /tmp/vsym_bench $R/tools/vsym_bench.hip && /tmp/vsym_bench && hipcc --offload-arch=gfx950 -O3 -w -DNRES=0 -o /tmp/v4_bench $R/tools/v4_bench.hip && /tmp/v4_bench ) > "$OUT/vsym_bench.txt" 2>&1 || exit 1
 if [ -f $R/mc-pilco_amd/libmcpilco_hip_stamps.so ]; then
   for n in 300 400; do
     MCPILCO_HIP_EXPERIMENT=1 MCPILCO_HIP_LIB=$R/mc-pilco_amd/libmcpilco_hip_stamps.so python3 $R/tools/chol_stamps.py $n > "$OUT/chol_stamps_n$n.txt" 2>&1 || exit 1

@@ -17,7 +17,7 @@ src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 SHAPES = {"c1": (400, 150, 112), "c3": (4000, 150, 112), "c5": (2000, 300, 384)}  # M, T, algorithmic HBM bytes per particle-step
 
-for cfg in list(SHAPES) + ["c1_script", "c2_script", "pms_script", "ur5_script"]:
+for cfg in list(SHAPES) + ["c1_script", "c2_script", "pms_script", "pms_script_n450", "c2_script_n360", "ur5_script"]:
     f = os.path.join(src, cfg + "_stats", cfg + "_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, cfg)))
@@ -29,7 +29,7 @@ for cfg in ("fit_c1", "fit_ur5"):  # GP training epochs (round 4)
     f = os.path.join(src, cfg + "_stats", cfg + "_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, cfg)))
-for name in ("chol_times.txt", "chol_stamps_n300.txt", "chol_stamps_n400.txt"):
+for name in ("chol_times.txt", "chol_stamps_n300.txt", "chol_stamps_n400.txt", "pretrain_times.txt", "vsym_bench.txt"):
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_%s" % (rnd, name)))
