@@ -169,9 +169,12 @@ int mcp_cov_build(const mcp_kernel* kern, int N1, const double* X1, int N2, cons
  * GP_prior.py:337-347). */
 int mcp_cov_diag(const mcp_kernel* kern, int N, const double* X, int add_noise, double* diag, void* stream);
 /* In place: A (symmetric, upper triangle read) -> U upper with A = U^T U; strictly-lower part
- * zeroed; logdet = 2 sum log U_ii.  torch.cholesky(K, upper=True) + log_det, GP_prior.py:106-107. */
+ * zeroed (from 600 rows on it serves as scratch on the way); logdet = 2 sum log U_ii.  N <= 8192.
+ * torch.cholesky(K, upper=True) + log_det, GP_prior.py:106-107. */
 int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32_t* status, void* stream);
-/* Uinv = U^-1 (upper) and Kinv = Uinv Uinv^T.  torch.inverse(U), GP_prior.py:109-110. */
+/* Uinv = U^-1 (upper) and Kinv = Uinv Uinv^T.  torch.inverse(U), GP_prior.py:109-110.  Only the upper 16 x 16 blocks of Uinv are written
+ * (and, beyond 1152 rows, its strictly-lower 128-row block rows are used as scratch and zeroed again): pass Uinv zero-filled for a clean lower
+ * triangle.  N <= 16384. */
 int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream);
 /* alpha = Kinv (Y - mean).  GP_prior.get_alpha, GP_prior.py:130-135. */
 int mcp_gp_alpha(int N, const double* Kinv, int ldk, const double* Y, double mean, double* alpha, void* stream);

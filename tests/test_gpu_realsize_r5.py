@@ -270,3 +270,30 @@ def test_sod_index_lists_at_real_sizes_vs_reference(golden, name):
     assert got == [int(i) for i in fx["idx"]]
     if "idx_script" in fx:
         assert ops.sod_select(sp, X, float(fx["thr_script"])) == [int(i) for i in fx["idx_script"]]
+
+
+def test_sod_beyond_1024_candidates_against_the_oracle():
+    """`sod_select_kernel` with more candidates than its 1024 threads (two candidates per thread, their running sums in the workspace instead of
+    registers): N = 1100 rows of the cart-pole trajectory data, a threshold that keeps a sixth of them, against orc.gp_get_sod (refactor from
+    scratch for every candidate, GP_prior.py:232-257): list exact; the smallest margin of the oracle's decisions is printed."""
+    from gpu_helpers import G, spec_from
+    from helpers import hyper
+    from mc_pilco_amd import ops, workloads
+
+    pb = workloads.numpy_problem("c1", N=1100)
+    X, Y = pb["Z"], pb["Ys"][0]
+    assert X.shape[0] == 1100
+    ls, sig, thr = pb["cfg"]["lengthscales"], 0.3, 0.7
+    h = hyper(ls, sig)
+    Xt, Yt = Tt(X), Tt(Y)
+    keep, mm = [0], np.inf
+    for i in range(1, X.shape[0]):  # orc.gp_get_sod's loop, with the margin recorded
+        _, var, *_ = orc.gp_estimate(h, Xt[keep, :], Yt[keep, :], Xt[i:i + 1, :])
+        sd = float(torch.sqrt(var))
+        mm = min(mm, abs(sd - thr))
+        if sd > thr:
+            keep.append(i)
+    got = ops.sod_select(spec_from(ls, sig), G(X), thr)
+    print("SOD N=1100: kept %d, smallest margin of the oracle's run %.3e" % (len(keep), mm))
+    assert 20 < len(keep) < 1000 and mm > 1e-9
+    assert got == keep
