@@ -1,51 +1,54 @@
 /*
- * mcpilco_hip_debug.h -- test and diagnostic hooks of libmcpilco_hip.so.  NOT part of the drop-in
- * boundary (include/mcpilco_hip.h): the product path never needs them.  They exist so that the
- * parity tests can force every kernel variant the automatic dispatch of mcp_rollout_fwd /
- * mcp_rollout_bwd may choose, so that bench.py / tools can report which variant ran, and so that
- * tools/phase_stamps.py can read per-phase cycle counters.  Process-wide settings, held in atomics (round 5:
- * no data race when another thread launches meanwhile -- PyTorch runs the adjoint sweep on its autograd thread, so a thread-local setting would not
- * reach it); they are meant for a test driver that forces ONE variant at a time, not for concurrent use with different settings.
+ * mcpilco_hip_debug.h -- test and diagnostic entry points of libmcpilco_hip.so.  NOT part of the drop-in boundary
+ * (include/mcpilco_hip.h): the product path never needs them.  They exist so that the parity tests can force every kernel variant the
+ * automatic dispatch of mcp_rollout_fwd / mcp_rollout_bwd / mcp_chol_* may choose, so that bench.py / tools can report which variant ran,
+ * and so that tools/phase_stamps.py can read per-phase cycle counters.
+ *
+ * Round 5: the request travels WITH THE CALL.  Every `_ex` entry point is its plain namesake plus a `mcp_dispatch*` (NULL or all zero =
+ * automatic: the plain entry points pass NULL); the library keeps no dispatch state of its own -- no setters, nothing process-wide.
  */
 #ifndef MCPILCO_HIP_DEBUG_H
 #define MCPILCO_HIP_DEBUG_H
+
+#include "mcpilco_hip.h"
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-/* forward rollout: particles per workgroup 1 / 2 / 4 (small-tile kernel) or 16 (matrix-core tile kernel); 0 = automatic */
-void mcp_debug_set_particles_per_wg(int p);
-/* what the last mcp_rollout_fwd / mcp_posterior_fwd launched (16 = tile kernel) */
-int mcp_debug_last_particles_per_wg(void);
-/* GP-sharded launch forms: -1 automatic, 0 never, 1 whenever the grid fits the device */
-void mcp_debug_set_gp_sharding(int mode);
-/* the policy of the GP-sharded 16-particle kernel: -1 automatic, 0 every member of a cluster evaluates all of it, 1 split over the members
- * whenever the shape allows it (partial sums W phi exchanged per step) */
-void mcp_debug_set_policy_split(int mode);
-/* number of GP-sharded launches the last forward call made (0 = unsharded) */
-int mcp_debug_last_gp_sharded(void);
-/* the latency-lean GP-sharded kernel of narrow SE-only models (rollout_fwd_lat_kernel): -1 / 1 wherever it applies, 0 never */
-void mcp_debug_set_fwd_lean(int mode);
-/* 1 when the last mcp_rollout_fwd ran that kernel */
-int mcp_debug_last_fwd_lean(void);
-/* small-tile kernel: xlds -1 automatic / 0 never stage the small operands in LDS; gb = GPs per pass (0 = as many as fit) */
-void mcp_debug_set_fwd_mode(int xlds, int gb);
-/* Cholesky / triangular inverse: 1 (default) the round-4 MFMA kernels (left-looking factorisation, four-wave inverse columns), 3 the same with
- * one wave per inverse column, 2 the round-3 forms (right-looking factorisation, block-diagonal sweep of the inverse), 0 the round-1/2 forms */
-void mcp_debug_set_chol_mfma(int on);
-/* backward sweep: particles per workgroup 1 / 2 / 4 (wide 512-thread class: also 8); 0 = automatic */
-void mcp_debug_set_bwd_particles(int pb);
-/* backward sweep of small swarms: -1 (default) the latency-lean kernel where it applies (automatic particle count only), 0 never;
-   1 when the last mcp_rollout_bwd ran it */
-void mcp_debug_set_bwd_lean(int mode);
-int mcp_debug_last_bwd_lean(void);
-/* device buffers of per-phase cycle totals (forward: 32 uint64, backward: 16) of one workgroup (NULL = off); the forward kernels stamp workgroup
-   `block` (0 by default; the partner of workgroup 0 in a 2-way GP-sharded launch of the small-tile kernel is workgroup 8) */
-void mcp_debug_set_stamp_buffer(void* device_u64x32); /* 32 uint64: every forward kernel writes per-phase totals to slots 0..15 and per-wave
-                                                         phase totals to slots 16..31 */
-void mcp_debug_set_stamp_block(int block);
-void mcp_debug_set_bwd_stamp_buffer(void* device_u64x16);
+typedef struct mcp_dispatch {
+  /* ---- requests (0 = automatic) ---- */
+  int32_t fwd_particles; /* forward: particles per workgroup 1 / 2 / 4 (small-tile kernels) or 16 (matrix-core tile kernel)                 */
+  int32_t gp_sharding;   /* GP-sharded launch forms: 1 never, 2 whenever the grid fits the device                                        */
+  int32_t fwd_lean;      /* the latency-lean GP-sharded kernel (rollout_fwd_lat_kernel): 1 never                                        */
+  int32_t policy_split;  /* GP-sharded 16-particle kernel: 1 every member evaluates the whole policy, 2 split whenever the shape allows */
+  int32_t fwd_no_xlds;   /* small-tile kernel: 1 never stage the small operands in LDS                                                  */
+  int32_t fwd_gb;        /* small-tile kernel: GPs per pass (0 = as many as fit)                                                        */
+  int32_t bwd_particles; /* backward sweep: particles per workgroup 1 / 2 / 4 / 8 (forces the general sweep)                            */
+  int32_t bwd_lean;      /* the latency-lean sweep (rollout_bwd_lat_kernel): 1 never                                                    */
+  int32_t chol_form;     /* mcp_chol_factor / _inverse: 1 the round-1/2 kernels, 2 the round-3 one-workgroup forms, 3 the round-4 forms
+                            with one-wave inverse columns (0: left-looking / panel factorisation, column-parallel / blocked inverse)     */
+  uint32_t stamp_block;  /* which workgroup of the forward launch writes its stamps                                                     */
+  void* fwd_stamps;      /* device buffer of 32 uint64 per-phase cycle totals of that workgroup (NULL = off)                            */
+  void* bwd_stamps;      /* device buffer of 16 uint64 (backward sweep)                                                                 */
+  /* ---- report (written by the call) ---- */
+  int32_t ran_particles;  /* forward / posterior: particles per workgroup launched (16 = tile kernel) */
+  int32_t ran_gp_sharded; /* number of GP-sharded launches the forward call made (0 = unsharded)      */
+  int32_t ran_fwd_lean;   /* 1: the lean forward kernel ran                                           */
+  int32_t ran_bwd_lean;   /* 1: the lean backward sweep ran                                           */
+} mcp_dispatch;
+
+int mcp_rollout_fwd_ex(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
+                       const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
+                       size_t workspace_bytes, void* stream, mcp_dispatch* d);
+int mcp_rollout_bwd_ex(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, const double* states,
+                       const double* inputs, const double* jac, const double* g_states, const double* g_inputs, double* g_log_ls,
+                       double* g_centers, double* g_weight, double* g_x0, void* workspace, size_t workspace_bytes, void* stream,
+                       mcp_dispatch* d);
+int mcp_posterior_fwd_ex(const mcp_gp* gp, int M, const double* Z, double* mu, double* var, double* Jmu, double* Jvar, uint32_t* status,
+                         void* stream, mcp_dispatch* d);
+int mcp_chol_factor_ex(int N, double* A, int lda, double* logdet, uint32_t* status, void* stream, const mcp_dispatch* d);
+int mcp_chol_inverse_ex(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream, const mcp_dispatch* d);
 
 #ifdef __cplusplus
 }

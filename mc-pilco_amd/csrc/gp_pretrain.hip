@@ -7,7 +7,7 @@
 #include <type_traits>
 
 #include "mcp_device.h"
-#include <atomic>
+#include "../../include/mcpilco_hip_debug.h"
 
 using namespace mcp;
 
@@ -1932,17 +1932,18 @@ static int launch_inverse_blocked(int N, const double* U, int ldu, double* Ui, i
   return MCP_OK;
 }
 
-static std::atomic<int> g_chol_mfma = 1;  // test hook: 0 = the round-1/2 kernels (scalar trailing update, one wave per column of the inverse); 2 = the round-3 forms
-                             // (right-looking factorization, block-diagonal sweep of the inverse)
-extern "C" void mcp_debug_set_chol_mfma(int on) { g_chol_mfma = on; }
+// which form of the factorisation / inverse a call runs: 1 (default) the round-4/5 kernels, 0 the round-1/2 ones, 2 the round-3 one-workgroup
+// forms, 3 the round-4 forms with one-wave inverse columns -- requested per call (mcp_dispatch.chol_form, include/mcpilco_hip_debug.h)
+static int chol_form_of(const mcp_dispatch* d) { return !d ? 1 : (d->chol_form == 1 ? 0 : (d->chol_form == 2 ? 2 : (d->chol_form == 3 ? 3 : 1))); }
 
-extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32_t* status, void* stream) {
+extern "C" int mcp_chol_factor_ex(int N, double* A, int lda, double* logdet, uint32_t* status, void* stream, const mcp_dispatch* d) {
+  const int g_chol_mfma = chol_form_of(d);
   if (!A || !logdet || !status || N <= 0 || lda < N) return MCP_ERR_ARG;
   if (N > 8192) return MCP_ERR_LIMIT;
   if (g_chol_mfma == 1 && N >= CHB_MIN) return launch_chol_blocked(N, A, lda, logdet, status, (hipStream_t)stream);  // panels across the chip
   if (N > 1152) return MCP_ERR_LIMIT;  // (the one-workgroup forms: test hooks 0, 2, 3)
   if (g_chol_mfma && N > 16) {
-    return launch_chol_mfma(g_chol_mfma == 3 ? 1 : g_chol_mfma.load(), N, A, lda, logdet, status, 1, 0, 0, (hipStream_t)stream);
+    return launch_chol_mfma(g_chol_mfma == 3 ? 1 : g_chol_mfma, N, A, lda, logdet, status, 1, 0, 0, (hipStream_t)stream);
   }
   size_t lds = sizeof(double) * ((size_t)CH_NB * (CH_NB + 1) + (size_t)CH_NB * N);
   MCP_ENSURE_MAX_LDS(chol_factor_kernel);
@@ -1951,7 +1952,12 @@ extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32
   return MCP_OK;
 }
 
-extern "C" int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream) {
+extern "C" int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32_t* status, void* stream) {
+  return mcp_chol_factor_ex(N, A, lda, logdet, status, stream, nullptr);
+}
+
+extern "C" int mcp_chol_inverse_ex(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream, const mcp_dispatch* d) {
+  const int g_chol_mfma = chol_form_of(d);
   if (!U || !Uinv || !Kinv || N <= 0 || ldu < N || ldi < N || ldk < N) return MCP_ERR_ARG;
   if (N > 16384) return MCP_ERR_LIMIT;
   if (g_chol_mfma == 1 && N > 1152) return launch_inverse_blocked(N, U, ldu, Uinv, ldi, Kinv, ldk, (hipStream_t)stream);
@@ -1969,6 +1975,10 @@ extern "C" int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, i
   hipLaunchKernelGGL(kinv_from_uinv_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, Uinv, ldi, Kinv, ldk, (size_t)0, (size_t)0);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
+}
+
+extern "C" int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream) {
+  return mcp_chol_inverse_ex(N, U, ldu, Uinv, ldi, Kinv, ldk, stream, nullptr);
 }
 
 extern "C" int mcp_gp_alpha(int N, const double* Kinv, int ldk, const double* Y, double mean, double* alpha, void* stream) {
@@ -2447,7 +2457,7 @@ extern "C" int mcp_nll_epoch(int G, const mcp_nll_gp* gps, int N, int D, int pol
   }
   MCP_LAUNCH_CHECK();
   {
-    const int rc = launch_chol_mfma(g_chol_mfma == 2 ? 2 : 1, N, g0 + L.K, N, g0 + L.logdet, status, G, L.per_gp, L.per_gp, st);
+    const int rc = launch_chol_mfma(1, N, g0 + L.K, N, g0 + L.logdet, status, G, L.per_gp, L.per_gp, st);
     if (rc != MCP_OK) return rc;
   }
   {

@@ -16,7 +16,7 @@
 // models), and  rollout_bwd_lat_kernel<GM>  -- narrow plain / angle policies on swarms up to 3072 particles: one chain wave per particle working
 // from registers beside RBF waves that prepare their step ahead of the barrier.
 #include "rollout_common.h"
-#include <atomic>
+#include "../../include/mcpilco_hip_debug.h"
 #include <type_traits>
 
 using namespace mcp;
@@ -1358,14 +1358,6 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(int nblk, int nparam, 
 // ---------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------
-static std::atomic<unsigned long long*> g_bwd_stamps = nullptr;  // diagnostic hook
-extern "C" void mcp_debug_set_bwd_stamp_buffer(void* p) { g_bwd_stamps = (unsigned long long*)p; }
-static std::atomic<int> g_force_bwd_pb = 0;  // test hook: particles per workgroup of the backward sweep (0 = automatic)
-extern "C" void mcp_debug_set_bwd_particles(int pb) { g_force_bwd_pb = pb; }
-static std::atomic<int> g_bwd_lean = -1;  // test hook: -1 automatic (the lean sweep where it applies), 0 never
-static std::atomic<int> g_last_bwd_lean = 0;
-extern "C" void mcp_debug_set_bwd_lean(int v) { g_bwd_lean = v; }
-extern "C" int mcp_debug_last_bwd_lean(void) { return g_last_bwd_lean; }
 // what rollout_bwd_lat_kernel covers: the narrow class with its lane roles (states on lanes 0-7, features on 8-15, inputs on 16-17),
 // up to 256 basis functions, plain / angle policies on the true or (measurement model) the measured state, disjoint index lists
 static bool bwd_lean_applies(const mcp_model* md, const mcp_policy* pl, int T) {
@@ -1422,10 +1414,10 @@ static int launch_bwd(const BwdArgs& a, int NT, hipStream_t st) {
   return pms ? launch_bwd_pms<PFM, UM, MAXNT, WPE, PB, true>(a, grid, NT, lds, st) : launch_bwd_pms<PFM, UM, MAXNT, WPE, PB, false>(a, grid, NT, lds, st);
 }
 
-extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T,
+static int rollout_bwd_impl(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T,
                                const double* states, const double* inputs, const double* jac, const double* g_states,
                                const double* g_inputs, double* g_log_ls, double* g_centers, double* g_weight, double* g_x0,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+                               void* workspace, size_t workspace_bytes, void* stream, unsigned long long* g_bwd_stamps, int g_force_bwd_pb, int g_bwd_lean, int& g_last_bwd_lean) {
   if (!noise || !states || !inputs || !g_log_ls || !g_centers || !g_weight || !workspace || !policy || M <= 0 || T <= 0) return MCP_ERR_ARG;
   if (T > 1 && !jac) return MCP_ERR_ARG;
   if (policy->meas.n > 0 && !policy->meas.meas) return MCP_ERR_ARG;
@@ -1461,7 +1453,7 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   // swarms keep one particle per workgroup to spread over the CUs
   // (two 256-thread workgroups per CU are resident: one particle per workgroup while M of them fit in one round, then 2, then 4;
   //  measured, tools/sweep_bwd_particles.py: M=800 1.74 / 1.34 / 1.92 ms, M=2000 3.24 / 2.51 / 2.07 ms for 1 / 2 / 4)
-  int PB = g_force_bwd_pb ? g_force_bwd_pb.load() : (M > 2816 ? 4 : (M > 512 ? 2 : 1));  // (round 3, after the RBF stage's diet: 2 particles win up to ~2800, tools/sweep_bwd_particles.py)
+  int PB = g_force_bwd_pb ? g_force_bwd_pb : (M > 2816 ? 4 : (M > 512 ? 2 : 1));  // (round 3, after the RBF stage's diet: 2 particles win up to ~2800, tools/sweep_bwd_particles.py)
   if (!g_force_bwd_pb && (PF > 16 || U > 4)) {
     PB = M > 1024 ? 4 : 1;
     // eight per sweep (round 4) where that saves resident rounds: a 512-thread workgroup of this class has a CU to itself (256 per round), and a
@@ -1540,3 +1532,20 @@ extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy,
   return MCP_OK;
 }
 
+extern "C" int mcp_rollout_bwd_ex(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T,
+                               const double* states, const double* inputs, const double* jac, const double* g_states,
+                               const double* g_inputs, double* g_log_ls, double* g_centers, double* g_weight, double* g_x0,
+                               void* workspace, size_t workspace_bytes, void* stream, mcp_dispatch* d) {
+  // (the request travels with the call: include/mcpilco_hip_debug.h; d == NULL: automatic)
+  int last_lean = 0;
+  const int rc = rollout_bwd_impl(model, policy, noise, M, T, states, inputs, jac, g_states, g_inputs, g_log_ls, g_centers, g_weight, g_x0, workspace, workspace_bytes, stream, d ? (unsigned long long*)d->bwd_stamps : nullptr, d ? d->bwd_particles : 0,
+                                  (d && d->bwd_lean == 1) ? 0 : -1, last_lean);
+  if (d) d->ran_bwd_lean = last_lean;
+  return rc;
+}
+extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T,
+                               const double* states, const double* inputs, const double* jac, const double* g_states,
+                               const double* g_inputs, double* g_log_ls, double* g_centers, double* g_weight, double* g_x0,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  return mcp_rollout_bwd_ex(model, policy, noise, M, T, states, inputs, jac, g_states, g_inputs, g_log_ls, g_centers, g_weight, g_x0, workspace, workspace_bytes, stream, nullptr);
+}

@@ -28,7 +28,7 @@
 // measurable systems, MC_PILCO.py:808-906) phase S also produces what the policy sees: noisy
 // positions, backward-difference velocities, first-order filter, three carried values per pair.
 #include "rollout_fwd_shared.h"
-#include <atomic>
+#include "../../include/mcpilco_hip_debug.h"
 
 using namespace mcp;
 
@@ -1183,35 +1183,35 @@ static int pick_particles_per_wg(int M) {
   return 16;  // falls back to 4 when the model does not fit the tile kernel
 }
 
-static std::atomic<int> g_force_ppw = 0;   // test hook: force particles per workgroup (0 = automatic)
-static std::atomic<int> g_force_xlds = -1; // test hook: -1 automatic, 0 never stage small operands in LDS, 1 = automatic
-static std::atomic<int> g_force_gb = 0;    // test hook: GPs per pass (0 = as many as fit)
-static std::atomic<int> g_last_ppw = 0;    // test hook: particles per workgroup of the last forward launch (16 = tile kernel)
-extern "C" void mcp_debug_set_particles_per_wg(int p) { g_force_ppw = p; }
-extern "C" int mcp_debug_last_particles_per_wg(void) { return g_last_ppw; }
-extern "C" void mcp_debug_set_fwd_mode(int xlds, int gb) {
-  g_force_xlds = xlds;
-  g_force_gb = gb;
+// What a call may be asked to do differently from the automatic dispatch, and what it reports back: carried by the call itself
+// (mcp_dispatch, include/mcpilco_hip_debug.h) -- the library holds no dispatch state.  The values below are the ones the dispatch code reads.
+struct FwdHooks {
+  int force_ppw = 0;     // particles per workgroup (0 = automatic)
+  int force_xlds = -1;   // -1 automatic, 0 never stage small operands in LDS
+  int force_gb = 0;      // GPs per pass (0 = as many as fit)
+  int gp_sharding = -1;  // -1 automatic, 0 never, 1 whenever the grid fits the device
+  int policy_split = -1; // -1 automatic, 0 every member evaluates the whole policy, 1 the split whenever the shape allows it
+  int fwd_lean = -1;     // -1 / 1 the latency-lean kernel wherever it applies, 0 never
+  unsigned long long* stamps = nullptr;
+  unsigned stamp_block = 0;
+  int last_ppw = 0, last_sharded = 0, last_lean = 0;  // report
+};
+static FwdHooks fwd_hooks(const mcp_dispatch* d) {
+  FwdHooks h;
+  if (d) {
+    h.force_ppw = d->fwd_particles;
+    h.force_xlds = d->fwd_no_xlds ? 0 : -1;
+    h.force_gb = d->fwd_gb;
+    h.gp_sharding = d->gp_sharding == 1 ? 0 : (d->gp_sharding == 2 ? 1 : -1);
+    h.policy_split = d->policy_split == 1 ? 0 : (d->policy_split == 2 ? 1 : -1);
+    h.fwd_lean = d->fwd_lean == 1 ? 0 : -1;
+    h.stamps = (unsigned long long*)d->fwd_stamps;
+    h.stamp_block = d->stamp_block;
+  }
+  return h;
 }
-static std::atomic<unsigned long long*> g_stamps = nullptr;  // diagnostic hook: device buffer of 16 u64 phase-cycle totals
-extern "C" void mcp_debug_set_stamp_buffer(void* p) { g_stamps = (unsigned long long*)p; }
-static std::atomic<unsigned> g_stamp_block = 0;
-extern "C" void mcp_debug_set_stamp_block(int b) { g_stamp_block = b > 0 ? (unsigned)b : 0u; }
-
-// ---- GP-sharded launch: G workgroups per particle cluster ----------------------------------------------------------
-static std::atomic<int> g_gp_sharding = -1;  // test hook: -1 automatic, 0 never, 1 whenever the grid fits the device
-static std::atomic<int> g_last_sharded = 0;  // test hook: number of GP-sharded launches the last forward call made (0 = not sharded)
 static const int g_gp_max_launches = 2;  // a swarm goes out GP-sharded when it fits this many resident grids (cart-pole shape, forward ms,
-                                   // tools/sweep_fwd_swarm.py: M=1024 two launches 4.9 vs 6.5 unsharded; M=1280 three launches 7.3 vs 6.9 on the tile kernel)
-extern "C" void mcp_debug_set_gp_sharding(int mode) { g_gp_sharding = mode; }
-static std::atomic<int> g_policy_split = -1;  // test hook: -1 automatic, 0 = every member of a cluster of the GP-sharded 16-particle kernel evaluates the whole policy
-                                 // (rounds 2-3), 1 = the split whenever the shape allows it
-extern "C" void mcp_debug_set_policy_split(int mode) { g_policy_split = mode; }
-extern "C" int mcp_debug_last_gp_sharded(void) { return g_last_sharded; }
-static std::atomic<int> g_fwd_lean = -1;  // test hook: -1 / 1 the latency-lean GP-sharded kernel wherever it applies, 0 never (the general one)
-static std::atomic<int> g_last_lean = 0;  // test hook: 1 when the last forward call ran the latency-lean kernel
-extern "C" void mcp_debug_set_fwd_lean(int mode) { g_fwd_lean = mode; }
-extern "C" int mcp_debug_last_fwd_lean(void) { return g_last_lean; }
+                                         // tools/sweep_fwd_swarm.py: M=1024 two launches 4.9 vs 6.5 unsharded; M=1280 three launches 7.3 vs 6.9 on the tile kernel)
 static int gsh_grid(int nclusters, int G) { return ((nclusters + 7) / 8) * 8 * G; }
 // every workgroup of a GP-sharded grid waits for its partners, so the whole grid must be resident: one 512-thread
 // workgroup per CU (the LDS footprint allows no more)
@@ -1266,9 +1266,9 @@ static int launch_fwd_sharded(const FwdArgs& a, size_t lds, hipStream_t st) {
   return a.maxdeg == 0 ? launch_fwd_deg<P, true, 0, true>(a, lds, st) : launch_fwd_deg<P, true, 2, true>(a, lds, st);
 }
 
-extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
-                               const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
-                               size_t workspace_bytes, void* stream) {
+static int rollout_fwd_impl(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
+                            const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
+                            size_t workspace_bytes, void* stream, FwdHooks& hk) {
   if (!noise || !x0 || !states || !inputs || !status || !policy || M <= 0 || T <= 0) return MCP_ERR_ARG;
   const bool no_gp_sharding = (particle_pred & MCP_FWD_NO_GP_SHARDING) != 0;  // (the recovery path after MCP_STATUS_SYNC keeps its workspace)
   particle_pred &= 1;
@@ -1299,8 +1299,8 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   a.inputs = inputs;
   a.jac = jac;
   a.status = status;
-  a.stamps = g_stamps;
-  a.stamp_block = g_stamp_block;
+  a.stamps = hk.stamps;
+  a.stamp_block = hk.stamp_block;
   a.xch = nullptr;
   a.xj = nullptr;
   a.xj_stride = 0;
@@ -1327,24 +1327,24 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   a.uxch = nullptr;
   hipStream_t st = (hipStream_t)stream;
   // configuration search: most particles per workgroup first, operands in LDS if they fit, all GPs per pass if they fit
-  int P0 = g_force_ppw ? g_force_ppw.load() : pick_particles_per_wg(M);
+  int P0 = hk.force_ppw ? hk.force_ppw : pick_particles_per_wg(M);
   if (P0 != 1 && P0 != 2 && P0 != 4 && P0 != 16) return MCP_ERR_ARG;
   if (policy->meas.n > 0 && !policy->meas.meas) return MCP_ERR_ARG;
   // small swarms: shard the GPs of a particle cluster over G workgroups (each streams one Kinv) when the whole grid is
   // resident at one workgroup per CU; smallest cluster size first (most CUs busy)
-  g_last_sharded = 0;
-  g_last_lean = 0;
-  if (g_gp_sharding != 0 && !no_gp_sharding && model->G >= 2 && T > 1 && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
-      (g_force_ppw == 0 || (g_gp_sharding == 1 && g_force_ppw != 16))) {
+  hk.last_sharded = 0;
+  hk.last_lean = 0;
+  if (hk.gp_sharding != 0 && !no_gp_sharding && model->G >= 2 && T > 1 && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
+      (hk.force_ppw == 0 || (hk.gp_sharding == 1 && hk.force_ppw != 16))) {
     const int cus = device_cu_count();
     int NC1 = 0;
     for (int g = 0; g < model->G; ++g) NC1 = imax(NC1, (model->gp[g].Npad + RF_CW - 1) / RF_CW);
-    const bool forced = g_force_ppw == 1 || g_force_ppw == 2 || g_force_ppw == 4;
+    const bool forced = hk.force_ppw == 1 || hk.force_ppw == 2 || hk.force_ppw == 4;
     const bool tile_sh = tile_sharded_cluster(model, policy, a.NpadMax, M, T) > 0;
     a.xch = (unsigned long long*)workspace;
     a.GB = 1;
     a.NCmax = NC1;
-    for (int P = forced ? g_force_ppw.load() : 1; P <= (forced ? g_force_ppw.load() : 4) && NC1 <= RF_MAX_CHUNKS; P <<= 1) {
+    for (int P = forced ? hk.force_ppw : 1; P <= (forced ? hk.force_ppw : 4) && NC1 <= RF_MAX_CHUNKS; P <<= 1) {
       // particles one resident grid takes at this cluster size (whole groups of 8 clusters, G workgroups each)
       const int cap = (cus / (8 * model->G)) * 8 * P;
       if (cap <= 0) break;
@@ -1355,7 +1355,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
       FwdLayout L = fwd_layout(P, model->S, model->U, model->D, model->G, policy->P, policy->B, a.NpadMax, a.maxdeg, 1, NC1, true, 1);
       size_t lds = sizeof(double) * (size_t)L.total;
       bool lean = false;
-      if (g_fwd_lean != 0 && a.kt) {
+      if (hk.fwd_lean != 0 && a.kt) {
         const size_t ll = fwd_lean_lds_bytes(model, policy, P, a.NpadMax, a.maxdeg);  // 0: the lean kernel does not take this shape
         if (ll > 0 && ll <= MCP_LDS_LIMIT) {
           lean = true;
@@ -1368,9 +1368,9 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
         const int rcp = launch_fwd_lean_pack(a, st);
         if (rcp != MCP_OK) return rcp;
       }
-      g_last_ppw = P;
-      g_last_sharded = nchunk;
-      g_last_lean = lean ? 1 : 0;
+      hk.last_ppw = P;
+      hk.last_sharded = nchunk;
+      hk.last_lean = lean ? 1 : 0;
       const int per = (((M + nchunk - 1) / nchunk + P - 1) / P) * P;  // particles per launch, whole clusters
       for (int off = 0; off < M; off += per) {
         a.m_off = off;
@@ -1383,7 +1383,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
       return MCP_OK;
     }
   }
-  if ((P0 == 16 || g_force_ppw == 0) && g_gp_sharding != 0 && !no_gp_sharding && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
+  if ((P0 == 16 || hk.force_ppw == 0) && hk.gp_sharding != 0 && !no_gp_sharding && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
       tile_sharded_cluster(model, policy, a.NpadMax, M, T) > 0) {
     // swarms beyond one resident grid of the small-tile kernel, up to 2048 particles at two GPs: the 16-particle kernel GP-sharded --
     // twice the workgroups, each with one GP's contractions (tools/sweep_fwd_swarm.py, cart-pole shape, forward ms: M=1024 3.8 vs 4.9
@@ -1400,7 +1400,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
         // automatic: clusters of three or more on small swarms (the UR5 launch script's M = 200: six members, the policy 1/6 of the step;
         // ur5_script 11.2 -> 10.5 ms).  Not with two members -- the exchange costs what half a cart-pole policy does -- and not on large
         // swarms, whose halves run another cluster size: they would no longer reproduce the whole bit for bit (tests: *_full_size_properties)
-        const bool want = g_policy_split == 1 || (g_policy_split < 0 && a.gsh_cs >= 3 && M <= 512);
+        const bool want = hk.policy_split == 1 || (hk.policy_split < 0 && a.gsh_cs >= 3 && M <= 512);
         if (want && (policy->B + 15) / 16 >= a.gsh_cs && workspace_bytes >= uoff + rollout_uxch_bytes(M, model->G, model->U)) {
           a.uxch = (unsigned long long*)((char*)workspace + uoff);
           if (hipMemsetAsync(a.uxch, 0, ub, st) != hipSuccess) return MCP_ERR_LAUNCH;
@@ -1408,8 +1408,8 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
       }
       const int rc = launch_fwd_tile_sharded(a, st);
       if (rc == MCP_OK) {
-        g_last_ppw = 16;
-        g_last_sharded = 1;
+        hk.last_ppw = 16;
+        hk.last_sharded = 1;
         return MCP_OK;
       }
       if (rc != MCP_ERR_LIMIT) return rc;
@@ -1421,14 +1421,14 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
   if (P0 == 16) {
     // large swarms: 16-particle tiles on the matrix cores (rollout_fwd_tile.hip) when the problem fits that kernel
     if (model->G >= 1 && T > 1 && fwd_tile_fits(model, policy)) {
-      g_last_ppw = 16;
+      hk.last_ppw = 16;
       return launch_fwd_tile(a, st);
     }
     P0 = 4;
   }
   for (int P = P0; P >= 1; P >>= 1) {
-    for (int xl = (g_force_xlds == 0 ? 0 : 1); xl >= 0; --xl) {
-      for (int GB = imax(1, (g_force_gb > 0 ? imin(g_force_gb, model->G) : model->G)); GB >= 1; --GB) {
+    for (int xl = (hk.force_xlds == 0 ? 0 : 1); xl >= 0; --xl) {
+      for (int GB = imax(1, (hk.force_gb > 0 ? imin(hk.force_gb, model->G) : model->G)); GB >= 1; --GB) {
         int NCmax = chunks_in_pass(model, GB);
         if (NCmax > RF_MAX_CHUNKS) continue;
         FwdLayout L = fwd_layout(P, model->S, model->U, model->D, model->G, policy->P, policy->B, a.NpadMax, a.maxdeg, GB, NCmax, xl != 0);
@@ -1436,7 +1436,7 @@ extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy,
         if (lds > MCP_LDS_LIMIT) continue;
         a.GB = GB;
         a.NCmax = NCmax;
-        g_last_ppw = P;
+        hk.last_ppw = P;
         if (P == 4) return xl ? launch_fwd<4, true>(a, lds, st) : launch_fwd<4, false>(a, lds, st);
         if (P == 2) return xl ? launch_fwd<2, true>(a, lds, st) : launch_fwd<2, false>(a, lds, st);
         return xl ? launch_fwd<1, true>(a, lds, st) : launch_fwd<1, false>(a, lds, st);
@@ -1454,8 +1454,27 @@ static int launch_post(const PostArgs& a, size_t lds, hipStream_t st) {
   return MCP_OK;
 }
 
-extern "C" int mcp_posterior_fwd(const mcp_gp* gp, int M, const double* Z, double* mu, double* var, double* Jmu, double* Jvar,
-                                 uint32_t* status, void* stream) {
+extern "C" int mcp_rollout_fwd_ex(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
+                                  const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
+                                  size_t workspace_bytes, void* stream, mcp_dispatch* d) {
+  FwdHooks hk = fwd_hooks(d);
+  const int rc = rollout_fwd_impl(model, policy, noise, M, T, particle_pred, x0, states, inputs, jac, status, workspace, workspace_bytes, stream, hk);
+  if (d) {
+    d->ran_particles = hk.last_ppw;
+    d->ran_gp_sharded = hk.last_sharded;
+    d->ran_fwd_lean = hk.last_lean;
+  }
+  return rc;
+}
+extern "C" int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
+                               const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  return mcp_rollout_fwd_ex(model, policy, noise, M, T, particle_pred, x0, states, inputs, jac, status, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int mcp_posterior_fwd_ex(const mcp_gp* gp, int M, const double* Z, double* mu, double* var, double* Jmu, double* Jvar,
+                                    uint32_t* status, void* stream, mcp_dispatch* d) {
+  FwdHooks hk = fwd_hooks(d);
   if (!gp || !Z || !mu || !var || M <= 0) return MCP_ERR_ARG;
   if ((Jmu == nullptr) != (Jvar == nullptr)) return MCP_ERR_ARG;
   if (gp->kern.D <= 0 || gp->kern.D > MCP_MAX_GPDIM || gp->N <= 0 || gp->Npad < gp->N || (gp->Npad % 16) != 0) return MCP_ERR_ARG;
@@ -1474,7 +1493,7 @@ extern "C" int mcp_posterior_fwd(const mcp_gp* gp, int M, const double* Z, doubl
   a.Jmu = Jmu;
   a.Jvar = Jvar;
   a.status = status;
-  int P0 = g_force_ppw ? g_force_ppw.load() : pick_particles_per_wg(M);
+  int P0 = hk.force_ppw ? hk.force_ppw : pick_particles_per_wg(M);
   if (P0 == 16) P0 = 4;  // (the single-step operator has no 16-particle form: more than 1024 test points run 4 per workgroup)
   if (P0 != 1 && P0 != 2 && P0 != 4) return MCP_ERR_ARG;
   for (int P = P0; P >= 1; P >>= 1) {
@@ -1482,11 +1501,16 @@ extern "C" int mcp_posterior_fwd(const mcp_gp* gp, int M, const double* Z, doubl
     size_t lds = sizeof(double) * (size_t)L.total;
     if (lds > MCP_LDS_LIMIT) continue;
     hipStream_t st = (hipStream_t)stream;
+    if (d) d->ran_particles = P;
     if (P == 4) return launch_post<4>(a, lds, st);
     if (P == 2) return launch_post<2>(a, lds, st);
     return launch_post<1>(a, lds, st);
   }
   return MCP_ERR_LIMIT;
+}
+extern "C" int mcp_posterior_fwd(const mcp_gp* gp, int M, const double* Z, double* mu, double* var, double* Jmu, double* Jvar,
+                                 uint32_t* status, void* stream) {
+  return mcp_posterior_fwd_ex(gp, M, Z, mu, var, Jmu, Jvar, status, stream, nullptr);
 }
 
 extern "C" int mcp_posterior_bwd(int M, int D, const double* gmu, const double* gvar, const double* Jmu, const double* Jvar, double* gZ,

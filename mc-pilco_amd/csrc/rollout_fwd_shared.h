@@ -44,8 +44,8 @@ struct FwdArgs {
   double* inputs;
   double* jac;
   uint32_t* status;
-  unsigned long long* stamps;  // diagnostic only (mcp_debug_set_stamp_buffer): per-phase cycle totals of workgroup `stamp_block`
-  unsigned stamp_block;        // (mcp_debug_set_stamp_block; 0 by default)
+  unsigned long long* stamps;  // diagnostic only (mcp_dispatch.fwd_stamps): per-phase cycle totals of workgroup `stamp_block`
+  unsigned stamp_block;        // (mcp_dispatch.stamp_block; 0 by default)
   double* xj;                  // packed phase-J operand of the wide 16-particle classes (workspace; null: not available), see rollout_xj_bytes
   int xj_stride;               // doubles per GP
   const double* kt;            // Kinv as MFMA operand tiles (lean small-swarm kernel, rollout_fwd.hip; workspace; null: not available)

@@ -83,6 +83,19 @@ class Cost(C.Structure):
                 ("n_used", C.c_int32), ("used", C.c_int32 * MAX_STATE), ("target_traj", dptr), ("lengthscales", dptr)]
 
 
+class Dispatch(C.Structure):
+    """include/mcpilco_hip_debug.h: struct mcp_dispatch -- the request a call carries (all zero = automatic) and what it reports back."""
+    _fields_ = [("fwd_particles", C.c_int32), ("gp_sharding", C.c_int32), ("fwd_lean", C.c_int32), ("policy_split", C.c_int32), ("fwd_no_xlds", C.c_int32),
+                ("fwd_gb", C.c_int32), ("bwd_particles", C.c_int32), ("bwd_lean", C.c_int32), ("chol_form", C.c_int32), ("stamp_block", C.c_uint32),
+                ("fwd_stamps", dptr), ("bwd_stamps", dptr), ("ran_particles", C.c_int32), ("ran_gp_sharded", C.c_int32), ("ran_fwd_lean", C.c_int32),
+                ("ran_bwd_lean", C.c_int32)]
+
+
+# The dispatch request of THIS PROCESS's calls through `ops` (all zero: automatic).  It lives here, in the host layer -- the library keeps no
+# dispatch state; tests and tools set its fields through the `mcp_debug_*` methods of `lib()` (the names the library itself exported until
+# round 4), every `ops` call passes it along and finds in it what ran.
+DISPATCH = Dispatch()
+
 _SIGS = {
     "mcp_abi_version": (C.c_int, []),
     "mcp_build_info": (C.c_char_p, []),
@@ -90,6 +103,8 @@ _SIGS = {
     "mcp_cov_diag": (C.c_int, [C.POINTER(Kernel), C.c_int, dptr, C.c_int, dptr, dptr]),
     "mcp_chol_factor": (C.c_int, [C.c_int, dptr, C.c_int, dptr, dptr, dptr]),
     "mcp_chol_inverse": (C.c_int, [C.c_int, dptr, C.c_int, dptr, C.c_int, dptr, C.c_int, dptr]),
+    "mcp_chol_factor_ex": (C.c_int, [C.c_int, dptr, C.c_int, dptr, dptr, dptr, C.POINTER(Dispatch)]),
+    "mcp_chol_inverse_ex": (C.c_int, [C.c_int, dptr, C.c_int, dptr, C.c_int, dptr, C.c_int, dptr, C.POINTER(Dispatch)]),
     "mcp_gp_alpha": (C.c_int, [C.c_int, dptr, C.c_int, dptr, C.c_double, dptr, dptr]),
     "mcp_sod_workspace_bytes": (C.c_size_t, [C.c_int]),
     "mcp_sod_select": (C.c_int, [C.POINTER(Kernel), C.c_int, dptr, C.c_double, dptr, dptr, dptr, C.c_size_t, dptr]),
@@ -97,12 +112,17 @@ _SIGS = {
     "mcp_nll_grad": (C.c_int, [C.POINTER(Kernel), C.c_int, dptr, dptr, C.c_int, dptr, dptr, dptr, C.c_size_t, dptr]),
     "mcp_gp_pack": (C.c_int, [C.c_int, C.c_int, dptr, dptr, dptr, C.c_int, C.c_int, dptr, dptr, dptr, dptr, dptr, dptr]),
     "mcp_posterior_fwd": (C.c_int, [C.POINTER(GP), C.c_int, dptr, dptr, dptr, dptr, dptr, dptr, dptr]),
+    "mcp_posterior_fwd_ex": (C.c_int, [C.POINTER(GP), C.c_int, dptr, dptr, dptr, dptr, dptr, dptr, dptr, C.POINTER(Dispatch)]),
     "mcp_posterior_bwd": (C.c_int, [C.c_int, C.c_int, dptr, dptr, dptr, dptr, dptr, dptr]),
     "mcp_rollout_workspace_bytes": (C.c_size_t, [C.POINTER(Model), C.POINTER(Policy), C.c_int, C.c_int]),
     "mcp_rollout_fwd": (C.c_int, [C.POINTER(Model), C.POINTER(Policy), C.POINTER(Noise), C.c_int, C.c_int, C.c_int, dptr, dptr, dptr,
                                   dptr, dptr, dptr, C.c_size_t, dptr]),
     "mcp_rollout_bwd": (C.c_int, [C.POINTER(Model), C.POINTER(Policy), C.POINTER(Noise), C.c_int, C.c_int, dptr, dptr, dptr, dptr, dptr,
                                   dptr, dptr, dptr, dptr, dptr, C.c_size_t, dptr]),
+    "mcp_rollout_fwd_ex": (C.c_int, [C.POINTER(Model), C.POINTER(Policy), C.POINTER(Noise), C.c_int, C.c_int, C.c_int, dptr, dptr, dptr,
+                                     dptr, dptr, dptr, C.c_size_t, dptr, C.POINTER(Dispatch)]),
+    "mcp_rollout_bwd_ex": (C.c_int, [C.POINTER(Model), C.POINTER(Policy), C.POINTER(Noise), C.c_int, C.c_int, dptr, dptr, dptr, dptr, dptr,
+                                     dptr, dptr, dptr, dptr, dptr, C.c_size_t, dptr, C.POINTER(Dispatch)]),
     "mcp_cost_fwd": (C.c_int, [C.POINTER(Cost), C.c_int, C.c_int, dptr, dptr, dptr, dptr, dptr]),
     "mcp_cost_finalize": (C.c_int, [C.c_int, C.c_int, dptr, C.POINTER(C.c_int64), dptr, dptr]),
     "mcp_cost_bwd": (C.c_int, [C.POINTER(Cost), C.c_int, C.c_int, dptr, dptr, C.c_double, dptr, dptr]),
@@ -119,23 +139,9 @@ _SIGS = {
     "mcp_comm_world": (C.c_int, []),
     "mcp_allreduce_grad": (C.c_int, [dptr, C.c_size_t, dptr]),
     "mcp_comm_destroy": (C.c_int, []),
-    "mcp_debug_set_particles_per_wg": (None, [C.c_int]),
-    "mcp_debug_last_particles_per_wg": (C.c_int, []),
-    "mcp_debug_set_bwd_particles": (None, [C.c_int]),
-    "mcp_debug_set_stamp_buffer": (None, [dptr]),
-    "mcp_debug_set_stamp_block": (None, [C.c_int]),
-    "mcp_debug_set_fwd_mode": (None, [C.c_int, C.c_int]),
-    "mcp_debug_set_bwd_stamp_buffer": (None, [dptr]),
-    "mcp_debug_set_gp_sharding": (None, [C.c_int]),
-    "mcp_debug_set_policy_split": (None, [C.c_int]),
-    "mcp_debug_last_gp_sharded": (C.c_int, []),
-    "mcp_debug_set_fwd_lean": (None, [C.c_int]),
-    "mcp_debug_set_chol_mfma": (None, [C.c_int]),
-    "mcp_debug_last_fwd_lean": (C.c_int, []),
-    "mcp_debug_set_bwd_lean": (None, [C.c_int]),
-    "mcp_debug_last_bwd_lean": (C.c_int, []),
 }
-EXPORTED = [k for k in _SIGS if not k.startswith("mcp_debug")]
+EXPORTED = [k for k in _SIGS if not k.endswith("_ex")]        # include/mcpilco_hip.h
+EXPORTED_DEBUG = [k for k in _SIGS if k.endswith("_ex")]      # include/mcpilco_hip_debug.h
 
 _lib = None
 
@@ -155,8 +161,66 @@ def lib():
             fn.argtypes = args
         if handle.mcp_abi_version() != ABI_VERSION:
             raise RuntimeError("libmcpilco_hip.so ABI version mismatch")
-        _lib = handle
+        _lib = _Lib(handle)
     return _lib
+
+
+class _Lib:
+    """The loaded library plus the `mcp_debug_*` names as HOST-SIDE accessors of DISPATCH (what the library exported as process-wide setters
+    until round 4): tests and tools keep their calls, the state they set is this module's, and it reaches the kernels with each call."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __getattr__(self, name):
+        return getattr(self._h, name)
+
+    # forward rollout: particles per workgroup 1 / 2 / 4 / 16, 0 = automatic
+    def mcp_debug_set_particles_per_wg(self, p):
+        DISPATCH.fwd_particles = int(p)
+
+    def mcp_debug_last_particles_per_wg(self):
+        return int(DISPATCH.ran_particles)
+
+    def mcp_debug_set_bwd_particles(self, pb):
+        DISPATCH.bwd_particles = int(pb)
+
+    def mcp_debug_set_stamp_buffer(self, p):
+        DISPATCH.fwd_stamps = p
+
+    def mcp_debug_set_stamp_block(self, b):
+        DISPATCH.stamp_block = max(0, int(b))
+
+    def mcp_debug_set_fwd_mode(self, xlds, gb):  # xlds 0: never stage the small operands in LDS; gb: GPs per pass (0 = as many as fit)
+        DISPATCH.fwd_no_xlds = 1 if int(xlds) == 0 else 0
+        DISPATCH.fwd_gb = int(gb)
+
+    def mcp_debug_set_bwd_stamp_buffer(self, p):
+        DISPATCH.bwd_stamps = p
+
+    def mcp_debug_set_gp_sharding(self, mode):  # -1 automatic, 0 never, 1 whenever the grid fits the device
+        DISPATCH.gp_sharding = {-1: 0, 0: 1, 1: 2}[int(mode)]
+
+    def mcp_debug_set_policy_split(self, mode):  # -1 automatic, 0 off, 1 whenever the shape allows
+        DISPATCH.policy_split = {-1: 0, 0: 1, 1: 2}[int(mode)]
+
+    def mcp_debug_last_gp_sharded(self):
+        return int(DISPATCH.ran_gp_sharded)
+
+    def mcp_debug_set_fwd_lean(self, mode):  # -1 / 1 wherever it applies, 0 never
+        DISPATCH.fwd_lean = 1 if int(mode) == 0 else 0
+
+    def mcp_debug_last_fwd_lean(self):
+        return int(DISPATCH.ran_fwd_lean)
+
+    def mcp_debug_set_chol_mfma(self, form):  # 1 default, 0 the round-1/2 kernels, 2 the round-3 forms, 3 one-wave inverse columns
+        DISPATCH.chol_form = {1: 0, 0: 1, 2: 2, 3: 3}[int(form)]
+
+    def mcp_debug_set_bwd_lean(self, mode):  # -1 automatic, 0 never
+        DISPATCH.bwd_lean = 1 if int(mode) == 0 else 0
+
+    def mcp_debug_last_bwd_lean(self):
+        return int(DISPATCH.ran_bwd_lean)
 
 
 def check(rc, what):

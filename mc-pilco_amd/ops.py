@@ -131,7 +131,8 @@ def chol_factor(K):
     N = U.shape[0]
     logdet = torch.zeros(1, dtype=DT, device=U.device)
     status = torch.zeros(1, dtype=torch.int32, device=U.device)
-    abi.check(abi.lib().mcp_chol_factor(N, abi.ptr(U), U.shape[1], abi.ptr(logdet), abi.ptr(status), abi.stream()), "mcp_chol_factor")
+    abi.check(abi.lib().mcp_chol_factor_ex(N, abi.ptr(U), U.shape[1], abi.ptr(logdet), abi.ptr(status), abi.stream(), C.byref(abi.DISPATCH)),
+              "mcp_chol_factor")
     return U, logdet[0], status
 
 
@@ -139,7 +140,8 @@ def chol_inverse(U):
     N = U.shape[0]
     Ui = torch.zeros(N, N, dtype=DT, device=U.device)
     Kinv = torch.empty(N, N, dtype=DT, device=U.device)
-    abi.check(abi.lib().mcp_chol_inverse(N, abi.ptr(U), U.shape[1], abi.ptr(Ui), N, abi.ptr(Kinv), N, abi.stream()), "mcp_chol_inverse")
+    abi.check(abi.lib().mcp_chol_inverse_ex(N, abi.ptr(U), U.shape[1], abi.ptr(Ui), N, abi.ptr(Kinv), N, abi.stream(), C.byref(abi.DISPATCH)),
+              "mcp_chol_inverse")
     return Ui, Kinv
 
 
@@ -389,10 +391,11 @@ def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, nois
     try:
         if ev is not None:
             ev[0].record()
-        abi.check(abi.lib().mcp_rollout_fwd(_mc(model), C.byref(pc), C.byref(nz), M, T,
-                                            int(bool(particle_pred)) | (0 if gp_sharding else abi.FWD_NO_GP_SHARDING), abi.ptr(x0),
-                                            abi.ptr(states), abi.ptr(inputs), abi.ptr(jac), abi.ptr(status), abi.ptr(ws), nbytes, abi.stream()),
-                  "mcp_rollout_fwd")
+        # (the `_ex` entry point = mcp_rollout_fwd + the process's dispatch request / report, all zero unless a test or tool set it)
+        abi.check(abi.lib().mcp_rollout_fwd_ex(_mc(model), C.byref(pc), C.byref(nz), M, T,
+                                               int(bool(particle_pred)) | (0 if gp_sharding else abi.FWD_NO_GP_SHARDING), abi.ptr(x0),
+                                               abi.ptr(states), abi.ptr(inputs), abi.ptr(jac), abi.ptr(status), abi.ptr(ws), nbytes, abi.stream(),
+                                               C.byref(abi.DISPATCH)), "mcp_rollout_fwd")
         if ev is not None:
             ev[1].record()
     finally:
@@ -429,9 +432,9 @@ def rollout_backward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseS
     try:
         if ev is not None:
             ev[0].record()
-        abi.check(abi.lib().mcp_rollout_bwd(_mc(model), C.byref(pc), C.byref(nz), M, T, abi.ptr(states), abi.ptr(inputs), abi.ptr(jac),
-                                            abi.ptr(gs), abi.ptr(gi), abi.ptr(g_ls), abi.ptr(g_c), abi.ptr(g_w), abi.ptr(g_x0), abi.ptr(ws),
-                                            nbytes, abi.stream()), "mcp_rollout_bwd")
+        abi.check(abi.lib().mcp_rollout_bwd_ex(_mc(model), C.byref(pc), C.byref(nz), M, T, abi.ptr(states), abi.ptr(inputs), abi.ptr(jac),
+                                               abi.ptr(gs), abi.ptr(gi), abi.ptr(g_ls), abi.ptr(g_c), abi.ptr(g_w), abi.ptr(g_x0), abi.ptr(ws),
+                                               nbytes, abi.stream(), C.byref(abi.DISPATCH)), "mcp_rollout_bwd")
         if ev is not None:
             ev[1].record()
     finally:
@@ -636,8 +639,8 @@ class PosteriorFunction(torch.autograd.Function):
         Jv = torch.empty(M, D, dtype=DT, device=Zc.device) if need else None
         status = torch.zeros(1, dtype=torch.int32, device=Zc.device)
         g = gp.to_c()
-        abi.check(abi.lib().mcp_posterior_fwd(C.byref(g), M, abi.ptr(Zc), abi.ptr(mu), abi.ptr(var), abi.ptr(Jm), abi.ptr(Jv), abi.ptr(status),
-                                              abi.stream()), "mcp_posterior_fwd")
+        abi.check(abi.lib().mcp_posterior_fwd_ex(C.byref(g), M, abi.ptr(Zc), abi.ptr(mu), abi.ptr(var), abi.ptr(Jm), abi.ptr(Jv), abi.ptr(status),
+                                                 abi.stream(), C.byref(abi.DISPATCH)), "mcp_posterior_fwd")
         if need:
             ctx.save_for_backward(Jm, Jv)
         return mu.reshape(-1, 1), var

@@ -31,12 +31,19 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libmcpilco_hip.so does not export %s" % n
     assert set(hipabi.EXPORTED) == set(names)
-    # the test / diagnostic hooks live in their own header, outside the boundary, and the binding knows exactly those
+    # the test / diagnostic entry points live in their own header, outside the boundary, and the binding knows exactly those: each is its plain
+    # namesake plus a per-call mcp_dispatch (round 5: the library exports no setter and keeps no dispatch state)
     dbg = declared_symbols(DEBUG_HEADER)
-    assert dbg and all(n.startswith("mcp_debug_") for n in dbg)
+    assert dbg and all(n.endswith("_ex") and n[:-3] in names for n in dbg)
     for n in dbg:
         assert hasattr(lib, n)
-    assert set(k for k in hipabi._SIGS if k.startswith("mcp_debug")) == set(dbg)
+    assert set(hipabi.EXPORTED_DEBUG) == set(dbg)
+    import ctypes
+
+    raw = ctypes.CDLL(hipabi.LIB_PATH)
+    for n in ("mcp_debug_set_particles_per_wg", "mcp_debug_set_gp_sharding", "mcp_debug_set_bwd_particles", "mcp_debug_set_chol_mfma",
+              "mcp_debug_last_fwd_lean"):
+        assert not hasattr(raw, n), "the library still exports the process-wide hook %s" % n
     # the header, the binding and the built library carry ONE version (a stale library or an old struct layout is rejected at load time)
     hdr = int(re.search(r"#define MCP_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
     assert lib.mcp_abi_version() == hipabi.ABI_VERSION == hdr == 5

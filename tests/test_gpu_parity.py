@@ -554,8 +554,10 @@ def test_gp_sharded_launch_needs_its_workspace():
         status = torch.zeros(1, dtype=torch.int32, device=dev())
         nbytes = hipabi.lib().mcp_rollout_workspace_bytes(C.byref(w.model.c), C.byref(pc), M, T)
         ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=dev())
-        rc = hipabi.lib().mcp_rollout_fwd(C.byref(w.model.c), C.byref(pc), C.byref(nz), M, T, 1, hipabi.ptr(x0), hipabi.ptr(states), hipabi.ptr(inputs),
-                                          None, hipabi.ptr(status), hipabi.ptr(ws) if with_ws else None, nbytes if with_ws else 0, hipabi.stream())
+        # (the `_ex` entry point: the plain call plus the report of what was launched)
+        rc = hipabi.lib().mcp_rollout_fwd_ex(C.byref(w.model.c), C.byref(pc), C.byref(nz), M, T, 1, hipabi.ptr(x0), hipabi.ptr(states), hipabi.ptr(inputs),
+                                             None, hipabi.ptr(status), hipabi.ptr(ws) if with_ws else None, nbytes if with_ws else 0, hipabi.stream(),
+                                             C.byref(hipabi.DISPATCH))
         assert rc == 0 and int(status.item()) == 0
         assert bool(hipabi.lib().mcp_debug_last_gp_sharded()) == with_ws
         out.append(states.clone())
