@@ -111,13 +111,27 @@ class GP_prior(torch.nn.Module):
     # ---- Gram / Cholesky / inverse ------------------------------------------------------------------------
     def forward(self, X):
         """(m_X, K_X, K_X_inv, log_det): K_X includes the noise, K_X_inv = U^-1 U^-T with U the upper
-        Cholesky factor, log_det = 2 sum log diag U."""
+        Cholesky factor, log_det = 2 sum log diag U.  With autograd on and trainable hyper-parameters the outputs carry a graph, as in the
+        reference (GP_prior.py:91-115): any criterion of them can be differentiated (``_ForwardFunction``)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return self._forward_autograd(X)
         K = self.get_covariance(X, flg_noise=self.GP_with_noise)
         U, log_det, status = ops.chol_factor(K)
         if ops.status_flags(status)["not_spd"]:
             raise RuntimeError("cholesky: the covariance matrix is not positive-definite")
         _, K_inv = ops.chol_inverse(U)
         return self.get_mean(X), K, K_inv, log_det
+
+    def _forward_autograd(self, X):
+        params = [p for p in self.parameters() if p.requires_grad]
+        K, K_inv, log_det = _ForwardFunction.apply(self, X, *params)
+        first = next(iter(self._leaves())) if isinstance(self, Combine_GP) else self
+        mp = getattr(first, "mean_par", None)
+        if mp is not None and mp.requires_grad and not getattr(first, "flg_no_mean", False) and mp.numel() == 1:
+            m_X = mp.reshape(1, -1).repeat(X.shape[0], 1)  # (the constant prior mean of the first child, differentiable)
+        else:
+            m_X = self.get_mean(X)
+        return m_X, K, K_inv, log_det
 
     def get_alpha(self, X, Y):
         m_X, _, K_X_inv, _ = self(X)
@@ -177,14 +191,41 @@ class GP_prior(torch.nn.Module):
 
     # ---- hyper-parameter training --------------------------------------------------------------------------------
     def fit_model(self, trainloader=None, optimizer=None, criterion=None, N_epoch=1, N_epoch_print=1, f_saving_model=None, f_print=None):
-        """Full-batch optimisation of the marginal likelihood with the caller's optimizer.  ``criterion``
-        is called on ``self(inputs)`` like in the reference; gradients come from the analytic NLL
-        derivative evaluated by the HIP kernels (``criterion`` must be a Marginal_log_likelihood)."""
+        """Optimisation of ``criterion(self(inputs), labels)`` with the caller's optimizer, as in the reference.  For the
+        Marginal_log_likelihood the gradient is the analytic NLL derivative evaluated by the HIP kernels (one full batch: the whole epoch on
+        the device); any other criterion runs the reference's loop on the differentiable forward."""
         from mc_pilco_amd.gpr_lib.Likelihood.Gaussian_likelihood import Marginal_log_likelihood
 
-        if not isinstance(criterion, Marginal_log_likelihood):
-            raise NotImplementedError("fit_model on the HIP path supports the Marginal_log_likelihood criterion")
         from mc_pilco_amd import nll
+
+        if not isinstance(criterion, Marginal_log_likelihood):
+            # any other criterion of [m_X, K_X, K_X_inv, log_det]: the reference's own loop (GP_prior.py:179-230) on the differentiable forward
+            print("\nInitial parameters:")
+            self.print_model()
+            t0 = time.time()
+            for epoch in range(N_epoch):
+                running, nb = 0.0, 0
+                optimizer.zero_grad()
+                for inputs, labels in trainloader:
+                    optimizer.zero_grad()
+                    loss = criterion(self(inputs), labels.to(self.device))
+                    loss.backward()
+                    optimizer.step()
+                    running += loss.item()
+                    nb += 1
+                if epoch % N_epoch_print == 0:
+                    print("\nEPOCH:", epoch)
+                    self.print_model()
+                    print("Running loss:", running / max(nb, 1))
+                    print("Time elapsed:", time.time() - t0)
+                    t0 = time.time()
+                    if f_saving_model is not None:
+                        f_saving_model(epoch)
+                    if f_print is not None:
+                        f_print()
+            print("\nFinal parameters:")
+            self.print_model()
+            return
 
         # one full batch, the textbook Adam, a squared-exponential (+ Volterra) kernel: the whole epoch is two C calls (mcp_nll_epoch +
         # mcp_adam_step_guarded), no torch op and no host sync in between (mc_pilco_amd/nll.py: BatchedFit, here with one GP)
@@ -219,6 +260,43 @@ class GP_prior(torch.nn.Module):
         nll.check_status(self)
         print("\nFinal parameters:")
         self.print_model()
+
+
+class _ForwardFunction(torch.autograd.Function):
+    """(K_X, K_X_inv, log_det) of ``GP_prior.forward`` as a differentiable function of the GP's trainable hyper-parameters -- what autograd
+    records through get_covariance / torch.cholesky / torch.inverse in the reference (GP_prior.py:91-115).  Forward: the HIP Gram,
+    factorisation and inverse.  Backward: with the upstream gradients G_K, G_Kinv, g_logdet the Gram matrix's own gradient is
+        Wm = G_K - Kinv G_Kinv Kinv + g_logdet Kinv          (d Kinv = -Kinv dK Kinv,  d logdet = tr(Kinv dK); Kinv symmetric)
+    -- two plain library GEMMs -- and  dL/dtheta = sum_ij Wm_ij dK_ij/dtheta  comes from the HIP gradient kernel (nll.cov_weighted_grad)."""
+
+    @staticmethod
+    def forward(ctx, gp, X, *params):
+        Xc = gp._cols(X)
+        K = ops.cov_build(gp.kernel_spec_dev(), Xc, None, noise=gp.GP_with_noise)
+        U, log_det, status = ops.chol_factor(K)
+        if ops.status_flags(status)["not_spd"]:
+            raise RuntimeError("cholesky: the covariance matrix is not positive-definite")
+        _, K_inv = ops.chol_inverse(U)
+        ctx.gp, ctx.Xc, ctx.params = gp, Xc, params
+        ctx.save_for_backward(K_inv)
+        ctx.set_materialize_grads(False)
+        return K, K_inv, log_det.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_K, g_Kinv, g_ld):
+        from mc_pilco_amd import nll
+
+        (K_inv,) = ctx.saved_tensors
+        Wm = torch.zeros_like(K_inv)
+        if g_K is not None:
+            Wm = Wm + g_K
+        if g_Kinv is not None:
+            Wm = Wm - K_inv @ g_Kinv @ K_inv
+        if g_ld is not None:
+            Wm = Wm + g_ld * K_inv
+        g = nll.cov_weighted_grad(ctx.gp, ctx.Xc, Wm)
+        got = {id(p): v for p, v in nll.kernel_param_grads(ctx.gp, g, ctx.Xc.shape[1])}
+        return (None, None) + tuple(got.get(id(p)) for p in ctx.params)
 
 
 class Combine_GP(GP_prior):

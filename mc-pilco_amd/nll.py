@@ -48,28 +48,56 @@ def nll_loss_and_grad(gp, X, Y):
     abi.check(abi.lib().mcp_nll_grad(C.byref(kc), N, abi.ptr(Xc), abi.ptr(Kinv), N, abi.ptr(alpha), abi.ptr(g), abi.ptr(ws), nbytes,
                                      abi.stream()), "mcp_nll_grad")
 
+    for p, val in kernel_param_grads(gp, g, D):
+        p.grad = val
+    first = _leaves(gp)[0]
+    for leaf in _leaves(gp):  # only the first child's mean enters the model (GP_prior.py:306-312)
+        if hasattr(leaf, "mean_par") and isinstance(leaf, Stationary_GP.RBF) and leaf.mean_par.requires_grad:
+            leaf.mean_par.grad = (-alpha.sum()).reshape(leaf.mean_par.shape).to(leaf.mean_par.dtype).clone() if leaf is first else torch.zeros_like(leaf.mean_par)
+    return loss.detach()
+
+
+def kernel_param_grads(gp, g, D):
+    """[(parameter, gradient)] of the trainable KERNEL hyper-parameters of ``gp`` from the library's gradient vector ``g`` (layout of
+    mcp_nll_grad: [0, D) log lengthscales | D log lambda | D + 1 noise variance | MPK_1 (D + 1) | MPK_2 factor 0 (D) | factor 1 (D))."""
+    from .gpr_lib.GP_prior import Sparse_GP, Stationary_GP
+
+    out = []
+
     def put(p, val):
         if p.requires_grad:
-            p.grad = val.reshape(p.shape).to(p.dtype).clone()
+            out.append((p, val.reshape(p.shape).to(p.dtype).clone()))
 
-    first = True
     for leaf in _leaves(gp):
         if leaf.GP_with_noise:
             put(leaf.sigma_n_log, g[D + 1] * 2.0 * torch.exp(2.0 * leaf.sigma_n_log.detach()))
         if isinstance(leaf, Stationary_GP.RBF):
             put(leaf.log_lengthscales_par, g[0:D] if leaf.flg_ARD else g[0:D].sum())
             put(leaf.log_lambda_par, g[D])
-            if first:  # only the first child's mean enters the model (GP_prior.py:306-312)
-                put(leaf.mean_par, -alpha.sum())
-            elif leaf.mean_par.requires_grad:
-                leaf.mean_par.grad = torch.zeros_like(leaf.mean_par)
         elif isinstance(leaf, Sparse_GP.MPK_GP):
             if leaf.poly_deg == 1:
                 put(leaf.Sigma_pos_par, g[D + 2:2 * D + 3] if leaf.flg_offset else g[D + 2:2 * D + 2])
             else:
                 put(leaf.Sigma_pos_par, torch.cat([g[2 * D + 3:3 * D + 3], g[3 * D + 3:4 * D + 3]]))
-        first = False
-    return loss.detach()
+    return out
+
+
+def cov_weighted_grad(gp, Xc, Wm):
+    """sum_ij Wm_ij dK_ij/dtheta for every kernel log-parameter (the library's vector, layout above): the chain rule's last step for ANY
+    function of the Gram matrix.  Through mcp_nll_grad, which evaluates 1/2 sum_ij (Kinv - a a^T)_ij dK_ij/dtheta: called with 2 Wm in the
+    place of Kinv and a = 0."""
+    dev = gp.device
+    N, D = Xc.shape
+    spec = gp.kernel_spec_dev()
+    nbytes = abi.lib().mcp_nll_workspace_bytes(N, D)
+    ws = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev)
+    g = torch.empty(4 * D + 3, dtype=DT, device=dev)
+    W2 = (2.0 * Wm).to(DT).contiguous()
+    zero = torch.zeros(N, dtype=DT, device=dev)
+    kc = spec.to_c(dev)
+    abi.check(abi.lib().mcp_nll_grad(C.byref(kc), N, abi.ptr(Xc), abi.ptr(W2), N, abi.ptr(zero), abi.ptr(g), abi.ptr(ws), nbytes, abi.stream()),
+              "mcp_nll_grad")
+    return g
 
 
 def check_status(gp):
