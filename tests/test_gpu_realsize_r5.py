@@ -102,6 +102,9 @@ def _run_both_routes(gp, X, Y):
     for p in gp.parameters():
         p.grad = None
     fit = nll.BatchedFit([gp], X, [Y], [1.0], [torch.optim.Adam(gp.parameters(), lr=0.0)], 1, 10 ** 9)
+    if X.shape[0] > 1152:  # (the batched epoch's one-workgroup factorisation stops there: fit_model takes the per-GP route, checked above)
+        assert not fit.eligible
+        return (loss_a, grads_a), (loss_a, grads_a)
     assert fit.eligible
     with quiet():
         fit.run()
@@ -136,7 +139,7 @@ def test_training_epoch_at_real_sizes_vs_reference_autograd(golden, name, D, deg
         print("%s %s: loss rel %.2e, worst gradient error %.2e" % (name, which, abs(loss - ref_loss) / abs(ref_loss), worst))
 
 
-@pytest.mark.parametrize("N,D,deg", [(300, 6, 0), (300, 6, 2), (400, 24, 1)])
+@pytest.mark.parametrize("N,D,deg", [(300, 6, 0), (300, 6, 2), (400, 24, 1), (1300, 6, 0)])
 def test_training_epoch_at_real_sizes_vs_oracle_autograd(N, D, deg):
     """The same against orc.marginal_nll + autograd on OTHER hyper-parameters than the fixtures' (seeded: lengthscales, noise, lambda,
     polynomial weights away from their launch-script values), the data of the bench workloads."""
@@ -144,7 +147,7 @@ def test_training_epoch_at_real_sizes_vs_oracle_autograd(N, D, deg):
     from helpers import hyper
     from mc_pilco_amd import workloads
 
-    pb = workloads.numpy_problem("c1" if D == 6 else "c5")
+    pb = workloads.numpy_problem("c1" if D == 6 else "c5", N=N if N > 400 else None)  # (N = 1300: beyond the batched epoch, the panel factorisation)
     X, Y = pb["Z"][:N], pb["Ys"][1][:N]
     assert X.shape == (N, D)
     rs = np.random.RandomState(N + deg)
