@@ -351,7 +351,9 @@ def _mc(model):
 
 def _workspace(model, policy, pc, M, T, which):
     """(bytes, tensor) of the rollout workspace for this (model, policy shape, M, T), kept on the model object: the forward and the
-    backward call each have their own (a step's backward runs after its forward on the same stream, and the next forward after that)."""
+    backward call each have their own (a step's backward runs after its forward on the same stream, and the next forward after that).
+    One rollout at a time per model object: two host threads driving the SAME PackedModel on different streams would share these buffers
+    (give each its own PackedModel; the operand tensors can be shared)."""
     if model is None:  # (policy-only evaluation: nothing to keep it on)
         nbytes = abi.lib().mcp_rollout_workspace_bytes(None, C.byref(pc), M, T)
         return nbytes, (torch.empty((nbytes + 7) // 8, dtype=DT, device=policy.device) if nbytes else None)
