@@ -1390,7 +1390,7 @@ extern "C" size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_
   if (!policy || M <= 0 || T <= 0) return 0;
   size_t nparam = (size_t)policy->P + (size_t)policy->B * policy->P + (size_t)policy->U * policy->B + (size_t)policy->U;  // (+ U: dJ/dbias)
   const size_t bwd = sizeof(double) * nparam * (size_t)bwd_blocks(M);   // mcp_rollout_bwd: per-workgroup gradient slabs
-  const size_t fwd = model ? rollout_xch_bytes(M, model->G) + rollout_xj_bytes(model) + rollout_kt_bytes(model) + rollout_uxch_bytes(M, model->G, model->U) : 0;  // mcp_rollout_fwd: hand-off granules (GP-sharded launch) + packed phase-J operand (wide classes)
+  const size_t fwd = model ? rollout_xch_bytes(M, model->G) + rollout_xj_bytes(model) + rollout_kt_bytes(model) + rollout_uxch_bytes(M, model->G, model->U) + rollout_rxch_bytes(model, M) : 0;  // mcp_rollout_fwd: hand-off granules (GP-sharded launch) + packed phase-J operand (wide classes)
   return bwd > fwd ? bwd : fwd;
 }
 

@@ -1192,9 +1192,10 @@ struct FwdHooks {
   int gp_sharding = -1;  // -1 automatic, 0 never, 1 whenever the grid fits the device
   int policy_split = -1; // -1 automatic, 0 every member evaluates the whole policy, 1 the split whenever the shape allows it
   int fwd_lean = -1;     // -1 / 1 the latency-lean kernel wherever it applies, 0 never
+  int row_split = -1;    // -1 automatic, 0 one workgroup per (tile, GP range), 1 two (row halves of Kinv) whenever the shape allows it
   unsigned long long* stamps = nullptr;
   unsigned stamp_block = 0;
-  int last_ppw = 0, last_sharded = 0, last_lean = 0;  // report
+  int last_ppw = 0, last_sharded = 0, last_lean = 0, last_row_split = 0;  // report
 };
 static FwdHooks fwd_hooks(const mcp_dispatch* d) {
   FwdHooks h;
@@ -1205,6 +1206,7 @@ static FwdHooks fwd_hooks(const mcp_dispatch* d) {
     h.gp_sharding = d->gp_sharding == 1 ? 0 : (d->gp_sharding == 2 ? 1 : -1);
     h.policy_split = d->policy_split == 1 ? 0 : (d->policy_split == 2 ? 1 : -1);
     h.fwd_lean = d->fwd_lean == 1 ? 0 : -1;
+    h.row_split = d->row_split == 1 ? 0 : (d->row_split == 2 ? 1 : -1);
     h.stamps = (unsigned long long*)d->fwd_stamps;
     h.stamp_block = d->stamp_block;
   }
@@ -1325,6 +1327,8 @@ static int rollout_fwd_impl(const mcp_model* model, const mcp_policy* policy, co
   a.m_cnt = M;
   a.gsh_cs = 0;
   a.uxch = nullptr;
+  a.gsh_rs = 1;
+  a.rxch = nullptr;
   hipStream_t st = (hipStream_t)stream;
   // configuration search: most particles per workgroup first, operands in LDS if they fit, all GPs per pass if they fit
   int P0 = hk.force_ppw ? hk.force_ppw : pick_particles_per_wg(M);
@@ -1334,6 +1338,7 @@ static int rollout_fwd_impl(const mcp_model* model, const mcp_policy* policy, co
   // resident at one workgroup per CU; smallest cluster size first (most CUs busy)
   hk.last_sharded = 0;
   hk.last_lean = 0;
+  hk.last_row_split = 0;
   if (hk.gp_sharding != 0 && !no_gp_sharding && model->G >= 2 && T > 1 && workspace && workspace_bytes >= rollout_xch_bytes(M, model->G) &&
       (hk.force_ppw == 0 || (hk.gp_sharding == 1 && hk.force_ppw != 16))) {
     const int cus = device_cu_count();
@@ -1406,15 +1411,31 @@ static int rollout_fwd_impl(const mcp_model* model, const mcp_policy* policy, co
           if (hipMemsetAsync(a.uxch, 0, ub, st) != hipSuccess) return MCP_ERR_LAUNCH;
         }
       }
+      {  // Two workgroups per (tile, GP range), one per half of the rows of Kinv, when the grid is still resident at twice the size: the UR5
+         // launch script's M = 200 is 13 tiles x 6 GPs = 78 workgroups on 256 CUs, each bound by ONE GP's phase V on ONE CU
+         // (profiles/r04_ur5_script_stamps.txt: V 50 k of 112 k cycles per step).  Wide classes with the per-tile phase J only (degree <= 1).
+        const size_t roff = rollout_xch_bytes(M, model->G) + rollout_xj_bytes(model) + rollout_kt_bytes(model) + rollout_uxch_bytes(M, model->G, model->U);
+        const size_t rb = rollout_rxch_bytes(model, M);
+        const bool can = a.xj && a.maxdeg <= 1 && a.NpadMax >= 128 && rb > 0 && workspace_bytes >= roff + rb &&
+                         ((ncl + 7) / 8) * 8 * a.gsh_cs * 2 <= device_cu_count();
+        if (can && hk.row_split != 0) {
+          a.gsh_rs = 2;
+          a.rxch = (unsigned long long*)((char*)workspace + roff);
+          if (hipMemsetAsync(a.rxch, 0, rb, st) != hipSuccess) return MCP_ERR_LAUNCH;
+        }
+      }
       const int rc = launch_fwd_tile_sharded(a, st);
       if (rc == MCP_OK) {
         hk.last_ppw = 16;
         hk.last_sharded = 1;
+        hk.last_row_split = a.gsh_rs > 1 ? 1 : 0;
         return MCP_OK;
       }
       if (rc != MCP_ERR_LIMIT) return rc;
       a.xch = nullptr;
       a.uxch = nullptr;
+      a.gsh_rs = 1;
+      a.rxch = nullptr;
       a.nclusters = 0;
     }
   }
@@ -1463,6 +1484,7 @@ extern "C" int mcp_rollout_fwd_ex(const mcp_model* model, const mcp_policy* poli
     d->ran_particles = hk.last_ppw;
     d->ran_gp_sharded = hk.last_sharded;
     d->ran_fwd_lean = hk.last_lean;
+    d->ran_row_split = hk.last_row_split;
   }
   return rc;
 }

@@ -505,7 +505,7 @@ __device__ __forceinline__ v4d tile_j_bytile_run(gptr2_t xa0, int bfirst, int nb
 }
 template <int DEG>
 __device__ __forceinline__ void tile_phase_j_bytile(const GpL& gp, const double* xj_g, int npb, const double* ks, const double* kv, double* scr, int RT,
-                                                    int nh, int wv, int lane, unsigned long long* dbg = nullptr) {
+                                                    int nh, int wv, int lane, unsigned long long* dbg = nullptr, int jb0 = 0, int jb1 = 1 << 30) {
   static_assert(DEG <= 1, "degree 2 keeps the split-j form (its mini-product would be repeated per weight kind)");
   constexpr int CT = TL_NCOL(DEG);
   unsigned long long tq0 = dbg ? clock64() : 0;
@@ -516,11 +516,13 @@ __device__ __forceinline__ void tile_phase_j_bytile(const GpL& gp, const double*
   // work items = (tile, j-half): RT x CT = 6 tiles are 12 items, wave w takes items w and w + 8, so that every SIMD (waves s, s + 4) gets three
   // half tiles; the two partial tiles of a tile go to scratch slots 0 / 1 and phase F adds them as it reads (nh = 1: whole tiles, one slot)
   const int ntile = RT * CT, slot = ntile * 256;
-  const int bh = (nbat + nh - 1) / nh;
+  // (row-split cluster: the batches [jb0, jb1) of my half of the rows only)
+  const int bbeg = imin(jb0, nbat), bend = imin(jb1, nbat);
+  const int bh = (bend - bbeg + nh - 1) / nh;
   for (int item = wv; item < nh * ntile; item += RF_NW) {
     const int hh = item / ntile, tile = item - hh * ntile;
     const int rt = tile / CT, ct = tile - rt * CT;  // wave-uniform
-    const int bfirst = hh * bh, nb = imin(nbat, bfirst + bh) - bfirst;
+    const int bfirst = bbeg + hh * bh, nb = imin(bend, bfirst + bh) - bfirst;
     // variant 0: [X^T; 1]   variant 1: its columns scaled by alpha_j (the weight kind kse alpha then needs no alpha of its own)
     const gptr2_t xa = (gptr2_t)((gptr_t)xj_g + (size_t)((ct == 0 ? 2 : 0) + rt) * npb * 128);
     v4d r = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -970,9 +972,21 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   int cluster = blockIdx.x, gbeg = 0, gend = G;  // the GPs [gbeg, gend) this workgroup evaluates
   int myc = 0;                                   // ... as member myc of its cluster of CS workgroups
   const int CS = GSH ? a.gsh_cs : 1;
+  // round 5: RS = 2 workgroups per (tile, GP range), one per half of the rows of Kinv (phases V and J; see FwdArgs.gsh_rs) -- only the instantiations
+  // that take the per-tile form of phase J carry the code
+  constexpr bool RSP = GSH && CLS >= 1 && MAXDEG <= 1;
+  const int RS = RSP ? imax(1, a.gsh_rs) : 1;
+  int hrow = 0;  // which half (the last one finishes the GP: moments, sample, hand-off -- it has the larger share of the blocks, so its partner's sums are there when it arrives)
   if (GSH) {  // blocks b and b + 8 share an XCD: the members of a cluster sit 8 apart (speed only)
-    const int b = blockIdx.x, grp = b / (8 * CS), r = b - grp * 8 * CS;
-    if (8 % CS == 0) {
+    const int CW = CS * RS;  // workgroups per cluster
+    const int b = blockIdx.x, grp = b / (8 * CW), r = b - grp * 8 * CW;
+    if (RS > 1) {
+      // the two halves of a GP range are neighbours in the member order: with one cluster per XCD they share its L2, as the CS members did
+      const int mt = r >> 3;
+      cluster = grp * 8 + (r & 7);
+      myc = mt / RS;
+      hrow = mt - myc * RS;
+    } else if (8 % CS == 0) {
       // Member c of every cluster goes to the XCDs [c * 8/CS, (c+1) * 8/CS) (blocks are dealt round-robin over the 8 XCDs), so
       // an XCD's L2 only ever holds the Kinv of ONE GP range: the UR5 shape needs 3.8 MB per range against 4 MB of L2 -- with both
       // members of a cluster on one XCD (round 1) its six Kinv thrashed the L2 (FETCH_SIZE 10.8 GB per launch, profiles/r02_c5_*).
@@ -987,7 +1001,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     gbeg = (myc * G) / CS;
     gend = ((myc + 1) * G) / CS;
   }
-  const bool writer = !GSH || gbeg == 0;  // states / inputs are identical in the workgroups of a cluster: one of them stores
+  const bool fin = hrow == RS - 1;              // this workgroup finishes its GPs
+  const bool writer = !GSH || (gbeg == 0 && fin);  // states / inputs are identical in the workgroups of a cluster: one of them stores
   // the policy: member myc evaluates the tiles [ptb, pte) of 16 basis functions and the members add their partial sums (a.uxch), or everyone all of it
   const bool psplit = GSH && a.uxch != nullptr;
   const int pnt = (B + 15) >> 4;
@@ -1203,8 +1218,10 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         const unsigned long long bits = (unsigned long long)__double_as_longlong(sacc);
         gu64_t ub = (gu64_t)a.uxch + ((size_t)(cluster * 2 + (t & 1)) * CS) * (size_t)(P * U * 2);
         gu64_t mine = ub + (size_t)myc * (P * U * 2) + 2 * tid;
-        store_granule(mine, (unsigned)t + 1u, (unsigned)bits);
-        store_granule(mine + 1, (unsigned)t + 1u, (unsigned)(bits >> 32));
+        if (fin) {  // (the other half of my GP range holds the same bits)
+          store_granule(mine, (unsigned)t + 1u, (unsigned)bits);
+          store_granule(mine + 1, (unsigned)t + 1u, (unsigned)(bits >> 32));
+        }
         // all partners' granules are requested together and re-read until every tag matches: one L2 round trip, not one per partner
         unsigned lo[MCP_MAX_GP], hi[MCP_MAX_GP];
         bool ok = false;
@@ -1289,7 +1306,9 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       // collects the partial tiles of the others through the scratch slots, in wave order (fixed summation order).
       {
         constexpr int NACC = MAXTASK + 1;
-        const int nblk = (Npad + 31) >> 5, nb = Npad >> 4;  // blocks; 16-row batches per block
+        const int nblk_all = (Npad + 31) >> 5, nb = Npad >> 4;  // blocks; 16-row batches per block
+        const int vb0 = RS > 1 ? (hrow * nblk_all) / RS : 0;      // my blocks [vb0, vb0 + nblk) (row split: one half of them)
+        const int nblk = (RS > 1 ? ((hrow + 1) * nblk_all) / RS : nblk_all) - vb0;
         const int nfull = nblk >> 3, rem = nblk & 7;
         const int nshare = imin(RF_NW, L.vslots + 1);  // waves that share the remainder run (one scratch slot per non-collecting piece)
         // batches per share; with too few scratch slots for equal shares, whole blocks (one per wave, no partial tiles at all)
@@ -1330,7 +1349,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           }
           if (pb < 0) continue;
           v4d te = (v4d){0.0, 0.0, 0.0, 0.0}, to = (v4d){0.0, 0.0, 0.0, 0.0};
-          tile_v_block(gp.Kinv, Npad, pb * 32, pjs, pje, kv, lane, te, to);
+          tile_v_block(gp.Kinv, Npad, (vb0 + pb) * 32, pjs, pje, kv, lane, te, to);
 #pragma unroll
           for (int q = 0; q < NACC; ++q) {
             if (q == r) {
@@ -1375,7 +1394,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           const int n = lane & 15, kq = lane >> 4;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int row = blk[r] * 32 + 2 * (kq + 4 * i);
+            const int row = (vb0 + blk[r]) * 32 + 2 * (kq + 4 * i);
             if (row < Npad) {
               kv[row * TL_KR + n] = acc[r][0][i];
               kv[(row + 1) * TL_KR + n] = acc[r][1][i];
@@ -1389,12 +1408,15 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       int CTg;
       const int jnh = (CLS >= 1 && a.xj && L.nslot >= 2 && (MAXDEG <= 1 || deg <= 1)) ? 2 : 1;  // partial tiles per tile left by the per-tile form of phase J
       const int panel_doubles = 2 * a.NpadMax * TL_KR;  // ks and kv are adjacent in the layout
+      // row-split cluster: phase J over the rows whose v this workgroup has (32-row blocks = two batches each)
+      const int nblk_j = (Npad + 31) >> 5;
+      const int jrb0 = RS > 1 ? 2 * ((hrow * nblk_j) / RS) : 0, jrb1 = RS > 1 ? 2 * (((hrow + 1) * nblk_j) / RS) : (1 << 30);
       if (CLS >= 1 && a.xj && (MAXDEG == 0 || deg == 0)) {
-        tile_phase_j_bytile<0>(gp, a.xj + (size_t)g * a.xj_stride, a.xj_stride / 512, ks, kv, scr, RT, jnh, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
+        tile_phase_j_bytile<0>(gp, a.xj + (size_t)g * a.xj_stride, a.xj_stride / 512, ks, kv, scr, RT, jnh, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr, jrb0, jrb1);
         lds_barrier();
         CTg = TL_NCOL(0);
       } else if (CLS >= 1 && a.xj && (MAXDEG == 1 || deg == 1)) {
-        tile_phase_j_bytile<1>(gp, a.xj + (size_t)g * a.xj_stride, a.xj_stride / 512, ks, kv, scr, RT, jnh, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr);
+        tile_phase_j_bytile<1>(gp, a.xj + (size_t)g * a.xj_stride, a.xj_stride / 512, ks, kv, scr, RT, jnh, wv, lane, (a.stamps && blockIdx.x == a.stamp_block && wv == 0) ? a.stamps : nullptr, jrb0, jrb1);
         lds_barrier();
         CTg = TL_NCOL(1);
       } else if (MAXDEG == 0 || deg == 0) {
@@ -1429,6 +1451,114 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       // ---- phase F: moments, sample, d delta/dz -------------------------------------------------
       const TileR Rr = {scr, CTg, jnh, RT * CTg * 256};
 #define TL_R(c, k, p) (CLS == 0 ? tile_r1(Rr, c, k, p) : tile_r(Rr, c, k, p))
+      if (RSP && RS > 1) {
+        // Row-split cluster: R holds the sums over MY half of the rows.  Everything phase F takes from R is linear in it, so each item (p, c)
+        // boils its share down to two values -- c < D: the mean-Jacobian difference and the variance-Jacobian sum; c == D: k^T Kinv k and (degree 0)
+        // the mean -- half 1 sends them (4 granules), half 0 adds them to its own (own + partner: fixed order) and finishes as the one-workgroup
+        // form does.
+        gu64_t rxb = (gu64_t)a.rxch + ((size_t)((cluster * 2 + (t & 1)) * G + g)) * (size_t)(P * (D + 1) * 4);
+        const bool rs_dbg = a.stamps && blockIdx.x == a.stamp_block && tid == 0;  // diagnostic: slots 9 (my sums), 10 (partner poll), 11 (finish), 14 (end of J to the end of the hand-off)
+        unsigned long long rs_t0 = rs_dbg ? clock64() : 0;
+        for (int it = tid; it < P * (D + 1); it += RF_NT) {
+          const int p = it / (D + 1), c = it - p * (D + 1);
+          const double* zp = z + p * D;
+          const double vscale = gp.var_scale;
+          double kzz = gp.lambda;
+          double ktv = TL_R(D, 1, p);
+          if (MAXDEG >= 1 && deg >= 1) {
+            double p1 = kp[KP_W1(D) + D];
+            double pv = kp[KP_W1(D) + D] * TL_R(D, 2, p);
+#pragma unroll 4
+            for (int d = 0; d < D; ++d) {
+              const double wz = kp[KP_W1(D) + d] * zp[d];
+              p1 = fma(wz, zp[d], p1);
+              pv = fma(wz, TL_R(d, 2, p), pv);
+            }
+            kzz += p1;
+            ktv += pv;
+          }
+          double v0, v1, il2 = 0.0, w1c = 0.0;
+          if (c == D) {
+            v0 = ktv;
+            v1 = MAXDEG >= 1 ? 0.0 : TL_R(D, 0, p);
+          } else {
+            const double il = kp[KP_INVLS(D) + c];
+            il2 = il * il;
+            v0 = fma(zp[c], TL_R(D, 0, p), -TL_R(c, 0, p));
+            v1 = 4.0 * il2 * fma(zp[c], TL_R(D, 1, p), -TL_R(c, 1, p));
+            if (MAXDEG >= 1 && deg >= 1) {
+              w1c = kp[KP_W1(D) + c];
+              v1 = fma(-2.0 * w1c, TL_R(c, 2, p), v1);
+            }
+          }
+          // granule (value q, half h) of item `it` sits at [2 q + h][it]: every store / load instruction of a wave covers 64 consecutive granules
+          const int nit = P * (D + 1);
+          gu64_t sl = rxb + it;
+          if (rs_dbg) { const unsigned long long now = clock64(); a.stamps[9] += now - rs_t0; rs_t0 = now; }
+          if (!fin) {
+            const unsigned long long b0 = (unsigned long long)__double_as_longlong(v0), b1 = (unsigned long long)__double_as_longlong(v1);
+            store_granule(sl, (unsigned)t + 1u, (unsigned)b0);
+            store_granule(sl + nit, (unsigned)t + 1u, (unsigned)(b0 >> 32));
+            store_granule(sl + 2 * nit, (unsigned)t + 1u, (unsigned)b1);
+            store_granule(sl + 3 * nit, (unsigned)t + 1u, (unsigned)(b1 >> 32));
+            continue;
+          }
+          // the partner's two values of this item and its k^T Kinv k of this particle: requested together, re-read until every tag matches
+          gu64_t sk = rxb + (p * (D + 1) + D);
+          unsigned long long x[6];
+          bool ok = false;
+          for (unsigned spins = 0; spins < RF_SPIN_LIMIT && !ok; ++spins) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = __hip_atomic_load(sl + q * nit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x[4] = __hip_atomic_load(sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x[5] = __hip_atomic_load(sk + nit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = true;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) ok = ok && (unsigned)(x[q] >> 32) == (unsigned)t + 1u;
+            if (!ok) __builtin_amdgcn_s_sleep(2);
+          }
+          if (!ok) *abortw = 1;
+          if (rs_dbg) { const unsigned long long now = clock64(); a.stamps[10] += now - rs_t0; rs_t0 = now; }
+          const double q0 = __longlong_as_double((long long)((x[1] << 32) | (x[0] & 0xffffffffull)));
+          const double q1 = __longlong_as_double((long long)((x[3] << 32) | (x[2] & 0xffffffffull)));
+          const double qk = __longlong_as_double((long long)((x[5] << 32) | (x[4] & 0xffffffffull)));
+          const double var = (kzz - (ktv + qk)) * vscale;
+          double eps = 0.0, wj = 0.0, sd = 0.0;
+          if (a.particle_pred) {
+            eps = epsb[(t & 1) * P * G + p * G + g];
+            sd = sqrt(var);
+            wj = eps / (2.0 * sd);
+          }
+          if (c == D) {
+            double mu = gp.mean;
+            if (MAXDEG >= 1) {
+#pragma unroll
+              for (int w = 0; w < RF_NW; ++w) mu += mup[w * P + p];
+            } else {
+              mu += v1 + q1;
+            }
+            const double dv = a.particle_pred ? fma(sd, eps, mu) : mu;
+            dl[p * G + g] = dv;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(dv);
+            gu64_t slot = (gu64_t)a.xch + xch_slot(cluster, t, G, g, P) + 2 * p;
+            store_granule(slot, (unsigned)t + 1u, (unsigned)bits);
+            store_granule(slot + 1, (unsigned)t + 1u, (unsigned)(bits >> 32));
+            if (m0 + p < M) {
+              if (a.particle_pred && var <= 0.0) bad |= MCP_STATUS_NONPOS_VAR;
+              if (is_bad(mu) || is_bad(var)) bad |= MCP_STATUS_NAN;
+            }
+          } else if (a.jac && m0 + p < M) {
+            double Jmu = -2.0 * il2 * (v0 + q0);
+            double Jvar = v1 + q1;
+            if (MAXDEG >= 1 && deg >= 1) {
+              Jmu = fma(w1c, kp[KP_AX(D) + c], Jmu);
+              Jvar = fma(2.0 * w1c, zp[c], Jvar);
+            }
+            a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
+          }
+          if (rs_dbg) { const unsigned long long now = clock64(); a.stamps[11] += now - rs_t0; rs_t0 = now; }
+        }
+      } else
       for (int it = tid; it < P * (D + 1); it += RF_NT) {
         const int p = it / (D + 1), c = it - p * (D + 1);
         const double* zp = z + p * D;
@@ -1520,7 +1650,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       if (GSH && wv == 0 && gi == gend - 1) {
         // collect the other workgroups' increments (rollout_fwd.hip): lane -> (other GP, particle, half), 64 granules per pass,
         // each pass re-read until every tag matches
-        const int nown = gend - gbeg, ngr = (G - nown) * P * 2;
+        const int nown = fin ? gend - gbeg : 0, ngr = (G - nown) * P * 2;  // (the half that does not finish its GPs collects them too)
         bool done = true;
         for (int base = 0; base < ngr && done; base += 64) {
           const int idx = base + lane;
@@ -1546,6 +1676,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           if (act) reinterpret_cast<unsigned*>(dl)[2 * ((r >> 1) * G + gq) + (r & 1)] = val;
         }
         if (!done && lane == 0) *abortw = 1;
+        if (RSP && RS > 1 && a.stamps && blockIdx.x == a.stamp_block && tid == 0) a.stamps[14] += clock64() - last_stamp;  // (since the end of phase J)
       }
       lds_barrier();  // R, k/v panels and the scratch are reused by the next GP
       TL_STAMP(7);
@@ -1600,7 +1731,7 @@ static int launch_tile_pms(const FwdArgs& a, size_t lds, hipStream_t st) {
 template <int MAXDEG, int CLS, bool PMS, bool XL>
 static int launch_tile_gsh(const FwdArgs& a, size_t lds, hipStream_t st) {
   MCP_ENSURE_MAX_LDS(rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true, XL>);
-  const int grid = ((a.nclusters + 7) / 8) * 8 * a.gsh_cs;
+  const int grid = ((a.nclusters + 7) / 8) * 8 * a.gsh_cs * (a.gsh_rs > 1 ? a.gsh_rs : 1);
   hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true, XL>), dim3(grid), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
@@ -1659,6 +1790,7 @@ int launch_fwd_tile_sharded(const FwdArgs& a, hipStream_t st) {
   if (a.NpadMax > 512) return MCP_ERR_LIMIT;
   const int cls = (D <= 7 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2);
   if (cls == 2) return MCP_ERR_LIMIT;
+  if (a.gsh_rs > 1 && (a.gsh_rs != 2 || cls == 0 || a.maxdeg > 1 || !a.xj || !a.rxch)) return MCP_ERR_ARG;  // (the row split exists in the per-tile form of phase J only)
   if (tile_xj_pack(a, st) != MCP_OK) return MCP_ERR_LAUNCH;
   switch (cls * 3 + a.maxdeg) {
     case 0: return launch_tile_gsh_deg<0, 0>(a, st);

@@ -85,10 +85,11 @@ class Cost(C.Structure):
 
 class Dispatch(C.Structure):
     """include/mcpilco_hip_debug.h: struct mcp_dispatch -- the request a call carries (all zero = automatic) and what it reports back."""
-    _fields_ = [("fwd_particles", C.c_int32), ("gp_sharding", C.c_int32), ("fwd_lean", C.c_int32), ("policy_split", C.c_int32), ("fwd_no_xlds", C.c_int32),
+    _fields_ = [("fwd_particles", C.c_int32), ("gp_sharding", C.c_int32), ("fwd_lean", C.c_int32), ("policy_split", C.c_int32), ("row_split", C.c_int32),
+                ("fwd_no_xlds", C.c_int32),
                 ("fwd_gb", C.c_int32), ("bwd_particles", C.c_int32), ("bwd_lean", C.c_int32), ("chol_form", C.c_int32), ("stamp_block", C.c_uint32),
                 ("fwd_stamps", dptr), ("bwd_stamps", dptr), ("ran_particles", C.c_int32), ("ran_gp_sharded", C.c_int32), ("ran_fwd_lean", C.c_int32),
-                ("ran_bwd_lean", C.c_int32)]
+                ("ran_bwd_lean", C.c_int32), ("ran_row_split", C.c_int32)]
 
 
 # The dispatch request of THIS PROCESS's calls through `ops` (all zero: automatic).  It lives here, in the host layer -- the library keeps no
@@ -203,6 +204,12 @@ class _Lib:
 
     def mcp_debug_set_policy_split(self, mode):  # -1 automatic, 0 off, 1 whenever the shape allows
         DISPATCH.policy_split = {-1: 0, 0: 1, 1: 2}[int(mode)]
+
+    def mcp_debug_set_row_split(self, mode):  # -1 automatic, 0 off, 1 whenever the shape allows
+        DISPATCH.row_split = {-1: 0, 0: 1, 1: 2}[int(mode)]
+
+    def mcp_debug_last_row_split(self):
+        return int(DISPATCH.ran_row_split)
 
     def mcp_debug_last_gp_sharded(self):
         return int(DISPATCH.ran_gp_sharded)

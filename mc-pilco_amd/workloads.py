@@ -29,6 +29,7 @@ CONFIGS = {
     "c1_script_n360": ("cartpole", 0, 360, 400, 60),   # the cart-pole scripts' last trial without a subset: 60 + 5 x 60 samples
     "c2_script_n360": ("cartpole", 2, 360, 400, 60),
     "c2p1_script": ("cartpole", 1, 300, 400, 60),  # the same with a degree-1 Volterra term (tests: the lean kernel's MAXDEG = 1 instantiations)
+    "ur5_se": ("ur5", 0, 400, 200, 200),            # (tests: the wide class's SE-only instantiations)
     "tiny": ("cartpole", 0, 48, 16, 6),
     "tiny_ur5": ("ur5", 1, 40, 8, 5),
 }

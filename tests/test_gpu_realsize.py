@@ -24,7 +24,7 @@ Tt = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
 REAL = {"se300": ("c1", 48, 8), "sep2_300": ("c3", 48, 8), "ur5_400": ("c5", 40, 6), "se300_long": ("c1", 32, 150), "sep1_300": ("c2p1_script", 48, 8),
         # round 5: the training sets the launch scripts grow to (4th entry: N) -- the lean kernel beyond Npad = 384
         "se360": ("c1", 48, 8, 360), "sep2_360": ("c3", 48, 8, 360), "se450": ("c1", 48, 8, 450), "sep1_500": ("c2p1_script", 48, 8, 500),
-        "se620": ("c1", 48, 8, 620),
+        "se620": ("c1", 48, 8, 620), "ur5se_400": ("ur5_se", 40, 6),
         # beyond the 1024 rows the fused kernels took until round 4 (the reference factorises any N: GP_prior.py:106-110)
         "se1500": ("c1", 24, 6, 1500), "sep2_1100": ("c3", 24, 6, 1100)}
 
@@ -334,6 +334,60 @@ def test_policy_split_over_the_cluster_of_the_gp_sharded_tile_kernel(key, mode):
     assert not torch.equal(out[1][1], torch.zeros_like(out[1][1]))
     if mode == "masks":
         assert float((out[1][0].cpu() - o["states"]).abs().max()) < 1e-9 and float((out[1][1].cpu() - o["inputs"]).abs().max()) < 2e-9
+
+
+@pytest.mark.parametrize("key", ["ur5_400", "ur5se_400"])
+@pytest.mark.parametrize("mode", ["masks", "philox"])
+def test_row_split_cluster_of_the_gp_sharded_tile_kernel(key, mode):
+    """Round 5: small swarms of the wide class (the UR5 launch script's M = 200: 13 tiles x 6 GPs on 256 CUs) run TWO workgroups per (tile, GP), one
+    per half of the rows of Kinv (`FwdArgs.gsh_rs`, phases V and J over the member's own rows, the partial sums of phase F handed to the half that
+    finishes the GP through `FwdArgs.rxch`).  Same states / inputs / Jacobians as one workgroup per (tile, GP) (`mcp_debug_set_row_split(0)`) up to
+    the summation order over the training points, identical noise and dropout bits in Philox mode, bitwise reproducible; with recorded masks
+    against the oracle at 1e-9 (states, inputs) and 1e-9 relative (gradients through the stored Jacobians).  SE + polynomial(1) and SE alone (both
+    instantiations that carry the split)."""
+    from gpu_helpers import dev, forced_variant
+    from mc_pilco_amd import hipabi, ops
+
+    o = oracle_answer(key)
+    w = hip_workload_on_oracle_operands(key)
+    if mode == "masks":
+        nz = ops.NoiseSpec(eps=o["eps"].to(dev()).contiguous(), masks=o["masks"].to(torch.uint8).to(dev()).contiguous())
+    else:
+        nz = ops.NoiseSpec(seed=11, call=2)
+    L = hipabi.lib()
+    out = {}
+    try:
+        for split in (1, 0, 1):
+            L.mcp_debug_set_row_split(1 if split else 0)
+            for q in w.params:
+                q.grad = None
+            with forced_variant(116) as fv:
+                st, inp, status = ops.rollout(w.model, w.policy, nz, o["x0"].to(dev()), w.T, o["p"])
+                assert L.mcp_debug_last_gp_sharded() == 1, "the shape was expected to run GP-sharded"
+                assert L.mcp_debug_last_row_split() == split
+                c, _ = ops.expected_cost(w.cost, st)
+                c.backward()
+            assert int(status.item()) == 0
+            res = (st.detach().clone(), inp.detach().clone(), [q.grad.clone() for q in w.params], float(c))
+            if split in out:
+                assert torch.equal(out[split][0], res[0]) and torch.equal(out[split][1], res[1])  # bitwise reproducible
+                assert all(torch.equal(a, b) for a, b in zip(out[split][2], res[2]))
+            out[split] = res
+    finally:
+        L.mcp_debug_set_row_split(-1)
+    es = float((out[1][0] - out[0][0]).abs().max())
+    eu = float((out[1][1] - out[0][1]).abs().max())
+    eg = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(out[1][2], out[0][2]))
+    print("row split vs one workgroup per GP (%s, %s): states %.2e inputs %.2e grads rel %.2e" % (key, mode, es, eu, eg))
+    assert float((out[1][1][0] - out[0][1][0]).abs().max()) == 0.0  # the first step's inputs come before any GP
+    assert es < 2e-9 and eu < 4e-9 and eg < 1e-8
+    assert not torch.equal(out[1][1], torch.zeros_like(out[1][1]))
+    if mode == "masks":
+        assert float((out[1][0].cpu() - o["states"]).abs().max()) < 1e-9 and float((out[1][1].cpu() - o["inputs"]).abs().max()) < 2e-9
+        assert abs(out[1][3] - o["cost"]) < 1e-11 * abs(o["cost"])
+        for q, k in zip(out[1][2], ["log_ls", "centers", "weight"]):
+            g = o["grads"][k]
+            assert float((q.cpu().reshape(g.shape) - g).abs().max()) < 1e-9 * float(g.abs().max()), k
 
 
 @pytest.mark.parametrize("mode", ["masks", "philox"])

@@ -60,3 +60,6 @@ if hipabi.lib().mcp_debug_last_fwd_lean():
     print("lean kernel, phase V per wave (own time, before the barrier):", " ".join("%.0f" % (v[16 + i] / (w.T - 1)) for i in range(8)))
 for n, c in zip(names, v):
     print("%-14s %12d  %5.1f%%  %8.0f cyc/step" % (n, c, 100.0 * c / tot, c / (w.T - 1)))
+if hipabi.lib().mcp_debug_last_row_split():
+    print("row-split cluster, phase F (thread 0, per step, all GPs): my sums %.0f | partner poll %.0f | finish %.0f | end of J -> end of hand-off %.0f cyc"
+          % tuple(v[i] / (w.T - 1) for i in (9, 10, 11, 14)))
