@@ -1459,41 +1459,76 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         gu64_t rxb = (gu64_t)a.rxch + ((size_t)((cluster * 2 + (t & 1)) * G + g)) * (size_t)(P * (D + 1) * 4);
         const bool rs_dbg = a.stamps && blockIdx.x == a.stamp_block && tid == 0;  // diagnostic: slots 9 (my sums), 10 (partner poll), 11 (finish), 14 (end of J to the end of the hand-off)
         unsigned long long rs_t0 = rs_dbg ? clock64() : 0;
-        for (int it = tid; it < P * (D + 1); it += RF_NT) {
-          const int p = it / (D + 1), c = it - p * (D + 1);
-          const double* zp = z + p * D;
-          const double vscale = gp.var_scale;
-          double kzz = gp.lambda;
-          double ktv = TL_R(D, 1, p);
-          if (MAXDEG >= 1 && deg >= 1) {
-            double p1 = kp[KP_W1(D) + D];
-            double pv = kp[KP_W1(D) + D] * TL_R(D, 2, p);
-#pragma unroll 4
-            for (int d = 0; d < D; ++d) {
-              const double wz = kp[KP_W1(D) + d] * zp[d];
-              p1 = fma(wz, zp[d], p1);
-              pv = fma(wz, TL_R(d, 2, p), pv);
-            }
-            kzz += p1;
-            ktv += pv;
-          }
-          double v0, v1, il2 = 0.0, w1c = 0.0;
-          if (c == D) {
-            v0 = ktv;
-            v1 = MAXDEG >= 1 ? 0.0 : TL_R(D, 0, p);
+        // One pass: P (D + 1) <= 16 x 25 items on 512 threads (this class has D <= 24).  k^T Kinv k and k(z, z) of a particle are sums over the
+        // D + 1 columns (degree 1): every item forms the term of its own column, the terms meet in the k panel (dead since phase J) and each item
+        // adds the D + 1 of its particle in column order -- instead of every item walking all columns through R by itself (5.6 k -> see NOTES).
+        const int nit = P * (D + 1);
+        const bool act = tid < nit;
+        const int it = act ? tid : 0;
+        const int p = it / (D + 1), c = it - p * (D + 1);
+        const double* zp = z + p * D;
+        const double vscale = gp.var_scale;
+        double v0 = 0.0, v1 = 0.0, il2 = 0.0, w1c = 0.0;
+        const bool lin = MAXDEG >= 1 && deg >= 1;  // (uniform)
+        if (lin) {
+          const double w = kp[KP_W1(D) + c];
+          double tk, tz;
+          if (c < D) {
+            const double wz = w * zp[c];
+            tk = wz * TL_R(c, 2, p);
+            tz = wz * zp[c];
           } else {
-            const double il = kp[KP_INVLS(D) + c];
-            il2 = il * il;
-            v0 = fma(zp[c], TL_R(D, 0, p), -TL_R(c, 0, p));
-            v1 = 4.0 * il2 * fma(zp[c], TL_R(D, 1, p), -TL_R(c, 1, p));
-            if (MAXDEG >= 1 && deg >= 1) {
-              w1c = kp[KP_W1(D) + c];
-              v1 = fma(-2.0 * w1c, TL_R(c, 2, p), v1);
-            }
+            tk = fma(w, TL_R(D, 2, p), TL_R(D, 1, p));
+            tz = w;
           }
-          // granule (value q, half h) of item `it` sits at [2 q + h][it]: every store / load instruction of a wave covers 64 consecutive granules
-          const int nit = P * (D + 1);
-          gu64_t sl = rxb + it;
+          if (act) {
+            ks[it] = tk;
+            ks[nit + it] = tz;
+          }
+        }
+        if (c < D) {
+          const double il = kp[KP_INVLS(D) + c];
+          il2 = il * il;
+          v0 = fma(zp[c], TL_R(D, 0, p), -TL_R(c, 0, p));
+          v1 = 4.0 * il2 * fma(zp[c], TL_R(D, 1, p), -TL_R(c, 1, p));
+          if (lin) {
+            w1c = kp[KP_W1(D) + c];
+            v1 = fma(-2.0 * w1c, TL_R(c, 2, p), v1);
+          }
+        } else if (MAXDEG == 0) {
+          v1 = TL_R(D, 0, p);
+        }
+        // granule (value q, half h) of item `it` sits at [2 q + h][it]: every store / load instruction of a wave covers 64 consecutive granules.
+        // The finishing half asks for its partner's values -- the two of this item and its k^T Kinv k of this particle -- BEFORE it adds up its own:
+        // the partner is half a block ahead, its granules are usually there and the round trip runs under the sums below.
+        gu64_t sl = rxb + it;
+        gu64_t sk = rxb + (p * (D + 1) + D);
+        unsigned long long x[6] = {0, 0, 0, 0, 0, 0};
+        auto ask = [&]() {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) x[q] = __hip_atomic_load(sl + q * nit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          x[4] = __hip_atomic_load(sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          x[5] = __hip_atomic_load(sk + nit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        if (fin && act) ask();
+        double kzz = gp.lambda;
+        double ktv = TL_R(D, 1, p);
+        if (lin) {
+          lds_barrier();
+          if (fin || c == D) {  // (the half that sends needs the sum in its c == D items only)
+            const double* fk = ks + p * (D + 1);
+            double sk_ = 0.0, sz_ = 0.0;
+#pragma unroll 5
+            for (int d = 0; d <= D; ++d) {
+              sk_ += fk[d];
+              sz_ += fk[nit + d];
+            }
+            ktv = sk_;
+            kzz += sz_;
+          }
+        }
+        if (c == D) v0 = ktv;
+        if (act) {
           if (rs_dbg) { const unsigned long long now = clock64(); a.stamps[9] += now - rs_t0; rs_t0 = now; }
           if (!fin) {
             const unsigned long long b0 = (unsigned long long)__double_as_longlong(v0), b1 = (unsigned long long)__double_as_longlong(v1);
@@ -1501,21 +1536,16 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
             store_granule(sl + nit, (unsigned)t + 1u, (unsigned)(b0 >> 32));
             store_granule(sl + 2 * nit, (unsigned)t + 1u, (unsigned)b1);
             store_granule(sl + 3 * nit, (unsigned)t + 1u, (unsigned)(b1 >> 32));
-            continue;
-          }
-          // the partner's two values of this item and its k^T Kinv k of this particle: requested together, re-read until every tag matches
-          gu64_t sk = rxb + (p * (D + 1) + D);
-          unsigned long long x[6];
+          } else {
+          // re-read until every tag matches
           bool ok = false;
-          for (unsigned spins = 0; spins < RF_SPIN_LIMIT && !ok; ++spins) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = __hip_atomic_load(sl + q * nit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            x[4] = __hip_atomic_load(sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            x[5] = __hip_atomic_load(sk + nit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (unsigned spins = 0; spins < RF_SPIN_LIMIT; ++spins) {
             ok = true;
 #pragma unroll
             for (int q = 0; q < 6; ++q) ok = ok && (unsigned)(x[q] >> 32) == (unsigned)t + 1u;
-            if (!ok) __builtin_amdgcn_s_sleep(2);
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(2);
+            ask();
           }
           if (!ok) *abortw = 1;
           if (rs_dbg) { const unsigned long long now = clock64(); a.stamps[10] += now - rs_t0; rs_t0 = now; }
@@ -1557,6 +1587,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
             a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
           }
           if (rs_dbg) { const unsigned long long now = clock64(); a.stamps[11] += now - rs_t0; rs_t0 = now; }
+          }
         }
       } else
       for (int it = tid; it < P * (D + 1); it += RF_NT) {
@@ -1790,7 +1821,7 @@ int launch_fwd_tile_sharded(const FwdArgs& a, hipStream_t st) {
   if (a.NpadMax > 512) return MCP_ERR_LIMIT;
   const int cls = (D <= 7 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2);
   if (cls == 2) return MCP_ERR_LIMIT;
-  if (a.gsh_rs > 1 && (a.gsh_rs != 2 || cls == 0 || a.maxdeg > 1 || !a.xj || !a.rxch)) return MCP_ERR_ARG;  // (the row split exists in the per-tile form of phase J only)
+  if (a.gsh_rs > 1 && (a.gsh_rs != 2 || cls == 0 || a.maxdeg > 1 || !a.xj || !a.rxch || TL_PT * (D + 1) > RF_NT)) return MCP_ERR_ARG;  // (the row split exists in the per-tile form of phase J only)
   if (tile_xj_pack(a, st) != MCP_OK) return MCP_ERR_LAUNCH;
   switch (cls * 3 + a.maxdeg) {
     case 0: return launch_tile_gsh_deg<0, 0>(a, st);
