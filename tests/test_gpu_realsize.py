@@ -390,6 +390,45 @@ def test_row_split_cluster_of_the_gp_sharded_tile_kernel(key, mode):
             assert float((q.cpu().reshape(g.shape) - g).abs().max()) < 1e-9 * float(g.abs().max()), k
 
 
+@pytest.mark.parametrize("name,N,M,T", [("ur5_script", 150, 40, 5), ("ur5_script", 448, 24, 4), ("ur5_se", 272, 200, 4), ("ur5_script", 400, 200, 3),
+                                        ("ur5_script", 128, 17, 6)])
+def test_row_split_cluster_block_shares(name, N, M, T):
+    """The row-split cluster over the block counts a training set can leave: Npad = 160 (5 blocks of 32 rows: 2 + 3), 448 (14: 7 + 7, the largest
+    this class's k / v panels leave room for), 272 (8.5: 4 + 5 with a half-empty last block), 400 (12.5: 6 + 7, the launch script's 13 tiles with a ragged last one), 128
+    (4: 2 + 2, one particle in the last tile).  On-device noise: the split and the one-workgroup form draw the same dropout bits and increments,
+    so states, inputs and the gradients through the stored Jacobians agree to the summation order."""
+    from gpu_helpers import dev, forced_variant
+    from mc_pilco_amd import hipabi, ops, workloads
+
+    w = workloads.build(name, device=dev(), M=M, T=T, N=N)
+    assert w.model.gps[0].N == N
+    torch.manual_seed(3)
+    x0 = w.sample_x0()
+    L = hipabi.lib()
+    out = {}
+    try:
+        for split in (1, 0):
+            L.mcp_debug_set_row_split(split)
+            for q in w.params:
+                q.grad = None
+            with forced_variant(116):
+                st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=5, call=1), x0, w.T, w.p_drop)
+                assert L.mcp_debug_last_gp_sharded() == 1 and L.mcp_debug_last_row_split() == split
+                c, _ = ops.expected_cost(w.cost, st)
+                c.backward()
+            assert int(status.item()) == 0
+            out[split] = (st.detach().clone(), inp.detach().clone(), [q.grad.clone() for q in w.params])
+    finally:
+        L.mcp_debug_set_row_split(-1)
+    es = float((out[1][0] - out[0][0]).abs().max())
+    eu = float((out[1][1] - out[0][1]).abs().max())
+    eg = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(out[1][2], out[0][2]))
+    print("row split vs one workgroup per GP (%s N=%d M=%d): states %.2e inputs %.2e grads rel %.2e" % (name, N, M, es, eu, eg))
+    assert torch.equal(out[1][1][0], out[0][1][0])  # the first step's inputs come before any GP
+    assert es < 2e-9 and eu < 4e-9 and eg < 1e-8
+    assert float(out[1][1].abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("mode", ["masks", "philox"])
 def test_eight_particles_per_backward_sweep_on_the_wide_class(mode):
     """Round 4: `rollout_bwd_kernel<24, 6, 512, 2, 8>` -- the UR5 class sweeps EIGHT particles per workgroup on large swarms (250 workgroups
