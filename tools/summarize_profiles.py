@@ -29,7 +29,7 @@ for cfg in ("fit_c1", "fit_ur5"):  # GP training epochs (round 4)
     f = os.path.join(src, cfg + "_stats", cfg + "_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, cfg)))
-for name in ("chol_times.txt", "chol_stamps_n300.txt", "chol_stamps_n400.txt", "pretrain_times.txt", "vsym_bench.txt"):
+for name in ("chol_times.txt", "chol_stamps_n300.txt", "chol_stamps_n400.txt", "pretrain_times.txt", "vsym_bench.txt", "ur5_script_half1_stamps.txt"):
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_%s" % (rnd, name)))
