@@ -338,6 +338,8 @@ class Runner:
         if L.mcp_debug_last_fwd_lean():
             return "rollout_fwd_lat_kernel (GP-sharded)"
         name = "rollout_fwd_tile_kernel" if L.mcp_debug_last_particles_per_wg() == 16 else "rollout_fwd_kernel"
+        if L.mcp_debug_last_row_split():
+            return name + " (GP-sharded, two workgroups per (tile, GP) on row halves)"
         return name + (" (GP-sharded)" if L.mcp_debug_last_gp_sharded() else "")
 
     def bwd_kernel_name(self):
