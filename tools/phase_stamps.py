@@ -49,7 +49,7 @@ if hipabi.lib().mcp_debug_last_bwd_lean():
 else:
     print("bwd per step cycles: serial(wave0) %.0f | barrier1 %.0f | RBF stage %.0f | park+barrier2 %.0f" % tuple(x / w.T for x in (v2[8], v2[9], v2[10], v2[11])))
 print("workload", name, "T", w.T, "M", w.M, "ppw forced", ppw, "launched", hipabi.lib().mcp_debug_last_particles_per_wg(), "gp-sharded", hipabi.lib().mcp_debug_last_gp_sharded(), "lean", hipabi.lib().mcp_debug_last_fwd_lean(), "total cycles", tot, "-> per step", tot / (w.T - 1))
-print("tile kernel detail (wave 0, per step, all GPs): K setup %.0f, K tiles %.0f | J setup %.0f, J batches %.0f cyc" % tuple(v[i] / (w.T - 1) for i in (12, 13, -1 if hipabi.lib().mcp_debug_last_row_split() else 14, 15)))
+print("tile kernel detail (wave 0, per step, all GPs): K setup %.0f, K tiles %.0f | J setup %.0f, J batches %.0f cyc" % tuple((0 if (i == 14 and hipabi.lib().mcp_debug_last_row_split()) else v[i]) / (w.T - 1) for i in (12, 13, 14, 15)))
 if not hipabi.lib().mcp_debug_last_row_split():  # (the row-split cluster's phase F uses these slots: printed at the end)
     print("J finish (wave 0, per step, all GPs): wait for the other waves %.0f, park + barrier %.0f, add + barrier %.0f cyc" % tuple(v[i] / (w.T - 1) for i in (9, 10, 11)))
 if hipabi.lib().mcp_debug_last_particles_per_wg() == 16:
