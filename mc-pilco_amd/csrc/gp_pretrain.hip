@@ -1464,6 +1464,267 @@ __global__ __launch_bounds__(SOD_NT) void sod_select_kernel(mcp_kernel kn, int N
 }
 
 // ---------------------------------------------------------------------------------------
+// The same selection ACROSS workgroups (round 5, N >= SODM_MIN = 256): one 1024-thread workgroup per 64 candidates (wave 0 holds them, one per lane,
+// with k(x_c, x_c) and ||w_c||^2 in registers; the 16 waves share the j range of the block's dot products).  At N = 600 the one-workgroup kernel
+// spends 18.7 us per accepted point streaming W (2.9 MB) through ONE CU's L2 path; here every workgroup streams its own 64 columns.
+// Per accepted point there is ONE exchange: every workgroup publishes its own first passing candidate -- index, reciprocal pivot and the
+// candidate's vector w_c[0 .. n] -- as tagged 8-byte granules (tag = round + 1, value = half a double; relaxed agent-scope stores, no fences: W
+// stays in its owner's L2), reads the G indices, takes the smallest and reads that workgroup's vector.  Two granule sets by round parity: a
+// workgroup can be at most one round ahead (it needs every index of a round to leave it).
+//   gx: hdr[g][parity][4] = {index, 1/pivot lo, hi, -} | vec[g][parity][N][2]
+// Every poll is bounded; a partner that never arrives ends the kernel with *n_out = -1 (the grid must be resident: G <= 64 workgroups).
+// ---------------------------------------------------------------------------------------
+#ifdef SODM_MIN_OVERRIDE  // (experiment builds: where the multi-workgroup form starts to pay)
+constexpr int SODM_MIN = SODM_MIN_OVERRIDE;
+#else
+constexpr int SODM_MIN = 256;  // (N = 300: 1.32 -> 0.83 ms; below, the one-workgroup kernel's 12 k cycles per point are at the exchange's level)
+#endif
+constexpr unsigned SODM_SPIN = 1u << 22;
+typedef unsigned long long __attribute__((address_space(1))) * sod_gu64_t;
+__device__ __forceinline__ void sod_put(sod_gu64_t g, unsigned tag, unsigned v) {
+  __hip_atomic_store(g, ((unsigned long long)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sod_put_double(sod_gu64_t g, unsigned tag, double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  sod_put(g, tag, (unsigned)b);
+  sod_put(g + 1, tag, (unsigned)(b >> 32));
+}
+// both halves of a double, re-read until both carry the tag (false: the spin limit ran out)
+__device__ __forceinline__ bool sod_get_double(sod_gu64_t g, unsigned tag, double& x) {
+  for (unsigned spins = 0; spins < SODM_SPIN; ++spins) {
+    const unsigned long long a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(a >> 32) == tag && (unsigned)(b >> 32) == tag) {
+      x = __longlong_as_double((long long)((b << 32) | (a & 0xffffffffull)));
+      return true;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+static size_t sod_multi_granules(int N) { const size_t G = ((size_t)N + 63) / 64; return G * 2 * 4 + G * 2 * (size_t)N * 2; }
+__global__ __launch_bounds__(SOD_NT) void sod_select_multi_kernel(mcp_kernel kn, int N, const double* __restrict__ X, double thr,
+                                                                  int32_t* __restrict__ idx_out, int32_t* __restrict__ n_out,
+                                                                  double* __restrict__ W, unsigned long long* __restrict__ gx, int LR,
+                                                                  const double* __restrict__ Kg) {
+  extern __shared__ __attribute__((aligned(16))) double sod_smem[];
+  double* wp = sod_smem;          // [N] the accepted point's vector
+  double* part = wp + N;          // [SOD_NT] the 16 waves' shares of the block's dot products
+  double* wnew = part + SOD_NT;   // [64] component n of the block's candidates
+  double* shd = wnew + 64;        // [2] 1 / pivot of the accepted point
+  int* shi = (int*)(shd + 2);     // [4] my first passing candidate | the accepted one | abort | the round's verdict on the predicted owner
+  double* wl = shd + 4;           // [LR][64] the first LR rows of the block's columns of W (what the LDS has room for): LDS latency instead of L2's
+  const int tid = threadIdx.x, lane = tid & 63, grp = tid >> 6, D = kn.D;
+  const int G = gridDim.x, g = blockIdx.x;
+  const int c = 64 * g + lane;
+  const double s2 = kern_sigma_n2(kn);
+  sod_gu64_t hdr = (sod_gu64_t)gx;
+  sod_gu64_t vec = (sod_gu64_t)gx + (size_t)G * 2 * 4;
+  double kd0 = 0.0, nrm0 = 0.0;
+  if (grp == 0 && c < N) kd0 = kern_diag(kn, X + (size_t)c * D, 1);
+  if (tid == 0) {
+    shd[0] = 1.0 / sqrt(kern_diag(kn, X, 1) + s2);  // the first point is always kept (GP_prior.py:240): its pivot needs no exchange
+    shi[2] = 0;
+  }
+  __syncthreads();
+  int n = 0, p = 0;
+  bool failed = false;
+#ifdef SODM_STAMPS
+  unsigned long long sst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stq = clock64();
+#define SODM_STAMP(k)                      \
+  {                                        \
+    unsigned long long tn_ = clock64();    \
+    sst[k] += tn_ - stq;                   \
+    stq = tn_;                             \
+  }
+#else
+#define SODM_STAMP(k)
+#endif
+  while (true) {
+    const unsigned tag = (unsigned)n + 1u;
+    const int par = n & 1;
+    if (g == 0 && tid == 0) idx_out[n] = p;
+    const double rd = shd[0];
+    const bool live = c < N && c > p;
+    // this wave's share of the dot products  sum_{j < n} W[j][c] w_p[j]
+    const int per = (n + 15) >> 4, j0 = grp * per, j1 = min(n, j0 + per);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    // k(x_c, x_p) of wave 0's candidates: row p of the Gram matrix the launch function built beforehand (cov_build_kernel, all CUs; evaluated
+    // here -- 2 D strided loads and an exp per lane -- it was 6 k of the 19 k cycles a round took, on the one wave every other waits for)
+    double kcp = 0.0;
+    if (grp == 0 && live) kcp = Kg[(size_t)p * N + c];
+    if (live) {
+      const double* wc = W + c;
+      const int jl = min(j1, LR);  // rows below LR: from the LDS copy
+      int j = j0;
+      for (; j + 4 <= jl; j += 4) {
+        a0 = fma(wl[j * 64 + lane], wp[j], a0);
+        a1 = fma(wl[(j + 1) * 64 + lane], wp[j + 1], a1);
+        a2 = fma(wl[(j + 2) * 64 + lane], wp[j + 2], a2);
+        a3 = fma(wl[(j + 3) * 64 + lane], wp[j + 3], a3);
+      }
+      for (; j < jl; ++j) a0 = fma(wl[j * 64 + lane], wp[j], a0);
+      for (; j + 16 <= j1; j += 16) {
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = wc[(size_t)(j + t) * N];
+        SOD_PIN16(v);
+#pragma unroll
+        for (int t = 0; t < 16; t += 4) {
+          a0 = fma(v[t], wp[j + t], a0);
+          a1 = fma(v[t + 1], wp[j + t + 1], a1);
+          a2 = fma(v[t + 2], wp[j + t + 2], a2);
+          a3 = fma(v[t + 3], wp[j + t + 3], a3);
+        }
+      }
+      if (j < j1) {
+        double v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) v[t] = wc[(size_t)min(j + t, j1 - 1) * N];
+        SOD_PIN16(v);
+#pragma unroll
+        for (int t = 0; t < 16; t += 4) {
+          a0 = fma(j + t < j1 ? v[t] : 0.0, wp[min(j + t, j1 - 1)], a0);
+          a1 = fma(j + t + 1 < j1 ? v[t + 1] : 0.0, wp[min(j + t + 1, j1 - 1)], a1);
+          a2 = fma(j + t + 2 < j1 ? v[t + 2] : 0.0, wp[min(j + t + 2, j1 - 1)], a2);
+          a3 = fma(j + t + 3 < j1 ? v[t + 3] : 0.0, wp[min(j + t + 3, j1 - 1)], a3);
+        }
+      }
+    }
+    part[tid] = (a0 + a1) + (a2 + a3);
+    SODM_STAMP(0)
+    __syncthreads();
+    SODM_STAMP(1)
+    if (grp == 0) {  // wave 0: the shares in wave order, component n, the test, my first passing candidate
+      double dot = part[lane];
+#pragma unroll
+      for (int q = 1; q < 16; ++q) dot += part[q * 64 + lane];
+      bool pass = false;
+      double w = 0.0;
+      if (live) {
+        w = (kcp - dot) * rd;
+        W[(size_t)n * N + c] = w;
+        nrm0 = fma(w, w, nrm0);
+        pass = sqrt(kd0 - nrm0) > thr;
+      }
+      wnew[lane] = w;
+      if (n < LR) wl[n * 64 + lane] = w;
+      const unsigned long long bal = __ballot(pass);
+      const int first = bal ? (int)__builtin_ctzll(bal) : -1;
+      sod_gu64_t h = hdr + ((size_t)g * 2 + par) * 4;
+      if (lane == (first < 0 ? 0 : first)) {
+        if (first >= 0) sod_put_double(h + 1, tag, 1.0 / sqrt(kd0 + s2 - nrm0));
+        sod_put(h, tag, (unsigned)(first < 0 ? N : 64 * g + first));
+        shi[0] = first < 0 ? N : 64 * g + first;
+      }
+    }
+    SODM_STAMP(2)
+    __syncthreads();
+    SODM_STAMP(3)
+    {  // my candidate's vector w_c[0 .. n] (row n from LDS: it was formed a moment ago)
+      const int cg = shi[0];
+      if (cg < N) {
+        sod_gu64_t vm = vec + (((size_t)g * 2 + par) * N) * 2;
+        for (int j = tid; j <= n; j += SOD_NT) sod_put_double(vm + 2 * (size_t)j, tag, j == n ? wnew[cg - 64 * g] : (j < LR ? wl[j * 64 + cg - 64 * g] : W[(size_t)j * N + cg]));
+      }
+    }
+    // Whose candidate wins is known before the indices are: the live candidates are c > p, so the lowest block that has any is block (p + 1) / 64, and
+    // if that block has a passing candidate it is the smallest.  Waves 1-15 therefore ask for THAT workgroup's vector while wave 0 collects the
+    // indices -- one round trip instead of two; when the block had no passing candidate (it publishes no vector) wave 0's verdict in LDS ends their
+    // wait and everybody reads the true owner's.
+    SODM_STAMP(4)
+    const int gpred = min(G - 1, (p + 1) >> 6);
+    volatile int* verdict = shi + 3;
+    if (grp == 0) {  // every workgroup's index of this round; the smallest is the next point
+      int best = N, mine = N;
+      double rmine = 0.0;  // (the pivot travels with the index: the lane that polled the winner hands it on)
+      for (int q = lane; q < G; q += 64) {
+        sod_gu64_t h = hdr + ((size_t)q * 2 + par) * 4;
+        bool ok = false;
+        for (unsigned spins = 0; spins < SODM_SPIN && !ok; ++spins) {
+          const unsigned long long a = __hip_atomic_load(h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long b0 = __hip_atomic_load(h + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long b1 = __hip_atomic_load(h + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int cq = (int)(unsigned)a;
+          ok = (unsigned)(a >> 32) == tag && (cq >= N || ((unsigned)(b0 >> 32) == tag && (unsigned)(b1 >> 32) == tag));
+          if (ok) {
+            if (cq < mine) {
+              mine = cq;
+              rmine = __longlong_as_double((long long)((b1 << 32) | (b0 & 0xffffffffull)));
+            }
+          } else {
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        if (!ok) shi[2] = 1;
+      }
+      best = mine;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) best = min(best, __shfl_xor(best, o));
+      if (best < N && mine == best) shd[0] = rmine;
+      if (lane == 0) {
+        shi[1] = best;
+        *verdict = (int)(2u * tag + ((best < N && (best >> 6) == gpred) ? 0u : 1u));  // (even: the predicted owner it is)
+      }
+    } else {
+      sod_gu64_t vq = vec + (((size_t)gpred * 2 + par) * N) * 2;
+      for (int j = tid - 64; j <= n; j += SOD_NT - 64) {
+        bool done = false;
+        for (unsigned spins = 0; spins < SODM_SPIN && !done; ++spins) {
+          const unsigned long long x0 = __hip_atomic_load(vq + 2 * (size_t)j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long x1 = __hip_atomic_load(vq + 2 * (size_t)j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)(x0 >> 32) == tag && (unsigned)(x1 >> 32) == tag) {
+            wp[j] = __longlong_as_double((long long)((x1 << 32) | (x0 & 0xffffffffull)));
+            done = true;
+          } else if (*verdict == (int)(2u * tag + 1u)) {
+            done = true;  // not the predicted owner (or nobody): no vector will come from there
+          } else {
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        if (!done) shi[2] = 1;
+      }
+    }
+    SODM_STAMP(5)
+    __syncthreads();
+    SODM_STAMP(6)
+    const int pn = shi[1];
+    const bool hit = *verdict == (int)(2u * tag);
+    if (shi[2]) {
+      failed = true;
+      break;
+    }
+    n += 1;
+    if (pn >= N) break;
+    {  // after a miss: the accepted point's vector from the workgroup that owns it
+      const int gw = pn >> 6;
+      sod_gu64_t vw = vec + (((size_t)gw * 2 + par) * N) * 2;
+      if (!hit) {
+        for (int j = tid; j < n; j += SOD_NT) {
+          double x = 0.0;
+          if (!sod_get_double(vw + 2 * (size_t)j, tag, x)) shi[2] = 1;
+          wp[j] = x;
+        }
+      }
+    }
+    p = pn;
+    __syncthreads();
+    SODM_STAMP(7)
+    if (shi[2]) {
+      failed = true;
+      break;
+    }
+  }
+#ifdef SODM_STAMPS
+  if (g == gridDim.x / 2 && (tid == 0 || tid == 512)) {  // (wave 0's lane 0 and a thread of wave 8, workgroup G / 2: into the one-workgroup kernel's tail of the workspace)
+    unsigned long long* o = (unsigned long long*)(W + (size_t)N * N) + (tid == 0 ? 0 : 8);
+    for (int k = 0; k < 8; ++k) o[k] = sst[k];
+  }
+#endif
+  if (g == 0 && tid == 0) *n_out = failed ? -1 : n;
+}
+
+// ---------------------------------------------------------------------------------------
 // Marginal-likelihood gradient (GP_prior.fit_model's objective, Gaussian_likelihood.py:15-24):
 //   L = 1/2 (r^T Kinv r + logdet K),   dL/dtheta = 1/2 sum_ij Wm_ij dK_ij/dtheta,   Wm = Kinv - alpha alpha^T.
 // One workgroup per row i: (1) threads over j stage Wm_ij, Wm_ij*kse_ij and the two MPK_2 factor values in LDS,
@@ -1998,14 +2259,37 @@ extern "C" int mcp_gp_pack(int N, int D, const double* X, const double* alpha, c
   return MCP_OK;
 }
 
-extern "C" size_t mcp_sod_workspace_bytes(int N) { return N > 0 ? sizeof(double) * ((size_t)N * N + 2 * (size_t)N) : 0; }
+// W [N][N] + the one-workgroup kernel's running sums [2 N]; from SODM_MIN candidates on also the granules of the multi-workgroup kernel (a caller that
+// passes the first part only gets the one-workgroup kernel)
+static size_t sod_base_bytes(int N) { return sizeof(double) * ((size_t)N * N + 2 * (size_t)N); }
+static bool sod_multi_applies(int N) { return N >= SODM_MIN && N <= 4096; }
+// (the multi-workgroup kernel's part: the exchange granules and the Gram matrix of the candidates)
+static size_t sod_multi_bytes(int N) { return sizeof(unsigned long long) * sod_multi_granules(N) + sizeof(double) * (size_t)N * N; }
+extern "C" size_t mcp_sod_workspace_bytes(int N) {
+  if (N <= 0) return 0;
+  return sod_base_bytes(N) + (sod_multi_applies(N) ? sod_multi_bytes(N) : 0);
+}
 
 extern "C" int mcp_sod_select(const mcp_kernel* kern, int N, const double* X, double threshold, int32_t* idx_out, int32_t* n_out,
                               void* workspace, size_t workspace_bytes, void* stream) {
   if (!kernel_ok(kern) || !X || !idx_out || !n_out || !workspace || N <= 0) return MCP_ERR_ARG;
-  if (workspace_bytes < mcp_sod_workspace_bytes(N)) return MCP_ERR_WORKSPACE;
+  if (workspace_bytes < sod_base_bytes(N)) return MCP_ERR_WORKSPACE;
   if (N > 16384) return MCP_ERR_LIMIT;  // the accepted point's vector [N] lives in LDS
   double* Uw = (double*)workspace;
+  if (sod_multi_applies(N) && workspace_bytes >= mcp_sod_workspace_bytes(N)) {
+    unsigned long long* gx = (unsigned long long*)((char*)workspace + sod_base_bytes(N));
+    if (hipMemsetAsync(gx, 0, sizeof(unsigned long long) * sod_multi_granules(N), (hipStream_t)stream) != hipSuccess) return MCP_ERR_LAUNCH;
+    double* Kg = (double*)(gx + sod_multi_granules(N));
+    hipLaunchKernelGGL(cov_build_kernel, dim3((N + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, *kern, N, X, N, X, 0, Kg, N);
+    MCP_LAUNCH_CHECK();
+    const size_t fixed = sizeof(double) * ((size_t)N + SOD_NT + 64 + 4);
+    const int LR = (int)std::min<size_t>((size_t)N, ((size_t)160 * 1024 - fixed) / (64 * sizeof(double)));  // rows of the block's columns kept in LDS
+    MCP_ENSURE_MAX_LDS(sod_select_multi_kernel);
+    hipLaunchKernelGGL(sod_select_multi_kernel, dim3((N + 63) / 64), dim3(SOD_NT), fixed + (size_t)LR * 64 * sizeof(double), (hipStream_t)stream, *kern, N,
+                       X, threshold, idx_out, n_out, Uw, gx, LR, Kg);
+    MCP_LAUNCH_CHECK();
+    return MCP_OK;
+  }
   MCP_ENSURE_MAX_LDS(sod_select_kernel);
   hipLaunchKernelGGL(sod_select_kernel, dim3(1), dim3(SOD_NT), sizeof(double) * ((size_t)N + SOD_NT + 4), (hipStream_t)stream, *kern, N, X,
                      threshold, idx_out, n_out, Uw);

@@ -153,11 +153,14 @@ def gp_alpha(Kinv, Y, mean=0.0):
     return alpha.reshape(-1, 1)
 
 
-def sod_select(spec: KernelSpec, X, threshold) -> List[int]:
+def sod_select(spec: KernelSpec, X, threshold, one_workgroup=False) -> List[int]:
+    """GP_prior.get_SOD (GP_prior.py:232-257) on the device.  From 256 candidates on the selection runs across workgroups (one per 64 candidates)
+    when the workspace has room for their exchange -- `mcp_sod_workspace_bytes` says how much; ``one_workgroup`` passes the first part only (W and
+    the running sums) and so keeps the one-workgroup kernel (tests, timing)."""
     X = _t(X, X.device)
     N = X.shape[0]
     dev = X.device
-    nbytes = abi.lib().mcp_sod_workspace_bytes(N)
+    nbytes = 8 * (N * N + 2 * N) if one_workgroup else abi.lib().mcp_sod_workspace_bytes(N)
     ws = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev)
     idx = torch.zeros(N, dtype=torch.int32, device=dev)
     n = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -165,6 +168,9 @@ def sod_select(spec: KernelSpec, X, threshold) -> List[int]:
     abi.check(abi.lib().mcp_sod_select(C.byref(kc), N, abi.ptr(X), float(threshold), abi.ptr(idx), abi.ptr(n), abi.ptr(ws), nbytes,
                                        abi.stream()), "mcp_sod_select")
     cnt = int(n.item())
+    if cnt < 0:
+        raise RuntimeError("mcp_sod_select: the workgroups of the selection never met (the device could not hold the grid); "
+                           "ops.sod_select(..., one_workgroup=True) runs it on one")
     return [int(i) for i in idx[:cnt].tolist()]
 
 

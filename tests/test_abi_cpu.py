@@ -85,7 +85,9 @@ def test_argument_validation_without_gpu():
     assert lib.mcp_rollout_workspace_bytes(C.byref(m), C.byref(p), 0, 0) == 0
     p.P, p.B, p.U = 5, 200, 1
     assert lib.mcp_rollout_workspace_bytes(C.byref(m), C.byref(p), 400, 150) == 8 * (5 + 200 * 5 + 200 + 1) * 400  # (+ U: dJ/dbias)
-    assert lib.mcp_sod_workspace_bytes(300) == 8 * (300 * 300 + 2 * 300)  # (+ the candidates' running sums and prior variances)
+    assert lib.mcp_sod_workspace_bytes(200) == 8 * (200 * 200 + 2 * 200)  # (W + the candidates' running sums and prior variances)
+    # from 256 candidates on: + the multi-workgroup kernel's exchange granules (G = 5 workgroups x 2 parities x (4 + 2 N)) and the Gram matrix
+    assert lib.mcp_sod_workspace_bytes(300) == 8 * (300 * 300 + 2 * 300) + 8 * (5 * 2 * 4 + 5 * 2 * 300 * 2) + 8 * 300 * 300
     # wide models (more than 15 GP-input dimensions): the forward part also holds the packed phase-J operands of the 16-particle kernel,
     # per GP 2 variants x 2 row tiles x Npad/8 pair-steps x 64 lanes x 2 doubles behind the hand-off granules
     m.G, m.D = 6, 24

@@ -305,3 +305,25 @@ def test_sod_beyond_1024_candidates_against_the_oracle():
     print("SOD N=1100: kept %d, smallest margin of the oracle's run %.3e" % (len(keep), mm))
     assert 20 < len(keep) < 1000 and mm > 1e-9
     assert got == keep
+
+
+@pytest.mark.parametrize("N,thr,sig", [(256, 0.2, 0.3), (300, 0.18, 0.36), (448, 0.3, 0.3), (600, 0.0, 0.36), (600, 0.25, 0.3), (1000, 0.5, 0.3), (2049, 0.6, 0.3)])
+def test_sod_across_workgroups_matches_the_one_workgroup_kernel(N, thr, sig):
+    """Round 5: from 256 candidates on `sod_select_multi_kernel` -- one workgroup per 64 candidates, one granule exchange per accepted point
+    (index, pivot, the candidate's vector) -- against `sod_select_kernel` on the same data (forced by passing the workspace without the
+    exchange area): the same list.  N = 256 (4 full blocks), 300 (the cart-pole scripts' size), 448 (7 blocks), 600 with threshold 0 (every point kept: 600 rounds, the UR5 pretrain's shape) and
+    with rejections, 1000, 2049 (33 blocks, one candidate in the last)."""
+    from gpu_helpers import G, spec_from
+    from mc_pilco_amd import hipabi, ops, workloads
+
+    pb = workloads.numpy_problem("c1", N=N)
+    X = pb["Z"]
+    assert X.shape[0] == N
+    sp = spec_from(pb["cfg"]["lengthscales"], sig)
+    assert hipabi.lib().mcp_sod_workspace_bytes(N) > 8 * (N * N + 2 * N)
+    one = ops.sod_select(sp, G(X), thr, one_workgroup=True)
+    many = ops.sod_select(sp, G(X), thr)
+    print("SOD N=%d thr %.2f: kept %d" % (N, thr, len(one)))
+    assert many == one
+    assert len(one) == N if thr == 0.0 else 10 < len(one) < N
+    assert ops.sod_select(sp, G(X), thr) == many  # (the granule area is zeroed per call: a second run meets fresh tags)
