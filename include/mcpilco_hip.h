@@ -180,7 +180,9 @@ int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, int ldi, dou
 int mcp_gp_alpha(int N, const double* Kinv, int ldk, const double* Y, double mean, double* alpha, void* stream);
 /* Greedy subset-of-data selection on the device, GP_prior.get_SOD (GP_prior.py:232-257):
  * idx_out[0..*n_out) receives the kept sample indices (ascending, bit-exact contract).
- * workspace: mcp_sod_workspace_bytes(N). */
+ * workspace: mcp_sod_workspace_bytes(N) -- W [N][N] and two running sums [N]; from 256 candidates on also the exchange area and the Gram matrix of
+ * the form that runs across workgroups (one per 64 candidates, all resident; N <= 4096).  With 8 (N^2 + 2 N) bytes only, the call keeps to one
+ * workgroup.  *n_out = -1: the workgroups never met (the device could not hold the grid) -- repeat with the smaller workspace. */
 size_t mcp_sod_workspace_bytes(int N);
 int mcp_sod_select(const mcp_kernel* kern, int N, const double* X, double threshold, int32_t* idx_out, int32_t* n_out,
                    void* workspace, size_t workspace_bytes, void* stream);
