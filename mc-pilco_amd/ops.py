@@ -168,9 +168,10 @@ def sod_select(spec: KernelSpec, X, threshold, one_workgroup=False) -> List[int]
     abi.check(abi.lib().mcp_sod_select(C.byref(kc), N, abi.ptr(X), float(threshold), abi.ptr(idx), abi.ptr(n), abi.ptr(ws), nbytes,
                                        abi.stream()), "mcp_sod_select")
     cnt = int(n.item())
-    if cnt < 0:
-        raise RuntimeError("mcp_sod_select: the workgroups of the selection never met (the device could not hold the grid); "
-                           "ops.sod_select(..., one_workgroup=True) runs it on one")
+    if cnt < 0:  # the workgroups never met (the device could not hold the grid, e.g. shared with another process): the one-workgroup kernel
+        if one_workgroup:
+            raise RuntimeError("mcp_sod_select reported %d kept rows" % cnt)
+        return sod_select(spec, X, threshold, one_workgroup=True)
     return [int(i) for i in idx[:cnt].tolist()]
 
 
