@@ -368,7 +368,7 @@ def time_pretrain(device, shape="cartpole", reps=5):
     gp = ml.gp_list[0]
     X = gp._cols(ml.gp_inputs)
     spec = gp.kernel_spec()
-    thr = float(0.5 * torch.sqrt(gp.get_sigma_n_2())) if shape == "cartpole" else 0.001
+    thr = float(0.5 * torch.sqrt(gp.get_sigma_n_2().detach())) if shape == "cartpole" else 0.001
     idx = ml.SOD_indices[0]
     Xs, Ys = X[idx, :].contiguous(), ml.gp_output_list[0][idx, :].contiguous()
     stages = {}
