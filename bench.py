@@ -242,6 +242,10 @@ class Runner:
         self.flops = workloads.flops_per_particle_step(self.w)
         self.flops_fwd = workloads.flops_per_particle_step(self.w, forward_only=True)
         self.bits = torch.tensor([1 << b for b in range(self.STATUS_BITS)], dtype=torch.int32, device=dev)
+        # the step's flat message [gradient | cost sums | flags], allocated once: the adjoint sweep writes its gradients into the head (the
+        # parameters' .grad are views of it), mcp_cost_sums into the middle; a sharded step all-reduces it in place (sharding.StepMessage)
+        self.msg = sharding.StepMessage(self.w.policy.grad_numel(), self.T, 1 + self.STATUS_BITS, dev)
+        self.w.policy.grad_flat = self.msg.grad
 
     def step(self, i, ev, sharded=None):
         torch, ops, w, args = self.torch, self.ops, self.w, self.args
@@ -262,10 +266,11 @@ class Runner:
         if sharded:
             # this rank's share of the pooled cost -> its own adjoint sweep -> ONE all-reduce of [gradient | cost sums | flags]; the
             # flags are one 0/1 entry per status bit (summed doubles are counts, not an OR) + "local share is NaN"
-            share, sums = ops.local_cost(w.cost, states, self.world * M, self.shift)
+            share, sums = ops.local_cost(w.cost, states, self.world * M, self.shift, sums_out=self.msg.sums)
             share.backward()
             fl = torch.cat([torch.isnan(share.detach()).reshape(1).to(torch.float64), ((status & self.bits) != 0).to(torch.float64)])
-            cost, _std, fl_all, self.shift = self.sharding.finish_step(_SumsCost, self.reducer, w.params, sums, fl, self.world * M, self.shift)
+            cost, _std, fl_all, self.shift = self.sharding.finish_step(_SumsCost, self.reducer, w.params, sums, fl, self.world * M, self.shift,
+                                                                       msg=self.msg)
             self.flags_sum += fl_all
         else:
             cost, _std = ops.expected_cost(w.cost, states)

@@ -29,8 +29,12 @@
 extern "C" {
 #endif
 
-#define MCP_ABI_VERSION 5 /* 5: mcp_kernel.scal, MCP_FWD_NO_GP_SHARDING, MCP_STATUS_NONPOS_VAR now means a FINITE variance <= 0, mcp_nll_epoch, \
-                             mcp_adam_step_guarded, mcp_policy_step_commit (round 4) */
+#define MCP_ABI_VERSION 6 /* 5: mcp_kernel.scal, MCP_FWD_NO_GP_SHARDING, MCP_STATUS_NONPOS_VAR now means a FINITE variance <= 0, mcp_nll_epoch, \
+                             mcp_adam_step_guarded, mcp_policy_step_commit (round 4).                                                            \
+                             6 (round 6; the round-5 contract changes, which had kept the number 5, are part of it): mcp_sod_select needs       \
+                             mcp_sod_workspace_bytes(N) = 8 (N^2 + 2 N) + the exchange area (was 8 N^2) and may report *n_out = -1;             \
+                             MCP_MAX_TRAIN 1024 -> 4096; the process-wide mcp_debug_* setters are gone (mcpilco_hip_debug.h: per-call           \
+                             mcp_dispatch); mcp_adam_step_guarded skips a not-SPD epoch; new: mcp_sym_sandwich */
 
 #define MCP_OK 0
 #define MCP_ERR_ARG (-1)       /* null pointer / non-positive size                       */
@@ -176,6 +180,10 @@ int mcp_chol_factor(int N, double* A, int lda, double* logdet, uint32_t* status,
  * (and, beyond 1152 rows, its strictly-lower 128-row block rows are used as scratch and zeroed again): pass Uinv zero-filled for a clean lower
  * triangle.  N <= 16384. */
 int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, int ldi, double* Kinv, int ldk, void* stream);
+/* out = A G A for a symmetric A [N][N] (K^-1) and any G [N][N]; scratch: N * N doubles; out, scratch, A, G distinct.  The chain rule through
+ * torch.inverse in GP_prior.forward's autograd graph (GP_prior.py:109-110: d K^-1 = - K^-1 dK K^-1) for criteria other than the marginal
+ * likelihood in GP_prior.fit_model (GP_prior.py:179-230).  N <= 16384. */
+int mcp_sym_sandwich(int N, const double* A, int lda, const double* G, int ldg, double* out, int ldo, double* scratch, void* stream);
 /* alpha = Kinv (Y - mean).  GP_prior.get_alpha, GP_prior.py:130-135. */
 int mcp_gp_alpha(int N, const double* Kinv, int ldk, const double* Y, double mean, double* alpha, void* stream);
 /* Greedy subset-of-data selection on the device, GP_prior.get_SOD (GP_prior.py:232-257):

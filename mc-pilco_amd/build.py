@@ -61,7 +61,27 @@ def _compile_all(jobs, verbose):
             list(ex.map(run, jobs))
 
 
+def _sources_digest():
+    """Identity of what the library is built from: every source, header and the flags."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.join(os.path.dirname(HERE), "include", "mcpilco_hip_debug.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+STAMP = LIB + ".stamp"
+
+
 def build(force=False, verbose=True):
+    """Compiles what is stale and links.  A library whose stamp (libmcpilco_hip.so.stamp: a digest of sources, headers and flags) matches is
+    up to date whatever the file times say and whether or not the objects are there -- a snapshot of the tree (gpurun, the driver's GPU box)
+    carries the library and its stamp, not the objects (.gpurunignore), and must not spend minutes rebuilding them."""
+    digest = _sources_digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read().strip() == digest:
+        return LIB
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -70,11 +90,13 @@ def build(force=False, verbose=True):
             jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
         objs.append(o)
     _compile_all(jobs, verbose)
-    if force or _stale(LIB, objs):
+    if force or jobs or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(digest + "\n")
     return LIB
 
 

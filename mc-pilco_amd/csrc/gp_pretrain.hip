@@ -2242,6 +2242,21 @@ extern "C" int mcp_chol_inverse(int N, const double* U, int ldu, double* Uinv, i
   return mcp_chol_inverse_ex(N, U, ldu, Uinv, ldi, Kinv, ldk, stream, nullptr);
 }
 
+// out = A G A for a SYMMETRIC A (K^-1) and any G: S = G^T A, out = S^T A -- two products in the transposed-left form of tn_gemm_kernel
+// (coalesced MFMA operands from row-major storage).  The chain rule through K^-1 of GP_prior.forward's autograd graph:
+// d K^-1 = - K^-1 dK K^-1  (GP_prior.py:109-110 under autograd; _ForwardFunction.backward).
+extern "C" int mcp_sym_sandwich(int N, const double* A, int lda, const double* G, int ldg, double* out, int ldo, double* scratch, void* stream) {
+  if (!A || !G || !out || !scratch || N <= 0 || lda < N || ldg < N || ldo < N) return MCP_ERR_ARG;
+  if (N > 16384) return MCP_ERR_LIMIT;
+  if (out == A || out == G || scratch == A || scratch == G || scratch == out) return MCP_ERR_ARG;
+  const dim3 grid((N + 63) / 64, (N + 63) / 64);
+  hipLaunchKernelGGL(tn_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, N, N, G, ldg, A, lda, scratch, N, 1.0, 0);
+  MCP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tn_gemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, N, N, N, scratch, N, A, lda, out, ldo, 1.0, 0);
+  MCP_LAUNCH_CHECK();
+  return MCP_OK;
+}
+
 extern "C" int mcp_gp_alpha(int N, const double* Kinv, int ldk, const double* Y, double mean, double* alpha, void* stream) {
   if (!Kinv || !Y || !alpha || N <= 0 || ldk < N) return MCP_ERR_ARG;
   hipLaunchKernelGGL(gp_alpha_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, N, Kinv, ldk, Y, mean, alpha);

@@ -60,8 +60,8 @@ struct FwdArgs {
   //   uxch[cluster][t & 1][member][p * U + k][half]   (zeroed per launch; null: every member evaluates the whole policy)
   unsigned long long* uxch;
   // GP-sharded 16-particle kernel, round 5: gsh_rs = 2 puts TWO workgroups on every (tile, GP range), each with one half of the rows of Kinv
-  // (phases V and J over its own rows; phase K, the small one, in both).  The half that does not finish the GP sends its partial sums of
-  // phase F -- two doubles per (particle, column c <= D) -- to the one that does:
+  // (phases V and J over its own rows; phase K, the small one, in both).  The half that does not finish the GP (half 0) sends its partial sums
+  // of phase F -- two doubles per (particle, column c <= D) -- to the one that does (half 1 = gsh_rs - 1, which adds own + partner in that order):
   //   rxch[cluster][t & 1][g][p * (D + 1) + c][2 values][half]   (granules, zeroed per launch; gsh_rs <= 1: unused)
   int gsh_rs;
   unsigned long long* rxch;

@@ -1454,8 +1454,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       if (RSP && RS > 1) {
         // Row-split cluster: R holds the sums over MY half of the rows.  Everything phase F takes from R is linear in it, so each item (p, c)
         // boils its share down to two values -- c < D: the mean-Jacobian difference and the variance-Jacobian sum; c == D: k^T Kinv k and (degree 0)
-        // the mean -- half 1 sends them (4 granules), half 0 adds them to its own (own + partner: fixed order) and finishes as the one-workgroup
-        // form does.
+        // the mean -- the half that does NOT finish the GP (half 0: `!fin`) sends them (4 granules), the finishing half (half 1 = RS - 1: `fin`, the
+        // one with the larger share of the blocks) adds them to its own (own + partner: fixed order) and finishes as the one-workgroup form does.
         gu64_t rxb = (gu64_t)a.rxch + ((size_t)((cluster * 2 + (t & 1)) * G + g)) * (size_t)(P * (D + 1) * 4);
         const bool rs_dbg = a.stamps && blockIdx.x == a.stamp_block && tid == 0;  // diagnostic: slots 9 (my sums), 10 (partner poll), 11 (finish), 14 (end of J to the end of the hand-off)
         unsigned long long rs_t0 = rs_dbg ? clock64() : 0;

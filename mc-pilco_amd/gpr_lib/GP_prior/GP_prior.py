@@ -267,35 +267,44 @@ class _ForwardFunction(torch.autograd.Function):
     records through get_covariance / torch.cholesky / torch.inverse in the reference (GP_prior.py:91-115).  Forward: the HIP Gram,
     factorisation and inverse.  Backward: with the upstream gradients G_K, G_Kinv, g_logdet the Gram matrix's own gradient is
         Wm = G_K - Kinv G_Kinv Kinv + g_logdet Kinv          (d Kinv = -Kinv dK Kinv,  d logdet = tr(Kinv dK); Kinv symmetric)
-    -- two plain library GEMMs -- and  dL/dtheta = sum_ij Wm_ij dK_ij/dtheta  comes from the HIP gradient kernel (nll.cov_weighted_grad)."""
+    -- two products on the library's MFMA GEMM (`mcp_sym_sandwich`, the `tn_gemm_kernel` of the factorisation) -- and
+    dL/dtheta = sum_ij Wm_ij dK_ij/dtheta  comes from the HIP gradient kernel (nll.cov_weighted_grad)."""
 
     @staticmethod
     def forward(ctx, gp, X, *params):
         Xc = gp._cols(X)
-        K = ops.cov_build(gp.kernel_spec_dev(), Xc, None, noise=gp.GP_with_noise)
+        spec = gp.kernel_spec_dev()  # a snapshot of the hyper-parameters (new tensors): backward differentiates the kernel THIS forward evaluated
+        K = ops.cov_build(spec, Xc, None, noise=gp.GP_with_noise)
         U, log_det, status = ops.chol_factor(K)
         if ops.status_flags(status)["not_spd"]:
             raise RuntimeError("cholesky: the covariance matrix is not positive-definite")
         _, K_inv = ops.chol_inverse(U)
-        ctx.gp, ctx.Xc, ctx.params = gp, Xc, params
+        ctx.gp, ctx.Xc, ctx.params, ctx.spec = gp, Xc, params, spec
+        # (the chain rule's last factors -- d sigma_n^2 / d sigma_n_log, d w / d Sigma_pos_par -- are formed from the live parameters in
+        #  backward: an in-place change in between must not go unnoticed, as torch's own version check would not let it in the reference)
+        ctx.versions = tuple(int(p._version) for p in gp.parameters())
         ctx.save_for_backward(K_inv)
         ctx.set_materialize_grads(False)
         return K, K_inv, log_det.reshape(())
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g_K, g_Kinv, g_ld):
         from mc_pilco_amd import nll
 
+        if tuple(int(p._version) for p in ctx.gp.parameters()) != ctx.versions:
+            raise RuntimeError("one of the GP's hyper-parameters was modified by an inplace operation between GP_prior.forward and the backward "
+                               "of its outputs (e.g. optimizer.step() before a second backward): run forward again")
         (K_inv,) = ctx.saved_tensors
         Wm = torch.zeros_like(K_inv)
         if g_K is not None:
             Wm = Wm + g_K
         if g_Kinv is not None:
-            Wm = Wm - K_inv @ g_Kinv @ K_inv
+            Wm = Wm - ops.sym_sandwich(K_inv, g_Kinv)  # Kinv G Kinv on the library's own MFMA GEMM (mcp_sym_sandwich)
         if g_ld is not None:
             Wm = Wm + g_ld * K_inv
-        g = nll.cov_weighted_grad(ctx.gp, ctx.Xc, Wm)
-        got = {id(p): v for p, v in nll.kernel_param_grads(ctx.gp, g, ctx.Xc.shape[1])}
+        g = nll.cov_weighted_grad(ctx.gp, ctx.Xc, Wm, spec=ctx.spec)
+        got = {id(p): v for p, v in nll.kernel_param_grads(ctx.gp, g, ctx.Xc.shape[1], spec=ctx.spec)}
         return (None, None) + tuple(got.get(id(p)) for p in ctx.params)
 
 

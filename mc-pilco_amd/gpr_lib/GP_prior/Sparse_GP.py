@@ -108,6 +108,24 @@ class Linear_GP(GP_prior.GP_prior):
         w1 = w if self.flg_offset else torch.cat([w, torch.zeros(1, dtype=torch.float64)])
         return ops.KernelSpec(torch.ones(D, dtype=torch.float64), 0.0, float(self.get_sigma_n_2()) if self.GP_with_noise else 0.0, 0.0, w1, None, None)
 
+    def kernel_spec_dev(self) -> ops.KernelSpec:
+        """kernel_spec with the weights and the noise left on the device (mcp_kernel.scal); what GP_prior.forward's autograd route and the
+        marginal-likelihood gradient read.  The structure checks of kernel_spec (diagonal Sigma: one host read) are made once per object."""
+        if not self.flg_no_mean:
+            raise NotImplementedError("a linear prior mean phi(X) w is not implemented by the HIP kernels")
+        Sigma = self.get_Sigma().detach().to(torch.float64)
+        if not self.__dict__.get("_sigma_is_diagonal", False):
+            if float((Sigma - torch.diag(torch.diag(Sigma))).abs().max()) != 0.0:
+                raise NotImplementedError("the HIP kernels implement diagonal Sigma matrices (one weight per feature)")
+            self.__dict__["_sigma_is_diagonal"] = True
+        D, dev = self.num_features, self.device
+        z = torch.zeros(1, dtype=torch.float64, device=dev)
+        w = torch.diag(Sigma)
+        w1 = w if self.flg_offset else torch.cat([w, z])
+        sig2 = self.get_sigma_n_2().detach().reshape(-1)[:1].to(torch.float64) if self.GP_with_noise else z
+        nan = float("nan")
+        return ops.KernelSpec(torch.ones(D, dtype=torch.float64, device=dev), nan, nan, nan, w1, None, None, scal=torch.cat([z, sig2, z]).contiguous())
+
     def get_parameters(self, X, Y, flg_print=False):
         """w_hat = Sigma phi(X)^T K^-1 (Y - m)  (valid when this is the only kernel of the model)."""
         m_X, _, K_X_inv = self.forward_for_estimate(X)

@@ -1,8 +1,9 @@
 """Marginal likelihood criterion -- drop-in for ``gpr_lib/Likelihood/Gaussian_likelihood.py:12-24``:
 loss = 1/2 ((Y-m)^T K^-1 (Y-m) + log det K)   (the 2 pi term is dropped, as in the reference).
 
-On the HIP path the GP's ``forward`` is not an autograd graph; ``loss_and_grad`` evaluates the loss and
-writes the analytic gradient  dL/dtheta = 1/2 tr((K^-1 - a a^T) dK/dtheta)  into ``param.grad``.
+``forward`` is the reference's expression on the outputs of ``GP_prior.forward`` (an autograd graph when hyper-parameters are trainable:
+``GP_prior._ForwardFunction``).  ``loss_and_grad`` is the route ``fit_model`` takes for this criterion: the loss and the analytic gradient
+dL/dtheta = 1/2 tr((K^-1 - a a^T) dK/dtheta)  from the HIP kernels, written into ``param.grad`` without building a graph.
 """
 import torch
 

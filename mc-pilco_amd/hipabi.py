@@ -20,7 +20,7 @@ if os.environ.get("MCPILCO_HIP_EXPERIMENT") == "1" and os.environ.get("MCPILCO_H
 MAX_GP, MAX_STATE, MAX_INPUT, MAX_GPDIM, MAX_PFEAT, MAX_BASIS, MAX_TRAIN = 8, 16, 8, 32, 32, 1024, 4096
 OK = 0
 ERRORS = {-1: "MCP_ERR_ARG", -2: "MCP_ERR_LIMIT", -3: "MCP_ERR_WORKSPACE", -4: "MCP_ERR_LAUNCH", -5: "MCP_ERR_COMM"}
-ABI_VERSION = 5
+ABI_VERSION = 6
 COMM_ID_BYTES = 128
 STATUS_NAN, STATUS_NONPOS_VAR, STATUS_NOT_SPD, STATUS_SYNC = 1, 2, 4, 8
 FWD_NO_GP_SHARDING = 2  # flag in mcp_rollout_fwd's particle_pred argument (MCP_FWD_NO_GP_SHARDING)
@@ -106,6 +106,7 @@ _SIGS = {
     "mcp_chol_inverse": (C.c_int, [C.c_int, dptr, C.c_int, dptr, C.c_int, dptr, C.c_int, dptr]),
     "mcp_chol_factor_ex": (C.c_int, [C.c_int, dptr, C.c_int, dptr, dptr, dptr, C.POINTER(Dispatch)]),
     "mcp_chol_inverse_ex": (C.c_int, [C.c_int, dptr, C.c_int, dptr, C.c_int, dptr, C.c_int, dptr, C.POINTER(Dispatch)]),
+    "mcp_sym_sandwich": (C.c_int, [C.c_int, dptr, C.c_int, dptr, C.c_int, dptr, C.c_int, dptr, dptr]),
     "mcp_gp_alpha": (C.c_int, [C.c_int, dptr, C.c_int, dptr, C.c_double, dptr, dptr]),
     "mcp_sod_workspace_bytes": (C.c_size_t, [C.c_int]),
     "mcp_sod_select": (C.c_int, [C.POINTER(Kernel), C.c_int, dptr, C.c_double, dptr, dptr, dptr, C.c_size_t, dptr]),

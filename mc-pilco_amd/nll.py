@@ -48,7 +48,7 @@ def nll_loss_and_grad(gp, X, Y):
     abi.check(abi.lib().mcp_nll_grad(C.byref(kc), N, abi.ptr(Xc), abi.ptr(Kinv), N, abi.ptr(alpha), abi.ptr(g), abi.ptr(ws), nbytes,
                                      abi.stream()), "mcp_nll_grad")
 
-    for p, val in kernel_param_grads(gp, g, D):
+    for p, val in kernel_param_grads(gp, g, D, spec=spec):
         p.grad = val
     first = _leaves(gp)[0]
     for leaf in _leaves(gp):  # only the first child's mean enters the model (GP_prior.py:306-312)
@@ -57,9 +57,10 @@ def nll_loss_and_grad(gp, X, Y):
     return loss.detach()
 
 
-def kernel_param_grads(gp, g, D):
+def kernel_param_grads(gp, g, D, spec=None):
     """[(parameter, gradient)] of the trainable KERNEL hyper-parameters of ``gp`` from the library's gradient vector ``g`` (layout of
-    mcp_nll_grad: [0, D) log lengthscales | D log lambda | D + 1 noise variance | MPK_1 (D + 1) | MPK_2 factor 0 (D) | factor 1 (D))."""
+    mcp_nll_grad: [0, D) log lengthscales | D log lambda | D + 1 noise variance | MPK_1 (D + 1) | MPK_2 factor 0 (D) | factor 1 (D)).
+    ``spec``: the kernel descriptor ``g`` was evaluated with (default: the current one) -- a plain Linear_GP leaf needs its w1."""
     from .gpr_lib.GP_prior import Sparse_GP, Stationary_GP
 
     out = []
@@ -79,16 +80,31 @@ def kernel_param_grads(gp, g, D):
                 put(leaf.Sigma_pos_par, g[D + 2:2 * D + 3] if leaf.flg_offset else g[D + 2:2 * D + 2])
             else:
                 put(leaf.Sigma_pos_par, torch.cat([g[2 * D + 3:3 * D + 3], g[3 * D + 3:4 * D + 3]]))
+        elif isinstance(leaf, Sparse_GP.Linear_GP):
+            # phi^T diag(w) phi' rides in the kernels' degree-1 slot: the library's entries are d/d log w_c = 2 w_c dL/dw_c of the TOTAL weight
+            # vector; dL/dw_c goes on to this leaf's own parameters through its Sigma_function by autograd (w = diag(Sigma), torch ops)
+            ps = [q for q in (leaf.Sigma_pos_par, leaf.Sigma_free_par) if q is not None and q.requires_grad]
+            if ps:
+                n = D + 1 if leaf.flg_offset else D
+                w_tot = (gp.kernel_spec_dev() if spec is None else spec).w1[:n].to(g.device)
+                dLdw = torch.where(w_tot != 0, g[D + 2:D + 2 + n] / (2.0 * w_tot), torch.zeros_like(w_tot))
+                with torch.enable_grad():
+                    w = torch.diag(leaf.get_Sigma()).to(DT)
+                    got = torch.autograd.grad(w, ps, grad_outputs=dLdw, allow_unused=True)
+                for q, v in zip(ps, got):
+                    put(q, torch.zeros_like(q) if v is None else v)
+        else:
+            raise NotImplementedError("no gradient mapping for the hyper-parameters of a %s leaf on the HIP path" % type(leaf).__name__)
     return out
 
 
-def cov_weighted_grad(gp, Xc, Wm):
+def cov_weighted_grad(gp, Xc, Wm, spec=None):
     """sum_ij Wm_ij dK_ij/dtheta for every kernel log-parameter (the library's vector, layout above): the chain rule's last step for ANY
     function of the Gram matrix.  Through mcp_nll_grad, which evaluates 1/2 sum_ij (Kinv - a a^T)_ij dK_ij/dtheta: called with 2 Wm in the
-    place of Kinv and a = 0."""
+    place of Kinv and a = 0.  ``spec``: the descriptor of the forward pass this is the backward of (default: the current hyper-parameters)."""
     dev = gp.device
     N, D = Xc.shape
-    spec = gp.kernel_spec_dev()
+    spec = gp.kernel_spec_dev() if spec is None else spec
     nbytes = abi.lib().mcp_nll_workspace_bytes(N, D)
     ws = torch.empty((nbytes + 7) // 8, dtype=DT, device=dev)
     g = torch.empty(4 * D + 3, dtype=DT, device=dev)

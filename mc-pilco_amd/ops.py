@@ -145,12 +145,26 @@ def chol_inverse(U):
     return Ui, Kinv
 
 
+def sym_sandwich(A, G):
+    """A G A for a symmetric A (K^-1) and any G, on the library's MFMA GEMM (mcp_sym_sandwich)."""
+    N = A.shape[0]
+    A = A.detach().to(dtype=DT).contiguous()
+    G = G.detach().to(device=A.device, dtype=DT).contiguous()
+    out = torch.empty(N, N, dtype=DT, device=A.device)
+    scratch = torch.empty(N, N, dtype=DT, device=A.device)
+    abi.check(abi.lib().mcp_sym_sandwich(N, abi.ptr(A), N, abi.ptr(G), N, abi.ptr(out), N, abi.ptr(scratch), abi.stream()), "mcp_sym_sandwich")
+    return out
+
+
 def gp_alpha(Kinv, Y, mean=0.0):
     N = Kinv.shape[0]
     Y = _t(Y, Kinv.device).reshape(-1)
     alpha = torch.empty(N, dtype=DT, device=Kinv.device)
     abi.check(abi.lib().mcp_gp_alpha(N, abi.ptr(Kinv), Kinv.shape[1], abi.ptr(Y), float(mean), abi.ptr(alpha), abi.stream()), "mcp_gp_alpha")
     return alpha.reshape(-1, 1)
+
+
+sod_fallbacks = 0  # calls of sod_select whose multi-workgroup launch reported "never met" and were repeated on one workgroup
 
 
 def sod_select(spec: KernelSpec, X, threshold, one_workgroup=False) -> List[int]:
@@ -171,6 +185,13 @@ def sod_select(spec: KernelSpec, X, threshold, one_workgroup=False) -> List[int]
     if cnt < 0:  # the workgroups never met (the device could not hold the grid, e.g. shared with another process): the one-workgroup kernel
         if one_workgroup:
             raise RuntimeError("mcp_sod_select reported %d kept rows" % cnt)
+        global sod_fallbacks
+        sod_fallbacks += 1
+        if sod_fallbacks == 1:  # (every such call has spun to its limit first -- seconds: say so once, keep counting)
+            import warnings
+
+            warnings.warn("mcp_sod_select: the workgroups of the multi-workgroup selection never met (is the GPU shared with another process?); "
+                          "this and later such calls are repeated on the one-workgroup kernel (ops.sod_fallbacks counts them)", RuntimeWarning)
         return sod_select(spec, X, threshold, one_workgroup=True)
     return [int(i) for i in idx[:cnt].tolist()]
 
@@ -263,6 +284,11 @@ class PackedPolicy:
         self.c = p
         self.kind, self.S, self.P, self.B, self.U = kind, int(S), int(P), int(B), int(U)
         self.device = dev
+        self.grad_flat = None  # optional caller-owned flat fp64 buffer the adjoint sweep writes its gradients into (rollout_backward_raw)
+
+    def grad_numel(self):
+        """Doubles of the flat gradient [log_ls | centers | weight | bias]."""
+        return self.P + self.B * self.P + self.U * self.B + (self.U if self.bias is not None else 0)
 
     def bind(self, p_drop):
         """Refreshes parameter pointers (they must be contiguous fp64 GPU tensors) and p_drop."""
@@ -428,11 +454,20 @@ def rollout_backward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseS
     pc = policy.bind(p_drop)
     nz = noise.to_c()
     nbytes, ws = _workspace(model, policy, pc, M, T, "bwd")
-    g_ls = torch.empty(1, policy.P, dtype=DT, device=dev)
-    g_c = torch.empty(policy.B, policy.P, dtype=DT, device=dev)
-    g_w = torch.empty(policy.U, policy.B, dtype=DT, device=dev)
+    # ONE flat buffer [dJ/dlog_ls (P) | dJ/dcenters (B P) | dJ/dweight (U B) | dJ/dbias (U)]: the three (four) gradients are views of it --
+    # autograd hands them to the parameters' .grad as they are, so a particle-sharded step all-reduces its message IN PLACE when the caller
+    # supplies the head of that message as ``policy.grad_flat`` (sharding.StepMessage); otherwise one allocation per step instead of four
+    P_, B_, U_ = policy.P, policy.B, policy.U
+    n_ls, n_c, n_w = P_, B_ * P_, U_ * B_
+    n_all = n_ls + n_c + n_w + (U_ if policy.bias is not None else 0)
+    flat = getattr(policy, "grad_flat", None)
+    if flat is None or flat.numel() < n_all or flat.dtype != DT or flat.device != dev or not flat.is_contiguous():
+        flat = torch.empty(n_all, dtype=DT, device=dev)
+    g_ls = flat[0:n_ls].view(1, P_)
+    g_c = flat[n_ls:n_ls + n_c].view(B_, P_)
+    g_w = flat[n_ls + n_c:n_ls + n_c + n_w].view(U_, B_)
+    g_b = flat[n_ls + n_c + n_w:n_all] if policy.bias is not None else None
     g_x0 = torch.empty(M, policy.S, dtype=DT, device=dev) if want_gx0 else None
-    g_b = torch.empty(policy.U, dtype=DT, device=dev) if policy.bias is not None else None
     pc.g_bias = None if g_b is None else g_b.data_ptr()
     gs = None if g_states is None else g_states.to(dtype=DT).contiguous()
     gi = None if g_inputs is None else g_inputs.to(dtype=DT).contiguous()
@@ -595,10 +630,14 @@ class LocalCostFunction(torch.autograd.Function):
     d(sum_t mean_m c)/dtheta],  sums [2T] = mcp_cost_sums: per time step sum_m (c - shift_t) and sum_m (c - shift_t)^2)."""
 
     @staticmethod
-    def forward(ctx, states, cost, m_total, shift):
+    def forward(ctx, states, cost, m_total, shift, sums_out=None):
         mom, _, _ = cost_moments(cost, states)
         T, M = states.shape[0], states.shape[1]
-        sums = torch.empty(2 * T, dtype=DT, device=states.device)
+        # (sums_out: a 1-tuple holding the caller's slot of the step's all-reduce message, sharding.StepMessage.sums -- in a tuple so that
+        #  autograd does not take the slot for an input of this function)
+        sums = sums_out[0] if sums_out is not None else torch.empty(2 * T, dtype=DT, device=states.device)
+        if sums.numel() != 2 * T or sums.dtype != DT or not sums.is_contiguous():
+            raise RuntimeError("sums_out must be a contiguous float64 tensor of 2 T entries")
         abi.check(abi.lib().mcp_cost_sums(T, M, abi.ptr(mom), abi.ptr(shift), abi.ptr(sums), abi.stream()), "mcp_cost_sums")
         local = cost_finalize(mom.unsqueeze(0), [M])[0] * (float(M) / float(m_total))
         ctx.cost, ctx.m_total = cost, int(m_total)
@@ -615,11 +654,11 @@ class LocalCostFunction(torch.autograd.Function):
         gc = g_local.detach().to(dtype=DT).reshape(1).contiguous()
         abi.check(abi.lib().mcp_cost_bwd(C.byref(ctx.cost.c), T, M, abi.ptr(st), abi.ptr(gc), 1.0 / float(ctx.m_total), abi.ptr(g), abi.stream()),
                   "mcp_cost_bwd")
-        return g, None, None, None
+        return g, None, None, None, None
 
 
-def local_cost(cost: PackedCost, states, m_total, shift=None):
-    return LocalCostFunction.apply(states, cost, int(m_total), shift)
+def local_cost(cost: PackedCost, states, m_total, shift=None, sums_out=None):
+    return LocalCostFunction.apply(states, cost, int(m_total), shift, None if sums_out is None else (sums_out,))
 
 
 def cost_from_sums(sums, n_total, shift=None, mean_out=None):

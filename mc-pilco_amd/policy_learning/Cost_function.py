@@ -47,12 +47,17 @@ class Expected_cost(torch.nn.modules.loss._Loss):
             return torch.sum(s1) / n + (torch.sum(mean) - torch.sum(s1.detach()) / n), torch.sum(torch.sqrt(m2 / (n - 1)))
         return torch.sum(torch.mean(costs, 1)), torch.sum(torch.std(costs.detach(), 1))
 
-    def local_moments(self, states_sequence, inputs_sequence, trial_index, m_total, shift=None):
+    def local_moments(self, states_sequence, inputs_sequence, trial_index, m_total, shift=None, sums_out=None):
         """This rank's share of a particle-sharded cost in summable form (sharding.StepReducer): (share = sum_t sum_m c / m_total,
-        differentiable;  sums [2T] = per time step sum_m (c - shift_t), sum_m (c - shift_t)^2, detached)."""
+        differentiable;  sums [2T] = per time step sum_m (c - shift_t), sum_m (c - shift_t)^2, detached).  ``sums_out``: where to leave the
+        sums (the slot of the step's all-reduce message, sharding.StepMessage.sums)."""
         costs = self.cost_function(states_sequence, inputs_sequence, trial_index)
         d = costs.detach() - (0.0 if shift is None else shift.reshape(-1, 1))
-        return costs.sum() / float(m_total), torch.cat([d.sum(1), (d * d).sum(1)])
+        sums = torch.cat([d.sum(1), (d * d).sum(1)])
+        if sums_out is not None:
+            sums_out.copy_(sums)
+            sums = sums_out
+        return costs.sum() / float(m_total), sums
 
     @staticmethod
     def from_sums(sums, n_total, shift=None, mean_out=None):
@@ -78,10 +83,10 @@ class _HipExpectedCost(Expected_cost):
             self._packed = self._pack(states_sequence)
         return ops.expected_cost(self._packed, states_sequence, group, counts)
 
-    def local_moments(self, states_sequence, inputs_sequence, trial_index, m_total, shift=None):
+    def local_moments(self, states_sequence, inputs_sequence, trial_index, m_total, shift=None, sums_out=None):
         if self._packed is None or self._packed.device != states_sequence.device:
             self._packed = self._pack(states_sequence)
-        return ops.local_cost(self._packed, states_sequence, m_total, shift)
+        return ops.local_cost(self._packed, states_sequence, m_total, shift, sums_out)
 
     @staticmethod
     def from_sums(sums, n_total, shift=None, mean_out=None):
@@ -130,9 +135,9 @@ class Expected_saturated_distance_from_trajectory(_HipExpectedCost):
         self._select(states_sequence, trial_index)
         return super().forward(states_sequence, inputs_sequence, trial_index, group, counts)
 
-    def local_moments(self, states_sequence, inputs_sequence, trial_index, m_total, shift=None):
+    def local_moments(self, states_sequence, inputs_sequence, trial_index, m_total, shift=None, sums_out=None):
         self._select(states_sequence, trial_index)
-        return super().local_moments(states_sequence, inputs_sequence, trial_index, m_total, shift)
+        return super().local_moments(states_sequence, inputs_sequence, trial_index, m_total, shift, sums_out)
 
 
 # ---- the two costs as plain functions (Cost_function.py:124-147, 170-182) -----------------------------------------------

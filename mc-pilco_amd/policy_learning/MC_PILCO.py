@@ -65,6 +65,7 @@ class MC_PILCO(torch.nn.Module):
         self.last_status = None
         self.gp_sharding = True    # cleared for good once a GP-sharded launch reports MCP_STATUS_SYNC (co-residency was not there)
         self._reducer = None       # sharding.StepReducer: the one all-reduce of a sharded optimizer step
+        self._step_msgs = {}       # sharding.StepMessage by (with gradients?): the persistent flat message of that all-reduce
         self._cost_shift = None    # previous step's pooled per-time-step mean cost (the shift of the summable cost moments)
         self.pipeline_depth = 1    # reinforce_policy reads an attempt's outcome this many attempts late (0: at once); see there
 
@@ -209,16 +210,29 @@ class MC_PILCO(torch.nn.Module):
         if self._cost_shift is None or self._cost_shift.numel() != T:
             self._cost_shift = torch.zeros(T, dtype=self.dtype, device=states.device)
         cf = self.cost_function
-        share, sums = cf.local_moments(states, inputs, trial_index, self._m_total, self._cost_shift)
         params = list(self.control_policy.parameters())
+        # the step's message [gradients | cost sums | flags], kept per (policy size, horizon, with / without gradients): the adjoint sweep and
+        # the cost kernels write straight into it and the all-reduce runs on it in place (sharding.StepMessage)
+        n_grad = sum(q.numel() for q in params if q.requires_grad) if backward else 0
+        msg = self._step_msgs.get(bool(backward))
+        if msg is None or not msg.fits(n_grad, T, 3, states.device):
+            msg = self._step_msgs[bool(backward)] = sharding.StepMessage(n_grad, T, 3, states.device, self.dtype)
+        packed = self.control_policy.packed() if (backward and isinstance(self.control_policy, _Policy.Sum_of_gaussians)) else None
+        share, sums = cf.local_moments(states, inputs, trial_index, self._m_total, self._cost_shift, sums_out=msg.sums)
         if backward:
-            share.backward(retain_graph=False)
+            if packed is not None and packed.grad_numel() == n_grad:
+                packed.grad_flat = msg.grad  # (mcp_rollout_bwd leaves log_ls | centers | weight | bias there: the order of `params`)
+            try:
+                share.backward(retain_graph=False)
+            finally:
+                if packed is not None:
+                    packed.grad_flat = None
             for q in params:  # a parameter the cost does not reach still takes part in the message (every rank sends the same layout)
                 if q.requires_grad and q.grad is None:
                     q.grad = torch.zeros_like(q)
         # one all-reduce; pooled cost / std; a NaN rollout neither poisons the next steps' shift nor goes unnoticed on the other ranks
         cost, std, flags, self._cost_shift = sharding.finish_step(cf, self._reducer, params if backward else [], sums, self._step_flags(share),
-                                                                  self._m_total, self._cost_shift)
+                                                                  self._m_total, self._cost_shift, msg=msg)
         return cost, std, flags
 
     # ------------------------------------------------------------------------------------------------------------

@@ -74,6 +74,37 @@ def allreduce_gradients(params, group) -> None:
         o += n
 
 
+class StepMessage:
+    """The flat fp64 message of a sharded optimizer step, allocated ONCE per (policy shape, horizon) and all-reduced in place:
+        [dJ/dlog_lengthscales | dJ/dcenters | dJ/dweight (| dJ/dbias) | sum_m (c_t - shift_t) (T) | sum_m (c_t - shift_t)^2 (T) | flags]
+    ``grad`` is handed to the adjoint sweep (``PackedPolicy.grad_flat``: mcp_rollout_bwd writes the gradients there and the parameters'
+    ``.grad`` become views of it), ``sums`` to the cost (``local_cost(..., sums_out=)``: mcp_cost_sums writes there), ``flags`` is filled by
+    one small copy -- no torch.cat before the collective and no copy back after it (round 5: cat + 3 copies per step)."""
+
+    def __init__(self, n_grad: int, T: int, n_flags: int, device, dtype=torch.float64):
+        self.n_grad, self.T, self.n_flags = int(n_grad), int(T), int(n_flags)
+        self.flat = torch.zeros(self.n_grad + 2 * self.T + self.n_flags, dtype=dtype, device=device)
+        self.grad = self.flat[:self.n_grad]
+        self.sums = self.flat[self.n_grad:self.n_grad + 2 * self.T]
+        self.flags = self.flat[self.n_grad + 2 * self.T:]
+
+    def fits(self, n_grad, T, n_flags, device):
+        return (self.n_grad, self.T, self.n_flags) == (int(n_grad), int(T), int(n_flags)) and self.flat.device == torch.device(device)
+
+    def holds(self, params) -> bool:
+        """True when the gradients of ``params`` (in that order; those with a gradient) ARE consecutive pieces of ``grad``, from its start."""
+        o, item = 0, self.flat.element_size()
+        for p in params:
+            g = p.grad
+            if g is None:
+                continue
+            if (g.dtype != self.flat.dtype or g.device != self.flat.device or not g.is_contiguous()
+                    or g.data_ptr() != self.flat.data_ptr() + o * item):
+                return False
+            o += g.numel()
+        return o == self.n_grad
+
+
 class StepReducer:
     """The single collective of a sharded optimizer step.  ``transport``: "torch" (torch.distributed on ``group``) or "abi"
     (libmcpilco_hip's RCCL communicator, created once per process; the unique id travels through torch.distributed's
@@ -86,6 +117,7 @@ class StepReducer:
         self.world = dist.get_world_size(self.group)
         self.rank = dist.get_rank(self.group)
         self.transport = transport
+        self.last_in_place = None  # whether the last reduce_message found the gradients already inside the message
         if transport == "abi":
             import ctypes as C
 
@@ -115,6 +147,35 @@ class StepReducer:
             dist.all_reduce(flat, group=self.group)
         return flat
 
+    def reduce_message(self, msg: "StepMessage", params, sums: torch.Tensor, flags: torch.Tensor):
+        """The step's ONE all-reduce on the caller's persistent message.  When the gradients already live in ``msg.grad`` (the adjoint sweep
+        wrote them there) and ``sums`` is ``msg.sums``, nothing is gathered or scattered: flags -> their slot (one small copy), all-reduce of
+        ``msg.flat`` in place, and the parameters' ``.grad`` hold the reduced values.  Anything else (a gradient that autograd accumulated
+        into a tensor of its own, an optimizer that replaced ``.grad``) falls back to copies in and out -- same result, same single message.
+        Returns (sums, flags) views of the reduced message (valid until the next step overwrites it)."""
+        ps = [p for p in params if p.grad is not None]
+        in_place = msg.holds(ps) if ps else False
+        if ps and not in_place:
+            o = 0
+            for p in ps:
+                n = p.numel()
+                msg.grad[o:o + n].copy_(p.grad.reshape(-1))
+                o += n
+            if o != msg.n_grad:
+                raise RuntimeError("the step's message was sized for %d gradient entries, the parameters hold %d" % (msg.n_grad, o))
+        if sums.data_ptr() != msg.sums.data_ptr():
+            msg.sums.copy_(sums.reshape(-1))
+        msg.flags.copy_(flags.reshape(-1).to(msg.flat.dtype))
+        self.allreduce_(msg.flat)
+        if ps and not in_place:
+            o = 0
+            for p in ps:
+                n = p.numel()
+                p.grad.copy_(msg.grad[o:o + n].reshape(p.shape))
+                o += n
+        self.last_in_place = bool(in_place)
+        return msg.sums, msg.flags
+
     def reduce(self, params, sums: torch.Tensor, flags: torch.Tensor):
         """params: tensors whose ``.grad`` (this rank's share, None = no gradient wanted) are summed in place; sums [2T] and
         flags [k] (non-negative doubles) are summed too and returned."""
@@ -130,7 +191,7 @@ class StepReducer:
         return flat[o:o + ns], flat[o + ns:]
 
 
-def finish_step(cost_cls, reducer: "StepReducer", params, sums: torch.Tensor, flags: torch.Tensor, m_total: int, shift: torch.Tensor):
+def finish_step(cost_cls, reducer: "StepReducer", params, sums: torch.Tensor, flags: torch.Tensor, m_total: int, shift: torch.Tensor, msg=None):
     """What follows a rank's own backward sweep in a sharded optimizer step: the ONE all-reduce of [gradients | cost sums | flags],
     the pooled (cost, std) from the reduced sums, and the shift of the next step's sums.
 
@@ -139,8 +200,8 @@ def finish_step(cost_cls, reducer: "StepReducer", params, sums: torch.Tensor, fl
     another rank's particles.  The shift is only the numerical centre of the summable moments; a component that came out
     non-finite (a NaN rollout) keeps its previous value, so the steps after a NaN rollout are not poisoned by it.
     ``cost_cls`` provides ``from_sums(sums, n_total, shift, mean_out)`` (policy_learning.Cost_function.Expected_cost or its HIP
-    subclasses)."""
-    sums_all, fl = reducer.reduce(params, sums, flags)
+    subclasses).  ``msg``: the step's persistent StepMessage -- the all-reduce then runs in place on it (StepReducer.reduce_message)."""
+    sums_all, fl = reducer.reduce(params, sums, flags) if msg is None else reducer.reduce_message(msg, params, sums, flags)
     new_shift = torch.empty_like(shift)
     cost, std = cost_cls.from_sums(sums_all, m_total, shift, new_shift)
     next_shift = torch.where(torch.isfinite(new_shift), new_shift, shift)

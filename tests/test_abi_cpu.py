@@ -46,7 +46,7 @@ def test_library_exports_every_declared_symbol():
         assert not hasattr(raw, n), "the library still exports the process-wide hook %s" % n
     # the header, the binding and the built library carry ONE version (a stale library or an old struct layout is rejected at load time)
     hdr = int(re.search(r"#define MCP_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
-    assert lib.mcp_abi_version() == hipabi.ABI_VERSION == hdr == 5
+    assert lib.mcp_abi_version() == hipabi.ABI_VERSION == hdr == 6
     assert b"gfx950" in lib.mcp_build_info()
 
 

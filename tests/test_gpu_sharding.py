@@ -48,9 +48,17 @@ def _run(rank, world, port, out_q, fused=True):
     st, inp, status = ops.rollout(w.model, w.policy, nz, x0_all[off:off + cnt], Tn, w.p_drop)
     if world > 1 and fused:
         shift = torch.full((Tn,), 0.4, dtype=torch.float64, device=dev)
-        share, sums = ops.local_cost(w.cost, st, m_total, shift)
+        # round 6: the step's message is ONE persistent flat buffer -- mcp_rollout_bwd writes the gradients into its head (the parameters'
+        # .grad are views of it), mcp_cost_sums into its middle -- and the all-reduce runs on it in place (sharding.StepMessage)
+        msg = sharding.StepMessage(w.policy.grad_numel(), Tn, 1, dev)
+        w.policy.grad_flat = msg.grad
+        share, sums = ops.local_cost(w.cost, st, m_total, shift, sums_out=msg.sums)
         share.backward()
-        sums_all, fl = sharding.StepReducer(group).reduce(w.params, sums, status.to(torch.float64))
+        w.policy.grad_flat = None
+        red = sharding.StepReducer(group)
+        assert msg.holds(w.params) and sums.data_ptr() == msg.sums.data_ptr()
+        sums_all, fl = red.reduce_message(msg, w.params, sums, status.to(torch.float64))
+        assert red.last_in_place and all(p.grad.untyped_storage().data_ptr() == msg.flat.untyped_storage().data_ptr() for p in w.params)
         cost, std = ops.cost_from_sums(sums_all, m_total, shift)
         assert float(fl.sum()) == 0.0
     else:

@@ -263,3 +263,87 @@ def test_eight_rank_shard_arithmetic_of_the_c4_swarm():
     cost, std = Expected_cost.from_sums(sum(sums), M, shift)
     assert abs(float(cost) - float(costs.mean(1).sum())) < 1e-12
     assert abs(float(std) - float(costs.std(1).sum())) < 1e-10
+
+
+def _worker_message(rank, world, port, m_total, out_q):
+    """Round 6: the step's persistent flat message (sharding.StepMessage) all-reduced IN PLACE -- gradients left there by the backward pass
+    (views handed to autograd, as ops.rollout_backward_raw does with PackedPolicy.grad_flat), cost sums written there by local_moments --
+    against the gather / scatter form (StepReducer.reduce) on the same data; then the fallback (gradients in tensors of their own)."""
+    import torch.distributed as dist
+
+    import mcp_boot  # noqa: F401
+    from mc_pilco_amd import sharding
+    from mc_pilco_amd.policy_learning.Cost_function import Expected_cost
+    from oracle import mcpilco_oracle as orc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fx = load_golden("rollout_se")
+    m, pp, cost_fn = oracle_model(fx, "se"), oracle_policy(fx, "se"), oracle_cost_fn(fx, "se")
+    off, cnt = sharding.shard_range(m_total, world, rank)
+    sl = slice(off, off + cnt)
+    Tn = fx["states"].shape[0]
+    prm = [pp.log_ls, pp.centers, pp.weight]
+    for p in prm:
+        p.requires_grad_(True)
+    red = sharding.StepReducer(dist.group.WORLD)
+    ec = Expected_cost(lambda x, u, k: cost_fn(x))
+    flags = torch.tensor([0.0, float(rank), 1.0], dtype=torch.float64)
+
+    def local_step(sums_out=None):
+        for p in prm:
+            p.grad = None
+        st, _ = orc.apply_policy(m, pp, T(fx["states"][0][sl]), Tn, float(fx["p_drop"]), T(fx["eps"][:, sl]), T(fx["masks"][:, sl]))
+        share, sums = ec.local_moments(st, None, 0, m_total, None, sums_out=sums_out)
+        share.backward()
+        return sums
+
+    # (1) the round-5 form: cat -> all-reduce -> copies back
+    sums = local_step()
+    s_ref, f_ref = red.reduce(prm, sums, flags)
+    g_ref = [p.grad.clone() for p in prm]
+    s_ref, f_ref = s_ref.clone(), f_ref.clone()
+    # (2) in place: the gradients become views of the message (what the adjoint sweep's flat output gives autograd)
+    n_grad = sum(p.numel() for p in prm)
+    msg = sharding.StepMessage(n_grad, Tn, 3, "cpu")
+    sums = local_step(sums_out=msg.sums)
+    assert sums.data_ptr() == msg.sums.data_ptr()
+    o = 0
+    for p in prm:
+        view = msg.grad[o:o + p.numel()].view(p.shape)
+        view.copy_(p.grad)
+        p.grad = view
+        o += p.numel()
+    assert msg.holds(prm)
+    s_in, f_in = red.reduce_message(msg, prm, sums, flags)
+    in_place = red.last_in_place and all(p.grad.untyped_storage().data_ptr() == msg.flat.untyped_storage().data_ptr() for p in prm)
+    same = all(torch.equal(p.grad, g) for p, g in zip(prm, g_ref)) and torch.equal(s_in, s_ref) and torch.equal(f_in, f_ref)
+    # (3) fallback: gradients in tensors of their own -> copied in and out, same numbers
+    sums = local_step(sums_out=msg.sums)
+    assert not msg.holds(prm)
+    s_fb, f_fb = red.reduce_message(msg, prm, sums, flags)
+    fallback_ok = (red.last_in_place is False) and all(torch.equal(p.grad, g) for p, g in zip(prm, g_ref)) and torch.equal(s_fb, s_ref)
+    out_q.put((rank, bool(in_place), bool(same), bool(fallback_ok), f_in.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,m_total", [(2, 24), (4, 23)])
+def test_step_message_is_reduced_in_place_and_matches_the_gather_scatter_form(world, m_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_message, args=(r, world, port, m_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, in_place, same, fallback_ok, fl in res:
+        assert in_place, "the message was not reduced in place"
+        assert same, "in-place reduction differs from the gather / scatter form"
+        assert fallback_ok
+        assert fl == [0.0, float(sum(range(world))), float(world)]
