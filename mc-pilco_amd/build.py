@@ -104,6 +104,9 @@ if __name__ == "__main__":
     if "--variant" in sys.argv:  # python build.py --variant TAG DEF1 DEF2 ...
         i = sys.argv.index("--variant")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:]))
+    elif "--variant-only" in sys.argv:  # python build.py --variant-only a.hip,b.hip TAG DEF1 DEF2 ...: recompiling the named sources only
+        i = sys.argv.index("--variant-only")
+        print(build_variant(sys.argv[i + 2], sys.argv[i + 3:], only=sys.argv[i + 1].split(",")))
     elif "--variant-fwd" in sys.argv:  # the same, recompiling rollout_fwd.hip only
         i = sys.argv.index("--variant-fwd")
         print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], only=["rollout_fwd.hip"]))

@@ -391,6 +391,19 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   double tgt_c = 0.0;                       // register chain, trajectory policies: the target entry of the step to come
   double xbr = 0.0, kp1 = 0.0, kp2 = 0.0;  // register chain: adjoint of x_t without the policy path; feature-map coefficients of step t+1
   unsigned long long last_stamp = clock64();
+#ifdef BWX_WSTAMPS  // experiment build: every wave's own intervals of a step (workgroup 0): chain + prefetch | barrier 1 | RBF stage | park | barrier 2
+  unsigned long long ws_[5] = {0, 0, 0, 0, 0}, wt_ = clock64();
+#define BW_WS(k)                                              \
+  do {                                                        \
+    if (a.stamps && blockIdx.x == 0) {                        \
+      const unsigned long long n_ = clock64();                \
+      ws_[k] += n_ - wt_;                                     \
+      wt_ = n_;                                               \
+    }                                                         \
+  } while (0)
+#else
+#define BW_WS(k)
+#endif
   for (int mbase = blockIdx.x * PB; mbase < M; mbase += gridDim.x * PB) {
     const int msp = imin(mbase + sp, M - 1);  // particle of this wave's serial chain
     const bool spvalid = mbase + sp < M;
@@ -597,8 +610,10 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       }
       if (FASTCHAIN && t > 0 && serial) prefetch(pre, t - 1, mbase);
       BW_STAMP(8);
+      BW_WS(0);
       lds_barrier();
       BW_STAMP(9);
+      BW_WS(1);
       // ---- RBF network, thread b owns basis b, loops over the particle slots -----------------------------
       // dropout keep bits: one Philox draw serves 4 consecutive bases of one particle (philox_keep); the lanes of a quad
       // draw for particle slots (b & 3) % PB and pass each other the word of the receiver's basis
@@ -735,9 +750,12 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         }
       }
       BW_STAMP(10);
+      BW_WS(2);
       if (t > 0) park(pre, cur ^ 1);
       cur ^= 1;
+      BW_WS(3);
       lds_barrier();
+      BW_WS(4);
     }
     // finish step 0: adjoint of x_0
     if constexpr (FASTCHAIN) {
@@ -783,6 +801,10 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
     lds_barrier();
   }
 
+#ifdef BWX_WSTAMPS
+  if (a.stamps && blockIdx.x == 0 && lane == 0)
+    for (int k = 0; k < 5; ++k) a.stamps[16 + wv * 5 + k] = ws_[k];
+#endif
   // ---- write this workgroup's partial parameter gradients ------------------------------------
   const int nparam = PF + B * PF + U * B;  // (+ U when the policy has a bias: the slab stride)
   double* out = a.slab + (size_t)blockIdx.x * (nparam + (pl.bias ? U : 0));

@@ -262,6 +262,9 @@ __device__ __forceinline__ void tile_v_mfma(const v2d (&A)[TL_VU], const double 
   }
 }
 
+// DEPTH = register batches in flight: 2 (one lands while one is consumed) or 3 (TLX_VDEPTH3, cart-pole class: the registers are there) -- two
+// waves share a SIMD's matrix pipe, so a batch's loads have the time of ONE batch of the wave's own MFMAs to land when the partner stalls too
+template <int DEPTH>
 __device__ __forceinline__ void tile_v_block(const double* Kinv, int Npad, int I0, int js, int je, const double* kv, int lane, v4d& acc_e, v4d& acc_o) {
   const int m = lane & 15, kk = lane >> 4;
   const int col = I0 + 2 * m;
@@ -274,6 +277,27 @@ __device__ __forceinline__ void tile_v_block(const double* Kinv, int Npad, int I
   const int bs = js >> 4;         // first batch
   v2d A0[TL_VU], A1[TL_VU];
   double B0[TL_VU], B1[TL_VU];
+  if constexpr (DEPTH == 3) {
+    v2d A2[TL_VU];
+    double B2[TL_VU];
+    const int bl = bs + nb - 1;  // past the end: reload the last batch (harmless) rather than branch
+    tile_v_load(A0, B0, a0 + (size_t)bs * abatch, astep, b0 + bs * bbatch);
+    const int b1s = imin(bs + 1, bl);
+    tile_v_load(A1, B1, a0 + (size_t)b1s * abatch, astep, b0 + b1s * bbatch);
+    int b = 0;
+    for (; b + 2 < nb; b += 3) {
+      const int c2 = bs + b + 2, c3 = imin(bs + b + 3, bl), c4 = imin(bs + b + 4, bl);
+      tile_v_load(A2, B2, a0 + (size_t)c2 * abatch, astep, b0 + c2 * bbatch);
+      tile_v_mfma(A0, B0, acc_e, acc_o);
+      tile_v_load(A0, B0, a0 + (size_t)c3 * abatch, astep, b0 + c3 * bbatch);
+      tile_v_mfma(A1, B1, acc_e, acc_o);
+      tile_v_load(A1, B1, a0 + (size_t)c4 * abatch, astep, b0 + c4 * bbatch);
+      tile_v_mfma(A2, B2, acc_e, acc_o);
+    }
+    if (b < nb) tile_v_mfma(A0, B0, acc_e, acc_o);
+    if (b + 1 < nb) tile_v_mfma(A1, B1, acc_e, acc_o);
+    return;
+  }
   tile_v_load(A0, B0, a0 + (size_t)bs * abatch, astep, b0 + bs * bbatch);
   for (int b = 0; b + 1 < nb; b += 2) {
     const int b1 = bs + b + 1;
@@ -1126,7 +1150,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       double* xc = xs + cur * P * S;
       xc[op * S + os] = xn;
       if (ovalid) {
-        if (writer) a.states[((size_t)t * M + m0 + op) * S + os] = xn;
+        if (writer) store_through(&a.states[((size_t)t * M + m0 + op) * S + os], xn);
         if (is_bad(xn)) bad |= MCP_STATUS_NAN;
       }
     }
@@ -1153,7 +1177,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           pm_prev_np = npos;
         }
         if (ovalid) {
-          if (writer) ms.meas[((size_t)t * M + m0 + op) * S + os] = xm;
+          if (writer) store_through(&ms.meas[((size_t)t * M + m0 + op) * S + os], xm);
           if (is_bad(xm)) bad |= MCP_STATUS_NAN;
         }
       }
@@ -1254,7 +1278,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
       us[p * U + k] = u;
       z[p * D + nna + 2 * na + k] = u;
       if (m0 + p < M) {
-        if (writer) a.inputs[((size_t)t * M + m0 + p) * U + k] = u;
+        if (writer) store_through(&a.inputs[((size_t)t * M + m0 + p) * U + k], u);
         if (is_bad(u)) bad |= MCP_STATUS_NAN;
       }
     }
@@ -1349,7 +1373,11 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           }
           if (pb < 0) continue;
           v4d te = (v4d){0.0, 0.0, 0.0, 0.0}, to = (v4d){0.0, 0.0, 0.0, 0.0};
-          tile_v_block(gp.Kinv, Npad, (vb0 + pb) * 32, pjs, pje, kv, lane, te, to);
+          #ifdef TLX_VDEPTH3
+          tile_v_block<CLS == 0 ? 3 : 2>(gp.Kinv, Npad, (vb0 + pb) * 32, pjs, pje, kv, lane, te, to);
+#else
+          tile_v_block<2>(gp.Kinv, Npad, (vb0 + pb) * 32, pjs, pje, kv, lane, te, to);
+#endif
 #pragma unroll
           for (int q = 0; q < NACC; ++q) {
             if (q == r) {
@@ -1584,7 +1612,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
               Jmu = fma(w1c, kp[KP_AX(D) + c], Jmu);
               Jvar = fma(2.0 * w1c, zp[c], Jvar);
             }
-            a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
+            store_through(&a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c], a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu);
           }
           if (rs_dbg) { const unsigned long long now = clock64(); a.stamps[11] += now - rs_t0; rs_t0 = now; }
           }
@@ -1673,7 +1701,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
               Jvar += 2.0 * zp[c] * (a_ * Sb + b_ * Sa) - 2.0 * (a_ * TL_R(c, 3, p) + b_ * TL_R(c, 4, p));
             }
           }
-          a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c] = a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu;
+          store_through(&a.jac[(((size_t)t * M + m0 + p) * G + g) * D + c], a.particle_pred ? fma(wj, Jvar * vscale, Jmu) : Jmu);
         }
       }
 #undef TL_R
