@@ -34,7 +34,7 @@ extern "C" {
                              6 (round 6; the round-5 contract changes, which had kept the number 5, are part of it): mcp_sod_select needs       \
                              mcp_sod_workspace_bytes(N) = 8 (N^2 + 2 N) + the exchange area (was 8 N^2) and may report *n_out = -1;             \
                              MCP_MAX_TRAIN 1024 -> 4096; the process-wide mcp_debug_* setters are gone (mcpilco_hip_debug.h: per-call           \
-                             mcp_dispatch); mcp_adam_step_guarded skips a not-SPD epoch; new: mcp_sym_sandwich */
+                             mcp_dispatch); mcp_adam_step_guarded skips a not-SPD epoch; new: mcp_sym_sandwich, mcp_noise.call_dev, MCP_FWD_KT_PACKED / MCP_FWD_XJ_PACKED */
 
 #define MCP_OK 0
 #define MCP_ERR_ARG (-1)       /* null pointer / non-positive size                       */
@@ -157,6 +157,9 @@ typedef struct mcp_noise {
   uint64_t seed;
   uint64_t call;          /* increments once per rollout so draws never repeat         */
   int64_t particle_offset;
+  const uint64_t* call_dev; /* optional DEVICE counter added to `call` when the kernels start (NULL: none): a rollout recorded into a HIP graph
+                               draws fresh numbers on every replay when the graph also advances this word -- the by-value `call` is frozen
+                               in the recorded kernel arguments (round 6: MC_PILCO.reinforce_policy replays its attempts) */
 } mcp_noise;
 
 /* ---- library ------------------------------------------------------------------------ */
@@ -249,6 +252,10 @@ int mcp_posterior_bwd(int M, int D, const double* gmu, const double* gvar, const
  * T-loop of Model_learning.get_next_state (Model_learning.py:210-229,685-718) and the policy
  * forward (Policy.py:242-265,323-335,389-403)) ----------------------------------------- */
 #define MCP_FWD_NO_GP_SHARDING 2 /* flag in mcp_rollout_fwd's particle_pred argument */
+#define MCP_FWD_KT_PACKED 4      /* flags in the same argument: the workspace still holds the packed operand copies an EARLIER call built from    */
+#define MCP_FWD_XJ_PACKED 8      /* this same model in this same workspace (KT: the lean small-swarm kernel's Kinv tiles; XJ: the wide classes'   */
+                                 /* phase-J operands) -- the call does not rebuild them (8 us per rollout at the cart-pole size).  The caller's  */
+                                 /* promise: nothing else wrote there and the model's arrays are unchanged.  Without the flags every call packs. */
 size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_policy* policy, int M, int T);
 /* x0 [M][S] -> states [T][M][S], inputs [T][M][U].  jac [T-1][M][G][D] (d delta_g/d z, sampling
  * included) is written when non-NULL and is what mcp_rollout_bwd consumes.
@@ -262,7 +269,8 @@ size_t mcp_rollout_workspace_bytes(const mcp_model* model, const mcp_policy* pol
  * unsharded launch to rounding.  MCP_STATUS_SYNC in `status` reports a hand-off that timed out
  * (the trajectories are then invalid).  Without a workspace the launch is never sharded.  For models with more
  * than 15 GP-input dimensions the workspace also takes the packed operand copies of the 16-particle kernel's
- * moment / Jacobian contraction (rebuilt by every call, on `stream`); without it that phase keeps its slower form. */
+ * moment / Jacobian contraction (rebuilt by every call, on `stream`, unless MCP_FWD_XJ_PACKED says an earlier call's copy stands); without it
+ * that phase keeps its slower form. */
 int mcp_rollout_fwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,
                     const double* x0, double* states, double* inputs, double* jac, uint32_t* status, void* workspace,
                     size_t workspace_bytes, void* stream);

@@ -223,6 +223,14 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
 #define MCP_STREAM_MASK 1u
 #define MCP_STREAM_POS 2u  // position measurement noise of the partially-measurable-system rollout
 
+// the launch's noise descriptor with the device counter (mcp_noise.call_dev, if any) folded into `call` -- read ONCE at the top of a kernel; the
+// draws below see a plain descriptor (graph replays: include/mcpilco_hip.h)
+__device__ __forceinline__ mcp_noise noise_of_launch(const mcp_noise& nz) {
+  mcp_noise r = nz;
+  if (nz.call_dev) r.call += *nz.call_dev;
+  return r;
+}
+
 __device__ __forceinline__ u32x4 philox_draw(const mcp_noise& nz, int64_t particle, int t, uint32_t stream, uint32_t index) {
   uint64_t gp = (uint64_t)(particle + nz.particle_offset);
   u32x4 c;

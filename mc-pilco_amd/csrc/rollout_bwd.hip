@@ -120,6 +120,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
+  const mcp_noise nzl = noise_of_launch(a.nz);
   int tid = threadIdx.x, lane = tid & 63;  // (not const: laundered once per time step, see the sweep loop)
   const int NT = blockDim.x, NW = NT >> 6;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -620,14 +621,14 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       uint32_t kw[PB];
 #pragma unroll
       for (int p = 0; p < PB; ++p) kw[p] = 0xFFFFFFFFu;
-      if (drop && !a.nz.masks) {
+      if (drop && !nzl.masks) {
         const int cq = b & 3;
         const int bq = imin(b, B - 1) >> 2;
         // (PB = 8: two rounds, slots cq and cq + 4)
         constexpr int PQ = PB < 4 ? PB : 4;  // slots served by one round of the quad
 #pragma unroll
         for (int rd = 0; rd < (PB + 3) / 4; ++rd) {
-          const u32x4 rnd = philox_draw(a.nz, imin(mbase + 4 * rd + (cq % PQ), M - 1), t, MCP_STREAM_MASK, (uint32_t)bq);
+          const u32x4 rnd = philox_draw(nzl, imin(mbase + 4 * rd + (cq % PQ), M - 1), t, MCP_STREAM_MASK, (uint32_t)bq);
           if (PB == 1) {
             kw[0] = cq == 0 ? rnd.x : cq == 1 ? rnd.y : cq == 2 ? rnd.z : rnd.w;
           } else {
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
           double phi = exp(-dist);
           double mk = 1.0;
           if (drop) {
-            bool keep = a.nz.masks ? (a.nz.masks[((size_t)t * M + mbase + p) * B + b] != 0) : (kw[p] >= drop_thr);
+            bool keep = nzl.masks ? (nzl.masks[((size_t)t * M + mbase + p) * B + b] != 0) : (kw[p] >= drop_thr);
             mk = keep ? keep_scale : 0.0;
           }
           double phibar = 0.0;
@@ -929,6 +930,7 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   __shared__ unsigned long long s_stamp[16];
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
+  const mcp_noise nzl = noise_of_launch(a.nz);
   // two particle slots per workgroup (each: one chain wave + the RBF waves behind it), so that M <= 512 particles are ONE resident round:
   // a 5-wave workgroup needs 3 waves on one SIMD, two of them do not share a CU, and 400 single-slot workgroups ran as two rounds
   const int WPS = (int)(blockDim.x >> 7);  // waves per slot
@@ -1233,13 +1235,13 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         uint32_t kwd = 0xFFFFFFFFu;
         uint8_t mk8 = 1;
         if (drop) {
-          if (a.nz.masks) {
-            mk8 = a.nz.masks[((size_t)t * M + m) * B + imin(b, B - 1)];
+          if (nzl.masks) {
+            mk8 = nzl.masks[((size_t)t * M + m) * B + imin(b, B - 1)];
           } else {
             const int ph = (T - 1 - t) & 3;
             if (ph == 0) {
               const int cq = b & 3;
-              const u32x4 rnd = philox_draw(a.nz, m, imax(t - cq, 0), MCP_STREAM_MASK, (uint32_t)(imin(b, B - 1) >> 2));
+              const u32x4 rnd = philox_draw(nzl, m, imax(t - cq, 0), MCP_STREAM_MASK, (uint32_t)(imin(b, B - 1) >> 2));
               uint32_t rc[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {  // rotation r: lane i receives from lane (i + r) & 3 that lane's word i
@@ -1267,7 +1269,7 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
         const double phi = exp(-dist);
         double mk = 1.0;
-        if (drop) mk = (a.nz.masks ? (mk8 != 0) : (kwd >= drop_thr)) ? keep_scale : 0.0;
+        if (drop) mk = (nzl.masks ? (mk8 != 0) : (kwd >= drop_thr)) ? keep_scale : 0.0;
         const double pm = act ? phi * mk : 0.0;
         if (wv == BL_SW) BL_STAMP(12);
         lds_barrier();

@@ -712,6 +712,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
+  const mcp_noise nzl = noise_of_launch(a.nz);
   const mcp_gp* gps = md.gp;
   const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int wv0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -863,7 +864,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
         const int pi = pm_pos >= 0 ? pm_pos : pm_vel;
         double npos = pm_pos >= 0 ? xn : xpair;
         if (pi >= 0 && t > 0) {
-          const double nn = ms.pos_noise ? ms.pos_noise[((size_t)(t - 1) * M + om) * ms.n + pi] : philox_normal(a.nz, om, t, pi, MCP_STREAM_POS);
+          const double nn = ms.pos_noise ? ms.pos_noise[((size_t)(t - 1) * M + om) * ms.n + pi] : philox_normal(nzl, om, t, pi, MCP_STREAM_POS);
           npos = fma(pm_std, nn, npos);
         }
         if (pm_pos >= 0) xm = npos;
@@ -921,18 +922,18 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       double ev = 0.0;
       if (a.particle_pred) {
         const int mm = imin(m0 + p, Mend - 1);
-        ev = a.nz.eps ? a.nz.eps[((size_t)t * M + mm) * G + g] : philox_normal(a.nz, mm, t, g);
+        ev = nzl.eps ? nzl.eps[((size_t)t * M + mm) * G + g] : philox_normal(nzl, mm, t, g);
       }
       epsb[e] = ev;
     }
-    else if (tid >= 128 && drop && !a.nz.masks) {
+    else if (tid >= 128 && drop && !nzl.masks) {
       // waves 2.. are idle here too: the step's dropout decisions, one Philox block per 4 basis functions (the integer
       // multiplies of a block cost more than the exp of the feature it gates; drawn per basis function in phase PHI they
       // were most of that phase)
       const int BQ = (B + 3) >> 2;
       for (int it = tid - 128; it < P * BQ; it += RF_NT - 128) {
         const int p = it / BQ, q = it - p * BQ;
-        const u32x4 r = philox_draw(a.nz, imin(m0 + p, Mend - 1), t, MCP_STREAM_MASK, (uint32_t)q);
+        const u32x4 r = philox_draw(nzl, imin(m0 + p, Mend - 1), t, MCP_STREAM_MASK, (uint32_t)q);
         mk[it] = (int)(r.x >= drop_thr) | ((int)(r.y >= drop_thr) << 1) | ((int)(r.z >= drop_thr) << 2) | ((int)(r.w >= drop_thr) << 3);
       }
     }
@@ -953,7 +954,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_kernel(FwdArgs a) {
       double phi = exp(-dist);
       if (drop) {
         int mm = imin(m0 + p, Mend - 1);
-        bool keep = a.nz.masks ? (a.nz.masks[((size_t)t * M + mm) * B + b] != 0) : (((mk[p * ((B + 3) >> 2) + (b >> 2)] >> (b & 3)) & 1) != 0);
+        bool keep = nzl.masks ? (nzl.masks[((size_t)t * M + mm) * B + b] != 0) : (((mk[p * ((B + 3) >> 2) + (b >> 2)] >> (b & 3)) & 1) != 0);
         phi = keep ? phi * keep_scale : 0.0;
       }
       ph[it] = phi;
@@ -1273,6 +1274,7 @@ static int rollout_fwd_impl(const mcp_model* model, const mcp_policy* policy, co
                             size_t workspace_bytes, void* stream, FwdHooks& hk) {
   if (!noise || !x0 || !states || !inputs || !status || !policy || M <= 0 || T <= 0) return MCP_ERR_ARG;
   const bool no_gp_sharding = (particle_pred & MCP_FWD_NO_GP_SHARDING) != 0;  // (the recovery path after MCP_STATUS_SYNC keeps its workspace)
+  const int operands_packed = ((particle_pred & MCP_FWD_KT_PACKED) ? 1 : 0) | ((particle_pred & MCP_FWD_XJ_PACKED) ? 2 : 0);
   particle_pred &= 1;
   mcp_model stub;
   if (!model) {
@@ -1290,6 +1292,7 @@ static int rollout_fwd_impl(const mcp_model* model, const mcp_policy* policy, co
   a.M = M;
   a.T = T;
   a.particle_pred = particle_pred;
+  a.operands_packed = operands_packed;
   a.NpadMax = 0;
   a.maxdeg = 0;
   for (int g = 0; g < model->G; ++g) {
@@ -1369,7 +1372,7 @@ static int rollout_fwd_impl(const mcp_model* model, const mcp_policy* policy, co
       }
       if (lds > MCP_LDS_LIMIT) break;
       if (hipMemsetAsync(workspace, 0, rollout_xch_bytes(M, model->G), st) != hipSuccess) return MCP_ERR_LAUNCH;
-      if (lean) {  // Kinv of every GP as MFMA operand tiles, in each wave's streaming order
+      if (lean && !(a.operands_packed & 1)) {  // Kinv of every GP as MFMA operand tiles, in each wave's streaming order (unless an earlier call left them)
         const int rcp = launch_fwd_lean_pack(a, st);
         if (rcp != MCP_OK) return rcp;
       }

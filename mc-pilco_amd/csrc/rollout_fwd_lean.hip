@@ -493,6 +493,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
   constexpr int NWC = lat_nw(MAXDEG), NCOL = P * NWC, NCG = lat_ncg(P, MAXDEG);  // phase-J weight columns: per particle, in all, groups of 8
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
+  const mcp_noise nzl = noise_of_launch(a.nz);
   const int tid0 = threadIdx.x;
   const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
   const int DS = D - U;
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
         double ev = 0.0;
         if (a.particle_pred) {
           const int mm = imin(m0 + lane, Mend - 1);
-          ev = a.nz.eps ? a.nz.eps[((size_t)ts * M + mm) * G + myg] : philox_normal(a.nz, mm, ts, myg);
+          ev = nzl.eps ? nzl.eps[((size_t)ts * M + mm) * G + myg] : philox_normal(nzl, mm, ts, myg);
         }
         epsb[(ts & 1) * P + lane] = ev;
       }
@@ -745,14 +746,14 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
         if (e >= 0 && e < P * np && ts + 1 < T) {
           const int pp = e / np, pi = e - pp * np, mm = imin(m0 + pp, Mend - 1);
           pnz[((ts + 1) & 1) * 32 + e] = pl.meas.pos_noise ? pl.meas.pos_noise[((size_t)ts * M + mm) * np + pi]
-                                                          : philox_normal(a.nz, mm, ts + 1, pi, MCP_STREAM_POS);
+                                                          : philox_normal(nzl, mm, ts + 1, pi, MCP_STREAM_POS);
         }
       }
-    } else if (wv >= 2 && wv != 4 && drop && !a.nz.masks) {
+    } else if (wv >= 2 && wv != 4 && drop && !nzl.masks) {
       const int ti = (wv - 2 - (wv > 4 ? 1 : 0)) * 64 + lane;
       for (int it = ti; it < P * BQ; it += 5 * 64) {
         const int p = it / BQ, q = it - p * BQ;
-        const u32x4 r = philox_draw(a.nz, imin(m0 + p, Mend - 1), ts, MCP_STREAM_MASK, (uint32_t)q);
+        const u32x4 r = philox_draw(nzl, imin(m0 + p, Mend - 1), ts, MCP_STREAM_MASK, (uint32_t)q);
         mk[it] = (int)(r.x >= drop_thr) | ((int)(r.y >= drop_thr) << 1) | ((int)(r.z >= drop_thr) << 2) | ((int)(r.w >= drop_thr) << 3);
       }
     }
@@ -950,8 +951,8 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
           for (int k = 0; k < RL_UM; ++k) wv_[k] = wgt[k * Bp + b];
           int kbits = 0;
           if (drop) {
-            if (a.nz.masks)
-              kbits = (b < B && a.nz.masks[((size_t)t * M + imin(m0 + pP, Mend - 1)) * B + b] != 0) ? 1 : 0;
+            if (nzl.masks)
+              kbits = (b < B && nzl.masks[((size_t)t * M + imin(m0 + pP, Mend - 1)) * B + b] != 0) ? 1 : 0;
             else
               kbits = (mk[pP * BQ + imin(b >> 2, BQ - 1)] >> (b & 3)) & 1;  // (b >= B: weight 0, whatever the bit)
           }

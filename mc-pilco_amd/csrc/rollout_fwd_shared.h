@@ -67,6 +67,7 @@ struct FwdArgs {
   //   rxch[cluster][t & 1][g][p * (D + 1) + c][2 values][half]   (granules, zeroed per launch; gsh_rs <= 1: unused)
   int gsh_rs;
   unsigned long long* rxch;
+  int operands_packed;  // host side only: bit 0 -- `kt` holds this model's tiles already, bit 1 -- `xj` does (MCP_FWD_KT_PACKED / MCP_FWD_XJ_PACKED)
   int m_off, m_cnt;  // the particles [m_off, m_off + m_cnt) of the swarm that this launch covers (a swarm too large for one
                      // resident GP-sharded grid goes out as a few launches back to back on the stream)
 };

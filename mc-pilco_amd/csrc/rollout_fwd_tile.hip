@@ -723,7 +723,7 @@ struct TilePolRConst {
 // loop the modes were scalar branches between the loads and the MFMAs, with conservative counter waits at their joins)
 template <int NQ, int UM, int DM>
 __device__ __forceinline__ void tile_polr_consume(const double (&cb)[NQ], const double (&wk)[UM], const TilePolRConst<NQ>& c, const FwdArgs& a,
-                                                 int B, int U, int t, int m0, int tile, int kk, int n, int lane, bool drop, double keep_scale,
+                                                 const mcp_noise& nzl, int B, int U, int t, int m0, int tile, int kk, int n, int lane, bool drop, double keep_scale,
                                                  uint32_t drop_thr, double (&uacc)[4][UM]) {
   double scc = 0.0;
 #pragma unroll
@@ -744,12 +744,12 @@ __device__ __forceinline__ void tile_polr_consume(const double (&cb)[NQ], const 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int mm = imin(m0 + kk + 4 * r, a.M - 1);
-        keep[r] = a.nz.masks[((size_t)t * a.M + mm) * B + bc] != 0;
+        keep[r] = nzl.masks[((size_t)t * a.M + mm) * B + bc] != 0;
       }
     } else {
       const int cq = n & 3;
       const int mm = imin(m0 + kk + 4 * cq, a.M - 1);
-      const u32x4 rnd = philox_draw(a.nz, mm, t, MCP_STREAM_MASK, (uint32_t)(bc >> 2));
+      const u32x4 rnd = philox_draw(nzl, mm, t, MCP_STREAM_MASK, (uint32_t)(bc >> 2));
       uint32_t wr[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) {
@@ -778,7 +778,7 @@ __device__ __forceinline__ void tile_polr_consume(const double (&cb)[NQ], const 
   }
 }
 template <int NQ, int UM, int DM>
-__device__ __forceinline__ void tile_policy_reg(const FwdArgs& a, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* upart,
+__device__ __forceinline__ void tile_policy_reg(const FwdArgs& a, const mcp_noise& nzl, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* upart,
                                             int B, int PF, int U, int t, int m0, int wv, int lane, bool drop, double keep_scale, uint32_t drop_thr, int tb, int te) {
   const int kk = lane >> 4, n = lane & 15;
   TilePolRConst<NQ> c;
@@ -811,11 +811,11 @@ __device__ __forceinline__ void tile_policy_reg(const FwdArgs& a, const double* 
     tile_polr_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, tb + wv, kk, n);
     for (int sI = 0; sI + 1 < nt; sI += 2) {
       tile_polr_load<NQ, UM>(c1, w1, cen, wgt, B, PF, U, tb + wv + RF_NW * (sI + 1), kk, n);
-      tile_polr_consume<NQ, UM, DM>(c0, w0, c, a, B, U, t, m0, tb + wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, uacc);
+      tile_polr_consume<NQ, UM, DM>(c0, w0, c, a, nzl, B, U, t, m0, tb + wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, uacc);
       tile_polr_load<NQ, UM>(c0, w0, cen, wgt, B, PF, U, tb + wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
-      tile_polr_consume<NQ, UM, DM>(c1, w1, c, a, B, U, t, m0, tb + wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
+      tile_polr_consume<NQ, UM, DM>(c1, w1, c, a, nzl, B, U, t, m0, tb + wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
     }
-    if (nt & 1) tile_polr_consume<NQ, UM, DM>(c0, w0, c, a, B, U, t, m0, tb + wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
+    if (nt & 1) tile_polr_consume<NQ, UM, DM>(c0, w0, c, a, nzl, B, U, t, m0, tb + wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, uacc);
   }
   // sum over the 16 basis lanes of each row; lane 15 of row kq holds the partial of particles kq + 4 r
 #pragma unroll
@@ -850,7 +850,8 @@ struct TilePolConst {
   double a_s[NQ], ilq[NQ], ss4[4];
 };
 template <int NQ, int DM>
-__device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const double (&wb)[4], const TilePolConst<NQ>& c, const FwdArgs& a, int B,
+__device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const double (&wb)[4], const TilePolConst<NQ>& c, const FwdArgs& a,
+                                                 const mcp_noise& nzl, int B,
                                                  int U, int t, int m0, int tile, int kk, int n, int lane, bool drop, double keep_scale,
                                                  uint32_t drop_thr, double* ptile, v4d& uacc) {
   double scc = 0.0;
@@ -872,12 +873,12 @@ __device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const d
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int mm = imin(m0 + kk + 4 * r, a.M - 1);
-        keep[r] = a.nz.masks[((size_t)t * a.M + mm) * B + bc] != 0;
+        keep[r] = nzl.masks[((size_t)t * a.M + mm) * B + bc] != 0;
       }
     } else {
       const int cq = n & 3;
       const int mm = imin(m0 + kk + 4 * cq, a.M - 1);
-      const u32x4 rnd = philox_draw(a.nz, mm, t, MCP_STREAM_MASK, (uint32_t)(bc >> 2));
+      const u32x4 rnd = philox_draw(nzl, mm, t, MCP_STREAM_MASK, (uint32_t)(bc >> 2));
       uint32_t wr[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int k4 = 0; k4 < 4; ++k4) {
@@ -912,7 +913,7 @@ __device__ __forceinline__ void tile_pol_consume(const double (&cb)[NQ], const d
   }
 }
 template <int NQ, int DM>
-__device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* ptile,
+__device__ __forceinline__ void tile_policy(const FwdArgs& a, const mcp_noise& nzl, const double* invl, const double* sf, gptr_t cen, gptr_t wgt, double* wslot, double* ptile,
                                             double* upart, int B, int PF, int U, int t, int m0, int wv, int lane, bool drop, double keep_scale,
                                             uint32_t drop_thr, int tb, int te) {
   const int kk = lane >> 4, n = lane & 15;
@@ -942,11 +943,11 @@ __device__ __forceinline__ void tile_policy(const FwdArgs& a, const double* invl
     tile_pol_load<NQ>(c0, w0, cen, wgt, B, PF, U, tb + wv, kk, n);
     for (int sI = 0; sI + 1 < nt; sI += 2) {
       tile_pol_load<NQ>(c1, w1, cen, wgt, B, PF, U, tb + wv + RF_NW * (sI + 1), kk, n);
-      tile_pol_consume<NQ, DM>(c0, w0, c, a, B, U, t, m0, tb + wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
+      tile_pol_consume<NQ, DM>(c0, w0, c, a, nzl, B, U, t, m0, tb + wv + RF_NW * sI, kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
       tile_pol_load<NQ>(c0, w0, cen, wgt, B, PF, U, tb + wv + RF_NW * imin(sI + 2, nt - 1), kk, n);
-      tile_pol_consume<NQ, DM>(c1, w1, c, a, B, U, t, m0, tb + wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
+      tile_pol_consume<NQ, DM>(c1, w1, c, a, nzl, B, U, t, m0, tb + wv + RF_NW * (sI + 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
     }
-    if (nt & 1) tile_pol_consume<NQ, DM>(c0, w0, c, a, B, U, t, m0, tb + wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
+    if (nt & 1) tile_pol_consume<NQ, DM>(c0, w0, c, a, nzl, B, U, t, m0, tb + wv + RF_NW * (nt - 1), kk, n, lane, drop, keep_scale, drop_thr, ptile, uacc);
   }
   if (n < U) {
 #pragma unroll
@@ -974,6 +975,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const mcp_model& md = a.model;
   const mcp_policy& pl = a.pol;
+  const mcp_noise nzl = noise_of_launch(a.nz);
   const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int wv0 = __builtin_amdgcn_readfirstlane(tid0 >> 6);
   const int S = md.S, U = md.U, G = md.G, D = md.D, B = pl.B, PF = pl.P, M = a.M, T = a.T;
@@ -1126,7 +1128,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     double e = 0.0;
     if (a.particle_pred) {
       const int mm = imin(m0 + ep, M - 1);
-      e = a.nz.eps ? a.nz.eps[((size_t)tt * M + mm) * G + eg] : philox_normal(a.nz, mm, tt, eg);
+      e = nzl.eps ? nzl.eps[((size_t)tt * M + mm) * G + eg] : philox_normal(nzl, mm, tt, eg);
     }
     epsb[(tt & 1) * P * G + et] = e;
   };
@@ -1160,7 +1162,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         const int pi = pm_pos >= 0 ? pm_pos : pm_vel;
         double npos = pm_pos >= 0 ? xn : xs[cur * P * S + op * S + pm_pair];
         if (pi >= 0 && t > 0) {
-          const double nn = ms.pos_noise ? ms.pos_noise[((size_t)(t - 1) * M + om) * ms.n + pi] : philox_normal(a.nz, om, t, pi, MCP_STREAM_POS);
+          const double nn = ms.pos_noise ? ms.pos_noise[((size_t)(t - 1) * M + om) * ms.n + pi] : philox_normal(nzl, om, t, pi, MCP_STREAM_POS);
           npos = fma(pm_std, nn, npos);
         }
         if (pm_pos >= 0) xm = npos;
@@ -1209,22 +1211,22 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
     TL_STAMP(0);
     // ---- policy: phi and W phi on the matrix cores, partial sums per wave -> LDS ----------------------
     {
-      const int dm = !drop ? 0 : (a.nz.masks ? 2 : 1);  // wave-uniform
+      const int dm = !drop ? 0 : (nzl.masks ? 2 : 1);  // wave-uniform
       double* pt_w = smem + L.ptile + wv * 16 * TL_PHP;
       if (CLS == 0) {
         if (dm == 1)
-          tile_policy_reg<NG, 2, 1>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
+          tile_policy_reg<NG, 2, 1>(a, nzl, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
         else if (dm == 2)
-          tile_policy_reg<NG, 2, 2>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
+          tile_policy_reg<NG, 2, 2>(a, nzl, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
         else
-          tile_policy_reg<NG, 2, 0>(a, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
+          tile_policy_reg<NG, 2, 0>(a, nzl, invl, sf, cen, wgt, scr + wv * 16, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
       } else {
         if (dm == 1)
-          tile_policy<NG, 1>(a, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
+          tile_policy<NG, 1>(a, nzl, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
         else if (dm == 2)
-          tile_policy<NG, 2>(a, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
+          tile_policy<NG, 2>(a, nzl, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
         else
-          tile_policy<NG, 0>(a, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
+          tile_policy<NG, 0>(a, nzl, invl, sf, cen, wgt, scr + wv * 16, pt_w, smem + L.upart, B, PF, U, t, m0, wv, lane, drop, keep_scale, drop_thr, ptb, pte);
       }
     }
     lds_barrier();
@@ -1816,7 +1818,7 @@ static int launch_tile_deg(const FwdArgs& a, hipStream_t st) {
 
 // builds the packed phase-J operand in the caller's workspace (wide classes with a workspace; a few microseconds per rollout)
 static int tile_xj_pack(const FwdArgs& a, hipStream_t st) {
-  if (!a.xj) return MCP_OK;
+  if (!a.xj || (a.operands_packed & 2)) return MCP_OK;
   const int npb = a.xj_stride / 512;
   hipLaunchKernelGGL(tile_xj_pack_kernel, dim3((npb * 128 + 255) / 256, a.model.G, 4), dim3(256), 0, st, a.model, a.xj, a.xj_stride, npb);
   MCP_LAUNCH_CHECK();

@@ -24,6 +24,7 @@ ABI_VERSION = 6
 COMM_ID_BYTES = 128
 STATUS_NAN, STATUS_NONPOS_VAR, STATUS_NOT_SPD, STATUS_SYNC = 1, 2, 4, 8
 FWD_NO_GP_SHARDING = 2  # flag in mcp_rollout_fwd's particle_pred argument (MCP_FWD_NO_GP_SHARDING)
+FWD_KT_PACKED, FWD_XJ_PACKED = 4, 8  # the workspace still holds the packed operand copies of an earlier call on the same model (MCP_FWD_*_PACKED)
 POLICY_PLAIN, POLICY_ANGLES, POLICY_TRAJ = 0, 1, 2
 COST_CARTPOLE, COST_TRAJ = 0, 1
 
@@ -60,7 +61,7 @@ class Policy(C.Structure):
 
 
 class Noise(C.Structure):
-    _fields_ = [("eps", dptr), ("masks", dptr), ("seed", C.c_uint64), ("call", C.c_uint64), ("particle_offset", C.c_int64)]
+    _fields_ = [("eps", dptr), ("masks", dptr), ("seed", C.c_uint64), ("call", C.c_uint64), ("particle_offset", C.c_int64), ("call_dev", dptr)]
 
 
 class OptState(C.Structure):

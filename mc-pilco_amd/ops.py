@@ -316,12 +316,17 @@ class NoiseSpec:
     seed: int = 0
     call: int = 0
     particle_offset: int = 0
+    call_dev: Optional[torch.Tensor] = None  # device int64 [1] added to ``call`` by the kernels (a rollout replayed from a HIP graph: the graph advances it)
 
     def to_c(self):
         n = abi.Noise()
         n.eps = None if self.eps is None else self.eps.data_ptr()
         n.masks = None if self.masks is None else self.masks.data_ptr()
         n.seed, n.call, n.particle_offset = int(self.seed) & (2**64 - 1), int(self.call) & (2**64 - 1), int(self.particle_offset)
+        if self.call_dev is not None:
+            if self.call_dev.dtype != torch.int64 or not self.call_dev.is_cuda or self.call_dev.numel() != 1:
+                raise RuntimeError("call_dev must be a one-element int64 GPU tensor")
+            n.call_dev = self.call_dev.data_ptr()
         return n
 
 
@@ -389,7 +394,7 @@ def _workspace(model, policy, pc, M, T, which):
     (give each its own PackedModel; the operand tensors can be shared)."""
     if model is None:  # (policy-only evaluation: nothing to keep it on)
         nbytes = abi.lib().mcp_rollout_workspace_bytes(None, C.byref(pc), M, T)
-        return nbytes, (torch.empty((nbytes + 7) // 8, dtype=DT, device=policy.device) if nbytes else None)
+        return nbytes, (torch.empty((nbytes + 7) // 8, dtype=DT, device=policy.device) if nbytes else None), None
     cache = model.__dict__.setdefault("_ws_cache", {})
     key = (which, int(M), int(T), policy.kind, policy.B, policy.P, policy.U, policy.c.meas.n)
     hit = cache.get(key)
@@ -397,7 +402,7 @@ def _workspace(model, policy, pc, M, T, which):
         nbytes = abi.lib().mcp_rollout_workspace_bytes(_mc(model), C.byref(pc), M, T)
         if len(cache) >= 8:  # (a few shapes per model at most: the warm-up rollout, the optimisation, an evaluation)
             cache.clear()
-        hit = cache[key] = (nbytes, torch.empty((nbytes + 7) // 8, dtype=DT, device=model.device) if nbytes else None)
+        hit = cache[key] = (nbytes, torch.empty((nbytes + 7) // 8, dtype=DT, device=model.device) if nbytes else None, {"packed": 0})
     return hit
 
 
@@ -421,18 +426,27 @@ def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, nois
     # workspace: the hand-off granules of the GP-sharded launch (small swarms) and the kernels' packed operand copies; the library zeroes /
     # rebuilds what it uses on the stream, so ONE buffer per (model, shape) serves every step of an optimisation (no size query, no
     # allocation per step)
-    nbytes, ws = _workspace(model, policy, pc, M, T, "fwd") if (model is not None and T > 1) else (0, None)
+    nbytes, ws, wstate = _workspace(model, policy, pc, M, T, "fwd") if (model is not None and T > 1) else (0, None, None)
+    # the packed operand copies in the workspace (the lean kernel's Kinv tiles, the wide classes' phase-J operands) are functions of the model's
+    # arrays alone: built by the first rollout that needs them, then kept -- a PackedModel's tensors are never written again, and this buffer
+    # belongs to it (MCP_FWD_KT_PACKED / MCP_FWD_XJ_PACKED)
+    pflags = 0 if wstate is None else wstate["packed"]
     ev = fwd_events
     try:
         if ev is not None:
             ev[0].record()
         # (the `_ex` entry point = mcp_rollout_fwd + the process's dispatch request / report, all zero unless a test or tool set it)
         abi.check(abi.lib().mcp_rollout_fwd_ex(_mc(model), C.byref(pc), C.byref(nz), M, T,
-                                               int(bool(particle_pred)) | (0 if gp_sharding else abi.FWD_NO_GP_SHARDING), abi.ptr(x0),
+                                               int(bool(particle_pred)) | (0 if gp_sharding else abi.FWD_NO_GP_SHARDING) | pflags, abi.ptr(x0),
                                                abi.ptr(states), abi.ptr(inputs), abi.ptr(jac), abi.ptr(status), abi.ptr(ws), nbytes, abi.stream(),
                                                C.byref(abi.DISPATCH)), "mcp_rollout_fwd")
         if ev is not None:
             ev[1].record()
+        if wstate is not None:  # what this call left in the workspace (it reports which kernel family ran)
+            if abi.DISPATCH.ran_fwd_lean:
+                wstate["packed"] |= abi.FWD_KT_PACKED
+            elif abi.DISPATCH.ran_particles == 16 and model.D + 1 > 16:
+                wstate["packed"] |= abi.FWD_XJ_PACKED
     finally:
         _set_meas(policy, None, T, M, None)
     if meas is not None:
@@ -453,7 +467,7 @@ def rollout_backward_raw(model: PackedModel, policy: PackedPolicy, noise: NoiseS
     T, M = states.shape[0], states.shape[1]
     pc = policy.bind(p_drop)
     nz = noise.to_c()
-    nbytes, ws = _workspace(model, policy, pc, M, T, "bwd")
+    nbytes, ws, _ = _workspace(model, policy, pc, M, T, "bwd")
     # ONE flat buffer [dJ/dlog_ls (P) | dJ/dcenters (B P) | dJ/dweight (U B) | dJ/dbias (U)]: the three (four) gradients are views of it --
     # autograd hands them to the parameters' .grad as they are, so a particle-sharded step all-reduces its message IN PLACE when the caller
     # supplies the head of that message as ``policy.grad_flat`` (sharding.StepMessage); otherwise one allocation per step instead of four
@@ -618,6 +632,19 @@ class ExpectedCostFunction(torch.autograd.Function):
         abi.check(abi.lib().mcp_cost_bwd(C.byref(ctx.cost.c), T, M, abi.ptr(st), abi.ptr(gc), 1.0 / float(ctx.m_total), abi.ptr(g), abi.stream()),
                   "mcp_cost_bwd")
         return g, None, None, None
+
+
+def expected_cost_raw(cost: PackedCost, states, g_one):
+    """(cost, std, dJ/dstates) of this process's particles without autograd: exactly the launches ExpectedCostFunction's forward and backward
+    make (``g_one``: a device scalar 1.0, the upstream gradient ``cost.backward()`` starts from).  For callers that replay the step from a
+    HIP graph (MC_PILCO.reinforce_policy): the autograd engine's own stream bookkeeping does not survive a stream capture."""
+    mom, _, _ = cost_moments(cost, states)
+    T, M, _ = states.shape
+    out = cost_finalize(mom.unsqueeze(0), [M])
+    st = states.detach().contiguous()
+    g = torch.empty_like(st)
+    abi.check(abi.lib().mcp_cost_bwd(C.byref(cost.c), T, M, abi.ptr(st), abi.ptr(g_one), 1.0 / float(M), abi.ptr(g), abi.stream()), "mcp_cost_bwd")
+    return out[0], out[1], g
 
 
 def expected_cost(cost: PackedCost, states, group=None, counts=None):

@@ -25,6 +25,7 @@ from torch.distributions.multivariate_normal import MultivariateNormal
 from torch.distributions.uniform import Uniform
 
 from mc_pilco_amd import ops, sharding
+from mc_pilco_amd.policy_learning import Cost_function as _Cost
 from mc_pilco_amd.policy_learning import Policy as _Policy
 from mc_pilco_amd.simulation_class import model as _sim
 
@@ -68,6 +69,9 @@ class MC_PILCO(torch.nn.Module):
         self._step_msgs = {}       # sharding.StepMessage by (with gradients?): the persistent flat message of that all-reduce
         self._cost_shift = None    # previous step's pooled per-time-step mean cost (the shift of the summable cost moments)
         self.pipeline_depth = 1    # reinforce_policy reads an attempt's outcome this many attempts late (0: at once); see there
+        self.capture_attempts = False  # True: reinforce_policy records an attempt into a HIP graph and replays it (pipelined loop only); see there
+        self._call_dev = None      # device int64 [1]: the rollout counter of replayed attempts (mcp_noise.call_dev), None while attempts run eagerly
+        self.attempts_replayed = 0  # attempts of the last reinforce_policy that ran as a graph replay (diagnostic)
 
     # ------------------------------------------------------------------------------------------------------------
     # particle sharding
@@ -99,8 +103,12 @@ class MC_PILCO(torch.nn.Module):
         if self.noise_mode != "reference" and not flg_uniform and not flg_multi_gauss:
             # same distribution as MultivariateNormal(mean, diag(var)) without building M covariance matrices and their Cholesky
             # factors on every optimizer step
-            mean, var = mean.to(self.device).reshape(1, -1), var.to(self.device).reshape(1, -1)
-            return mean + torch.sqrt(var) * torch.randn(num_particles, mean.shape[1], dtype=mean.dtype, device=self.device)
+            # (two launches per draw -- randn, addcmul -- instead of four: the standard deviations are kept per variance tensor and version)
+            mean = mean.to(self.device).reshape(1, -1)
+            hit = self.__dict__.get("_x0_std")
+            if hit is None or hit[0] is not var or hit[1] != int(var._version):
+                hit = self.__dict__["_x0_std"] = (var, int(var._version), torch.sqrt(var.to(self.device).reshape(1, -1)))
+            return torch.addcmul(mean, hit[2], torch.randn(num_particles, mean.shape[1], dtype=mean.dtype, device=self.device))
         on = torch.device("cpu") if self.noise_mode == "reference" else self.device
         mean, var = mean.to(on), var.to(on)
         if flg_uniform:
@@ -135,7 +143,14 @@ class MC_PILCO(torch.nn.Module):
             eps = self._shard_slice(torch.stack(eps) if eps else torch.zeros(0, Mt, G, dtype=self.dtype), 1).to(self.device).contiguous()
             mk = None if masks is None else self._shard_slice(torch.stack(masks).to(torch.uint8), 1).to(self.device).contiguous()
             return ops.NoiseSpec(eps=eps, masks=mk), p
-        return ops.NoiseSpec(seed=self.seed, call=self._rollout_calls, particle_offset=self._shard[0]), p
+        return self._philox_noise(), p
+
+    def _philox_noise(self):
+        """In-kernel noise keyed by (seed, rollout counter, global particle).  While an attempt is being recorded into a graph the counter is the
+        device word the graph advances (by-value part 0); the host's ``_rollout_calls`` mirrors it either way."""
+        if self._call_dev is not None:
+            return ops.NoiseSpec(seed=self.seed, call=0, particle_offset=self._shard[0], call_dev=self._call_dev)
+        return ops.NoiseSpec(seed=self.seed, call=self._rollout_calls, particle_offset=self._shard[0])
 
     def apply_policy(self, particles_initial_state_mean, particles_initial_state_var, flg_particles_init_uniform, particles_init_up_bound,
                      particles_init_low_bound, flg_particles_init_multi_gauss, num_particles, T_control, p_dropout=0.0):
@@ -363,27 +378,116 @@ class MC_PILCO(torch.nn.Module):
         rec_dev = torch.zeros(depth + 2, abi.OPT_RECORD_DOUBLES, dtype=dt, device=dev)
         seq = [0]
 
-        def enqueue():
-            """One attempt, start to finish, without a host sync."""
-            snap = (self._rollout_calls, torch.cuda.get_rng_state(dev) if depth > 0 else None)
+        # ---- one attempt = rollout -> cost -> adjoint -> guarded Adam -> commit: ~15 launches and as many host calls.  In the pipelined loop it
+        # is recorded ONCE into a HIP graph and replayed (round 6): everything an attempt reads that changes from one attempt to the next lives in
+        # device memory -- the parameters, the loop state, torch's generator offset (graph-safe) and the rollout counter of the in-kernel noise
+        # (mcp_noise.call_dev, advanced by the graph itself) -- so a replay takes the same step the eager calls would, bit for bit.  Two graphs
+        # alternate (each with its own trajectories and record row: an attempt voided while the host decides must not overwrite the outputs of
+        # the one before it).  The first two attempts after every (re)start run eagerly (they warm the launch paths); a host decision that
+        # changes a recorded value -- lr, dropout, new Adam moments, re-initialised parameters -- drops the graphs.
+        pol_ = self.control_policy
+        use_graph = (bool(getattr(self, "capture_attempts", False)) and depth > 0 and adam is not None and dev.type == "cuda"
+                     and type(self).apply_policy is MC_PILCO.apply_policy  # (the measurement-model rollout of MC_PILCO4PMS keeps the eager loop)
+                     and isinstance(pol_, _Policy.Sum_of_gaussians) and getattr(pol_, "_unit_scale", False)
+                     and hasattr(self.model_learning, "vel_indeces") and isinstance(self.cost_function, _Cost._HipExpectedCost))
+        cap = dict(on=use_graph, graphs=[None, None], outs=[None, None], eager=0, rec=torch.zeros(2, abi.OPT_RECORD_DOUBLES, dtype=dt, device=dev),
+                   one=torch.ones(1, dtype=dt, device=dev), last_flat=None)
+        self.attempts_replayed = 0
+
+        def drop_graphs():
+            cap["graphs"], cap["outs"], cap["eager"] = [None, None], [None, None], 0
+            self._call_dev = None
+
+        def commit(cost, std, flags, status, grads, rec_row):
+            cptr, sptr = abi.ptr(cost.detach().reshape(1)), abi.ptr(std.detach().reshape(1))
+            if adam is not None:
+                abi.check(lib.mcp_adam_step_guarded(len(ad["ps"]), ad["c_ps"], grads, ad["c_m"], ad["c_v"], ad["numel"], float(hs["lr"]), adam[1],
+                                                    adam[2], adam[3], abi.ptr(st), 0, n_steps, cptr, abi.ptr(flags), abi.ptr(status), abi.stream()),
+                          "mcp_adam_step_guarded")
+            abi.check(lib.mcp_policy_step_commit(abi.ptr(st), n_steps, cptr, sptr, abi.ptr(flags), abi.ptr(status), abi.ptr(cost_list),
+                                                 abi.ptr(std_list), abi.ptr(es1), abi.ptr(ratio), float(alpha_diff_cost),
+                                                 float(min(hs["min_step"], 1e300)), float(hs["min_diff"]), int(num_min_diff_cost),
+                                                 abi.ptr(rec_row), abi.stream()), "mcp_policy_step_commit")
+
+        def attempt_body(rec_row):
+            """The reference's lines (MC_PILCO.py:484-525) on the drop-in classes: apply_policy -> cost_function -> cost.backward() -> step."""
             for q in params:
                 q.grad = None
             states, inputs = self.apply_policy(p_dropout=hs["p_drop"], **sim)
             cost, std, flags = self._cost_backward(states, inputs, trial_index, flags_as_vector=self.dist_group is not None)
-            cptr, sptr = abi.ptr(cost.detach().reshape(1)), abi.ptr(std.detach().reshape(1))
             status = None if (flags is not None or self.last_status is None) else self.last_status
-            if adam is not None:
-                grads = (abi.dptr * len(ad["ps"]))(*[None if q.grad is None else q.grad.data_ptr() for q in ad["ps"]])
-                abi.check(lib.mcp_adam_step_guarded(len(ad["ps"]), ad["c_ps"], grads, ad["c_m"], ad["c_v"], ad["numel"], float(hs["lr"]), adam[1],
-                                                    adam[2], adam[3], abi.ptr(st), 0, n_steps, cptr, abi.ptr(flags), abi.ptr(status), abi.stream()),
-                          "mcp_adam_step_guarded")
+            grads = None if adam is None else (abi.dptr * len(ad["ps"]))(*[None if q.grad is None else q.grad.data_ptr() for q in ad["ps"]])
+            commit(cost, std, flags, status, grads, rec_row)
+            return states, inputs, cost, None
+
+        def attempt_body_raw(rec_row):
+            """The same attempt as the operators underneath make it, without the autograd engine (whose stream bookkeeping does not survive a
+            stream capture): x0 -> mcp_rollout_fwd -> mcp_cost_fwd / _finalize / _bwd -> mcp_rollout_bwd -> guarded Adam -> commit.  Identical
+            launches with identical arguments, hence identical bits; this is the form that is recorded and replayed."""
+            self._call_dev.add_(1)
+            world, rank = self._world()
+            self._shard = sharding.shard_range(int(sim["num_particles"]), world, rank)
+            self._m_total = int(sim["num_particles"])
+            M, T = self._shard[1], int(sim["T_control"])
+            x0 = self.sample_initial_particles(sim["particles_initial_state_mean"], sim["particles_initial_state_var"], sim["flg_particles_init_uniform"],
+                                               sim["particles_init_up_bound"], sim["particles_init_low_bound"], sim["flg_particles_init_multi_gauss"],
+                                               self._m_total)
+            noise, p = self._rollout_noise(M, T, hs["p_drop"])
+            model, pk = self.model_learning.packed(), pol_.packed()
+            states, inputs, jac, status = ops.rollout_forward_raw(model, pk, noise, x0, T, p, True, need_jac=True, gp_sharding=self.gp_sharding)
+            self.last_status = status
+            cf = self.cost_function
+            if hasattr(cf, "_select"):
+                cf._select(states, trial_index)
+            if cf._packed is None or cf._packed.device != states.device:
+                cf._packed = cf._pack(states)
+            cost, std, g_states = ops.expected_cost_raw(cf._packed, states, cap["one"])
+            g_ls, g_c, g_w, _, g_b = ops.rollout_backward_raw(model, pk, noise, states, inputs, jac, g_states, None, p)
+            by_param = {id(pol_.log_lengthscales): g_ls, id(pol_.centers): g_c, id(pol_.f_linear.weight): g_w}
+            if pol_.f_linear.bias is not None:
+                by_param[id(pol_.f_linear.bias)] = g_b
+            grads = (abi.dptr * len(ad["ps"]))(*[by_param[id(q)].data_ptr() for q in ad["ps"]])
+            commit(cost, std, None, status, grads, rec_row)
+            return states, inputs, cost, by_param
+
+        def enqueue():
+            """One attempt, start to finish, without a host sync."""
+            snap = (self._rollout_calls, torch.cuda.get_rng_state(dev) if depth > 0 else None)
             slot = seq[0] % (depth + 2)
+            gi = seq[0] & 1
             seq[0] += 1
-            abi.check(lib.mcp_policy_step_commit(abi.ptr(st), n_steps, cptr, sptr, abi.ptr(flags), abi.ptr(status), abi.ptr(cost_list),
-                                                 abi.ptr(std_list), abi.ptr(es1), abi.ptr(ratio), float(alpha_diff_cost),
-                                                 float(min(hs["min_step"], 1e300)), float(hs["min_diff"]), int(num_min_diff_cost),
-                                                 abi.ptr(rec_dev[slot]), abi.stream()), "mcp_policy_step_commit")
-            ring[slot].copy_(rec_dev[slot], non_blocking=True)
+            rec_src = None
+            if cap["on"] and cap["eager"] >= 2:
+                if cap["graphs"][gi] is None:
+                    # record: the kernels are not run here; the replay below is this attempt
+                    if self._call_dev is None:
+                        self._call_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+                    self._call_dev.fill_(self._rollout_calls)
+                    torch.cuda.synchronize(dev)
+                    g = torch.cuda.CUDAGraph()
+                    try:
+                        with torch.cuda.graph(g):
+                            cap["outs"][gi] = attempt_body_raw(cap["rec"][gi])
+                        cap["graphs"][gi] = g
+                    except Exception as e:  # noqa: BLE001  (a runtime that cannot record this sequence: the eager loop is the same loop)
+                        print("\nreinforce_policy: recording an attempt into a graph failed (%r) -- continuing with eager launches" % (e,))
+                        cap["on"] = False
+                        self._rollout_calls = snap[0]
+                        if snap[1] is not None:
+                            torch.cuda.set_rng_state(snap[1], dev)
+                        drop_graphs()
+                else:
+                    self._rollout_calls += 1  # (the host's mirror of the counter the replay advances)
+                if cap["graphs"][gi] is not None:
+                    cap["graphs"][gi].replay()
+                    self.attempts_replayed += 1
+                    states, inputs, cost, cap["last_flat"] = cap["outs"][gi]
+                    rec_src = cap["rec"][gi]
+            if rec_src is None:
+                cap["eager"] += 1
+                states, inputs, cost, cap["last_flat"] = attempt_body(rec_dev[slot])
+                rec_src = rec_dev[slot]
+            ring[slot].copy_(rec_src, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             return dict(states=states, inputs=inputs, rec=ring[slot], ev=ev, snap=snap, cost=cost)
@@ -428,6 +532,8 @@ class MC_PILCO(torch.nn.Module):
                     r = read(h)
                     assert r[1] == 1.0 and r[0] == 0.0, "an attempt enqueued past a host decision was not void"
                 self._rollout_calls = queue[0]["snap"][0]
+                if self._call_dev is not None:
+                    self._call_dev.fill_(self._rollout_calls)
                 if queue[0]["snap"][1] is not None:
                     torch.cuda.set_rng_state(queue[0]["snap"][1], dev)
                 queue.clear()
@@ -466,6 +572,7 @@ class MC_PILCO(torch.nn.Module):
                         adam = self._plain_adam(opt)
                         params = [q for q in self.control_policy.parameters()]
                         fresh_adam_state()
+                        drop_graphs()  # (new moments / learning rate / dropout / parameters: what the graphs recorded is gone)
                         done = 0
                     continue
                 # the attempt counted: step k was taken
@@ -484,12 +591,18 @@ class MC_PILCO(torch.nn.Module):
                             raise RuntimeError("f_optimizer must build the same kind of optimizer on every call")
                         adam = adam_now
                         fresh_adam_state()
+                        drop_graphs()  # (new moments / learning rate / dropout / parameters: what the graphs recorded is gone)
                     st[2:3].zero_()
                 if done >= n_steps:
                     discard(queue)
                     leave = True
         discard(queue)
         states, inputs = last["states"], last["inputs"]
+        if cap["last_flat"] is not None:  # (the last attempt was a replay: its gradients are where autograd would have left them)
+            for q in params:
+                g_ = cap["last_flat"].get(id(q))
+                q.grad = None if g_ is None else g_.reshape(q.shape)
+        drop_graphs()  # (rollouts after this call count by value again; the host's mirror of the counter is current)
         return (cost_list[0:done].detach().cpu().numpy(), std_list[0:done].detach().cpu().numpy(), states.detach().cpu().numpy(),
                 inputs.detach().cpu().numpy())
 
@@ -709,7 +822,7 @@ class MC_PILCO4PMS(MC_PILCO):
                                       self._shard_slice(torch.stack(masks).to(torch.uint8), 1).to(self.device).contiguous())
                 pos_noise = stack(pn, len(pos))
             else:
-                noise = ops.NoiseSpec(seed=self.seed, call=self._rollout_calls, particle_offset=self._shard[0])
+                noise = self._philox_noise()
                 pos_noise = None
             meas = ops.MeasSpec(pos=pos, vel=vel, std_pos=[float(v) for v in np.asarray(self.std_meas_noise_sim)[pos]], b=b, a=a,
                                 pos_noise=pos_noise)

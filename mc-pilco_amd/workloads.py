@@ -92,7 +92,7 @@ class Workload:
     def sample_x0(self, M=None, generator=None):
         M = M or self.M
         e = torch.randn(M, self.x0_mean.numel(), dtype=DT, device=self.x0_mean.device, generator=generator)
-        return self.x0_mean + self.x0_std * e
+        return torch.addcmul(self.x0_mean, self.x0_std, e)
 
 
 def spec_for(c, sigma_n, poly_w):

@@ -896,17 +896,22 @@ def test_zero_predictive_variance_raises_like_the_reference_normal():
 
 # ---- round 4: the optimizer loop without a host sync per step ------------------------------------------------------------------------
 def _nan_on_rollout_calls(obj, nan_calls):
-    """Wraps obj.cost_function: the expected cost is NaN for the rollouts whose number (obj._rollout_calls, the counter that keys the
-    in-kernel noise) is in ``nan_calls`` -- a key that means the same attempt at every pipeline depth."""
-    inner = obj.cost_function
+    """The rollouts whose number (obj._rollout_calls, the counter that keys the in-kernel noise) is in ``nan_calls`` start from NaN particles, so
+    their cost is NaN -- a key that means the same attempt at every pipeline depth.  Round 6: an attempt replayed from a HIP graph keeps that
+    counter on the device (mcp_noise.call_dev), and so must this decision: a factor of NaN or exactly 1 on x0, chosen by a device comparison
+    while ``obj._call_dev`` is set, by the host's counter otherwise."""
+    inner = obj.sample_initial_particles
     nan_calls = set(int(i) for i in nan_calls)
+    nan_t = torch.tensor(sorted(nan_calls), dtype=torch.int64, device=dev()).reshape(1, -1)
 
-    class Wrapped(torch.nn.Module):
-        def forward(self, states_sequence, inputs_sequence=None, trial_index=None, group=None, counts=None):
-            cost, std = inner(states_sequence, inputs_sequence, trial_index)
-            return (cost * float("nan") if obj._rollout_calls in nan_calls else cost), std
+    def wrapped(*a, **k):
+        x0 = inner(*a, **k)
+        if obj._call_dev is not None:  # (advanced at the top of the recorded attempt: it holds THIS rollout's number)
+            bad = (obj._call_dev.reshape(1, 1) == nan_t).any()
+            return x0 * torch.where(bad, torch.full_like(x0[:1, :1], float("nan")), torch.ones_like(x0[:1, :1]))
+        return x0 * float("nan") if (obj._rollout_calls + 1) in nan_calls else x0  # (the counter advances behind the draw)
 
-    obj.cost_function = Wrapped()
+    obj.sample_initial_particles = wrapped
 
 
 @pytest.mark.parametrize("case", ["plain", "nan_retry", "reinit", "lr_and_exit", "last_step_fails"])
@@ -933,6 +938,7 @@ def test_pipelined_optimizer_loop_takes_exactly_the_synchronous_steps(golden, ca
         obj = _trace_setup(fx)
         obj.noise_mode = "philox"
         obj.pipeline_depth = depth
+        obj.capture_attempts = True  # (opt-in since round 6's measurement: a replay is no faster than the eager launches on this runtime; depth 0 never replays)
         _nan_on_rollout_calls(obj, nan_calls)
         torch.manual_seed(1234)
         buf = io.StringIO()
@@ -945,10 +951,14 @@ def test_pipelined_optimizer_loop_takes_exactly_the_synchronous_steps(golden, ca
                                                           weight_par=10.0), **kw)
         pol = obj.control_policy
         import re
-        out[depth] = dict(res=res, calls=obj._rollout_calls, rng=torch.cuda.get_rng_state(dev()).clone(),
+        # round 6: the pipelined loop replays its attempts from HIP graphs (the first two after every restart run eagerly); the synchronous one never
+        assert (obj.attempts_replayed > 0) == (depth == 1), (depth, obj.attempts_replayed)
+        assert obj._call_dev is None
+        out[depth] = dict(res=res, calls=obj._rollout_calls, rng=torch.cuda.get_rng_state(dev()).clone(), replayed=obj.attempts_replayed,
                           par=[q.detach().cpu().numpy().copy() for q in pol.parameters()],
                           txt=re.sub(r"time elapsed:  [0-9.e+-]+", "time elapsed", buf.getvalue()))
     a, b = out[0], out[1]
+    print("%s: %d attempts in all, %d of them graph replays in the pipelined run" % (case, b["calls"] - 1, b["replayed"]))
     for x, y in zip(a["res"], b["res"]):
         assert x.shape == y.shape and np.array_equal(x, y, equal_nan=True)
     for x, y in zip(a["par"], b["par"]):
