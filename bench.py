@@ -352,7 +352,7 @@ class Runner:
 
         return "rollout_bwd_lat_kernel" if hipabi.lib().mcp_debug_last_bwd_lean() else "rollout_bwd_kernel"
 
-    def roofline(self, fwd_ms, step_s, traffic):
+    def roofline(self, fwd_ms, step_s, traffic, profile=None):
         """The dominant kernel is the forward rollout.  `frac` = ITS OWN algorithmic flops (the forward terms of SURVEY 8d's figure)
         x M x T / its mean launch duration (HIP events on the launch stream right around mcp_rollout_fwd) / the fp64 peak -- the
         number that follows from profiles/*_kernel_stats.csv.  `kernels` lists forward and backward the same way; `frac_step`
@@ -375,7 +375,7 @@ class Runner:
                          {"name": self.bwd_kernel_name(), "avg_ms": self.bwd_ms, "alg_flops_per_unit": flops_bwd, "frac": ach_bwd / FP64_PEAK_TFLOPS,
                           "note": "mcp_rollout_bwd: the adjoint sweep(s) + the fixed-order gradient reduction"}],
              "achieved_basis": "the forward kernel's own algorithmic flops per particle-step (SURVEY 8d, forward terms) x M x T / its mean launch "
-                               "duration (HIP events on the launch stream around mcp_rollout_fwd; profiles/r05_*_kernel_stats.csv is the rocprofv3 "
+                               "duration (HIP events on the launch stream around mcp_rollout_fwd; profiles/r06_*_kernel_stats.csv is the rocprofv3 "
                                "average of the same kernel); frac_step: fwd+bwd flops / ms_per_step",
              "regime": ("T-sequential chain of 4 barrier-separated phases per step + the per-CU L2->CU stream of one Kinv per workgroup and "
                         "step; fp64 flop roof not reachable at M=400 (DESIGN.md 4.0)") if small else
@@ -383,7 +383,36 @@ class Runner:
         if traffic:
             gbps = traffic / (fwd_ms * 1e-3) / 1e9
             r["hbm_gbps"], r["hbm_frac"] = gbps, gbps / HBM_PEAK_GBPS
+        if name.startswith("rollout_fwd_lat"):
+            r["l1_fill"] = self.l1_fill(fwd_ms, profile or {})
         return r
+
+    def l1_fill(self, fwd_ms, profile):
+        """The second roof of the lean small-swarm kernel: every workgroup pulls its GP's Kinv through its CU's L1 once per
+        time step, less what stays in registers -- 8 waves x 3 resident register buffers x 6 KB --, and a CU's L1 delivers 64 B per clock.  `bytes_per_wg_step`
+        / 64 = the cycles that stream needs per step; `cycles_per_step` = the forward kernel's measured time per step at 2.4 GHz; from
+        profiles/traffic.json (tools/collect_profiles.sh, same kernel sources only) the phase's own cycles with both sides, with the MFMAs compiled out
+        (stream only) and with the loads compiled out (MFMAs only), and the launch's L1 -> L2 read requests (counter)."""
+        npad = max(g.Npad for g in self.w.model.gps)
+        kinv = npad * npad * 8
+        resident = 8 * 3 * 6 * 64 * 16
+        streamed = max(0, kinv - resident)
+        out = {"bound": "per-CU L1 fill (64 B/clk) of one Kinv per workgroup and time step", "kinv_bytes": kinv, "register_resident_bytes": resident,
+               "bytes_per_wg_step": streamed, "cycles_at_64B_clk": streamed / 64.0, "clock_ghz": 2.4,
+               "cycles_per_step": fwd_ms * 1e-3 * 2.4e9 / max(1, self.T - 1),
+               "stream_share_of_step": (streamed / 64.0) / (fwd_ms * 1e-3 * 2.4e9 / max(1, self.T - 1))}
+        pv = profile.get("c1_phase_v_cycles") if self.name == "c1" else None
+        if pv:
+            out["measured_cycles"] = {"phase_v_plus_j": pv["both"]["v_plus_j"], "phase_v_slowest_wave": pv["both"]["slowest_wave_v"],
+                                      "stream_only_slowest_wave": pv["stream_only"]["slowest_wave_v"], "mfma_only_slowest_wave": pv["mfma_only"]["slowest_wave_v"],
+                                      "what": "tools/phase_stamps.py c1 on the kernel and on its RLX_NOFMA / RLX_NOLOAD experiment builds (profiles/r06_c1_*stamps.txt)"}
+        if self.name == "c1" and profile.get("c1_tcp_tcc_read_req"):
+            units = 200 * (self.T - 1)
+            out["tcp_tcc_read_req_per_launch"] = profile["c1_tcp_tcc_read_req"]
+            out["l1_to_l2_bytes_per_wg_step_at_64B_per_request"] = profile["c1_tcp_tcc_read_req"] * 64.0 / units
+        if self.name == "c1" and profile.get("c1_mfma_pipe_busy") is not None:
+            out["mfma_pipe_busy"] = profile["c1_mfma_pipe_busy"]
+        return out
 
 
 class _SumsCost:
@@ -541,7 +570,7 @@ def main():
     # schedule, so the other ranks simply wait at the final barrier); only rank 0 prints
     out = None
     if rank == 0:
-        roof = main_run.roofline(fwd_ms, block_s / args.steps, traffic_of(tkey))
+        roof = main_run.roofline(fwd_ms, block_s / args.steps, traffic_of(tkey), traffic_all if traffic_ok else None)
         if not traffic_ok:
             roof["traffic_note"] = "profiles/traffic.json was collected for other kernel sources (%s != %s): not quoted" % (
                 traffic_all.get("kernel_sources_sha16"), sha)

@@ -30,6 +30,10 @@ for w in c1 c3 c5; do
   run "$w fetch" rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/${w}_fetch" -o $w -- $B --workload $w --steps $st --warmup 1 > "$OUT/${w}_fetch.log" 2>&1
   run "$w write" rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/${w}_write" -o $w -- $B --workload $w --steps $st --warmup 1 > "$OUT/${w}_write.log" 2>&1
 done
+# round 6: the headline (lean) kernel's own counter passes -- matrix-pipe busy cycles, and the L1 -> L2 read requests of the launch (the "one Kinv per
+# workgroup and step through the CU's L1" claim as a counter)
+run "c1 mfma" rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/c1_mfma" -o c1 -- $B --steps 4 --warmup 1 > "$OUT/c1_mfma.log" 2>&1
+run "c1 tcp" rocprofv3 --output-format csv --pmc TCP_TCC_READ_REQ_sum -d "$OUT/c1_tcp" -o c1 -- $B --steps 4 --warmup 1 > "$OUT/c1_tcp.log" 2>&1
 run "c3 mfma" rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/c3_mfma" -o c3 -- $B --workload c3 --steps 3 --warmup 1 > "$OUT/c3_mfma.log" 2>&1
 run "c5 mfma" rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/c5_mfma" -o c5 -- $B --workload c5 --steps 2 --warmup 1 > "$OUT/c5_mfma.log" 2>&1
 # GP training epoch (round 4): per-kernel statistics at the cart-pole and the UR5 shape, the factorisation kernels alone, and -- when the
@@ -38,6 +42,18 @@ run "fit c1 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT
 run "fit ur5 stats" rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/fit_ur5_stats" -o fit_ur5 -- python3 $R/tools/time_fit_ur5.py 100 > "$OUT/fit_ur5_stats.log" 2>&1
 run "chol times" python3 $R/tools/time_chol.py 300 400 500 600 1000 1153 2048 4096 > "$OUT/chol_times.txt" 2>&1
 run "pretrain times" python3 $R/tools/time_pretrain.py > "$OUT/pretrain_times.txt" 2>&1
+# round 6: what bounds phase V of the lean kernel -- the kernel itself with one side compiled out (experiment builds, when they are there:
+#   python mc-pilco_amd/build.py --variant-lean nofma RLX_NOFMA;  ... --variant-lean noload RLX_NOLOAD), and the issue microbenchmark
+for t in nofma noload; do
+  if [ -f $R/mc-pilco_amd/libmcpilco_hip_$t.so ]; then
+    MCPILCO_HIP_EXPERIMENT=1 MCPILCO_HIP_LIB=$R/mc-pilco_amd/libmcpilco_hip_$t.so python3 $R/tools/phase_stamps.py c1 > "$OUT/c1_${t}_stamps.txt" 2>&1 || exit 1
+  fi
+done
+( hipcc --offload-arch=gfx950 -O3 -w -o /tmp/vissue_bench $R/tools/vissue_bench.hip && /tmp/vissue_bench ) > "$OUT/vissue_bench.txt" 2>&1 || exit 1
+if [ -f $R/mc-pilco_amd/libmcpilco_hip_bws.so ]; then
+  for w in c3 c5; do MCPILCO_HIP_EXPERIMENT=1 MCPILCO_HIP_LIB=$R/mc-pilco_amd/libmcpilco_hip_bws.so python3 $R/tools/bwd_wave_stamps.py $w > "$OUT/${w}_bwd_wave_stamps.txt" 2>&1 || exit 1; done
+fi
+run "loop times" python3 $R/tools/time_reinforce_policy.py --capture-ab > "$OUT/loop_times.txt" 2>&1
 # the symmetric phase-V experiment of round 5 (measured and dropped) beside the full stream it would replace
 ( hipcc --offload-arch=gfx950 -O3 -w -o /tmp/vsym_bench $R/tools/vsym_bench.hip && /tmp/vsym_bench && hipcc --offload-arch=gfx950 -O3 -w -DNRES=0 -o /tmp/v4_bench $R/tools/v4_bench.hip && /tmp/v4_bench ) > "$OUT/vsym_bench.txt" 2>&1 || exit 1
 if [ -f $R/mc-pilco_amd/libmcpilco_hip_stamps.so ]; then

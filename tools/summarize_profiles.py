@@ -29,7 +29,8 @@ for cfg in ("fit_c1", "fit_ur5"):  # GP training epochs (round 4)
     f = os.path.join(src, cfg + "_stats", cfg + "_kernel_stats.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, cfg)))
-for name in ("chol_times.txt", "chol_stamps_n300.txt", "chol_stamps_n400.txt", "pretrain_times.txt", "vsym_bench.txt", "ur5_script_half1_stamps.txt"):
+for name in ("chol_times.txt", "chol_stamps_n300.txt", "chol_stamps_n400.txt", "pretrain_times.txt", "vsym_bench.txt", "ur5_script_half1_stamps.txt",
+             "c1_nofma_stamps.txt", "c1_noload_stamps.txt", "vissue_bench.txt", "c3_bwd_wave_stamps.txt", "c5_bwd_wave_stamps.txt", "loop_times.txt"):
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_%s" % (rnd, name)))
@@ -64,6 +65,49 @@ for cfg, (M, T, balg) in SHAPES.items():
             out[cfg + "_mfma_pipe_busy"] = util
             print("tile kernel (%s): MFMA busy %.3e cycles per launch = %.3e v_mfma_f64_16x16x4 at 64 cycles, matrix-pipe utilisation %.1f %%"
                   % (cfg, busy[-1], busy[-1] / 64, 100 * util))
+# round 6: the lean (headline) kernel -- matrix-pipe busy share, L1 -> L2 read requests per launch, and phase V with one side compiled out
+import re
+
+
+def _lean_rows(path, counter):
+    if not os.path.exists(path):
+        return []
+    return [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter and "rollout_fwd_lat" in r["Kernel_Name"]]
+
+
+f = os.path.join(src, "c1_mfma", "c1_counter_collection.csv.rollout")
+if os.path.exists(f):
+    shutil.copy(f, os.path.join(dst, "%s_c1_pmc_mfma_busy.csv" % rnd))
+    busy, act = _lean_rows(f, "SQ_VALU_MFMA_BUSY_CYCLES"), _lean_rows(f, "GRBM_GUI_ACTIVE")
+    if busy and act:
+        out["c1_mfma_pipe_busy"] = busy[-1] / (act[-1] / 8 * 1024)
+        print("lean kernel (c1): MFMA busy %.3e cycles per launch, matrix-pipe utilisation %.1f %% of all 1024 SIMDs (200 of 256 CUs hold a workgroup)"
+              % (busy[-1], 100 * out["c1_mfma_pipe_busy"]))
+f = os.path.join(src, "c1_tcp", "c1_counter_collection.csv.rollout")
+if os.path.exists(f):
+    shutil.copy(f, os.path.join(dst, "%s_c1_pmc_tcp_tcc_read_req.csv" % rnd))
+    req = _lean_rows(f, "TCP_TCC_READ_REQ_sum")
+    if req:
+        out["c1_tcp_tcc_read_req"] = req[-1]
+        print("lean kernel (c1): TCP_TCC_READ_REQ_sum %.4e per launch" % req[-1])
+
+
+def _phase_v(path):
+    """(V + J interval, slowest wave's own phase V) in cycles per step from a tools/phase_stamps.py output."""
+    if not os.path.exists(path):
+        return None
+    t = open(path).read()
+    m1 = re.search(r"V \+ J \(to the barrier\)\s+\d+\s+[0-9.]+%\s+(\d+) cyc/step", t)
+    m2 = re.search(r"phase V per wave \(own time, before the barrier\): ([0-9 ]+)", t)
+    if not (m1 and m2):
+        return None
+    return {"v_plus_j": int(m1.group(1)), "slowest_wave_v": max(int(x) for x in m2.group(1).split())}
+
+
+pv = {k: _phase_v(os.path.join(src, n)) for k, n in (("both", "c1_stamps.txt"), ("stream_only", "c1_nofma_stamps.txt"), ("mfma_only", "c1_noload_stamps.txt"))}
+if all(pv.values()):
+    out["c1_phase_v_cycles"] = pv
+    print("lean kernel (c1), phase V per step:", pv)
 # identity of what was measured: bench.py quotes these numbers only while the kernel sources are the ones profiled
 sys.path.insert(0, ROOT)
 import datetime
