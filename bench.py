@@ -392,7 +392,7 @@ class Runner:
         time step, less what stays in registers -- 8 waves x 3 resident register buffers x 6 KB --, and a CU's L1 delivers 64 B per clock.  `bytes_per_wg_step`
         / 64 = the cycles that stream needs per step; `cycles_per_step` = the forward kernel's measured time per step at 2.4 GHz; from
         profiles/traffic.json (tools/collect_profiles.sh, same kernel sources only) the phase's own cycles with both sides, with the MFMAs compiled out
-        (stream only) and with the loads compiled out (MFMAs only), and the launch's L1 -> L2 read requests (counter)."""
+        (stream only) and with the loads compiled out (MFMAs only), and the launch's L1 -> L2 read requests (counter TCP_TCC_READ_REQ_sum, 128-byte lines)."""
         npad = max(g.Npad for g in self.w.model.gps)
         kinv = npad * npad * 8
         resident = 8 * 3 * 6 * 64 * 16
@@ -409,7 +409,8 @@ class Runner:
         if self.name == "c1" and profile.get("c1_tcp_tcc_read_req"):
             units = 200 * (self.T - 1)
             out["tcp_tcc_read_req_per_launch"] = profile["c1_tcp_tcc_read_req"]
-            out["l1_to_l2_bytes_per_wg_step_at_64B_per_request"] = profile["c1_tcp_tcc_read_req"] * 64.0 / units
+            # (a request = one 128-byte line: 1.405e8 per launch / (200 workgroups x 149 steps) x 128 B = 603 KB, the streamed 592 KB + the start-up)
+            out["l1_to_l2_bytes_per_wg_step_at_128B_per_request"] = profile["c1_tcp_tcc_read_req"] * 128.0 / units
         if self.name == "c1" and profile.get("c1_mfma_pipe_busy") is not None:
             out["mfma_pipe_busy"] = profile["c1_mfma_pipe_busy"]
         return out
