@@ -22,7 +22,8 @@ typedef struct mcp_dispatch {
   int32_t gp_sharding;   /* GP-sharded launch forms: 1 never, 2 whenever the grid fits the device                                        */
   int32_t fwd_lean;      /* the latency-lean GP-sharded kernel (rollout_fwd_lat_kernel): 1 never                                        */
   int32_t policy_split;  /* GP-sharded 16-particle kernel: 1 every member evaluates the whole policy, 2 split whenever the shape allows */
-  int32_t row_split;     /* GP-sharded 16-particle kernel: 1 one workgroup per (tile, GP range), 2 two (row halves of Kinv) whenever allowed  */
+  int32_t row_split;     /* GP-sharded 16-particle kernel: 1 one workgroup per (tile, GP range), 2 / 3 that many (row parts of Kinv) whenever allowed */
+  int32_t cluster_map;   /* ... its row-split form: 1 the workgroups of a tile on one XCD, 2 dealt row part major                        */
   int32_t fwd_no_xlds;   /* small-tile kernel: 1 never stage the small operands in LDS                                                  */
   int32_t fwd_gb;        /* small-tile kernel: GPs per pass (0 = as many as fit)                                                        */
   int32_t bwd_particles; /* backward sweep: particles per workgroup 1 / 2 / 4 / 8 (forces the general sweep)                            */
@@ -37,7 +38,7 @@ typedef struct mcp_dispatch {
   int32_t ran_gp_sharded; /* number of GP-sharded launches the forward call made (0 = unsharded)      */
   int32_t ran_fwd_lean;   /* 1: the lean forward kernel ran                                           */
   int32_t ran_bwd_lean;   /* 1: the lean backward sweep ran                                           */
-  int32_t ran_row_split;  /* 1: the forward launch put two workgroups on every (tile, GP range)       */
+  int32_t ran_row_split;  /* 2 / 3: the forward launch put that many workgroups on every (tile, GP range) */
 } mcp_dispatch;
 
 int mcp_rollout_fwd_ex(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,

@@ -56,11 +56,11 @@ static inline size_t rollout_kt_bytes(const mcp_model* m) {
   return sizeof(double) * ((size_t)m->G * npad * npad + 6 * 128);  // (+ one register buffer of slack: the last stream may be read past its end)
 }
 
-// partial phase-F sums of the row-split cluster (FwdArgs.rxch): clusters x 2 (step parity) x G x 16 particles x (D + 1) columns x 2 values x
+// partial phase-F sums of the row-split cluster (FwdArgs.rxch): clusters x 2 (step parity) x G x 2 senders x 16 particles x (D + 1) columns x 2 values x
 // 2 granules, last in the caller's workspace; wide models on swarms that can be resident at two workgroups per (tile, GP) only
 static inline size_t rollout_rxch_bytes(const mcp_model* m, int M) {
   if (!m || rollout_xj_bytes(m) == 0 || M > 1024) return 0;
-  return (size_t)((M + 15) / 16) * 2 * (size_t)m->G * 16 * (size_t)(m->D + 1) * 4 * sizeof(unsigned long long);
+  return (size_t)((M + 15) / 16) * 2 * (size_t)m->G * 2 * 16 * (size_t)(m->D + 1) * 4 * sizeof(unsigned long long);  // (two senders: gsh_rs = 3)
 }
 
 static inline bool model_ok(const mcp_model* m) {

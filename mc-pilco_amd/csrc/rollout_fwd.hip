@@ -1186,6 +1186,13 @@ static int pick_particles_per_wg(int M) {
 
 // What a call may be asked to do differently from the automatic dispatch, and what it reports back: carried by the call itself
 // (mcp_dispatch, include/mcpilco_hip_debug.h) -- the library holds no dispatch state.  The values below are the ones the dispatch code reads.
+// the automatic row split of the GP-sharded 16-particle kernel: parts and deal (experiment builds may change them: -DMCP_ROW_PARTS_DEFAULT=2 ...)
+#ifndef MCP_ROW_PARTS_DEFAULT
+#define MCP_ROW_PARTS_DEFAULT 3
+#endif
+#ifndef MCP_ROW_PART_MAJOR_DEFAULT
+#define MCP_ROW_PART_MAJOR_DEFAULT 1
+#endif
 struct FwdHooks {
   int force_ppw = 0;     // particles per workgroup (0 = automatic)
   int force_xlds = -1;   // -1 automatic, 0 never stage small operands in LDS
@@ -1193,7 +1200,8 @@ struct FwdHooks {
   int gp_sharding = -1;  // -1 automatic, 0 never, 1 whenever the grid fits the device
   int policy_split = -1; // -1 automatic, 0 every member evaluates the whole policy, 1 the split whenever the shape allows it
   int fwd_lean = -1;     // -1 / 1 the latency-lean kernel wherever it applies, 0 never
-  int row_split = -1;    // -1 automatic, 0 one workgroup per (tile, GP range), 1 two (row halves of Kinv) whenever the shape allows it
+  int row_split = -1;    // -1 automatic, 0 one workgroup per (tile, GP range), 2 / 3 that many (row parts of Kinv) whenever the shape allows it
+  int cluster_map = -1;  // -1 automatic, 0 the members of a tile on one XCD, 1 row part major (FwdArgs.gsh_map)
   unsigned long long* stamps = nullptr;
   unsigned stamp_block = 0;
   int last_ppw = 0, last_sharded = 0, last_lean = 0, last_row_split = 0;  // report
@@ -1207,7 +1215,8 @@ static FwdHooks fwd_hooks(const mcp_dispatch* d) {
     h.gp_sharding = d->gp_sharding == 1 ? 0 : (d->gp_sharding == 2 ? 1 : -1);
     h.policy_split = d->policy_split == 1 ? 0 : (d->policy_split == 2 ? 1 : -1);
     h.fwd_lean = d->fwd_lean == 1 ? 0 : -1;
-    h.row_split = d->row_split == 1 ? 0 : (d->row_split == 2 ? 1 : -1);
+    h.row_split = d->row_split == 1 ? 0 : ((d->row_split == 2 || d->row_split == 3) ? d->row_split : -1);
+    h.cluster_map = d->cluster_map == 1 ? 0 : (d->cluster_map == 2 ? 1 : -1);
     h.stamps = (unsigned long long*)d->fwd_stamps;
     h.stamp_block = d->stamp_block;
   }
@@ -1331,6 +1340,7 @@ static int rollout_fwd_impl(const mcp_model* model, const mcp_policy* policy, co
   a.gsh_cs = 0;
   a.uxch = nullptr;
   a.gsh_rs = 1;
+  a.gsh_map = 0;
   a.rxch = nullptr;
   hipStream_t st = (hipStream_t)stream;
   // configuration search: most particles per workgroup first, operands in LDS if they fit, all GPs per pass if they fit
@@ -1419,25 +1429,35 @@ static int rollout_fwd_impl(const mcp_model* model, const mcp_policy* policy, co
          // (profiles/r04_ur5_script_stamps.txt: V 50 k of 112 k cycles per step).  Wide classes with the per-tile phase J only (degree <= 1).
         const size_t roff = rollout_xch_bytes(M, model->G) + rollout_xj_bytes(model) + rollout_kt_bytes(model) + rollout_uxch_bytes(M, model->G, model->U);
         const size_t rb = rollout_rxch_bytes(model, M);
-        const bool can = a.xj && a.maxdeg <= 1 && a.NpadMax >= 128 && rb > 0 && workspace_bytes >= roff + rb &&
-                         ((ncl + 7) / 8) * 8 * a.gsh_cs * 2 <= device_cu_count();
+        // Round 6: THREE row parts where three times the grid is resident (13 x 6 x 3 = 234), and the workgroups dealt row part major
+        // (FwdArgs.gsh_map): one workgroup per CU, at most 32 per XCD -- the grid is rounded up to a multiple of 8, the XCDs take its blocks in turn.
+        const bool can = a.xj && a.maxdeg <= 1 && a.NpadMax >= 128 && rb > 0 && workspace_bytes >= roff + rb;
+        const int cus = device_cu_count();
+        const int map = hk.cluster_map < 0 ? MCP_ROW_PART_MAJOR_DEFAULT : hk.cluster_map;
+        auto resident = [&](int rs) { return map == 1 ? ((ncl * a.gsh_cs * rs + 7) / 8) * 8 <= cus : ((ncl + 7) / 8) * 8 * a.gsh_cs * rs <= cus && ((ncl + 7) / 8) * a.gsh_cs * rs <= cus / 8; };
         if (can && hk.row_split != 0) {
-          a.gsh_rs = 2;
-          a.rxch = (unsigned long long*)((char*)workspace + roff);
-          if (hipMemsetAsync(a.rxch, 0, rb, st) != hipSuccess) return MCP_ERR_LAUNCH;
+          const int want = hk.row_split < 0 ? MCP_ROW_PARTS_DEFAULT : hk.row_split;
+          const int rs = (want >= 3 && resident(3)) ? 3 : (resident(2) ? 2 : 1);
+          if (rs > 1) {
+            a.gsh_rs = rs;
+            a.gsh_map = map;
+            a.rxch = (unsigned long long*)((char*)workspace + roff);
+            if (hipMemsetAsync(a.rxch, 0, rb, st) != hipSuccess) return MCP_ERR_LAUNCH;
+          }
         }
       }
       const int rc = launch_fwd_tile_sharded(a, st);
       if (rc == MCP_OK) {
         hk.last_ppw = 16;
         hk.last_sharded = 1;
-        hk.last_row_split = a.gsh_rs > 1 ? 1 : 0;
+        hk.last_row_split = a.gsh_rs > 1 ? a.gsh_rs : 0;
         return MCP_OK;
       }
       if (rc != MCP_ERR_LIMIT) return rc;
       a.xch = nullptr;
       a.uxch = nullptr;
       a.gsh_rs = 1;
+      a.gsh_map = 0;
       a.rxch = nullptr;
       a.nclusters = 0;
     }

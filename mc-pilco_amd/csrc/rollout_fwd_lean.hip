@@ -1089,6 +1089,9 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
     RL_STAMP(3);
     // ---- phase V, second half: v = Kinv k on the 4x4x4 MFMA, then the phase-J weights of this wave's rows ----
     const unsigned long long tv0_ = stamping ? clock64() : 0;
+#ifdef RLX_PRIO  // experiment: issue priority for the waves that end the phase (1: the younger wave of every SIMD, 2: the waves with three row tiles)
+    if (RLX_PRIO == 1 ? wv >= 4 : vnrt >= 3) __builtin_amdgcn_s_setprio(2);
+#endif
     if (vnrt > 0) {
       double jacc[NCG][2];  // this wave's partial tile of phase J (both segments)
 #pragma unroll
@@ -1123,6 +1126,9 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_lat_kernel(FwdArgs a) {
 #pragma unroll
       for (int g = 0; g < NCG; ++g) red[(wv * NCG + g) * 64 + lane] = 0.0;  // (a wave without rows)
     }
+#ifdef RLX_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     lds_barrier();  // B4
     RL_STAMP(6);
     if (wv == 0) {

@@ -64,8 +64,13 @@ struct FwdArgs {
   // GP-sharded 16-particle kernel, round 5: gsh_rs = 2 puts TWO workgroups on every (tile, GP range), each with one half of the rows of Kinv
   // (phases V and J over its own rows; phase K, the small one, in both).  The half that does not finish the GP (half 0) sends its partial sums
   // of phase F -- two doubles per (particle, column c <= D) -- to the one that does (half 1 = gsh_rs - 1, which adds own + partner in that order):
-  //   rxch[cluster][t & 1][g][p * (D + 1) + c][2 values][half]   (granules, zeroed per launch; gsh_rs <= 1: unused)
+  //   rxch[cluster][t & 1][g][sender][2 values][half][p * (D + 1) + c]   (granules, zeroed per launch; gsh_rs <= 1: unused)
+  // Round 6: gsh_rs = 3 -- three row parts, two senders (the part with the last rows finishes and adds own + sender 0 + sender 1) -- where three
+  // times the grid is still resident (the UR5 script's M = 200: 13 tiles x 6 GPs x 3 = 234 workgroups).  gsh_map = 1 deals the workgroups
+  // ROW PART major: the ceil(n / 8) blocks of an XCD are consecutive items of the order (member, row part, tile) -- an XCD's L2 then holds the
+  // rows of Kinv of two or three (GP, row part) pairs instead of every GP's (gsh_map = 0: all members of a tile on one XCD, round 5).
   int gsh_rs;
+  int gsh_map;
   unsigned long long* rxch;
   int operands_packed;  // host side only: bit 0 -- `kt` holds this model's tiles already, bit 1 -- `xj` does (MCP_FWD_KT_PACKED / MCP_FWD_XJ_PACKED)
   int m_off, m_cnt;  // the particles [m_off, m_off + m_cnt) of the swarm that this launch covers (a swarm too large for one

@@ -1006,7 +1006,15 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
   if (GSH) {  // blocks b and b + 8 share an XCD: the members of a cluster sit 8 apart (speed only)
     const int CW = CS * RS;  // workgroups per cluster
     const int b = blockIdx.x, grp = b / (8 * CW), r = b - grp * 8 * CW;
-    if (RS > 1) {
+    if (RSP && a.gsh_map == 1) {
+      // row part major (round 6): XCD x = the blocks b = x (mod 8) hosts the items [x per, (x + 1) per) of the order ((member, row part), tile)
+      const int per = (int)gridDim.x >> 3, j = (b & 7) * per + (b >> 3);
+      if (j >= CW * a.nclusters) return;
+      const int combo = j / a.nclusters;
+      cluster = j - combo * a.nclusters;
+      myc = combo / RS;
+      hrow = combo - myc * RS;
+    } else if (RS > 1) {
       // the two halves of a GP range are neighbours in the member order: with one cluster per XCD they share its L2, as the CS members did
       const int mt = r >> 3;
       cluster = grp * 8 + (r & 7);
@@ -1376,7 +1384,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           if (pb < 0) continue;
           v4d te = (v4d){0.0, 0.0, 0.0, 0.0}, to = (v4d){0.0, 0.0, 0.0, 0.0};
           #ifdef TLX_VDEPTH3
-          tile_v_block<CLS == 0 ? 3 : 2>(gp.Kinv, Npad, (vb0 + pb) * 32, pjs, pje, kv, lane, te, to);
+          tile_v_block<(CLS == 0 || (TLX_VDEPTH3 + 0) > 1) ? 3 : 2>(gp.Kinv, Npad, (vb0 + pb) * 32, pjs, pje, kv, lane, te, to);  // (-DTLX_VDEPTH3=2: every class)
 #else
           tile_v_block<2>(gp.Kinv, Npad, (vb0 + pb) * 32, pjs, pje, kv, lane, te, to);
 #endif
@@ -1486,7 +1494,7 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         // boils its share down to two values -- c < D: the mean-Jacobian difference and the variance-Jacobian sum; c == D: k^T Kinv k and (degree 0)
         // the mean -- the half that does NOT finish the GP (half 0: `!fin`) sends them (4 granules), the finishing half (half 1 = RS - 1: `fin`, the
         // one with the larger share of the blocks) adds them to its own (own + partner: fixed order) and finishes as the one-workgroup form does.
-        gu64_t rxb = (gu64_t)a.rxch + ((size_t)((cluster * 2 + (t & 1)) * G + g)) * (size_t)(P * (D + 1) * 4);
+        gu64_t rxb = (gu64_t)a.rxch + ((size_t)((cluster * 2 + (t & 1)) * G + g)) * (size_t)(2 * P * (D + 1) * 4);  // [sender < 2][4][nit]
         const bool rs_dbg = a.stamps && blockIdx.x == a.stamp_block && tid == 0;  // diagnostic: slots 9 (my sums), 10 (partner poll), 11 (finish), 14 (end of J to the end of the hand-off)
         unsigned long long rs_t0 = rs_dbg ? clock64() : 0;
         // One pass: P (D + 1) <= 16 x 25 items on 512 threads (this class has D <= 24).  k^T Kinv k and k(z, z) of a particle are sums over the
@@ -1531,14 +1539,20 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
         // granule (value q, half h) of item `it` sits at [2 q + h][it]: every store / load instruction of a wave covers 64 consecutive granules.
         // The finishing half asks for its partner's values -- the two of this item and its k^T Kinv k of this particle -- BEFORE it adds up its own:
         // the partner is half a block ahead, its granules are usually there and the round trip runs under the sums below.
-        gu64_t sl = rxb + it;
+        // (three row parts: the senders 0 and 1 own a block of 4 nit granules each)
+        gu64_t sl = rxb + (fin ? 0 : hrow * 4 * nit) + it;
         gu64_t sk = rxb + (p * (D + 1) + D);
-        unsigned long long x[6] = {0, 0, 0, 0, 0, 0};
+        unsigned long long x[2][6] = {{0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0}};
         auto ask = [&]() {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) x[q] = __hip_atomic_load(sl + q * nit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          x[4] = __hip_atomic_load(sk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          x[5] = __hip_atomic_load(sk + nit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int sd = 0; sd < 2; ++sd) {
+            if (sd < RS - 1) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) x[sd][q] = __hip_atomic_load(sl + (sd * 4 + q) * nit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              x[sd][4] = __hip_atomic_load(sk + sd * 4 * nit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              x[sd][5] = __hip_atomic_load(sk + (sd * 4 + 1) * nit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
         };
         if (fin && act) ask();
         double kzz = gp.lambda;
@@ -1572,16 +1586,27 @@ __global__ __launch_bounds__(RF_NT) void rollout_fwd_tile_kernel(FwdArgs a) {
           for (unsigned spins = 0; spins < RF_SPIN_LIMIT; ++spins) {
             ok = true;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) ok = ok && (unsigned)(x[q] >> 32) == (unsigned)t + 1u;
+            for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+              for (int q = 0; q < 6; ++q) ok = ok && (sd >= RS - 1 || (unsigned)(x[sd][q] >> 32) == (unsigned)t + 1u);
             if (ok) break;
             __builtin_amdgcn_s_sleep(2);
             ask();
           }
           if (!ok) *abortw = 1;
           if (rs_dbg) { const unsigned long long now = clock64(); a.stamps[10] += now - rs_t0; rs_t0 = now; }
-          const double q0 = __longlong_as_double((long long)((x[1] << 32) | (x[0] & 0xffffffffull)));
-          const double q1 = __longlong_as_double((long long)((x[3] << 32) | (x[2] & 0xffffffffull)));
-          const double qk = __longlong_as_double((long long)((x[5] << 32) | (x[4] & 0xffffffffull)));
+          // own + sender 0 (+ sender 1), in that order: the senders' values are folded into the own ones here, the formulas below stay the two-part ones
+          double q0 = __longlong_as_double((long long)((x[0][1] << 32) | (x[0][0] & 0xffffffffull)));
+          double q1 = __longlong_as_double((long long)((x[0][3] << 32) | (x[0][2] & 0xffffffffull)));
+          double qk = __longlong_as_double((long long)((x[0][5] << 32) | (x[0][4] & 0xffffffffull)));
+          if (RS > 2) {  // (uniform)
+            v0 += q0;
+            v1 += q1;
+            ktv += qk;
+            q0 = __longlong_as_double((long long)((x[1][1] << 32) | (x[1][0] & 0xffffffffull)));
+            q1 = __longlong_as_double((long long)((x[1][3] << 32) | (x[1][2] & 0xffffffffull)));
+            qk = __longlong_as_double((long long)((x[1][5] << 32) | (x[1][4] & 0xffffffffull)));
+          }
           const double var = (kzz - (ktv + qk)) * vscale;
           double eps = 0.0, wj = 0.0, sd = 0.0;
           if (a.particle_pred) {
@@ -1792,7 +1817,8 @@ static int launch_tile_pms(const FwdArgs& a, size_t lds, hipStream_t st) {
 template <int MAXDEG, int CLS, bool PMS, bool XL>
 static int launch_tile_gsh(const FwdArgs& a, size_t lds, hipStream_t st) {
   MCP_ENSURE_MAX_LDS(rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true, XL>);
-  const int grid = ((a.nclusters + 7) / 8) * 8 * a.gsh_cs * (a.gsh_rs > 1 ? a.gsh_rs : 1);
+  const int rs = a.gsh_rs > 1 ? a.gsh_rs : 1;
+  const int grid = a.gsh_map == 1 ? ((a.nclusters * a.gsh_cs * rs + 7) / 8) * 8 : ((a.nclusters + 7) / 8) * 8 * a.gsh_cs * rs;
   hipLaunchKernelGGL((rollout_fwd_tile_kernel<MAXDEG, CLS, PMS, true, XL>), dim3(grid), dim3(RF_NT), lds, st, a);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
@@ -1851,7 +1877,8 @@ int launch_fwd_tile_sharded(const FwdArgs& a, hipStream_t st) {
   if (a.NpadMax > 512) return MCP_ERR_LIMIT;
   const int cls = (D <= 7 && PF <= 8 && U <= 2) ? 0 : ((D <= 24 && PF <= 24 && U <= 6) ? 1 : 2);
   if (cls == 2) return MCP_ERR_LIMIT;
-  if (a.gsh_rs > 1 && (a.gsh_rs != 2 || cls == 0 || a.maxdeg > 1 || !a.xj || !a.rxch || TL_PT * (D + 1) > RF_NT)) return MCP_ERR_ARG;  // (the row split exists in the per-tile form of phase J only)
+  if (a.gsh_map == 1 && (a.gsh_rs < 2 || cls == 0 || a.maxdeg > 1)) return MCP_ERR_ARG;  // (the row-part-major deal exists where the row split does)
+  if (a.gsh_rs > 1 && (a.gsh_rs > 3 || cls == 0 || a.maxdeg > 1 || !a.xj || !a.rxch || TL_PT * (D + 1) > RF_NT)) return MCP_ERR_ARG;  // (the row split exists in the per-tile form of phase J only)
   if (tile_xj_pack(a, st) != MCP_OK) return MCP_ERR_LAUNCH;
   switch (cls * 3 + a.maxdeg) {
     case 0: return launch_tile_gsh_deg<0, 0>(a, st);

@@ -87,7 +87,7 @@ class Cost(C.Structure):
 class Dispatch(C.Structure):
     """include/mcpilco_hip_debug.h: struct mcp_dispatch -- the request a call carries (all zero = automatic) and what it reports back."""
     _fields_ = [("fwd_particles", C.c_int32), ("gp_sharding", C.c_int32), ("fwd_lean", C.c_int32), ("policy_split", C.c_int32), ("row_split", C.c_int32),
-                ("fwd_no_xlds", C.c_int32),
+                ("cluster_map", C.c_int32), ("fwd_no_xlds", C.c_int32),
                 ("fwd_gb", C.c_int32), ("bwd_particles", C.c_int32), ("bwd_lean", C.c_int32), ("chol_form", C.c_int32), ("stamp_block", C.c_uint32),
                 ("fwd_stamps", dptr), ("bwd_stamps", dptr), ("ran_particles", C.c_int32), ("ran_gp_sharded", C.c_int32), ("ran_fwd_lean", C.c_int32),
                 ("ran_bwd_lean", C.c_int32), ("ran_row_split", C.c_int32)]
@@ -207,8 +207,11 @@ class _Lib:
     def mcp_debug_set_policy_split(self, mode):  # -1 automatic, 0 off, 1 whenever the shape allows
         DISPATCH.policy_split = {-1: 0, 0: 1, 1: 2}[int(mode)]
 
-    def mcp_debug_set_row_split(self, mode):  # -1 automatic, 0 off, 1 whenever the shape allows
-        DISPATCH.row_split = {-1: 0, 0: 1, 1: 2}[int(mode)]
+    def mcp_debug_set_row_split(self, mode):  # -1 automatic, 0 off, 1 / 2 two row parts whenever the shape allows, 3 three
+        DISPATCH.row_split = {-1: 0, 0: 1, 1: 2, 2: 2, 3: 3}[int(mode)]
+
+    def mcp_debug_set_cluster_map(self, mode):  # -1 automatic, 0 the workgroups of a tile on one XCD, 1 row part major
+        DISPATCH.cluster_map = {-1: 0, 0: 1, 1: 2}[int(mode)]
 
     def mcp_debug_last_row_split(self):
         return int(DISPATCH.ran_row_split)

@@ -95,7 +95,7 @@ def test_argument_validation_without_gpu():
         m.gp[g].Npad = 400
     p.P, p.B, p.U = 24, 8, 6  # (tiny policy: the backward slabs stay below the forward part)
     xch = ((16 + 16) * 2 * 6 * 2 * 8 + 15) & ~15
-    rxch = 1 * 2 * 6 * 16 * 25 * 4 * 8  # (round 5: the row-split cluster's partial sums -- tiles x 2 x G x 16 x (D + 1) x 2 values x 2 granules)
+    rxch = 1 * 2 * 6 * 2 * 16 * 25 * 4 * 8  # (the row-split cluster's partial sums -- tiles x 2 x G x 2 senders x 16 x (D + 1) x 2 values x 2 granules)
     assert lib.mcp_rollout_workspace_bytes(C.byref(m), C.byref(p), 16, 5) == max(xch + 6 * 2 * 2 * 50 * 64 * 2 * 8 + rxch, 8 * (24 + 8 * 24 + 6 * 8 + 6) * 16)
     c = hipabi.Cost()
     c.kind, c.S = 7, 4

@@ -336,15 +336,20 @@ def test_policy_split_over_the_cluster_of_the_gp_sharded_tile_kernel(key, mode):
         assert float((out[1][0].cpu() - o["states"]).abs().max()) < 1e-9 and float((out[1][1].cpu() - o["inputs"]).abs().max()) < 2e-9
 
 
+ROW_SPLIT_FORMS = [(2, 0), (2, 1), (3, 1)]  # (row parts, deal of the workgroups: 0 a tile's members on one XCD, 1 row part major -- round 6)
+
+
 @pytest.mark.parametrize("key", ["ur5_400", "ur5se_400"])
 @pytest.mark.parametrize("mode", ["masks", "philox"])
-def test_row_split_cluster_of_the_gp_sharded_tile_kernel(key, mode):
+@pytest.mark.parametrize("parts,cmap", ROW_SPLIT_FORMS)
+def test_row_split_cluster_of_the_gp_sharded_tile_kernel(key, mode, parts, cmap):
     """Round 5: small swarms of the wide class (the UR5 launch script's M = 200: 13 tiles x 6 GPs on 256 CUs) run TWO workgroups per (tile, GP), one
     per half of the rows of Kinv (`FwdArgs.gsh_rs`, phases V and J over the member's own rows, the partial sums of phase F handed to the half that
     finishes the GP through `FwdArgs.rxch`).  Same states / inputs / Jacobians as one workgroup per (tile, GP) (`mcp_debug_set_row_split(0)`) up to
     the summation order over the training points, identical noise and dropout bits in Philox mode, bitwise reproducible; with recorded masks
     against the oracle at 1e-9 (states, inputs) and 1e-9 relative (gradients through the stored Jacobians).  SE + polynomial(1) and SE alone (both
-    instantiations that carry the split)."""
+    instantiations that carry the split).  Round 6: three row parts (two senders, the finishing part adds own + sender 0 + sender 1) and the
+    row-part-major deal of the workgroups, each against the same one-workgroup form and the oracle."""
     from gpu_helpers import dev, forced_variant
     from mc_pilco_amd import hipabi, ops
 
@@ -357,14 +362,15 @@ def test_row_split_cluster_of_the_gp_sharded_tile_kernel(key, mode):
     L = hipabi.lib()
     out = {}
     try:
+        L.mcp_debug_set_cluster_map(cmap)
         for split in (1, 0, 1):
-            L.mcp_debug_set_row_split(1 if split else 0)
+            L.mcp_debug_set_row_split(parts if split else 0)
             for q in w.params:
                 q.grad = None
             with forced_variant(116) as fv:
                 st, inp, status = ops.rollout(w.model, w.policy, nz, o["x0"].to(dev()), w.T, o["p"])
                 assert L.mcp_debug_last_gp_sharded() == 1, "the shape was expected to run GP-sharded"
-                assert L.mcp_debug_last_row_split() == split
+                assert L.mcp_debug_last_row_split() == (parts if split else 0)
                 c, _ = ops.expected_cost(w.cost, st)
                 c.backward()
             assert int(status.item()) == 0
@@ -375,10 +381,11 @@ def test_row_split_cluster_of_the_gp_sharded_tile_kernel(key, mode):
             out[split] = res
     finally:
         L.mcp_debug_set_row_split(-1)
+        L.mcp_debug_set_cluster_map(-1)
     es = float((out[1][0] - out[0][0]).abs().max())
     eu = float((out[1][1] - out[0][1]).abs().max())
     eg = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(out[1][2], out[0][2]))
-    print("row split vs one workgroup per GP (%s, %s): states %.2e inputs %.2e grads rel %.2e" % (key, mode, es, eu, eg))
+    print("row split (%d parts, deal %d) vs one workgroup per GP (%s, %s): states %.2e inputs %.2e grads rel %.2e" % (parts, cmap, key, mode, es, eu, eg))
     assert float((out[1][1][0] - out[0][1][0]).abs().max()) == 0.0  # the first step's inputs come before any GP
     assert es < 2e-9 and eu < 4e-9 and eg < 1e-8
     assert not torch.equal(out[1][1], torch.zeros_like(out[1][1]))
@@ -392,7 +399,8 @@ def test_row_split_cluster_of_the_gp_sharded_tile_kernel(key, mode):
 
 @pytest.mark.parametrize("name,N,M,T", [("ur5_script", 150, 40, 5), ("ur5_script", 448, 24, 4), ("ur5_se", 272, 200, 4), ("ur5_script", 400, 200, 3),
                                         ("ur5_script", 128, 17, 6)])
-def test_row_split_cluster_block_shares(name, N, M, T):
+@pytest.mark.parametrize("parts,cmap", ROW_SPLIT_FORMS)
+def test_row_split_cluster_block_shares(name, N, M, T, parts, cmap):
     """The row-split cluster over the block counts a training set can leave: Npad = 160 (5 blocks of 32 rows: 2 + 3), 448 (14: 7 + 7, the largest
     this class's k / v panels leave room for), 272 (8.5: 4 + 5 with a half-empty last block), 400 (12.5: 6 + 7, the launch script's 13 tiles with a ragged last one), 128
     (4: 2 + 2, one particle in the last tile).  On-device noise: the split and the one-workgroup form draw the same dropout bits and increments,
@@ -407,13 +415,14 @@ def test_row_split_cluster_block_shares(name, N, M, T):
     L = hipabi.lib()
     out = {}
     try:
+        L.mcp_debug_set_cluster_map(cmap)
         for split in (1, 0):
-            L.mcp_debug_set_row_split(split)
+            L.mcp_debug_set_row_split(parts if split else 0)
             for q in w.params:
                 q.grad = None
             with forced_variant(116):
                 st, inp, status = ops.rollout(w.model, w.policy, ops.NoiseSpec(seed=5, call=1), x0, w.T, w.p_drop)
-                assert L.mcp_debug_last_gp_sharded() == 1 and L.mcp_debug_last_row_split() == split
+                assert L.mcp_debug_last_gp_sharded() == 1 and L.mcp_debug_last_row_split() == (parts if split else 0)
                 c, _ = ops.expected_cost(w.cost, st)
                 c.backward()
             assert int(status.item()) == 0

@@ -146,6 +146,40 @@ __global__ __launch_bounds__(512) void rate(int mode, int nit, double* out, unsi
       }
     }
     s0 = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+  } else if (mode >= 9 && mode <= 14) {
+    // round 6: what separates the 8.2 cycles per SIMD of mode 0 from the 17.3 phase V of the lean kernel sees (tools/vissue_bench.hip)?  The number of
+    // accumulators in rotation (NA) and the number of distinct operand registers (NO A operands, NO / 2 B operands), separately
+    //   9: NA 4, 4 operand registers    10: NA 8, 12 + 6 distinct    11: NA 4, 12 + 6 (the kernel at two row tiles)    12: NA 6, 12 + 6 (three row tiles)
+    //  13: NA 12, 12 + 6                14: NA 2, 12 + 6
+    double A[12], B[6], c[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { A[i] = x + 0.01 * i; c[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) B[i] = y + 0.02 * i;
+    const int NA = mode == 9 ? 4 : (mode == 10 ? 8 : (mode == 11 ? 4 : (mode == 12 ? 6 : (mode == 13 ? 12 : 2))));
+    for (int it = 0; it < nit; ++it) {
+      if (mode == 9) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { MFI(c[0], x, y); MFI(c[1], x1, y); MFI(c[2], y, x); MFI(c[3], y1, x); }
+      } else if (NA == 8) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) MFI(c[u % 8], A[u % 12], B[(u / 2) % 6]);
+      } else if (NA == 4) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) MFI(c[u % 4], A[u % 12], B[(u / 2) % 6]);
+      } else if (NA == 6) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) MFI(c[u % 6], A[u % 12], B[(u / 3) % 6]);
+      } else if (NA == 12) {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) MFI(c[u % 12], A[u % 12], B[(u / 2) % 6]);
+      } else {
+#pragma unroll
+        for (int u = 0; u < 32; ++u) MFI(c[u % 2], A[u % 12], B[(u / 2) % 6]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s0 += c[i];
   } else {  // dependent chain of 4x4x4 on one accumulator
     for (int it = 0; it < nit; ++it) {
 #pragma unroll
@@ -184,9 +218,9 @@ int main() {
   double* out; unsigned long long* cyc;
   hipMalloc(&out, 512 * 512 * 8); hipMalloc(&cyc, 64);
   const int nit = 200;
-  const char* names[9] = {"4x4x4_4b, 8 independent accumulators", "16x16x4, 4 independent accumulators", "4x4x4_4b, one dependent chain",
-                          "4x4x4_4b, 8 acc + 6 v_mov_b32_dpp per 8", "4x4x4_4b, 8 acc + one LDS read per 8", "4x4x4_4b, 8 acc + one v_add_u32 per MFMA", "4x4x4_4b, 16 acc, 4 A x 4 B operands", "4x4x4_4b, 8 acc, result register != addend register", "4x4x4_4b, 8 acc in place (inline asm)"};
-  for (int mode = 0; mode < 9; ++mode) {
+  const char* names[15] = {"4x4x4_4b, 8 independent accumulators", "16x16x4, 4 independent accumulators", "4x4x4_4b, one dependent chain",
+                          "4x4x4_4b, 8 acc + 6 v_mov_b32_dpp per 8", "4x4x4_4b, 8 acc + one LDS read per 8", "4x4x4_4b, 8 acc + one v_add_u32 per MFMA", "4x4x4_4b, 16 acc, 4 A x 4 B operands", "4x4x4_4b, 8 acc, result register != addend register", "4x4x4_4b, 8 acc in place (inline asm)", "4 acc, 4 operand registers", "8 acc, 12 A + 6 B distinct operand registers", "4 acc, 12 A + 6 B", "6 acc, 12 A + 6 B", "12 acc, 12 A + 6 B", "2 acc, 12 A + 6 B"};
+  for (int mode = 0; mode < 15; ++mode) {
     hipLaunchKernelGGL(rate, dim3(256), dim3(512), 0, 0, mode, nit, out, cyc);
     hipLaunchKernelGGL(rate, dim3(256), dim3(512), 0, 0, mode, nit, out, cyc);
     hipDeviceSynchronize();
