@@ -23,8 +23,11 @@ done
 for w in c1 c1_script c2_script pms_script pms_script_n450 ur5_script c3 c5; do
   run "$w stamps" python3 $R/tools/phase_stamps.py $w > "$OUT/${w}_stamps.txt" 2>&1
 done
-# the finishing half of a row-split pair (round 5: block 8 = cluster 0, GP 0, rows 192..399; block 0 above is the half that sends its sums)
-echo "[$(date +%T)] ur5_script stamps, finishing half"; MCP_STAMP_BLOCK=8 python3 $R/tools/phase_stamps.py ur5_script > "$OUT/ur5_script_half1_stamps.txt" 2>&1 || exit 1
+# the finishing part of a row-split cluster (round 6, three row parts dealt row part major: block 208 = item 26 = tile 0, GP 0, the last rows; block 0
+# above is the first sender).  Then the forward time of every form of the cluster (tools/row_split_soak.py) and the 4x4x4 MFMA probes.
+echo "[$(date +%T)] ur5_script stamps, finishing part"; MCP_STAMP_BLOCK=208 python3 $R/tools/phase_stamps.py ur5_script > "$OUT/ur5_script_half1_stamps.txt" 2>&1 || exit 1
+run "row split forms" python3 $R/tools/row_split_soak.py 20 > "$OUT/ur5_row_split_forms.txt" 2>&1
+( hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma4x4_probe $R/tools/mfma4x4_probe.hip && /tmp/mfma4x4_probe && hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_bank_probe $R/tools/mfma_bank_probe.hip && /tmp/mfma_bank_probe ) > "$OUT/mfma4x4_probe.txt" 2>&1 || exit 1
 for w in c1 c3 c5; do
   st=4; [ $w = c5 ] && st=2
   run "$w fetch" rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/${w}_fetch" -o $w -- $B --workload $w --steps $st --warmup 1 > "$OUT/${w}_fetch.log" 2>&1
