@@ -1,3 +1,5 @@
+// (The last column: the same run on the wall clock.  All 256 CUs issuing fp64 MFMAs back to back run at about half the clock the rollout kernels see --
+//  64 flop per cycle and SIMD, 78 TFLOP/s = the datasheet figure on the wall clock.)
 // Does the register BANK of its operands decide the issue rate of v_mfma_f64_4x4x4_4b_f64 on gfx950?  (round 6; tools/mfma4x4_probe.hip: 8.2 cycles per
 // SIMD with four operand registers used over and over, 17.8 with 12 + 6 distinct ones -- the lean kernel's phase V streams fresh operands.)
 // Eight accumulators in rotation, 12 A operands, 6 B operands, every register pair placed by hand: pair at v[base + 4 i + off], off = 0 -> banks 0, 1,
@@ -143,6 +145,40 @@
   MF(5, 5, 2, 2, 0, 0) \
   MF(6, 6, 3, 0, 2, 2) \
   MF(7, 7, 3, 2, 0, 2)
+// v_mfma_f64_16x16x4_f64, four accumulators of eight registers in rotation, the same fresh operands
+#define BODY16(AO, BO, CO) \
+  "v_mfma_f64_16x16x4_f64 v[200+0*8:200+0*8+7], v[100+0*4:100+0*4+1], v[160+0*4:160+0*4+1], v[200+0*8:200+0*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+1*8:200+1*8+7], v[100+1*4:100+1*4+1], v[160+0*4:160+0*4+1], v[200+1*8:200+1*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+2*8:200+2*8+7], v[100+2*4:100+2*4+1], v[160+1*4:160+1*4+1], v[200+2*8:200+2*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+3*8:200+3*8+7], v[100+3*4:100+3*4+1], v[160+1*4:160+1*4+1], v[200+3*8:200+3*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+0*8:200+0*8+7], v[100+4*4:100+4*4+1], v[160+2*4:160+2*4+1], v[200+0*8:200+0*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+1*8:200+1*8+7], v[100+5*4:100+5*4+1], v[160+2*4:160+2*4+1], v[200+1*8:200+1*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+2*8:200+2*8+7], v[100+6*4:100+6*4+1], v[160+3*4:160+3*4+1], v[200+2*8:200+2*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+3*8:200+3*8+7], v[100+7*4:100+7*4+1], v[160+3*4:160+3*4+1], v[200+3*8:200+3*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+0*8:200+0*8+7], v[100+8*4:100+8*4+1], v[160+4*4:160+4*4+1], v[200+0*8:200+0*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+1*8:200+1*8+7], v[100+9*4:100+9*4+1], v[160+4*4:160+4*4+1], v[200+1*8:200+1*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+2*8:200+2*8+7], v[100+10*4:100+10*4+1], v[160+5*4:160+5*4+1], v[200+2*8:200+2*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+3*8:200+3*8+7], v[100+11*4:100+11*4+1], v[160+5*4:160+5*4+1], v[200+3*8:200+3*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+0*8:200+0*8+7], v[100+0*4:100+0*4+1], v[160+0*4:160+0*4+1], v[200+0*8:200+0*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+1*8:200+1*8+7], v[100+1*4:100+1*4+1], v[160+0*4:160+0*4+1], v[200+1*8:200+1*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+2*8:200+2*8+7], v[100+2*4:100+2*4+1], v[160+1*4:160+1*4+1], v[200+2*8:200+2*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+3*8:200+3*8+7], v[100+3*4:100+3*4+1], v[160+1*4:160+1*4+1], v[200+3*8:200+3*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+0*8:200+0*8+7], v[100+4*4:100+4*4+1], v[160+2*4:160+2*4+1], v[200+0*8:200+0*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+1*8:200+1*8+7], v[100+5*4:100+5*4+1], v[160+2*4:160+2*4+1], v[200+1*8:200+1*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+2*8:200+2*8+7], v[100+6*4:100+6*4+1], v[160+3*4:160+3*4+1], v[200+2*8:200+2*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+3*8:200+3*8+7], v[100+7*4:100+7*4+1], v[160+3*4:160+3*4+1], v[200+3*8:200+3*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+0*8:200+0*8+7], v[100+8*4:100+8*4+1], v[160+4*4:160+4*4+1], v[200+0*8:200+0*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+1*8:200+1*8+7], v[100+9*4:100+9*4+1], v[160+4*4:160+4*4+1], v[200+1*8:200+1*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+2*8:200+2*8+7], v[100+10*4:100+10*4+1], v[160+5*4:160+5*4+1], v[200+2*8:200+2*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+3*8:200+3*8+7], v[100+11*4:100+11*4+1], v[160+5*4:160+5*4+1], v[200+3*8:200+3*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+0*8:200+0*8+7], v[100+0*4:100+0*4+1], v[160+0*4:160+0*4+1], v[200+0*8:200+0*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+1*8:200+1*8+7], v[100+1*4:100+1*4+1], v[160+0*4:160+0*4+1], v[200+1*8:200+1*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+2*8:200+2*8+7], v[100+2*4:100+2*4+1], v[160+1*4:160+1*4+1], v[200+2*8:200+2*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+3*8:200+3*8+7], v[100+3*4:100+3*4+1], v[160+1*4:160+1*4+1], v[200+3*8:200+3*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+0*8:200+0*8+7], v[100+4*4:100+4*4+1], v[160+2*4:160+2*4+1], v[200+0*8:200+0*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+1*8:200+1*8+7], v[100+5*4:100+5*4+1], v[160+2*4:160+2*4+1], v[200+1*8:200+1*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+2*8:200+2*8+7], v[100+6*4:100+6*4+1], v[160+3*4:160+3*4+1], v[200+2*8:200+2*8+7]\n" \
+  "v_mfma_f64_16x16x4_f64 v[200+3*8:200+3*8+7], v[100+7*4:100+7*4+1], v[160+3*4:160+3*4+1], v[200+3*8:200+3*8+7]\n"
 #define CLOB "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231"
 #define VARIANT(NAME, BODYM, AO, BO, CO)                                              \
   __device__ __forceinline__ void NAME(int nit) {                                      \
@@ -155,6 +191,7 @@ VARIANT(v_a0b0c2, BODY, 0, 0, 2)
 VARIANT(r_a0b2c0, BODYR, 0, 2, 0)
 VARIANT(r_a0b0c0, BODYR, 0, 0, 0)
 VARIANT(v_alt, BODYALT, 0, 0, 0)
+VARIANT(v_16, BODY16, 0, 0, 0)
 VARIANT(v_alt2, BODYALT2, 0, 0, 0)
 __global__ __launch_bounds__(512) void rate(int mode, int nit, unsigned long long* cyc) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -272,7 +309,8 @@ __global__ __launch_bounds__(512) void rate(int mode, int nit, unsigned long lon
   else if (mode == 4) r_a0b2c0(nit);
   else if (mode == 5) r_a0b0c0(nit);
   else if (mode == 6) v_alt(nit);
-  else v_alt2(nit);
+  else if (mode == 7) v_alt2(nit);
+  else v_16(nit);
   asm volatile("s_nop 15\ns_nop 15" ::: "memory");
   const unsigned long long t1 = clock64();
   if (lane == 0 && blockIdx.x == 0) cyc[wv] = t1 - t0;
@@ -281,16 +319,28 @@ int main() {
   unsigned long long* cyc;
   (void)hipMalloc(&cyc, 64);
   const int nit = 200;
-  const char* names[8] = {"fresh operands: A banks 0,1  B banks 2,3  C banks 0,1", "fresh operands: A, B, C all banks 0,1", "fresh operands: A banks 0,1  B, C banks 2,3",
-                          "fresh operands: A, B banks 0,1  C banks 2,3", "4 + 2 operand registers: A 0,1  B 2,3  C 0,1", "4 + 2 operand registers: all banks 0,1", "fresh operands, (A, B, C) banks (01, 23, 01) / (23, 01, 23) in turn", "fresh operands, A / B alternate, C alternates every second"};
-  for (int mode = 0; mode < 8; ++mode) {
+  const char* names[9] = {"fresh operands: A banks 0,1  B banks 2,3  C banks 0,1", "fresh operands: A, B, C all banks 0,1", "fresh operands: A banks 0,1  B, C banks 2,3",
+                          "fresh operands: A, B banks 0,1  C banks 2,3", "4 + 2 operand registers: A 0,1  B 2,3  C 0,1", "4 + 2 operand registers: all banks 0,1", "fresh operands, (A, B, C) banks (01, 23, 01) / (23, 01, 23) in turn", "fresh operands, A / B alternate, C alternates every second", "v_mfma_f64_16x16x4_f64, 4 accumulators, fresh operands"};
+  for (int mode = 0; mode < 9; ++mode) {
     hipLaunchKernelGGL(rate, dim3(256), dim3(512), 0, 0, mode, nit, cyc);
     hipLaunchKernelGGL(rate, dim3(256), dim3(512), 0, 0, mode, nit, cyc);
     (void)hipDeviceSynchronize();
     unsigned long long h[8];
     (void)hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);
     const double per_wave = (double)h[0] / (nit * 32.0);
-    printf("%-58s %6.1f cycles per instruction and wave, %5.1f per SIMD\n", names[mode], per_wave, per_wave / 2);
+    // the same on the wall clock (the cycle counter need not tick at the clock the matrix pipe runs at): 20 x the iterations between two events
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(rate, dim3(256), dim3(512), 0, 0, mode, 20 * nit, cyc);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (mode == 8 ? 2048.0 : 512.0) * 256.0 * 8.0 * 20.0 * nit * 32.0;
+    (void)hipMemcpy(h, cyc, 64, hipMemcpyDeviceToHost);  // (wave 0's cycle count of the long run: cycles / wall time = the clock the run had)
+    printf("%-58s %6.1f cycles per instruction and wave, %5.1f per SIMD | wall clock: %.3f ms, %.1f TFLOP/s on 256 CUs, %.2f GHz\n", names[mode], per_wave, per_wave / 2, ms,
+           flop / (ms * 1e-3) * 1e-12, (double)h[0] / (ms * 1e-3) * 1e-9);
   }
   return 0;
 }
