@@ -343,8 +343,9 @@ class Runner:
         if L.mcp_debug_last_fwd_lean():
             return "rollout_fwd_lat_kernel (GP-sharded)"
         name = "rollout_fwd_tile_kernel" if L.mcp_debug_last_particles_per_wg() == 16 else "rollout_fwd_kernel"
-        if L.mcp_debug_last_row_split():
-            return name + " (GP-sharded, two workgroups per (tile, GP) on row halves)"
+        rs = L.mcp_debug_last_row_split()
+        if rs:
+            return name + " (GP-sharded, %d workgroups per (tile, GP) on row parts of Kinv)" % rs
         return name + (" (GP-sharded)" if L.mcp_debug_last_gp_sharded() else "")
 
     def bwd_kernel_name(self):
@@ -378,7 +379,7 @@ class Runner:
                                "duration (HIP events on the launch stream around mcp_rollout_fwd; profiles/r06_*_kernel_stats.csv is the rocprofv3 "
                                "average of the same kernel); frac_step: fwd+bwd flops / ms_per_step",
              "regime": ("T-sequential chain of 4 barrier-separated phases per step + the per-CU L2->CU stream of one Kinv per workgroup and "
-                        "step; fp64 flop roof not reachable at M=400 (DESIGN.md 4.0)") if small else
+                        "step; fp64 flop roof not reachable at M=400 (DESIGN.md 4.1)") if small else
                        "fp64 matrix pipe (MFMA 16x16x4) beside VALU exp / Philox phases"}
         if traffic:
             gbps = traffic / (fwd_ms * 1e-3) / 1e9
