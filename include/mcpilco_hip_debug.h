@@ -28,6 +28,7 @@ typedef struct mcp_dispatch {
   int32_t fwd_gb;        /* small-tile kernel: GPs per pass (0 = as many as fit)                                                        */
   int32_t bwd_particles; /* backward sweep: particles per workgroup 1 / 2 / 4 / 8 (forces the general sweep)                            */
   int32_t bwd_lean;      /* the latency-lean sweep (rollout_bwd_lat_kernel): 1 never                                                    */
+  int32_t bwd_pipe;      /* general sweep, one particle per workgroup on the wide classes: 1 never the pipelined form (chain beside the RBF stage) */
   int32_t chol_form;     /* mcp_chol_factor / _inverse: 1 the round-1/2 kernels, 2 the round-3 one-workgroup forms, 3 the round-4 forms
                             with one-wave inverse columns (0: left-looking / panel factorisation, column-parallel / blocked inverse)     */
   uint32_t stamp_block;  /* which workgroup of the forward launch writes its stamps                                                     */
@@ -39,6 +40,7 @@ typedef struct mcp_dispatch {
   int32_t ran_fwd_lean;   /* 1: the lean forward kernel ran                                           */
   int32_t ran_bwd_lean;   /* 1: the lean backward sweep ran                                           */
   int32_t ran_row_split;  /* 2 / 3: the forward launch put that many workgroups on every (tile, GP range) */
+  int32_t ran_bwd_pipe;   /* 1: the general sweep ran in its pipelined form                              */
 } mcp_dispatch;
 
 int mcp_rollout_fwd_ex(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T, int particle_pred,

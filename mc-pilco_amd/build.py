@@ -10,7 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["gp_pretrain.hip", "rollout_fwd.hip", "rollout_fwd_lean.hip", "rollout_fwd_tile.hip", "rollout_bwd.hip", "cost.hip", "policy_opt.hip", "comm.hip"]
 HEADERS = [os.path.join(CSRC, "mcp_device.h"), os.path.join(CSRC, "rollout_common.h"), os.path.join(CSRC, "rollout_fwd_shared.h"),
-           os.path.join(os.path.dirname(HERE), "include", "mcpilco_hip.h")]
+           os.path.join(os.path.dirname(HERE), "include", "mcpilco_hip.h"),
+           os.path.join(os.path.dirname(HERE), "include", "mcpilco_hip_debug.h")]  # (mcp_dispatch: every translation unit must see the same layout)
 LIB = os.path.join(HERE, "libmcpilco_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -disable-machine-licm: the machine-level loop-invariant hoisting pulls the ~60 double-precision literals of exp / sincos / log /
@@ -66,7 +67,7 @@ def _sources_digest():
     import hashlib
 
     h = hashlib.sha256(" ".join(FLAGS).encode())
-    for f in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.join(os.path.dirname(HERE), "include", "mcpilco_hip_debug.h")]:
+    for f in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()

@@ -39,6 +39,7 @@ struct BwdArgs {
   double* g_x0;
   unsigned long long* stamps;  // diagnostic only: per-stage cycle totals of workgroup 0 (slots 8..11)
   int m_base, slab_accum;      // rollout_bwd_lat_kernel: first particle of this launch; its slabs add to what an earlier launch left
+  int pipe;                    // rollout_bwd_kernel, one particle per workgroup, register chain: wave 0 runs the chain only and the launch has a wave more (see PIPEC)
 };
 
 #define BW_STAMP(k)                                 \
@@ -131,6 +132,13 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   // bound with four 256-thread workgroups per CU and must stay within 128 registers for that: the chain's batch of operands then spills (24-40
   // VGPRs) and the gain measured 1.5 % (C3 backward 1.64 -> 1.62 ms) -- not kept; small swarms of the narrow class run rollout_bwd_lat_kernel.
   constexpr bool FASTCHAIN = !PMS && PFM > 8 && MAXNT <= 512;  // (the 1024-thread forms have 128 registers: the LDS-staged chain)
+  // Round 6, one particle per workgroup on the wide classes (the UR5 launch script's M = 200): the sweep was chain (wave 0, 4.4 k cycles) -> barrier ->
+  // RBF stage (5.2 k) -> park -> barrier per step.  With a wave more than the basis functions need (a.pipe) wave 0 owns NO basis function and the step
+  // becomes  [chain of step t on wave 0  |  the RBF waves: exp / Philox / distances of step t, park the record of t - 1]  -> barrier ->
+  // [the RBF waves: the adjoint half of step t  |  wave 0: sincos + policy features of step t - 1 from the parked record]  -> barrier:
+  // what does not depend on the adjoint runs beside the chain, and the chain starts from features prepared a step earlier.
+  constexpr bool PIPEC = PB == 1 && !PMS && PFM > 8 && MAXNT == 512;
+  const bool pipe = PIPEC && a.pipe != 0;  // (uniform)
   constexpr bool CENREG = PFM <= 8 && MAXNT <= 512;  // narrow policies keep their centres in registers; wider ones -- and the 1024-thread forms with their 128 registers -- in LDS (transposed: conflict-free)
   const BwdLayout L = bwd_layout(S, U, D, G, PF, NW, PB, pms, !CENREG);
   const int NR = bwd_rec_len(S, U, D, G, pms);
@@ -169,8 +177,8 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
   int* t_pos = t_vel + MCP_MAX_GP;
   int* t_pna = t_pos + MCP_MAX_GP;      // policy non_angle[]
   int* t_pan = t_pna + MCP_MAX_STATE;   // policy angle[]
-  const int b = tid;
-  const bool act = b < B;
+  const int b = (PIPEC && pipe) ? tid - 64 : tid;
+  const bool act = b >= 0 && b < B;
   const bool drop = pl.p_drop > 0.0;
   const double keep_scale = 1.0 / (1.0 - pl.p_drop);
   const uint32_t drop_thr = drop_threshold(pl.p_drop);
@@ -423,6 +431,33 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       tgt_c = (ri[6] >> 8) == 3 ? pl.target_traj[(size_t)(T - 1) * S + ri[0]] : 0.0;
     }
     lds_barrier();
+    // pipelined form: what the chain of a step takes from the step's own record alone -- prepared here for T - 1, then a step ahead
+    double p_sv = 0.0, p_cv = 1.0, p_fn = 0.0;
+    auto chain_prep = [&](int tt, int buf) {
+      const double* rrow = rtab + lane * BW_RT;
+      const int4 ra = *reinterpret_cast<const int4*>(rrow), rb = *reinterpret_cast<const int4*>(rrow + 2);
+      const bw_v2d rk2f = *reinterpret_cast<const bw_v2d*>(rrow + 6);
+      const int fl = rb.z & 255, ftype = rb.z >> 8;
+      const bool ft_l = fl & 2;
+      clds_t r = (clds_t)(smem + L.rec) + buf * NRP + sp * NR;
+      const double xs = r[oX + ra.x];
+      const double tgt = tgt_c;  // (trajectory policies: loaded a step ahead)
+      if (pl.kind == MCP_POLICY_TRAJ && ftype == 3 && tt > 0) tgt_c = pl.target_traj[(size_t)(tt - 1) * S + ra.x];
+      double sv = 0.0, cv = 1.0;
+      if (any_trig) sincos_fast(xs, &sv, &cv);
+      const double fn = ftype == 0 ? xs : (ftype == 1 ? cv : (ftype == 2 ? sv : tgt - xs));
+      if (ft_l) sf[lane - BW_FL0] = fn * rk2f.y;
+      p_sv = sv;
+      p_cv = cv;
+      p_fn = fn;
+    };
+    if (PIPEC && pipe) {
+      if (serial) {
+        chain_prep(T - 1, cur);
+        for (int q = lane; q < PF; q += 64) red[(sp * NW + wv) * PF + q] = 0.0;  // (wave 0 has no basis function: its row of partial feature adjoints stays zero)
+      }
+      lds_barrier();
+    }
     for (int t = T - 1; t >= 0; --t) {
       // thread / lane ids are laundered per step: what the unrolled feature loops derive from them (LDS addresses, predicates) is
       // recomputed where it is used instead of being hoisted out of the sweep, kept live next to the accumulators and spilled
@@ -431,14 +466,81 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         lane = tid & 63;
         pf_tid = pf_split ? tid - 64 * PB : tid;
       }
-      const int b = tid;
+      const int b = (PIPEC && pipe) ? tid - 64 : tid;
       BW_STAMP(11);
       // the next step's record: issued at the top by the waves that have no chain to run, BEHIND the chain by the serial waves (the loads
       // have the whole RBF stage to land; their registers and ~50 address instructions stay off the chain)
       if (t > 0 && !(FASTCHAIN && serial)) prefetch(pre, t - 1, mbase);
       // ---- serial section: wave p for particle slot p -----------------------------------------------
       if (serial) {
-        if constexpr (FASTCHAIN) {
+        if (PIPEC && pipe) {
+          // ---- the register chain, pipelined form: sincos / features of this step are in p_sv, p_cv, p_fn (chain_prep, a step earlier) ----
+          const double* rrow = rtab + lane * BW_RT;
+          const int4 ra = *reinterpret_cast<const int4*>(rrow), rb = *reinterpret_cast<const int4*>(rrow + 2);
+          const bw_v2d rk01 = *reinterpret_cast<const bw_v2d*>(rrow + 4), rk2f = *reinterpret_cast<const bw_v2d*>(rrow + 6),
+                       row_ = *reinterpret_cast<const bw_v2d*>(rrow + 8);
+          const int fl = rb.z & 255;
+          const bool st_l = fl & 1, in_l = fl & 4, zang = fl & 8, pang = fl & 16, has_j = fl & 32;
+          const int uk = in_l ? lane - BW_UL0 : 0;
+          clds_t r = (clds_t)(smem + L.rec) + cur * NRP + sp * NR;
+          const bool last = (t == T - 1);
+          const double gb = r[st_l ? oGX + lane : oGU + uk];
+          const double uu = r[oU + uk];
+          constexpr int GMX = MCP_MAX_GP;
+          double Ja[GMX], Jb[GMX];
+#pragma unroll
+          for (int g = 0; g < GMX; ++g) {
+            if (g < G) {
+              Ja[g] = r[oJ + g * D + ra.y];
+              Jb[g] = r[oJ + g * D + ra.z];
+            } else {
+              Ja[g] = Jb[g] = 0.0;
+            }
+          }
+          double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+          if (!last) {
+            const vlds_t redp = red + sp * NW * PF;
+            for (int w0 = 0; w0 < NW; w0 += 2) {  // (two waves' partials per pass: six reads in flight)
+              const int wa = w0, wb = imin(w0 + 1, NW - 1);
+              const double a0 = ((clds_t)redp)[wa * PF + ra.w], a1 = ((clds_t)redp)[wa * PF + rb.x], a2 = ((clds_t)redp)[wa * PF + rb.y];
+              const double b0 = ((clds_t)redp)[wb * PF + ra.w], b1 = ((clds_t)redp)[wb * PF + rb.x], b2 = ((clds_t)redp)[wb * PF + rb.y];
+              const bool okb = w0 + 1 < NW;
+              c0 += a0;
+              c1 += a1;
+              c2 += a2;
+              c0 += okb ? b0 : 0.0;
+              c1 += okb ? b1 : 0.0;
+              c2 += okb ? b2 : 0.0;
+            }
+          }
+          const double sv = p_sv, cv = p_cv, fn = p_fn;
+          const double s = last ? 0.0 : fma(kp2, c2, fma(kp1, c1, rk01.x * c0));
+          if (!last) glacc = fma(-fprev, s, glacc);  // feature lanes: - f_q(t+1) * (adjoint of f_q(t+1))
+          const double xnr = xbr + s;                 // state lanes: adjoint of x_{t+1}
+          double val = fma(row_.x, xnr, gb);
+#pragma unroll
+          for (int g = 0; g < GMX; ++g) {
+            if (g < G) {
+              const int lv = md.vel[g], lp = md.not_vel[g];
+              const double xnv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xnr), lv), __builtin_amdgcn_readlane(__double2loint(xnr), lv));
+              const double xnp = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(xnr), lp), __builtin_amdgcn_readlane(__double2loint(xnr), lp));
+              const double dbg = fma(0.5 * md.Ts, xnp, xnv);
+              const double jc = zang ? fma(Ja[g], cv, -(Jb[g] * sv)) : Ja[g];
+              val = fma(g == rb.w ? md.Ts : 0.0, xnp, val);
+              val = fma(dbg, has_j ? jc : 0.0, val);
+            }
+          }
+          xbr = val;
+          const double th = uu * row_.y;
+          const double abv = (in_l && pl.squash) ? val * (1.0 - th * th) : val;
+          if (in_l) {
+            ab[uk] = abv;
+            if (spvalid) gbacc += abv;
+          }
+          kp1 = pang ? -sv * rk01.y : rk01.y;
+          kp2 = pang ? cv * rk2f.x : 0.0;
+          fprev = fn;
+        } else if constexpr (FASTCHAIN) {
           // ---- the register chain (see the role table above) ----
           const double* rrow = rtab + lane * BW_RT;
           const int4 ra = *reinterpret_cast<const int4*>(rrow), rb = *reinterpret_cast<const int4*>(rrow + 2);
@@ -610,18 +712,20 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         }
       }
       if (FASTCHAIN && t > 0 && serial) prefetch(pre, t - 1, mbase);
-      BW_STAMP(8);
-      BW_WS(0);
-      lds_barrier();
-      BW_STAMP(9);
-      BW_WS(1);
+      if (!(PIPEC && pipe)) {  // (pipelined form: the barrier comes behind the RBF stage's first half, below)
+        BW_STAMP(8);
+        BW_WS(0);
+        lds_barrier();
+        BW_STAMP(9);
+        BW_WS(1);
+      }
       // ---- RBF network, thread b owns basis b, loops over the particle slots -----------------------------
       // dropout keep bits: one Philox draw serves 4 consecutive bases of one particle (philox_keep); the lanes of a quad
       // draw for particle slots (b & 3) % PB and pass each other the word of the receiver's basis
       uint32_t kw[PB];
 #pragma unroll
       for (int p = 0; p < PB; ++p) kw[p] = 0xFFFFFFFFu;
-      if (drop && !nzl.masks) {
+      if (drop && !nzl.masks && !(PIPEC && pipe && serial)) {  // (pipelined form: wave 0 has no basis function to draw for)
         const int cq = b & 3;
         const int bq = imin(b, B - 1) >> 2;
         // (PB = 8: two rounds, slots cq and cq + 4)
@@ -654,11 +758,13 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         const bool pv = mbase + p < M;
         double dd = 0.0;  // adjoint of dist_b (0 for idle threads and empty slots, so they add nothing below)
         constexpr bool KEEPRR = PFM > BW_MASK_FROM && MAXNT <= 512;  // (the 1024-thread forms have 128 registers: they read twice)
+        static_assert(!PIPEC || KEEPRR, "the pipelined form rewrites the features while the adjoint half runs: it needs the kept differences");
         double rrk[KEEPRR ? PFM : 1];  // wide classes: the scaled differences, kept for the adjoint pass (no second LDS pass)
         if constexpr (KEEPRR) {
 #pragma unroll
           for (int q = 0; q < PFM; ++q) rrk[q] = 0.0;
         }
+        double phi = 0.0, mk = 1.0;
         if (act && pv) {
           double dist = 0.0;
           if constexpr (PFM > BW_MASK_FROM) {
@@ -693,12 +799,22 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
               }
             }
           }
-          double phi = exp(-dist);
-          double mk = 1.0;
+          phi = exp(-dist);
           if (drop) {
             bool keep = nzl.masks ? (nzl.masks[((size_t)t * M + mbase + p) * B + b] != 0) : (kw[p] >= drop_thr);
             mk = keep ? keep_scale : 0.0;
           }
+        }
+        if (PIPEC && pipe) {
+          // ---- pipelined form: everything above ran beside the chain; the record of step t - 1 has had that time to land ----
+          if (t > 0) park(pre, cur ^ 1);
+          BW_STAMP(8);
+          BW_WS(0);
+          lds_barrier();
+          BW_STAMP(9);
+          BW_WS(1);
+        }
+        if (act && pv) {
           double phibar = 0.0;
 #pragma unroll
           for (int k = 0; k < UM; ++k) {
@@ -718,7 +834,7 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
         // 8 features at a time: their wave sums interleave (ILP) without keeping all PFM partial products live
 #pragma unroll
         for (int q0 = 0; q0 < PFM; q0 += 8) {
-          if (q0 < PF) {
+          if (q0 < PF && !(PIPEC && pipe && serial)) {  // (pipelined form: wave 0 has no basis function -- its row of `red` was zeroed once)
             double t2v[8];  // 2 dd rr / l: the adjoint of the policy feature, before the sum over bases
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -752,7 +868,11 @@ __global__ __launch_bounds__(MAXNT, WPE) void rollout_bwd_kernel(BwdArgs a) {
       }
       BW_STAMP(10);
       BW_WS(2);
-      if (t > 0) park(pre, cur ^ 1);
+      if (PIPEC && pipe) {
+        if (serial && t > 0) chain_prep(t - 1, cur ^ 1);  // (beside the RBF waves' adjoint half: the record was parked before the barrier)
+      } else if (t > 0) {
+        park(pre, cur ^ 1);
+      }
       cur ^= 1;
       BW_WS(3);
       lds_barrier();
@@ -1441,7 +1561,8 @@ static int launch_bwd(const BwdArgs& a, int NT, hipStream_t st) {
 static int rollout_bwd_impl(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T,
                                const double* states, const double* inputs, const double* jac, const double* g_states,
                                const double* g_inputs, double* g_log_ls, double* g_centers, double* g_weight, double* g_x0,
-                               void* workspace, size_t workspace_bytes, void* stream, unsigned long long* g_bwd_stamps, int g_force_bwd_pb, int g_bwd_lean, int& g_last_bwd_lean) {
+                               void* workspace, size_t workspace_bytes, void* stream, unsigned long long* g_bwd_stamps, int g_force_bwd_pb, int g_bwd_lean, int& g_last_bwd_lean,
+                               int g_bwd_pipe = -1, int* g_last_bwd_pipe = nullptr) {
   if (!noise || !states || !inputs || !g_log_ls || !g_centers || !g_weight || !workspace || !policy || M <= 0 || T <= 0) return MCP_ERR_ARG;
   if (T > 1 && !jac) return MCP_ERR_ARG;
   if (policy->meas.n > 0 && !policy->meas.meas) return MCP_ERR_ARG;
@@ -1471,6 +1592,7 @@ static int rollout_bwd_impl(const mcp_model* model, const mcp_policy* policy, co
   a.stamps = g_bwd_stamps;
   a.m_base = 0;
   a.slab_accum = 0;
+  a.pipe = 0;
   hipStream_t st = (hipStream_t)stream;
   const int PF = policy->P, U = policy->U;
   // particles per workgroup: large swarms are latency bound per workgroup, so several particles share one sweep; small
@@ -1518,6 +1640,8 @@ static int rollout_bwd_impl(const mcp_model* model, const mcp_policy* policy, co
   // register budget: 3*PFM + 2*UM doubles of per-thread accumulators plus the prefetched record; the launch bound is the
   // tightest that fits the thread count, capped so that two 256-thread workgroups share a CU
   for (; PB >= 1 && rc == MCP_ERR_LIMIT; PB >>= 1) {
+    // one particle per workgroup on the 512-thread wide instantiations, no measurement model, a wave to spare: the pipelined form (PIPEC)
+    a.pipe = (PB == 1 && g_bwd_pipe != 0 && !(PF <= 16 && U <= 4) && NT > 256 && NT + 64 <= 512 && policy->meas.n == 0) ? 1 : 0;
     if (PF <= 8 && U <= 2) {
       if (NT <= 256)
         rc = PB == 4 ? launch_bwd<8, 2, 256, BW_WPE_A, 4>(a, NT, st) : PB == 2 ? launch_bwd<8, 2, 256, BW_WPE_A, 2>(a, NT, st) : launch_bwd<8, 2, 256, BW_WPE_A, 1>(a, NT, st);
@@ -1535,7 +1659,7 @@ static int rollout_bwd_impl(const mcp_model* model, const mcp_policy* policy, co
         rc = PB == 8   ? launch_bwd<24, 6, 512, 2, 8>(a, NT, st)
              : PB == 4 ? launch_bwd<24, 6, 512, 2, 4>(a, NT, st)
              : PB == 2 ? launch_bwd<24, 6, 512, 2, 2>(a, NT, st)
-             : PB == 1 ? launch_bwd<24, 6, 512, 2, 1>(a, NT, st)
+             : PB == 1 ? launch_bwd<24, 6, 512, 2, 1>(a, NT + 64 * a.pipe, st)
                        : MCP_ERR_LIMIT;
     } else {
       if (NT <= 256)
@@ -1543,11 +1667,12 @@ static int rollout_bwd_impl(const mcp_model* model, const mcp_policy* policy, co
                      : PB == 1 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 256, BW_WPE_A, 1>(a, NT, st) : MCP_ERR_LIMIT;
       else
         rc = PB == 2 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 512, 2, 2>(a, NT, st)
-                     : PB == 1 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 512, 2, 1>(a, NT, st) : MCP_ERR_LIMIT;
+                     : PB == 1 ? launch_bwd<MCP_MAX_PFEAT, MCP_MAX_INPUT, 512, 2, 1>(a, NT + 64 * a.pipe, st) : MCP_ERR_LIMIT;
     }
     if (rc == MCP_ERR_LIMIT && PB > 1) NT = imax(bwd_threads(policy->B), 64 * (PB >> 1));
   }
   if (rc < 0) return rc;
+  if (g_last_bwd_pipe) *g_last_bwd_pipe = a.pipe;  // (set by the launch that went out; 0 when the lean sweep ran)
   const int grid = rc;
   const int nparam = PF + policy->B * PF + U * policy->B + (policy->bias ? U : 0);
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((nparam + 63) / 64), dim3(256), 0, st, grid, nparam, PF, policy->B * PF, U * policy->B, a.slab,
@@ -1561,10 +1686,11 @@ extern "C" int mcp_rollout_bwd_ex(const mcp_model* model, const mcp_policy* poli
                                const double* g_inputs, double* g_log_ls, double* g_centers, double* g_weight, double* g_x0,
                                void* workspace, size_t workspace_bytes, void* stream, mcp_dispatch* d) {
   // (the request travels with the call: include/mcpilco_hip_debug.h; d == NULL: automatic)
-  int last_lean = 0;
+  int last_lean = 0, last_pipe = 0;
   const int rc = rollout_bwd_impl(model, policy, noise, M, T, states, inputs, jac, g_states, g_inputs, g_log_ls, g_centers, g_weight, g_x0, workspace, workspace_bytes, stream, d ? (unsigned long long*)d->bwd_stamps : nullptr, d ? d->bwd_particles : 0,
-                                  (d && d->bwd_lean == 1) ? 0 : -1, last_lean);
+                                  (d && d->bwd_lean == 1) ? 0 : -1, last_lean, (d && d->bwd_pipe == 1) ? 0 : -1, &last_pipe);
   if (d) d->ran_bwd_lean = last_lean;
+  if (d) d->ran_bwd_pipe = last_pipe;
   return rc;
 }
 extern "C" int mcp_rollout_bwd(const mcp_model* model, const mcp_policy* policy, const mcp_noise* noise, int M, int T,

@@ -88,9 +88,9 @@ class Dispatch(C.Structure):
     """include/mcpilco_hip_debug.h: struct mcp_dispatch -- the request a call carries (all zero = automatic) and what it reports back."""
     _fields_ = [("fwd_particles", C.c_int32), ("gp_sharding", C.c_int32), ("fwd_lean", C.c_int32), ("policy_split", C.c_int32), ("row_split", C.c_int32),
                 ("cluster_map", C.c_int32), ("fwd_no_xlds", C.c_int32),
-                ("fwd_gb", C.c_int32), ("bwd_particles", C.c_int32), ("bwd_lean", C.c_int32), ("chol_form", C.c_int32), ("stamp_block", C.c_uint32),
+                ("fwd_gb", C.c_int32), ("bwd_particles", C.c_int32), ("bwd_lean", C.c_int32), ("bwd_pipe", C.c_int32), ("chol_form", C.c_int32), ("stamp_block", C.c_uint32),
                 ("fwd_stamps", dptr), ("bwd_stamps", dptr), ("ran_particles", C.c_int32), ("ran_gp_sharded", C.c_int32), ("ran_fwd_lean", C.c_int32),
-                ("ran_bwd_lean", C.c_int32), ("ran_row_split", C.c_int32)]
+                ("ran_bwd_lean", C.c_int32), ("ran_row_split", C.c_int32), ("ran_bwd_pipe", C.c_int32)]
 
 
 # The dispatch request of THIS PROCESS's calls through `ops` (all zero: automatic).  It lives here, in the host layer -- the library keeps no
@@ -200,6 +200,12 @@ class _Lib:
 
     def mcp_debug_set_bwd_stamp_buffer(self, p):
         DISPATCH.bwd_stamps = p
+
+    def mcp_debug_last_bwd_pipe(self):
+        return int(DISPATCH.ran_bwd_pipe)
+
+    def mcp_debug_set_bwd_pipe(self, mode):  # -1 / 1 wherever it applies, 0 never
+        DISPATCH.bwd_pipe = 1 if int(mode) == 0 else 0
 
     def mcp_debug_set_gp_sharding(self, mode):  # -1 automatic, 0 never, 1 whenever the grid fits the device
         DISPATCH.gp_sharding = {-1: 0, 0: 1, 1: 2}[int(mode)]

@@ -234,3 +234,53 @@ def test_linear_gp_forward_and_gradients(offset, in_sum):
         lin.Sigma_pos_par.add_(0.01)
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         out[3].backward()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["masks", "philox"])
+def test_pipelined_backward_sweep_of_the_wide_class(mode):
+    """Round 6: one particle per workgroup on the wide classes (the UR5 launch script's M = 200) -- `rollout_bwd_kernel<24, 6, 512, 2, 1>` with a wave
+    more than the basis functions need runs the chain of step t on wave 0 BESIDE the adjoint-independent half of the RBF stage (exp, Philox, distances)
+    and prepares the features of step t - 1 beside the other half (`BwdArgs.pipe`).  Same arithmetic per basis function and per chain lane; the partial
+    feature adjoints are summed over other groups of 64 basis functions, so the gradients agree with the sequential form to rounding (1e-12 relative)
+    and, with recorded masks, with the oracle (1e-9, as the sequential form does)."""
+    import torch
+    from gpu_helpers import dev
+    from mc_pilco_amd import hipabi, ops
+    from test_gpu_realsize import oracle_answer, hip_workload_on_oracle_operands
+
+    o = oracle_answer("ur5_400")
+    w = hip_workload_on_oracle_operands("ur5_400")
+    if mode == "masks":
+        nz = ops.NoiseSpec(eps=o["eps"].to(dev()).contiguous(), masks=o["masks"].to(torch.uint8).to(dev()).contiguous())
+    else:
+        nz = ops.NoiseSpec(seed=11, call=2)
+    L = hipabi.lib()
+    out = {}
+    try:
+        L.mcp_debug_set_bwd_particles(1)
+        for pipe in (1, 0, 1):
+            L.mcp_debug_set_bwd_pipe(pipe)
+            for q in w.params:
+                q.grad = None
+            st, inp, status = ops.rollout(w.model, w.policy, nz, o["x0"].to(dev()), w.T, o["p"])
+            c, _ = ops.expected_cost(w.cost, st)
+            c.backward()
+            assert int(status.item()) == 0
+            assert L.mcp_debug_last_bwd_pipe() == pipe and not L.mcp_debug_last_bwd_lean()
+            g = [q.grad.clone() for q in w.params]
+            if pipe in out:
+                assert all(torch.equal(a, b) for a, b in zip(out[pipe], g))  # bitwise reproducible
+            out[pipe] = g
+    finally:
+        L.mcp_debug_set_bwd_particles(0)
+        L.mcp_debug_set_bwd_pipe(-1)
+    for a, b, k in zip(out[1], out[0], ["log_ls", "centers", "weight"]):
+        rel = float((a - b).abs().max() / b.abs().max())
+        print("pipelined vs sequential sweep (%s) %s: rel %.2e" % (mode, k, rel))
+        assert rel < 1e-12, k
+        assert float(b.abs().max()) > 0.0
+    if mode == "masks":
+        for q, k in zip(out[1], ["log_ls", "centers", "weight"]):
+            g = o["grads"][k]
+            assert float((q.cpu().reshape(g.shape) - g).abs().max()) < 1e-9 * float(g.abs().max()), k

@@ -47,7 +47,11 @@ if hipabi.lib().mcp_debug_last_bwd_lean():
     print("bwd (lean sweep) per step cycles, wave 0: chain %.0f | wait at barrier 1 %.0f | prepare next step %.0f | wait at barrier 2 %.0f" % tuple(x / w.T for x in (v2[8], v2[9], v2[10], v2[11])))
     print("bwd (lean sweep) per step cycles, wave 1: before barrier 1 (exp, Philox, distances) %.0f | wait %.0f | after it (fma, wave sum) %.0f | wait at barrier 2 %.0f" % tuple(x / w.T for x in (v2[12], v2[13], v2[14], v2[15])))
 else:
-    print("bwd per step cycles: serial(wave0) %.0f | barrier1 %.0f | RBF stage %.0f | park+barrier2 %.0f" % tuple(x / w.T for x in (v2[8], v2[9], v2[10], v2[11])))
+    if hipabi.lib().mcp_debug_last_bwd_pipe():  # (round 6: one particle per workgroup on the wide classes -- wave 0's view of a step)
+        print("bwd (pipelined form) per step cycles, wave 0: chain %.0f | wait for the RBF waves' first half + park %.0f | features of the next step %.0f | wait for their adjoint half %.0f"
+              % tuple(x / w.T for x in (v2[8], v2[9], v2[10], v2[11])))
+    else:
+        print("bwd per step cycles: serial(wave0) %.0f | barrier1 %.0f | RBF stage %.0f | park+barrier2 %.0f" % tuple(x / w.T for x in (v2[8], v2[9], v2[10], v2[11])))
 print("workload", name, "T", w.T, "M", w.M, "ppw forced", ppw, "launched", hipabi.lib().mcp_debug_last_particles_per_wg(), "gp-sharded", hipabi.lib().mcp_debug_last_gp_sharded(), "lean", hipabi.lib().mcp_debug_last_fwd_lean(), "total cycles", tot, "-> per step", tot / (w.T - 1))
 print("tile kernel detail (wave 0, per step, all GPs): K setup %.0f, K tiles %.0f | J setup %.0f, J batches %.0f cyc" % tuple((0 if (i == 14 and hipabi.lib().mcp_debug_last_row_split()) else v[i]) / (w.T - 1) for i in (12, 13, 14, 15)))
 if not hipabi.lib().mcp_debug_last_row_split():  # (the row-split cluster's phase F uses these slots: printed at the end)
