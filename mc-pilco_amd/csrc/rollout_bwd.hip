@@ -1467,13 +1467,15 @@ __global__ __launch_bounds__(640) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // sum the per-workgroup slabs in a fixed order (deterministic, no atomics): 64 parameters per workgroup, its 4 waves take a
 // quarter of the slabs each (4 independent partial sums per thread keep loads in flight), partials meet in LDS.  (One thread per
 // parameter walking all slabs left 5 workgroups on the device: 34 us for 3.9 MB at the headline shape.)
-__global__ __launch_bounds__(256) void grad_reduce_kernel(int nblk, int nparam, int PF, int BPF, int UB, const double* __restrict__ slab,
-                                                          double* __restrict__ g_log_ls, double* __restrict__ g_centers,
-                                                          double* __restrict__ g_weight, double* __restrict__ g_bias) {
-  __shared__ double part[4][64];
+// (round 6: sixteen waves per 64 parameters instead of four -- 200 slabs are 13 loads in a row per thread, not 50: 10.3 -> 4 us at the headline shape)
+#define GR_NW 16
+__global__ __launch_bounds__(64 * GR_NW) void grad_reduce_kernel(int nblk, int nparam, int PF, int BPF, int UB, const double* __restrict__ slab,
+                                                                 double* __restrict__ g_log_ls, double* __restrict__ g_centers,
+                                                                 double* __restrict__ g_weight, double* __restrict__ g_bias) {
+  __shared__ double part[GR_NW][64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + lane;
-  const int per = (nblk + 3) / 4, k0 = q * per, k1 = imin(nblk, k0 + per);
+  const int per = (nblk + GR_NW - 1) / GR_NW, k0 = imin(nblk, q * per), k1 = imin(nblk, k0 + per);
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (i < nparam) {
     int k = k0;
@@ -1488,7 +1490,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(int nblk, int nparam, 
   part[q][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (q != 0 || i >= nparam) return;
-  const double s = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+  double s = 0.0;
+#pragma unroll
+  for (int w = 0; w < GR_NW; w += 4) s += (part[w][lane] + part[w + 1][lane]) + (part[w + 2][lane] + part[w + 3][lane]);  // (fixed order)
   if (i < PF)
     g_log_ls[i] = s;
   else if (i < PF + BPF)
@@ -1675,7 +1679,7 @@ static int rollout_bwd_impl(const mcp_model* model, const mcp_policy* policy, co
   if (g_last_bwd_pipe) *g_last_bwd_pipe = a.pipe;  // (set by the launch that went out; 0 when the lean sweep ran)
   const int grid = rc;
   const int nparam = PF + policy->B * PF + U * policy->B + (policy->bias ? U : 0);
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3((nparam + 63) / 64), dim3(256), 0, st, grid, nparam, PF, policy->B * PF, U * policy->B, a.slab,
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((nparam + 63) / 64), dim3(64 * GR_NW), 0, st, grid, nparam, PF, policy->B * PF, U * policy->B, a.slab,
                      g_log_ls, g_centers, g_weight, policy->bias ? policy->g_bias : nullptr);
   MCP_LAUNCH_CHECK();
   return MCP_OK;
