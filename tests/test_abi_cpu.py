@@ -73,6 +73,28 @@ def test_struct_layout_matches_header(tmp_path):
     assert got == want
 
 
+def test_dispatch_struct_layout_matches_the_debug_header_and_every_object_depends_on_it(tmp_path):
+    """`mcp_dispatch` (include/mcpilco_hip_debug.h) travels with every `_ex` call: the ctypes mirror must lay out every field where the header does
+    (offset by offset), and -- round 6: a new field once left the forward's object on the old layout, its report words landed in what the backward read
+    as the stamp pointer -- the build must count the header among the dependencies of EVERY object."""
+    import re
+
+    from mc_pilco_amd import build, hipabi
+
+    hdr = open(os.path.join(ROOT, "include", "mcpilco_hip_debug.h")).read()
+    body = hdr[hdr.index("typedef struct mcp_dispatch {"):hdr.index("} mcp_dispatch;")]
+    names = re.findall(r"^\s*(?:int32_t|uint32_t|void\*)\s+(\w+);", body, re.M)
+    assert names == [f[0] for f in hipabi.Dispatch._fields_]
+    src = tmp_path / "dz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mcpilco_hip_debug.h"\nint main(){printf("%zu", sizeof(mcp_dispatch));'
+                   + "".join('printf(" %%zu", offsetof(mcp_dispatch, %s));' % n for n in names) + "return 0;}\n")
+    exe = tmp_path / "dz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == [C.sizeof(hipabi.Dispatch)] + [getattr(hipabi.Dispatch, n).offset for n in names]
+    assert any(h.endswith("mcpilco_hip_debug.h") for h in build.HEADERS) and any(h.endswith("mcpilco_hip.h") for h in build.HEADERS)
+
+
 def test_argument_validation_without_gpu():
     """Bad descriptors are rejected on the host (negative MCP_ERR_*), before any launch."""
     from mc_pilco_amd import hipabi
