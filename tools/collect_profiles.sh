@@ -27,6 +27,7 @@ done
 # above is the first sender).  Then the forward time of every form of the cluster (tools/row_split_soak.py) and the 4x4x4 MFMA probes.
 echo "[$(date +%T)] ur5_script stamps, finishing part"; MCP_STAMP_BLOCK=208 python3 $R/tools/phase_stamps.py ur5_script > "$OUT/ur5_script_half1_stamps.txt" 2>&1 || exit 1
 run "row split forms" python3 $R/tools/row_split_soak.py 20 > "$OUT/ur5_row_split_forms.txt" 2>&1
+( hipcc --offload-arch=gfx950 -O3 -w -o /tmp/smo $R/tools/stream_mfma_overlap.hip && /tmp/smo ) > "$OUT/stream_mfma_overlap.txt" 2>&1 || exit 1
 ( hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma4x4_probe $R/tools/mfma4x4_probe.hip && /tmp/mfma4x4_probe && hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_bank_probe $R/tools/mfma_bank_probe.hip && /tmp/mfma_bank_probe ) > "$OUT/mfma4x4_probe.txt" 2>&1 || exit 1
 for w in c1 c3 c5; do
   st=4; [ $w = c5 ] && st=2

@@ -30,7 +30,7 @@ for cfg in ("fit_c1", "fit_ur5"):  # GP training epochs (round 4)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_%s_kernel_stats.csv" % (rnd, cfg)))
 for name in ("chol_times.txt", "chol_stamps_n300.txt", "chol_stamps_n400.txt", "pretrain_times.txt", "vsym_bench.txt", "ur5_script_half1_stamps.txt",
-             "c1_nofma_stamps.txt", "c1_noload_stamps.txt", "vissue_bench.txt", "ur5_row_split_forms.txt", "mfma4x4_probe.txt", "c3_bwd_wave_stamps.txt", "c5_bwd_wave_stamps.txt", "loop_times.txt"):
+             "c1_nofma_stamps.txt", "c1_noload_stamps.txt", "vissue_bench.txt", "ur5_row_split_forms.txt", "mfma4x4_probe.txt", "stream_mfma_overlap.txt", "c3_bwd_wave_stamps.txt", "c5_bwd_wave_stamps.txt", "loop_times.txt"):
     f = os.path.join(src, name)
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_%s" % (rnd, name)))
