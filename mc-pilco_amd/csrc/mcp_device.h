@@ -6,6 +6,13 @@
 
 #include "../../include/mcpilco_hip.h"
 
+// Experiment build (-DMCPX_WALL_STAMPS: python mc-pilco_amd/build.py --variant wall MCPX_WALL_STAMPS): every diagnostic stamp of the kernels reads the
+// constant 100 MHz counter instead of the shader clock -- tools/phase_stamps.py then prints 10 ns ticks.  The shader clock follows the load (fp64
+// MFMA phases run at half the clock of the others: profiles/NOTES.md), so shares of CYCLES are not shares of TIME.
+#ifdef MCPX_WALL_STAMPS
+#define clock64() wall_clock64()
+#endif
+
 #define MCP_WAVE 64
 
 #define MCP_LAUNCH_CHECK()                                  \
