@@ -261,8 +261,9 @@ class Runner:
             p.grad = None
         # HIP events on the launch stream right around mcp_rollout_fwd / mcp_rollout_bwd (ops.fwd_events / ops.bwd_events)
         ops.fwd_events, ops.bwd_events = (None, None) if ev is None else ((ev[0], ev[1]), (ev[2], ev[3]))
-        states, inputs, status = ops.rollout(w.model, w.policy, nz, x0, T, w.p_drop, meas=self.meas)
-        self.status_or |= status
+        # (the kernels OR their flags into ONE word for the whole run -- checked after the timed blocks, check_flags -- instead of a fresh word and an
+        #  OR launch per step: 8 us of launches that are the bench's own bookkeeping, not the path's)
+        states, inputs, status = ops.rollout(w.model, w.policy, nz, x0, T, w.p_drop, meas=self.meas, status=self.status_or)
         if sharded:
             # this rank's share of the pooled cost -> its own adjoint sweep -> ONE all-reduce of [gradient | cost sums | flags]; the
             # flags are one 0/1 entry per status bit (summed doubles are counts, not an OR) + "local share is NaN"

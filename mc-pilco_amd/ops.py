@@ -407,9 +407,11 @@ def _workspace(model, policy, pc, M, T, which):
 
 
 def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, noise: NoiseSpec, x0, T, p_drop, particle_pred=True, need_jac=True,
-                        meas: Optional[MeasSpec] = None, gp_sharding=True):
+                        meas: Optional[MeasSpec] = None, gp_sharding=True, status=None):
     """model None (only with T == 1) evaluates the policy alone.  gp_sharding False: the library never launches GP-sharded (the
-    recovery path after MCP_STATUS_SYNC) -- by a flag, the workspace with the kernels' packed operand copies is still passed."""
+    recovery path after MCP_STATUS_SYNC) -- by a flag, the workspace with the kernels' packed operand copies is still passed.
+    ``status``: an int32[1] on the device that the kernels OR their flags INTO (a caller that only looks at the flags of many rollouts together
+    passes one buffer to all of them: no zero-fill launch per rollout); None: a fresh zeroed word."""
     dev = policy.device if model is None else model.device
     x0 = x0.detach().to(device=dev, dtype=DT).contiguous()
     M = x0.shape[0]
@@ -418,7 +420,10 @@ def rollout_forward_raw(model: Optional[PackedModel], policy: PackedPolicy, nois
     states = torch.empty(T, M, policy.S, dtype=DT, device=dev)
     inputs = torch.empty(T, M, policy.U, dtype=DT, device=dev)
     jac = torch.empty(max(T - 1, 1), M, max(G, 1), D, dtype=DT, device=dev) if (need_jac and T > 1) else None
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    if status is None:
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+    elif status.dtype != torch.int32 or status.numel() != 1 or status.device != x0.device or not status.is_contiguous():
+        raise RuntimeError("status must be a one-element int32 tensor on the rollout's device")
     pc = policy.bind(p_drop)
     nz = noise.to_c()
     meas_buf = torch.empty(T, M, policy.S, dtype=DT, device=dev) if meas is not None else None
@@ -507,11 +512,13 @@ class RolloutFunction(torch.autograd.Function):
     parameters (and x0); the GP model is frozen, as after ``Model_learning.set_eval_mode``."""
 
     @staticmethod
-    def forward(ctx, x0, log_ls, centers, weight, bias, model, policy, noise, T, p_drop, particle_pred, meas=None, gp_sharding=True):
+    def forward(ctx, x0, log_ls, centers, weight, bias, model, policy, noise, T, p_drop, particle_pred, meas=None, gp_sharding=True, status_acc=None):
         need = any(ctx.needs_input_grad[:5])
         ctx.set_materialize_grads(False)  # (an output the cost does not use -- usually the inputs -- arrives as None, not as a zero-filled tensor)
-        out = rollout_forward_raw(model, policy, noise, x0, T, p_drop, particle_pred, need_jac=need, meas=meas, gp_sharding=gp_sharding)
+        out = rollout_forward_raw(model, policy, noise, x0, T, p_drop, particle_pred, need_jac=need, meas=meas, gp_sharding=gp_sharding, status=status_acc)
         states, inputs, jac, status = out[:4]
+        if status_acc is not None:
+            status = status.view(1)  # (an output must not BE an input; a view launches nothing)
         ctx.model, ctx.policy, ctx.noise, ctx.p_drop = model, policy, noise, p_drop
         ctx.meas, ctx.meas_buf = meas, (out[4] if meas is not None else None)
         ctx.has_jac = jac is not None
@@ -530,15 +537,15 @@ class RolloutFunction(torch.autograd.Function):
                                                          want_gx0=ctx.needs_input_grad[0], meas=ctx.meas, meas_buf=ctx.meas_buf)
         if g_b is not None:
             g_b = g_b.reshape(ctx.policy.bias.shape)
-        return g_x0, g_ls.reshape(ctx.policy.log_ls.shape), g_c, g_w, g_b, None, None, None, None, None, None, None, None
+        return g_x0, g_ls.reshape(ctx.policy.log_ls.shape), g_c, g_w, g_b, None, None, None, None, None, None, None, None, None
 
 
-def rollout(model, policy, noise, x0, T, p_drop=0.0, particle_pred=True, meas: Optional[MeasSpec] = None, gp_sharding=True):
+def rollout(model, policy, noise, x0, T, p_drop=0.0, particle_pred=True, meas: Optional[MeasSpec] = None, gp_sharding=True, status=None):
     """Differentiable fused rollout.  Returns (states, inputs, status).  ``meas``: measurement model between the particles and
     the policy (partially measurable systems); None = the policy sees the true state.  ``gp_sharding`` False forbids the
-    GP-sharded launch forms (used to repeat a step whose hand-off reported MCP_STATUS_SYNC)."""
+    GP-sharded launch forms (used to repeat a step whose hand-off reported MCP_STATUS_SYNC).  ``status``: see rollout_forward_raw."""
     return RolloutFunction.apply(x0, policy.log_ls, policy.centers, policy.weight, policy.bias, model, policy, noise, int(T), float(p_drop),
-                                 bool(particle_pred), meas, bool(gp_sharding))
+                                 bool(particle_pred), meas, bool(gp_sharding), status)
 
 
 # --------------------------------------------------------------------------------------
